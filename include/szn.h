@@ -1,0 +1,220 @@
+/* szn.h -- C-ABI of libszn_hip.so: the MI355X (gfx950) kernels underneath the SZN pixel-embedding
+ * training path.
+ *
+ * The reference (RohanDoshi2018/ZeroshotSemanticSegmentation) has no FFI of its own: its "operator
+ * interface" for this path is the set of torch calls made by models.py / utils.py / train.py.  Each
+ * entry point below names the reference call site (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Every pointer is a CALLER-OWNED DEVICE pointer
+ *     (the library never allocates, frees or retains them) unless the comment says "host".
+ *   - every function returns int: 0 = SZN_OK, <0 = error; szn_last_error() gives the text
+ *     (thread-local).  No host synchronisation happens inside any entry point; every launch goes
+ *     to the hipStream_t passed as `stream` (pass torch.cuda.current_stream().cuda_stream).
+ *   - activations are NHWC [B][H][W][C] ("pixel-major"), conv weights OHWI [Cout][KH][KW][Cin]
+ *     (== torch channels_last storage of an (O,I,KH,KW) tensor), element type given by `dtype`
+ *     (SZN_F32 parity path / SZN_BF16 throughput path); accumulation is always fp32.
+ *   - the network-boundary tensors keep the reference's layout: input image (B,3,H,W) NCHW f32,
+ *     score (B,E,H,W) NCHW f32, labels (B,H,W) int64 with -1 = ignore.
+ */
+#ifndef SZN_H_
+#define SZN_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* szn_stream_t; /* hipStream_t */
+
+enum { SZN_OK = 0, SZN_ERR_ARG = -1, SZN_ERR_LAUNCH = -2, SZN_ERR_UNSUPPORTED = -3 };
+enum { SZN_F32 = 0, SZN_BF16 = 1 };
+
+/* ---- library -------------------------------------------------------------------------------- */
+const char* szn_last_error(void);
+int szn_version(void); /* major*10000 + minor*100 + patch */
+typedef struct {
+    char name[128];
+    char arch[32];
+    int compute_units;
+    int wavefront;
+    int lds_bytes_per_block;
+    int64_t hbm_bytes;
+    int clock_mhz;
+} szn_device_info_t;
+int szn_device_info(int device, szn_device_info_t* out /* host */);
+
+/* ---- stride-1 convolution as implicit GEMM on MFMA --------------------------------------------
+ * Replaces nn.Conv2d forward/backward for conv1_2..conv5_3 (3x3 pad 1), fc6 (7x7 valid), fc7 and
+ * score_fr || seenmask_score (1x1): models.py:45-97 (construction), models.py:117-149 (forward),
+ * and their autograd backward triggered by trainer_fcn.py:157 / trainer_seenmask.py:81.
+ * Ci must be a multiple of 64 (bf16) / 32 (f32); Co is arbitrary.                               */
+typedef struct {
+    int dtype;        /* SZN_F32 | SZN_BF16: element type of in / w / gate / out                 */
+    int B, Hi, Wi, Ci; /* input  [B][Hi][Wi][Ci], pixel stride ldi >= Ci elements                 */
+    int Ho, Wo, Co;   /* output [B][Ho][Wo][Co], pixel stride ldo >= Co; Ho = Hi + 2*pad - KH + 1 */
+    int KH, KW, pad;
+    int ldi, ldo, ldg; /* pixel strides (elements) of in / out / gate                            */
+    int relu;         /* epilogue max(v,0)  (nn.ReLU, models.py:44..90)                           */
+    int out_f32;      /* store out as float even when dtype == SZN_BF16                           */
+} szn_conv_desc_t;
+
+/* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
+ * epi(v):  relu -> (gate ? (gate[m][n] > 0 ? v : 0) : v) -> (chan_scale ? v*chan_scale[b][n] : v)
+ * bias, gate, chan_scale may be NULL.  chan_scale is the Dropout2d factor per (image, channel)
+ * (models.py:86,91: 0 or 1/(1-p)).                                                               */
+int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias,
+                   const void* gate, const float* chan_scale, void* out, szn_stream_t stream);
+
+/* wT[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]: the weight image szn_conv2d_dgrad consumes.  */
+int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, const void* w, void* wT,
+                          szn_stream_t stream);
+
+/* d (forward geometry) -> din[B][Hi][Wi][Ci] = conv(dout, wT) with pad' = KH-1-pad; epilogue as
+ * above with gate = the forward INPUT activation (ReLU backward) and chan_scale = the dropout
+ * factors that were applied to that input.  d->ldo is the pixel stride of DOUT, d->ldi of DIN.   */
+int szn_conv2d_dgrad(const szn_conv_desc_t* d, const void* dout, const void* wT, const void* gate,
+                     const float* chan_scale, void* din, szn_stream_t stream);
+
+/* dw[co][kh][kw][ci] (+)= sum_pixels dout[p][co] * in[p shifted by (kh,kw)][ci]   (fp32, OHWI)
+ * accumulate != 0 adds into dw (split-K partial sums are added with fp32 atomics; dw must then be
+ * zero or hold a running gradient); accumulate == 0 zeroes dw first on the same stream.           */
+int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw,
+                     int accumulate, szn_stream_t stream);
+
+/* db[n] (+)= sum_m dout[m][n], m < M rows with pixel stride ldd.                                  */
+int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
+                  szn_stream_t stream);
+
+/* the "pixel projection" of the north star: score_fr (|| seenmask_score) 1x1 conv, models.py:93,97,
+ * 145,149.  Thin aliases of the conv entry points with KH=KW=1, pad=0 (M = B*h*w rows).           */
+int szn_gemm_proj_fwd(int dtype, long M, int K, int N, int ldo, const void* x, const void* w,
+                      const float* bias, float* out_f32, szn_stream_t stream);
+int szn_gemm_proj_dgrad(int dtype, long M, int K, int N, int ldd, const void* dout, const void* wT,
+                        const void* gate, const float* chan_scale, void* dx, szn_stream_t stream);
+int szn_gemm_proj_wgrad(int dtype, long M, int K, int N, int ldd, const void* x, const void* dout,
+                        float* dw, int accumulate, szn_stream_t stream);
+
+/* ---- conv1_1: 3 -> 64 channels, 3x3, pad 100, reads the NCHW f32 image directly ----------------
+ * models.py:43,116 (+ ReLU models.py:44).  w is OHWI f32 [64][3][3][3], out NHWC dtype.           */
+int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const float* x_nchw, const float* w,
+                    const float* bias, void* out, szn_stream_t stream);
+/* dw[64][3][3][3], db[64] from dout (already ReLU-gated) -- no dgrad: the image needs no gradient */
+int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const float* x_nchw,
+                      const void* dout, float* dw, float* db, int accumulate, szn_stream_t stream);
+
+/* ---- MaxPool2d(2, stride 2, ceil_mode=True): models.py:47,54,63,72,81 ---------------------------- */
+int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out,
+                            szn_stream_t stream);
+/* din = relu_bwd(pool_bwd(dout)): the gradient goes to the FIRST maximum of each window (torch
+ * scan order) and is then gated by in > 0 (the ReLU that precedes every pool).                    */
+int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void* in,
+                            const void* out, const void* dout, void* din, szn_stream_t stream);
+
+/* ---- upscore: ConvTranspose2d(E,E,64,stride 32,bias=False) with the fixed bilinear kernel of
+ * get_upsampling_weight (models.py:11-24,94,146) fused with the crop [19:19+H] (models.py:147).
+ * coarse is NHWC f32 [B][h][w] with pixel stride ldc, channels [c0, c0+E); score is NCHW f32.     */
+int szn_bilinear_up32_crop_fwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                               const float* coarse, float* score_nchw, szn_stream_t stream);
+/* dcoarse[b][i][j][c0+c] = sum_{y,x} dscore[b][c][y][x] * filt[y+crop-32i][x+crop-32j]            */
+int szn_bilinear_up32_crop_bwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                               const float* dscore_nchw, float* dcoarse, szn_stream_t stream);
+
+/* ---- seenmask_upscore: ConvTranspose2d(C,C,64,stride 32,bias=False) with a LEARNED dense kernel
+ * (models.py:98,150-151; trained in phase 2, train.py:170-175).  weight is torch layout
+ * (Cin,Cout,64,64) f32; C <= 4.                                                                   */
+int szn_deconv64s32_fwd(int B, int h, int w, int C, int ldc, int c0, int H, int W, int crop,
+                        const float* coarse, const float* weight, float* out_nchw,
+                        szn_stream_t stream);
+int szn_deconv64s32_dgrad(int B, int h, int w, int C, int ldc, int c0, int H, int W, int crop,
+                          const float* dout_nchw, const float* weight, float* dcoarse,
+                          szn_stream_t stream);
+int szn_deconv64s32_wgrad(int B, int h, int w, int C, int ldc, int c0, int H, int W, int crop,
+                          const float* coarse, const float* dout_nchw, float* dweight,
+                          int accumulate, szn_stream_t stream);
+
+/* ---- losses (utils.py) --------------------------------------------------------------------------
+ * score (B,E,H,W) NCHW f32; target (B,H,W) int64, <0 = ignore.  The target embedding of a pixel is
+ * either gathered from embed[K][E] by label (target_embed == NULL; ignore pixels use row 0 exactly
+ * like context_dataset.py:128-141) or read from target_embed (B,E,H,W) NCHW f32.
+ * Batched definition (the reference is n = 1 only): per-image loss, mean over images.
+ * stats: f32 [B][2] = {sum over valid px of the per-pixel term, number of valid px};
+ * loss: f32 [1].  workspace: szn_loss_workspace_bytes(B,H,W).                                       */
+size_t szn_loss_workspace_bytes(int B, int H, int W);
+/* utils.py:75-102  loss_b = (N_b - sum cos) / N_b                                                  */
+int szn_cosine_loss_fwd(int B, int E, int H, int W, int K, const float* score,
+                        const int64_t* target, const float* embed, const float* target_embed,
+                        float* loss, float* stats, void* workspace, szn_stream_t stream);
+/* dscore = gout * dloss/dscore  (gout: device scalar, NULL = 1)                                    */
+int szn_cosine_loss_bwd(int B, int E, int H, int W, int K, const float* score,
+                        const int64_t* target, const float* embed, const float* target_embed,
+                        const float* stats, const float* gout, float* dscore, szn_stream_t stream);
+/* utils.py:50-73  loss_b = sum_{valid px, c} (s - t)^2 / N_b                                       */
+int szn_mse_loss_fwd(int B, int E, int H, int W, int K, const float* score, const int64_t* target,
+                     const float* embed, const float* target_embed, float* loss, float* stats,
+                     void* workspace, szn_stream_t stream);
+int szn_mse_loss_bwd(int B, int E, int H, int W, int K, const float* score, const int64_t* target,
+                     const float* embed, const float* target_embed, const float* stats,
+                     const float* gout, float* dscore, szn_stream_t stream);
+/* utils.py:19-48  cross_entropy2d: sum over ALL valid pixels of the batch of -log_softmax[target];
+ * size_average divides by the number of valid pixels.  pred (may be NULL) receives the channel
+ * argmax (score.data.max(1)[1], trainer_fcn.py:117 / trainer_seenmask.py:67) as int64 (B,H,W).     */
+int szn_ce2d_fwd(int B, int C, int H, int W, const float* score, const int64_t* target,
+                 int size_average, float* loss, float* stats, int64_t* pred, void* workspace,
+                 szn_stream_t stream);
+int szn_ce2d_bwd(int B, int C, int H, int W, const float* score, const int64_t* target,
+                 int size_average, const float* stats, const float* gout, float* dscore,
+                 szn_stream_t stream);
+
+/* ---- nearest-class-embedding inference (utils.py:159-205) --------------------------------------
+ * sim[k] = (score_px . embed[k]) / (||score_px|| * (||embed[k]|| == 0 ? 1 : ||embed[k]||)),
+ * pred = first argmax_k.  embed[K][E] f32, K <= 64.
+ * mode 0 (infer_lbl):    all K rows of embed compete.
+ * mode 1 (stich_seen_unseen_with_mask / infer_lbl_szn / infer_lbl_forced_unseen):
+ *        rows with bit k of unseen_bits set form the "unseen-only" matrix, the others the
+ *        "seen-only" matrix (the other group's rows zeroed, trainer_fcn.py:56-64, which score
+ *        exactly 0 and still compete); a pixel takes the unseen-only prediction when
+ *          - seenmask != NULL: argmax over the 2 channels of seenmask (B,2,H,W) is 0
+ *            (utils.py:197-198), or
+ *          - seenmask == NULL: its target label is an unseen class (utils.py:190-191).
+ * pred: int64 (B,H,W).                                                                             */
+int szn_embed_argmax(int B, int E, int H, int W, int K, const float* score, const float* embed,
+                     int mode, uint64_t unseen_bits, const float* seenmask, const int64_t* target,
+                     int64_t* pred, szn_stream_t stream);
+
+/* ---- confusion histogram (utils.py:104-154) ------------------------------------------------------
+ * hist[3][K][K] int64 += bincount(K*gt+pred) over pixels with 0 <= gt < K, for {all, gt in seen,
+ * gt in unseen}; unseen_bits == 0 fills only hist[0].                                              */
+int szn_confusion_hist(long npix, int K, const int64_t* label_true, const int64_t* label_pred,
+                       uint64_t unseen_bits, int64_t* hist, szn_stream_t stream);
+
+/* ---- fused head: coarse -> (loss, prediction, dcoarse) without materialising (B,E,H,W) ----------
+ * Equivalent to szn_bilinear_up32_crop_fwd -> szn_cosine_loss_fwd -> szn_embed_argmax ->
+ * szn_cosine_loss_bwd -> szn_bilinear_up32_crop_bwd (models.py:146-147 + utils.py:75-102,159-185)
+ * evaluated algebraically per 32x32 cell.  pred / dcoarse may be NULL.  dcoarse is written in
+ * `dcoarse_dtype` with pixel stride ldc (channels [c0,c0+E) only).                                 */
+size_t szn_fused_head_workspace_bytes(int B, int h, int w, int E, int K);
+int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
+                   const float* coarse, const float* embed, const int64_t* target,
+                   float* loss, float* stats, int64_t* pred, int dcoarse_dtype, void* dcoarse,
+                   void* workspace, szn_stream_t stream);
+
+/* ---- optimizers (train.py:126-133,174-175; torch.optim.Adam / SGD semantics) ----------------------
+ * One launch per flat fp32 parameter buffer.  grad_scale multiplies the gradient first (1/world
+ * after a sum all-reduce).  If w_lp != NULL the updated weight is also written as bf16.             */
+int szn_adam_step(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  float grad_scale, void* w_lp, szn_stream_t stream);
+int szn_sgd_momentum_step(long n, float* param, const float* grad, float* momentum_buf, float lr,
+                          float momentum, float weight_decay, int first_step, float grad_scale,
+                          void* w_lp, szn_stream_t stream);
+
+/* ---- small utilities -------------------------------------------------------------------------------- */
+int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, szn_stream_t stream);
+/* Dropout2d factors: scale[i] = (u_i >= p) ? 1/(1-p) : 0 with a counter-based generator (seed, i)   */
+int szn_dropout2d_mask(long n, float p, uint64_t seed, uint64_t offset, float* scale,
+                       szn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SZN_H_ */

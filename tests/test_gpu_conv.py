@@ -1,0 +1,182 @@
+"""GPU parity tests of the MFMA convolution kernels (forward / dgrad / wgrad, conv1_1, pools) through the
+C-ABI, against a plain torch fp32 reference of the same op computed on the CPU (floating-point kernels).
+
+Tolerances: fp32 path 1e-3 relative (north_star), measured ~1e-6; bf16 path compares against the fp32
+reference evaluated on bf16-rounded operands with 2e-2 relative to the output scale.
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from zeroshotsemanticsegmentation_amd import _lib as L
+
+
+def nhwc(t):  # (B,C,H,W) logical -> physical NHWC contiguous tensor [B][H][W][C]
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    a, b = a.detach(), b.detach()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+CASES = [
+    # B, Hi, Wi, Ci, Co, K, pad
+    (2, 19, 23, 64, 96, 3, 1),
+    (1, 9, 9, 128, 200, 7, 0),
+    (3, 5, 7, 192, 302, 1, 0),
+    (1, 33, 17, 64, 64, 3, 1),
+    (2, 12, 12, 64, 130, 3, 2),
+]
+
+
+def conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad, relu=0, out_f32=0, ldg=0):
+    Ho, Wo = Hi + 2 * pad - K + 1, Wi + 2 * pad - K + 1
+    ldo = (Co + 7) // 8 * 8          # padded pixel stride of the output (e.g. 302 -> 304)
+    return L.ConvDesc(dt, B, Hi, Wi, Ci, Ho, Wo, Co, K, K, pad, Ci, ldo, ldg, relu, out_f32), Ho, Wo
+
+
+def pad_c(t, ld):  # NHWC tensor -> channel dimension zero-padded to ld
+    return F.pad(t, (0, ld - t.shape[-1])).contiguous()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    B, Hi, Wi, Ci, Co, K, pad = case
+    g = torch.Generator().manual_seed(1337 + Ci + Co)
+    x = torch.randn(B, Ci, Hi, Wi, generator=g)
+    w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    x.requires_grad_(True); w.requires_grad_(True)
+    ref = F.relu(F.conv2d(x, w, bias, padding=pad))
+    dt = L.dtype_code(dtype)
+    d, Ho, Wo = conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad, relu=1)
+    dev = "cuda"
+    xd = nhwc(x.detach()).to(dev, dtype)
+    wd = nhwc(w.detach()).to(dev, dtype)       # OHWI
+    bd = bias.to(dev)
+    out = torch.full((B, Ho, Wo, d.ldo), float("nan"), device=dev, dtype=dtype)
+    L.call("szn_conv2d_fwd", C.byref(d), L.ptr(xd), L.ptr(wd), L.ptr(bd), None, None, L.ptr(out), L.stream_ptr())
+    torch.cuda.synchronize()
+    got = out[..., :Co].float().cpu().permute(0, 3, 1, 2)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert relerr(got, ref) < tol, ("fwd", relerr(got, ref))
+
+    # ---- backward: dout random, gate = x > 0 is applied by the dgrad epilogue
+    dout = torch.randn(B, Co, Ho, Wo, generator=g)
+    if dtype == torch.bfloat16:
+        dout = dout.bfloat16().float()
+    pre = F.conv2d(x, w, bias, padding=pad)
+    pre.backward(dout)
+    dx_ref = x.grad * (x.detach() > 0)
+    dw_ref = w.grad
+    db_ref = dout.sum((0, 2, 3))
+    doutd = pad_c(nhwc(dout), d.ldo).to(dev, dtype)
+    wT = torch.empty(Ci, K, K, Co, device=dev, dtype=dtype)
+    L.call("szn_pack_weight_dgrad", dt, Co, K, K, Ci, L.ptr(wd), L.ptr(wT), L.stream_ptr())
+    wT_ref = w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()
+    torch.cuda.synchronize()
+    assert torch.equal(wT.float().cpu(), wT_ref.to(dtype).float())
+    dgd, _, _ = conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad, ldg=Ci)
+    din = torch.full((B, Hi, Wi, Ci), float("nan"), device=dev, dtype=dtype)
+    if Co % (64 if dtype == torch.bfloat16 else 32) == 0:
+        L.call("szn_conv2d_dgrad", C.byref(dgd), L.ptr(doutd), L.ptr(wT), L.ptr(xd), None, L.ptr(din), L.stream_ptr())
+        torch.cuda.synchronize()
+        got = din.float().cpu().permute(0, 3, 1, 2)
+        assert relerr(got, dx_ref) < tol, ("dgrad", relerr(got, dx_ref))
+    dw = torch.full((Co, K, K, Ci), float("nan"), device=dev)
+    db = torch.full((Co,), float("nan"), device=dev)
+    L.call("szn_conv2d_wgrad", C.byref(dgd), L.ptr(xd), L.ptr(doutd), L.ptr(dw), 0, L.stream_ptr())
+    L.call("szn_bias_grad", dt, B * Ho * Wo, Co, d.ldo, L.ptr(doutd), L.ptr(db), 0, L.stream_ptr())
+    torch.cuda.synchronize()
+    got = dw.cpu().permute(0, 3, 1, 2)
+    assert relerr(got, dw_ref) < tol, ("wgrad", relerr(got, dw_ref))
+    assert relerr(db.cpu(), db_ref) < 1e-4, ("bias", relerr(db.cpu(), db_ref))
+    # accumulate = 1 adds on top
+    L.call("szn_conv2d_wgrad", C.byref(dgd), L.ptr(xd), L.ptr(doutd), L.ptr(dw), 1, L.stream_ptr())
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu().permute(0, 3, 1, 2), 2 * dw_ref) < tol
+
+
+def test_conv_epilogue_scale_and_padded_strides():
+    # chan_scale (Dropout2d factors) and out_f32 with a padded output stride (score buffer layout)
+    B, Hi, Wi, Ci, Co, ldo = 2, 4, 5, 64, 22, 32
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Ci, Hi, Wi, generator=g).bfloat16().float()
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) / 8).bfloat16().float()
+    bias = torch.randn(Co, generator=g)
+    scale = (torch.rand(B, Co, generator=g) > 0.5).float() * 2
+    ref = F.conv2d(x, w, bias) * scale[:, :, None, None]
+    d = L.ConvDesc(L.SZN_BF16, B, Hi, Wi, Ci, Hi, Wi, Co, 1, 1, 0, Ci, ldo, 0, 0, 1)
+    out = torch.zeros(B, Hi, Wi, ldo, device="cuda")
+    xd, wd, bd, sd = nhwc(x).cuda().bfloat16(), nhwc(w).cuda().bfloat16(), bias.cuda(), scale.cuda()   # keep alive
+    L.call("szn_conv2d_fwd", C.byref(d), L.ptr(xd), L.ptr(wd), L.ptr(bd), None, L.ptr(sd), L.ptr(out), L.stream_ptr())
+    torch.cuda.synchronize()
+    assert relerr(out[..., :Co].cpu().permute(0, 3, 1, 2), ref) < 1e-5
+    assert float(out[..., Co:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv1_1(dtype):
+    B, H, W, pad = 2, 13, 9, 100
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 3, H, W, generator=g) * 50
+    w = torch.randn(64, 3, 3, 3, generator=g) / 5
+    bias = torch.randn(64, generator=g)
+    x.requires_grad_(False); w.requires_grad_(True)
+    pre = F.conv2d(x, w, bias, padding=pad)
+    ref = F.relu(pre)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    dt = L.dtype_code(dtype)
+    out = torch.empty(B, Ho, Wo, 64, device="cuda", dtype=dtype)
+    wd, xd, bd = nhwc(w.detach()).cuda(), x.cuda(), bias.cuda()   # keep the device tensors alive across the calls
+    L.call("szn_conv1_1_fwd", dt, B, H, W, pad, L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(out), L.stream_ptr())
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert relerr(out.float().cpu().permute(0, 3, 1, 2), ref) < tol
+    dout = torch.randn(B, 64, Ho, Wo, generator=g)
+    if dtype == torch.bfloat16:
+        dout = dout.bfloat16().float()
+    pre.backward(dout)
+    dw = torch.empty(64, 3, 3, 3, device="cuda"); db = torch.empty(64, device="cuda")
+    doutd = nhwc(dout).cuda().to(dtype)
+    L.call("szn_conv1_1_wgrad", dt, B, H, W, pad, L.ptr(xd), L.ptr(doutd), L.ptr(dw), L.ptr(db), 0, L.stream_ptr())
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu().permute(0, 3, 1, 2), w.grad) < 1e-4
+    assert relerr(db.cpu(), dout.sum((0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(7, 9), (8, 8), (1, 1), (23, 23)])
+def test_maxpool(dtype, hw):
+    B, Cc = 2, 64
+    Hi, Wi = hw
+    g = torch.Generator().manual_seed(11)
+    # post-ReLU activations with many exact zeros and ties
+    x = F.relu(torch.randn(B, Cc, Hi, Wi, generator=g)).to(dtype).float()
+    x = (x * 4).round() / 4
+    x.requires_grad_(True)
+    ref = F.max_pool2d(x, 2, 2, ceil_mode=True)
+    Ho, Wo = ref.shape[2:]
+    dt = L.dtype_code(dtype)
+    xd = nhwc(x.detach()).cuda().to(dtype)
+    out = torch.empty(B, Ho, Wo, Cc, device="cuda", dtype=dtype)
+    L.call("szn_maxpool2x2_ceil_fwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref.detach())
+    dout = torch.randn(B, Cc, Ho, Wo, generator=g).to(dtype).float()
+    ref.backward(dout)
+    dref = x.grad * (x.detach() > 0)
+    din = torch.empty(B, Hi, Wi, Cc, device="cuda", dtype=dtype)
+    doutd = nhwc(dout).cuda().to(dtype)
+    L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(din.float().cpu().permute(0, 3, 1, 2), dref)

@@ -1,0 +1,120 @@
+"""ctypes binding of libszn_hip.so (the C-ABI declared in include/szn.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, `SznError` is raised.
+Every wrapper takes torch tensors (device memory owners) and passes raw pointers + the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libszn_hip.so")
+
+SZN_F32, SZN_BF16 = 0, 1
+
+
+class SznError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int),
+                ("wavefront", C.c_int), ("lds_bytes_per_block", C.c_int), ("hbm_bytes", C.c_int64),
+                ("clock_mhz", C.c_int)]
+
+
+_P, _I, _L, _F, _U64, _SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_size_t
+_D = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every symbol of include/szn.h (tests/test_abi.py checks that)
+SIGNATURES = {
+    "szn_last_error": (C.c_char_p, []),
+    "szn_version": (_I, []),
+    "szn_device_info": (_I, [_I, C.POINTER(DeviceInfo)]),
+    "szn_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "szn_pack_weight_dgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
+    "szn_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "szn_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
+    "szn_bias_grad": (_I, [_I, _L, _I, _I, _P, _P, _I, _P]),
+    "szn_gemm_proj_fwd": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "szn_gemm_proj_dgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "szn_gemm_proj_wgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "szn_conv1_1_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "szn_conv1_1_wgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "szn_maxpool2x2_ceil_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
+    "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "szn_bilinear_up32_crop_fwd": (_I, [_I] * 9 + [_P, _P, _P]),
+    "szn_bilinear_up32_crop_bwd": (_I, [_I] * 9 + [_P, _P, _P]),
+    "szn_deconv64s32_fwd": (_I, [_I] * 9 + [_P, _P, _P, _P]),
+    "szn_deconv64s32_dgrad": (_I, [_I] * 9 + [_P, _P, _P, _P]),
+    "szn_deconv64s32_wgrad": (_I, [_I] * 9 + [_P, _P, _P, _I, _P]),
+    "szn_loss_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "szn_cosine_loss_fwd": (_I, [_I] * 5 + [_P] * 8),
+    "szn_cosine_loss_bwd": (_I, [_I] * 5 + [_P] * 8),
+    "szn_mse_loss_fwd": (_I, [_I] * 5 + [_P] * 8),
+    "szn_mse_loss_bwd": (_I, [_I] * 5 + [_P] * 8),
+    "szn_ce2d_fwd": (_I, [_I] * 4 + [_P, _P, _I, _P, _P, _P, _P, _P]),
+    "szn_ce2d_bwd": (_I, [_I] * 4 + [_P, _P, _I, _P, _P, _P, _P]),
+    "szn_embed_argmax": (_I, [_I] * 5 + [_P, _P, _I, _U64, _P, _P, _P, _P]),
+    "szn_confusion_hist": (_I, [_L, _I, _P, _P, _U64, _P, _P]),
+    "szn_fused_head_workspace_bytes": (_SZ, [_I] * 5),
+    "szn_fused_head": (_I, [_I] * 10 + [_P] * 6 + [_I, _P, _P, _P]),
+    "szn_adam_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _P, _P]),
+    "szn_sgd_momentum_step": (_I, [_L, _P, _P, _P, _F, _F, _F, _I, _F, _P, _P]),
+    "szn_cast": (_I, [_I, _I, _L, _P, _P, _P]),
+    "szn_dropout2d_mask": (_I, [_L, _F, _U64, _U64, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libszn_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SznError("libszn_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the product path has no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SznError("%s failed (%d): %s" % (what, rc, load().szn_last_error().decode()))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def dtype_code(t):
+    if t == torch.float32:
+        return SZN_F32
+    if t == torch.bfloat16:
+        return SZN_BF16
+    raise SznError("unsupported dtype %s" % t)
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)

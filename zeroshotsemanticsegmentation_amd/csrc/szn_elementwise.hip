@@ -1,0 +1,416 @@
+// szn_elementwise.hip -- HBM-bound kernels around the MFMA convolutions: conv1_1 (Cin = 3), max-pool
+// forward / backward(+ReLU gate), casts, Dropout2d factors, Adam / SGD-momentum steps, library info.
+//
+// Reference sites: models.py:43-47 (conv1_1, pools), models.py:86,91 (Dropout2d), train.py:126-133,174-175
+// (torch.optim.SGD / Adam with two parameter groups).
+#include "szn_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+// ---- error plumbing -----------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void szn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* szn_last_error(void) { return g_err; }
+extern "C" int szn_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int szn_device_info(int device, szn_device_info_t* out) {
+    if (!out) SZN_FAIL(SZN_ERR_ARG, "device_info: null output");
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "device_info: %s", hipGetErrorString(e));
+    memset(out, 0, sizeof(*out));
+    strncpy(out->name, p.name, sizeof(out->name) - 1);
+    strncpy(out->arch, p.gcnArchName, sizeof(out->arch) - 1);
+    out->compute_units = p.multiProcessorCount;
+    out->wavefront = p.warpSize;
+    out->lds_bytes_per_block = (int)p.sharedMemPerBlock;
+    out->hbm_bytes = (int64_t)p.totalGlobalMem;
+    out->clock_mhz = p.clockRate / 1000;
+    return SZN_OK;
+}
+
+namespace {
+
+// ---- conv1_1: 3 -> 64, 3x3, pad P, reads NCHW f32, writes NHWC T ---------------------------------
+// thread = (output pixel, group of 8 couts); weights staged in LDS as [tap*3+ci][64 co].
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, T* __restrict__ out, int B,
+                                                          int H, int W, int pad, int Ho, int Wo) {
+    __shared__ __attribute__((aligned(16))) float wl[27][64];
+    __shared__ float bl[64];
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+        const int co = i & 63, t = i >> 6;   // t = (kh*3+kw)*3+ci, matches OHWI order of w
+        wl[t][co] = w[co * 27 + t];
+    }
+    if (threadIdx.x < 64) bl[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const long npix = (long)B * Ho * Wo;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long p = gid >> 3;
+    const int cg = (int)(gid & 7);
+    if (p >= npix) return;
+    const int b = (int)(p / ((long)Ho * Wo));
+    const int r = (int)(p - (long)b * Ho * Wo);
+    const int oh = r / Wo, ow = r - oh * Wo;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const long plane = (long)H * W;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh + kh - pad;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow + kw - pad;
+            const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float xv = ok ? x[((long)b * 3 + ci) * plane + (long)ih * W + iw] : 0.f;
+                const float* wr = &wl[(kh * 3 + kw) * 3 + ci][cg * 8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(xv, wr[e], acc[e]);
+            }
+        }
+    }
+    T* o = out + p * 64 + cg * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) elem<T>::st(o + e, fmaxf(acc[e] + bl[cg * 8 + e], 0.f));
+}
+
+// dw[co][t] += sum over the (H+2)x(W+2) output pixels whose window touches the image.
+// lane = cout; a wave walks pixels; the 27 inputs of a pixel are wave-uniform.
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dout,
+                                                            float* __restrict__ dw, int B, int H, int W, int pad,
+                                                            int Ho, int Wo, int pix_per_wave) {
+    __shared__ float red[4][27][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int RW = W + 2, RH = H + 2;            // region of outputs with a non-zero window
+    const long nreg = (long)B * RH * RW;
+    long q0 = ((long)blockIdx.x * 4 + wave) * pix_per_wave;
+    const long q1 = min(nreg, q0 + pix_per_wave);
+    float acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+    const long plane = (long)H * W;
+    for (long q = q0; q < q1; ++q) {
+        const int b = (int)(q / ((long)RH * RW));
+        const int r = (int)(q - (long)b * RH * RW);
+        const int oh = r / RW + (pad - 2), ow = r % RW + (pad - 2);
+        if (oh < 0 || ow < 0 || oh >= Ho || ow >= Wo) continue;
+        const float d = elem<T>::ld(dout + (((long)b * Ho + oh) * Wo + ow) * 64 + lane);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh + kh - pad;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow + kw - pad;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float xv = ok ? x[((long)b * 3 + ci) * plane + (long)ih * W + iw] : 0.f;
+                    acc[(kh * 3 + kw) * 3 + ci] = fmaf(d, xv, acc[(kh * 3 + kw) * 3 + ci]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t) red[wave][t][lane] = acc[t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+        const int co = i & 63, t = i >> 6;
+        const float s = red[0][t][co] + red[1][t][co] + red[2][t][co] + red[3][t][co];
+        if (s != 0.f) atomicAdd(dw + co * 27 + t, s);
+    }
+}
+
+// ---- MaxPool2d(2,2,ceil_mode=True) on NHWC: thread = (output pixel, 16-B channel chunk) -----------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Hi,
+                                                          int Wi, int C, int Ho, int Wo) {
+    constexpr int CH = elem<T>::kPer16B;
+    const int cpp = C / CH;
+    const long total = (long)B * Ho * Wo * cpp;
+    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+        const int cc = (int)(gid % cpp);
+        const long p = gid / cpp;
+        const int ow = (int)(p % Wo);
+        const long t = p / Wo;
+        const int oh = (int)(t % Ho), b = (int)(t / Ho);
+        float best[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) best[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int ih = 2 * oh + dy;
+            if (ih >= Hi) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int iw = 2 * ow + dx;
+                if (iw >= Wi) continue;
+                const u32x4_t v = *(const u32x4_t*)(in + (((long)b * Hi + ih) * Wi + iw) * C + cc * CH);
+                const T* ve = (const T*)&v;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) best[e] = fmaxf(best[e], elem<T>::ld(ve + e));
+            }
+        }
+        u32x4_t o;
+        T* oe = (T*)&o;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) elem<T>::st(oe + e, best[e]);
+        *(u32x4_t*)(out + p * C + cc * CH) = o;
+    }
+}
+
+// din[b][ih][iw][c] = (in is the FIRST max of its window, scan order (0,0),(0,1),(1,0),(1,1)) ? dout[win] : 0,
+// then gated by in > 0 (the ReLU in front of every pool).  thread = (input pixel, 16-B chunk).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ in, const T* __restrict__ out,
+                                                          const T* __restrict__ dout, T* __restrict__ din, int B, int Hi,
+                                                          int Wi, int C, int Ho, int Wo) {
+    constexpr int CH = elem<T>::kPer16B;
+    const int cpp = C / CH;
+    const long total = (long)B * Hi * Wi * cpp;
+    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+        const int cc = (int)(gid % cpp);
+        const long p = gid / cpp;
+        const int iw = (int)(p % Wi);
+        const long t = p / Wi;
+        const int ih = (int)(t % Hi), b = (int)(t / Hi);
+        const int oh = ih >> 1, ow = iw >> 1;
+        const long po = ((long)b * Ho + oh) * Wo + ow;
+        const u32x4_t vm = *(const u32x4_t*)(out + po * C + cc * CH);
+        const u32x4_t vd = *(const u32x4_t*)(dout + po * C + cc * CH);
+        const u32x4_t vs = *(const u32x4_t*)(in + p * C + cc * CH);
+        const T* me = (const T*)&vm; const T* de = (const T*)&vd; const T* se = (const T*)&vs;
+        bool earlier[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) earlier[e] = false;
+        const int myidx = (ih & 1) * 2 + (iw & 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k >= myidx) break;
+            const int jh = 2 * oh + (k >> 1), jw = 2 * ow + (k & 1);
+            if (jh >= Hi || jw >= Wi) continue;
+            const u32x4_t vo = *(const u32x4_t*)(in + (((long)b * Hi + jh) * Wi + jw) * C + cc * CH);
+            const T* oe = (const T*)&vo;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) earlier[e] = earlier[e] || (elem<T>::ld(oe + e) == elem<T>::ld(me + e));
+        }
+        u32x4_t o;
+        T* oe = (T*)&o;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const float s = elem<T>::ld(se + e);
+            const bool win = (s == elem<T>::ld(me + e)) && !earlier[e] && (s > 0.f);
+            elem<T>::st(oe + e, win ? elem<T>::ld(de + e) : 0.f);
+        }
+        *(u32x4_t*)(din + p * C + cc * CH) = o;
+    }
+}
+
+// ---- casts / dropout / optimizers -----------------------------------------------------------------
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        elem<D>::st(d + i, elem<S>::ld(s + i));
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void dropout_mask_kernel(float* __restrict__ scale, long n, float p, uint64_t seed, uint64_t offset) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = splitmix64(seed * 0xD1342543DE82EF95ull + offset + (uint64_t)i);
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);   // 24-bit uniform in [0,1)
+    scale[i] = (u >= p) ? 1.0f / (1.0f - p) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                   float b1, float b2, float eps, float wd, float step_size,
+                                                   float inv_bc2_sqrt, float gscale, uint16_t* __restrict__ wlp) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float pi = p[i];
+        float gi = g[i] * gscale;
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        pi -= step_size * (mi / denom);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+        if (wlp) wlp[i] = f32_to_bf16_bits(pi);
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, long n, float lr, float mom, float wd,
+                                                  int first, float gscale, uint16_t* __restrict__ wlp) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float pi = p[i];
+        float gi = g[i] * gscale;
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float bi = first ? gi : mom * buf[i] + gi;
+        buf[i] = bi;
+        pi -= lr * bi;
+        p[i] = pi;
+        if (wlp) wlp[i] = f32_to_bf16_bits(pi);
+    }
+}
+
+inline int grid_for(long n, int per_block = 256, int cap = 8192) {
+    long b = (n + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const float* x, const float* w,
+                               const float* bias, void* out, szn_stream_t stream) {
+    if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || pad < 0) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd: bad argument");
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    if (Ho <= 0 || Wo <= 0) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd: empty output");
+    const long threads = (long)B * Ho * Wo * 8;
+    const long blocks = (threads + 255) / 256;
+    if (blocks >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd: grid too large");
+    if (dtype == SZN_BF16)
+        hipLaunchKernelGGL(conv1_1_fwd_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (bf16_raw*)out, B, H, W, pad, Ho, Wo);
+    else if (dtype == SZN_F32)
+        hipLaunchKernelGGL(conv1_1_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (float*)out, B, H, W, pad, Ho, Wo);
+    else
+        SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd: bad dtype %d", dtype);
+    SZN_CHECK_LAUNCH("conv1_1_fwd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw,
+                                 float* db, int accumulate, szn_stream_t stream) {
+    if (!x || !dout || !dw || B <= 0 || H <= 0 || W <= 0 || pad < 2) SZN_FAIL(SZN_ERR_ARG, "conv1_1_wgrad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dw, 0, 64 * 27 * sizeof(float), st);
+        if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "conv1_1_wgrad memset: %s", hipGetErrorString(e));
+    }
+    const long nreg = (long)B * (H + 2) * (W + 2);
+    int ppw = (int)((nreg + 4095) / 4096);
+    if (ppw < 16) ppw = 16;
+    const int blocks = szn_div_up(nreg, (long)ppw * 4);
+    if (dtype == SZN_BF16)
+        hipLaunchKernelGGL(conv1_1_wgrad_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, x, (const bf16_raw*)dout, dw, B, H,
+                           W, pad, Ho, Wo, ppw);
+    else if (dtype == SZN_F32)
+        hipLaunchKernelGGL(conv1_1_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, x, (const float*)dout, dw, B, H, W,
+                           pad, Ho, Wo, ppw);
+    else
+        SZN_FAIL(SZN_ERR_ARG, "conv1_1_wgrad: bad dtype %d", dtype);
+    SZN_CHECK_LAUNCH("conv1_1_wgrad_kernel");
+    if (db) return szn_bias_grad(dtype, (long)B * Ho * Wo, 64, 64, dout, db, accumulate, stream);
+    return SZN_OK;
+}
+
+extern "C" int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out,
+                                       szn_stream_t stream) {
+    if (!in || !out || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_fwd: bad argument");
+    const int ch = dtype == SZN_BF16 ? 8 : 4;
+    if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_fwd: C must be a multiple of %d", ch);
+    const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
+    const long total = (long)B * Ho * Wo * (C / ch);
+    if (dtype == SZN_BF16)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_raw>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_raw*)in, (bf16_raw*)out, B, Hi, Wi, C, Ho, Wo);
+    else if (dtype == SZN_F32)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)in, (float*)out, B, Hi, Wi, C, Ho, Wo);
+    else
+        SZN_FAIL(SZN_ERR_ARG, "maxpool_fwd: bad dtype %d", dtype);
+    SZN_CHECK_LAUNCH("maxpool_fwd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void* in, const void* out,
+                                       const void* dout, void* din, szn_stream_t stream) {
+    if (!in || !out || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0)
+        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad argument");
+    const int ch = dtype == SZN_BF16 ? 8 : 4;
+    if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd: C must be a multiple of %d", ch);
+    const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
+    const long total = (long)B * Hi * Wi * (C / ch);
+    if (dtype == SZN_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_raw>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_raw*)in, (const bf16_raw*)out, (const bf16_raw*)dout, (bf16_raw*)din, B, Hi, Wi, C,
+                           Ho, Wo);
+    else if (dtype == SZN_F32)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)in, (const float*)out, (const float*)dout, (float*)din, B, Hi, Wi, C, Ho, Wo);
+    else
+        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad dtype %d", dtype);
+    SZN_CHECK_LAUNCH("maxpool_bwd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, szn_stream_t stream) {
+    if (!src || !dst || n < 0) SZN_FAIL(SZN_ERR_ARG, "cast: bad argument");
+    if (n == 0) return SZN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(n);
+    if (src_dtype == SZN_F32 && dst_dtype == SZN_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_raw>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16_raw*)dst, n);
+    else if (src_dtype == SZN_BF16 && dst_dtype == SZN_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_raw, float>), dim3(grid), dim3(256), 0, st, (const bf16_raw*)src, (float*)dst, n);
+    else if (src_dtype == SZN_F32 && dst_dtype == SZN_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    else
+        SZN_FAIL(SZN_ERR_ARG, "cast: unsupported dtype pair %d -> %d", src_dtype, dst_dtype);
+    SZN_CHECK_LAUNCH("cast_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_dropout2d_mask(long n, float p, uint64_t seed, uint64_t offset, float* scale, szn_stream_t stream) {
+    if (!scale || n <= 0 || p < 0.f || p >= 1.f) SZN_FAIL(SZN_ERR_ARG, "dropout2d_mask: bad argument");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scale, n, p,
+                       seed, offset);
+    SZN_CHECK_LAUNCH("dropout_mask_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_adam_step(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             void* w_lp, szn_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) SZN_FAIL(SZN_ERR_ARG, "adam_step: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale,
+                       (uint16_t*)w_lp);
+    SZN_CHECK_LAUNCH("adam_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_sgd_momentum_step(long n, float* param, const float* grad, float* momentum_buf, float lr,
+                                     float momentum, float weight_decay, int first_step, float grad_scale, void* w_lp,
+                                     szn_stream_t stream) {
+    if (!param || !grad || !momentum_buf || n <= 0) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step: bad argument");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale, (uint16_t*)w_lp);
+    SZN_CHECK_LAUNCH("sgd_kernel");
+    return SZN_OK;
+}

@@ -1,0 +1,637 @@
+// szn_head.hip -- the per-pixel head of the SZN path (HBM-bound): bilinear x32 upsample + crop, the
+// learned seen-mask deconvolution, cosine / MSE / cross-entropy losses with their gradients, the
+// nearest-class-embedding argmax (infer_lbl family) and the confusion histogram.
+//
+// Reference sites: models.py:11-24,94,98,146-151 (upscore / seenmask_upscore + crop),
+// utils.py:19-48 (cross_entropy2d), :50-73 (mse_loss), :75-102 (cosine_loss), :104-154 (metrics),
+// :159-205 (infer_lbl, infer_lbl_forced_unseen, infer_lbl_szn, stich_seen_unseen_with_mask).
+//
+// Arithmetic contract shared with oracle/szn_oracle.c (bit-exact argmax): every per-pixel dot product
+// and squared norm is an fmaf chain over the channel index in ascending order, norms use correctly
+// rounded sqrtf, similarities use IEEE division; this file is compiled with -ffp-contract=off.
+#include "szn_common.h"
+
+namespace {
+
+// 1-D bilinear tap of get_upsampling_weight(k=64): factor 32, center 31.5 (models.py:13-20), in double
+__device__ __forceinline__ double bil1d(int t) { return 1.0 - fabs((double)t - 31.5) / 32.0; }
+
+// ---- upscore forward: thread = one output element of the NCHW score ---------------------------
+__global__ __launch_bounds__(256) void up32_fwd_kernel(const float* __restrict__ coarse, float* __restrict__ out, int B,
+                                                       int h, int w, int E, int ldc, int c0, int H, int W, int crop) {
+    const long total = (long)B * E * H * W;
+    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+        const int x = (int)(gid % W);
+        long t = gid / W;
+        const int y = (int)(t % H); t /= H;
+        const int c = (int)(t % E);
+        const int b = (int)(t / E);
+        const int Y = y + crop, X = x + crop;
+        const int i1 = Y >> 5, j1 = X >> 5, ty = Y & 31, tx = X & 31;
+        const double fy1 = bil1d(ty), fy0 = bil1d(ty + 32), fx1 = bil1d(tx), fx0 = bil1d(tx + 32);
+        const float* base = coarse + (long)b * h * w * ldc + c0 + c;
+        float acc = 0.f;
+        if (i1 - 1 >= 0 && i1 - 1 < h) {
+            if (j1 - 1 >= 0 && j1 - 1 < w) acc = fmaf(base[((long)(i1 - 1) * w + (j1 - 1)) * ldc], (float)(fy0 * fx0), acc);
+            if (j1 < w) acc = fmaf(base[((long)(i1 - 1) * w + j1) * ldc], (float)(fy0 * fx1), acc);
+        }
+        if (i1 < h) {
+            if (j1 - 1 >= 0 && j1 - 1 < w) acc = fmaf(base[((long)i1 * w + (j1 - 1)) * ldc], (float)(fy1 * fx0), acc);
+            if (j1 < w) acc = fmaf(base[((long)i1 * w + j1) * ldc], (float)(fy1 * fx1), acc);
+        }
+        out[gid] = acc;
+    }
+}
+
+// ---- upscore backward: one wave per (b, c, i, j); lane = x offset in the 64-wide window --------
+__global__ __launch_bounds__(256) void up32_bwd_kernel(const float* __restrict__ dscore, float* __restrict__ dcoarse,
+                                                       int B, int h, int w, int E, int ldc, int c0, int H, int W,
+                                                       int crop) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long total = (long)B * h * w * E;
+    if (wid >= total) return;
+    // channel fastest so that the 4 waves of a block write neighbouring dcoarse elements
+    const int c = (int)(wid % E);
+    long t = wid / E;
+    const int j = (int)(t % w); t /= w;
+    const int i = (int)(t % h);
+    const int b = (int)(t / h);
+    const int x = 32 * j - crop + lane;
+    const double fx = bil1d(lane);
+    float acc = 0.f;
+    if (x >= 0 && x < W) {
+        const float* plane = dscore + ((long)b * E + c) * H * W;
+        for (int ty = 0; ty < 64; ++ty) {
+            const int y = 32 * i - crop + ty;
+            if (y < 0 || y >= H) continue;
+            acc = fmaf(plane[(long)y * W + x], (float)(bil1d(ty) * fx), acc);
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dcoarse[(((long)b * h + i) * w + j) * ldc + c0 + c] = acc;
+}
+
+// ---- seenmask_upscore (dense learned ConvTranspose2d, C <= 4) -----------------------------------
+// weight: torch layout (Cin, Cout, 64, 64)
+__global__ __launch_bounds__(256) void deconv_fwd_kernel(const float* __restrict__ coarse, const float* __restrict__ wt,
+                                                         float* __restrict__ out, int B, int h, int w, int C, int ldc,
+                                                         int c0, int H, int W, int crop) {
+    const long total = (long)B * C * H * W;
+    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+        const int x = (int)(gid % W);
+        long t = gid / W;
+        const int y = (int)(t % H); t /= H;
+        const int co = (int)(t % C);
+        const int b = (int)(t / C);
+        const int Y = y + crop, X = x + crop;
+        const int i1 = Y >> 5, j1 = X >> 5, ty = Y & 31, tx = X & 31;
+        float acc = 0.f;
+        for (int ci = 0; ci < C; ++ci) {
+            const float* wk = wt + ((long)ci * C + co) * 4096;
+            const float* base = coarse + (long)b * h * w * ldc + c0 + ci;
+#pragma unroll
+            for (int di = 0; di < 2; ++di) {
+                const int i = i1 - 1 + di, ky = ty + 32 - 32 * di;
+                if (i < 0 || i >= h) continue;
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj) {
+                    const int j = j1 - 1 + dj, kx = tx + 32 - 32 * dj;
+                    if (j < 0 || j >= w) continue;
+                    acc = fmaf(base[((long)i * w + j) * ldc], wk[ky * 64 + kx], acc);
+                }
+            }
+        }
+        out[gid] = acc;
+    }
+}
+
+// dcoarse[b][i][j][ci] = sum_co sum_window dout[b][co][y][x] * wt[ci][co][ky][kx]; wave per (b,i,j,ci)
+__global__ __launch_bounds__(256) void deconv_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ wt,
+                                                           float* __restrict__ dcoarse, int B, int h, int w, int C,
+                                                           int ldc, int c0, int H, int W, int crop) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long total = (long)B * h * w * C;
+    if (wid >= total) return;
+    const int ci = (int)(wid % C);
+    long t = wid / C;
+    const int j = (int)(t % w); t /= w;
+    const int i = (int)(t % h);
+    const int b = (int)(t / h);
+    const int x = 32 * j - crop + lane;
+    float acc = 0.f;
+    if (x >= 0 && x < W) {
+        for (int co = 0; co < C; ++co) {
+            const float* plane = dout + ((long)b * C + co) * H * W;
+            const float* wk = wt + ((long)ci * C + co) * 4096;
+            for (int ky = 0; ky < 64; ++ky) {
+                const int y = 32 * i - crop + ky;
+                if (y < 0 || y >= H) continue;
+                acc = fmaf(plane[(long)y * W + x], wk[ky * 64 + lane], acc);
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dcoarse[(((long)b * h + i) * w + j) * ldc + c0 + ci] = acc;
+}
+
+// dwt[ci][co][ky][kx] (+)= sum_{b,i,j} coarse[b][i][j][ci] * dout[b][co][32i+ky-crop][32j+kx-crop]
+__global__ __launch_bounds__(256) void deconv_wgrad_kernel(const float* __restrict__ coarse, const float* __restrict__ dout,
+                                                           float* __restrict__ dwt, int B, int h, int w, int C, int ldc,
+                                                           int c0, int H, int W, int crop, int accumulate) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= C * C * 4096) return;
+    const int kx = gid & 63, ky = (gid >> 6) & 63;
+    const int co = (gid >> 12) % C, ci = (gid >> 12) / C;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* plane = dout + ((long)b * C + co) * H * W;
+        for (int i = 0; i < h; ++i) {
+            const int y = 32 * i - crop + ky;
+            if (y < 0 || y >= H) continue;
+            for (int j = 0; j < w; ++j) {
+                const int x = 32 * j - crop + kx;
+                if (x < 0 || x >= W) continue;
+                acc = fmaf(coarse[(((long)b * h + i) * w + j) * ldc + c0 + ci], plane[(long)y * W + x], acc);
+            }
+        }
+    }
+    dwt[gid] = accumulate ? dwt[gid] + acc : acc;
+}
+
+// ---- block reduction of (sum, count) into a per-(image, block) partial --------------------------
+__device__ __forceinline__ void block_partial(double v, double n, double* part /* [2] */) {
+    __shared__ double sv[4], sn[4];
+    v = wave_sum_d(v); n = wave_sum_d(n);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[wave] = v; sn[wave] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) { part[0] = sv[0] + sv[1] + sv[2] + sv[3]; part[1] = sn[0] + sn[1] + sn[2] + sn[3]; }
+}
+
+// mode 0: cosine  loss = mean_b (N_b - S_b) / N_b ; mode 1: mse  loss = mean_b S_b / N_b ;
+// mode 2: CE      loss = sum_b S_b  (/ sum_b N_b if size_average)
+__global__ void loss_finalize_kernel(const double* __restrict__ part, int B, int nblk, int mode, int size_average,
+                                     float* __restrict__ loss, float* __restrict__ stats) {
+    const int lane = threadIdx.x;   // 64 threads
+    double tot = 0.0, totn = 0.0, acc = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s = 0.0, n = 0.0;
+        for (int k = lane; k < nblk; k += 64) { s += part[((long)b * nblk + k) * 2]; n += part[((long)b * nblk + k) * 2 + 1]; }
+        s = wave_sum_d(s); n = wave_sum_d(n);
+        if (lane == 0) { stats[2 * b] = (float)s; stats[2 * b + 1] = (float)n; }
+        tot += s; totn += n;
+        if (mode == 0) acc += (n - s) / n;
+        else if (mode == 1) acc += s / n;
+    }
+    if (lane == 0) {
+        if (mode == 2) loss[0] = (float)(size_average ? tot / totn : tot);
+        else loss[0] = (float)(acc / B);
+    }
+}
+
+// ---- cosine / mse forward: thread = pixel, grid (blocks per image, B) -----------------------------
+template <int MODE>   // 0 cosine, 1 mse
+__global__ __launch_bounds__(256) void embed_loss_fwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
+                                                             const float* __restrict__ embed, const float* __restrict__ tembed,
+                                                             double* __restrict__ part, int E, int HW, int K) {
+    extern __shared__ __attribute__((aligned(16))) float emb_l[];   // [K][E] when gathering
+    if (!tembed) {
+        for (int i = threadIdx.x; i < K * E; i += 256) emb_l[i] = embed[i];
+        __syncthreads();
+    }
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    double term = 0.0, cnt = 0.0;
+    if (p < HW) {
+        const long lbl = target[(long)b * HW + p];
+        if (lbl >= 0) {
+            const float* sp = score + (long)b * E * HW + p;
+            const float* tp = tembed ? tembed + (long)b * E * HW + p : nullptr;
+            const float* er = emb_l + (lbl < K ? lbl : 0) * E;
+            float ss = 0.f, st = 0.f, tt = 0.f;
+            for (int c = 0; c < E; ++c) {
+                const float s = sp[(long)c * HW];
+                const float t = tp ? tp[(long)c * HW] : er[c];
+                if (MODE == 0) { ss = fmaf(s, s, ss); st = fmaf(s, t, st); tt = fmaf(t, t, tt); }
+                else { const float d = s - t; ss = fmaf(d, d, ss); }
+            }
+            term = (MODE == 0) ? (double)(st / (sqrtf(ss) * sqrtf(tt))) : (double)ss;
+            cnt = 1.0;
+        }
+    }
+    block_partial(term, cnt, part + ((long)b * gridDim.x + blockIdx.x) * 2);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void embed_loss_bwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
+                                                             const float* __restrict__ embed, const float* __restrict__ tembed,
+                                                             const float* __restrict__ stats, const float* __restrict__ gout,
+                                                             float* __restrict__ dscore, int B, int E, int HW, int K) {
+    extern __shared__ __attribute__((aligned(16))) float emb_l[];
+    if (!tembed) {
+        for (int i = threadIdx.x; i < K * E; i += 256) emb_l[i] = embed[i];
+        __syncthreads();
+    }
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const long lbl = target[(long)b * HW + p];
+    const float* sp = score + (long)b * E * HW + p;
+    float* dp = dscore + (long)b * E * HW + p;
+    if (lbl < 0) {
+        for (int c = 0; c < E; ++c) dp[(long)c * HW] = 0.f;
+        return;
+    }
+    const float* tp = tembed ? tembed + (long)b * E * HW + p : nullptr;
+    const float* er = emb_l + (lbl < K ? lbl : 0) * E;
+    const float g = (gout ? gout[0] : 1.f) / ((float)B * stats[2 * b + 1]);
+    if (MODE == 0) {
+        float ss = 0.f, st = 0.f, tt = 0.f;
+        for (int c = 0; c < E; ++c) {
+            const float s = sp[(long)c * HW];
+            const float t = tp ? tp[(long)c * HW] : er[c];
+            ss = fmaf(s, s, ss); st = fmaf(s, t, st); tt = fmaf(t, t, tt);
+        }
+        const float ns = sqrtf(ss), nt = sqrtf(tt);
+        const float cosv = st / (ns * nt);
+        const float a = g / (ns * nt);       // coefficient of t_c
+        const float bq = g * cosv / ss;      // coefficient of s_c
+        for (int c = 0; c < E; ++c) {
+            const float s = sp[(long)c * HW];
+            const float t = tp ? tp[(long)c * HW] : er[c];
+            dp[(long)c * HW] = bq * s - a * t;
+        }
+    } else {
+        for (int c = 0; c < E; ++c) {
+            const float s = sp[(long)c * HW];
+            const float t = tp ? tp[(long)c * HW] : er[c];
+            dp[(long)c * HW] = 2.f * g * (s - t);
+        }
+    }
+}
+
+// ---- cross_entropy2d --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
+                                                     double* __restrict__ part, int64_t* __restrict__ pred, int C, int HW) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    double term = 0.0, cnt = 0.0;
+    if (p < HW) {
+        const float* sp = score + (long)b * C * HW + p;
+        float mx = sp[0];
+        int am = 0;
+        for (int c = 1; c < C; ++c) { const float s = sp[(long)c * HW]; if (s > mx) { mx = s; am = c; } }
+        if (pred) pred[(long)b * HW + p] = am;
+        const long lbl = target[(long)b * HW + p];
+        if (lbl >= 0 && lbl < C) {
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += expf(sp[(long)c * HW] - mx);
+            term = (double)(-(sp[lbl * (long)HW] - mx - logf(se)));
+            cnt = 1.0;
+        }
+    }
+    block_partial(term, cnt, part + ((long)b * gridDim.x + blockIdx.x) * 2);
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ stats, const float* __restrict__ gout,
+                                                     float* __restrict__ dscore, int B, int C, int HW, int size_average) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float* sp = score + (long)b * C * HW + p;
+    float* dp = dscore + (long)b * C * HW + p;
+    const long lbl = target[(long)b * HW + p];
+    if (lbl < 0 || lbl >= C) {
+        for (int c = 0; c < C; ++c) dp[(long)c * HW] = 0.f;
+        return;
+    }
+    float g = gout ? gout[0] : 1.f;
+    if (size_average) {
+        float n = 0.f;
+        for (int i = 0; i < B; ++i) n += stats[2 * i + 1];
+        g /= n;
+    }
+    float mx = sp[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, sp[(long)c * HW]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(sp[(long)c * HW] - mx);
+    const float inv = 1.f / se;
+    for (int c = 0; c < C; ++c) {
+        const float sm = expf(sp[(long)c * HW] - mx) * inv;
+        dp[(long)c * HW] = g * (sm - (c == lbl ? 1.f : 0.f));
+    }
+}
+
+// ---- nearest-class-embedding argmax: thread = pixel, KP accumulators in registers --------------------
+template <int KP>
+__global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restrict__ score, const float* __restrict__ embed,
+                                                           const float* __restrict__ seenmask,
+                                                           const int64_t* __restrict__ target, int64_t* __restrict__ pred,
+                                                           int E, int HW, int K, int mode, uint64_t unseen_bits) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // embT [E][KP] | en [KP]
+    float* embT = sm;
+    float* en = sm + (long)E * KP;
+    for (int i = threadIdx.x; i < E * KP; i += 256) {
+        const int k = i % KP, c = i / KP;
+        embT[i] = (k < K) ? embed[(long)k * E + c] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < KP) {
+        float s = 0.f;
+        for (int c = 0; c < E; ++c) { const float v = embT[c * KP + threadIdx.x]; s = fmaf(v, v, s); }
+        const float n = sqrtf(s);
+        en[threadIdx.x] = (n == 0.f) ? 1.f : n;     // utils.py:175
+    }
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float* sp = score + (long)b * E * HW + p;
+    float acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) acc[k] = 0.f;
+    float ss = 0.f;
+    for (int c = 0; c < E; ++c) {
+        const float s = sp[(long)c * HW];
+        ss = fmaf(s, s, ss);
+        const float4* er = (const float4*)(embT + c * KP);
+#pragma unroll
+        for (int k4 = 0; k4 < KP / 4; ++k4) {
+            const float4 e = er[k4];
+            acc[4 * k4 + 0] = fmaf(s, e.x, acc[4 * k4 + 0]);
+            acc[4 * k4 + 1] = fmaf(s, e.y, acc[4 * k4 + 1]);
+            acc[4 * k4 + 2] = fmaf(s, e.z, acc[4 * k4 + 2]);
+            acc[4 * k4 + 3] = fmaf(s, e.w, acc[4 * k4 + 3]);
+        }
+    }
+    const float sn = sqrtf(ss);
+    int best = 0;
+    if (mode == 0) {
+        float bv = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            if (k < K) {
+                const float sim = acc[k] / (sn * en[k]);
+                if (k == 0 || sim > bv) { bv = sim; best = k; }
+            }
+        }
+    } else {
+        // one pass over all K similarities gives both the seen-only and the unseen-only prediction:
+        // a zeroed row scores (0 / (sn * 1)) and still competes, exactly like utils.py:173-179
+        const float zero_sim = 0.f / (sn * 1.f);
+        float bs = 0.f, bu = 0.f;
+        int is = 0, iu = 0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            if (k < K) {
+                const float sim = acc[k] / (sn * en[k]);
+                const bool un = (unseen_bits >> k) & 1ull;
+                const float vs = un ? zero_sim : sim, vu = un ? sim : zero_sim;
+                if (k == 0 || vs > bs) { bs = vs; is = k; }
+                if (k == 0 || vu > bu) { bu = vu; iu = k; }
+            }
+        }
+        bool take_unseen;
+        if (seenmask) {
+            const float s0 = seenmask[((long)b * 2 + 0) * HW + p], s1 = seenmask[((long)b * 2 + 1) * HW + p];
+            take_unseen = !(s1 > s0);          // argmax over 2 channels == 0  (utils.py:197-198)
+        } else {
+            const long t = target[(long)b * HW + p];
+            take_unseen = (t >= 0 && t < 64) && ((unseen_bits >> t) & 1ull);   // np.in1d(target, unseen)
+        }
+        best = take_unseen ? iu : is;
+    }
+    pred[(long)b * HW + p] = best;
+}
+
+// ---- confusion histogram -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hist_kernel(const int64_t* __restrict__ lt, const int64_t* __restrict__ lp, long n,
+                                                   int K, uint64_t unseen_bits, unsigned long long* __restrict__ hist) {
+    extern __shared__ unsigned int hl[];   // [nh][K*K]
+    const int nh = unseen_bits ? 3 : 1;
+    for (int i = threadIdx.x; i < nh * K * K; i += 256) hl[i] = 0;
+    __syncthreads();
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long t = lt[i], p = lp[i];
+        if (t >= 0 && t < K && p >= 0 && p < K) {
+            const int idx = (int)(t * K + p);
+            atomicAdd(&hl[idx], 1u);
+            if (unseen_bits) atomicAdd(&hl[(((unseen_bits >> t) & 1ull) ? 2 : 1) * K * K + idx], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nh * K * K; i += 256)
+        if (hl[i]) atomicAdd(&hist[i], (unsigned long long)hl[i]);
+}
+
+inline int grid_for(long n, int cap) {
+    long b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int check_up(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, const void* a, const void* b) {
+    if (!a || !b || B <= 0 || h <= 0 || w <= 0 || E <= 0 || c0 < 0 || ldc < c0 + E || H <= 0 || W <= 0 || crop < 0)
+        SZN_FAIL(SZN_ERR_ARG, "upsample: bad argument");
+    if (H + crop > 32 * h + 32 || W + crop > 32 * w + 32)
+        SZN_FAIL(SZN_ERR_ARG, "upsample: crop window [%d,%d)+%d exceeds the %dx%d deconv output", H, W, crop, 32 * h + 32,
+                 32 * w + 32);
+    return SZN_OK;
+}
+
+constexpr size_t kMaxDynLds = 160 * 1024 - 2048;
+
+}  // namespace
+
+extern "C" int szn_bilinear_up32_crop_fwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                                          const float* coarse, float* score, szn_stream_t stream) {
+    int rc = check_up(B, h, w, E, ldc, c0, H, W, crop, coarse, score);
+    if (rc) return rc;
+    hipLaunchKernelGGL(up32_fwd_kernel, dim3(grid_for((long)B * E * H * W, 1 << 20)), dim3(256), 0, (hipStream_t)stream,
+                       coarse, score, B, h, w, E, ldc, c0, H, W, crop);
+    SZN_CHECK_LAUNCH("up32_fwd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_bilinear_up32_crop_bwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                                          const float* dscore, float* dcoarse, szn_stream_t stream) {
+    int rc = check_up(B, h, w, E, ldc, c0, H, W, crop, dscore, dcoarse);
+    if (rc) return rc;
+    const long waves = (long)B * h * w * E;
+    hipLaunchKernelGGL(up32_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dscore, dcoarse,
+                       B, h, w, E, ldc, c0, H, W, crop);
+    SZN_CHECK_LAUNCH("up32_bwd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_deconv64s32_fwd(int B, int h, int w, int C, int ldc, int c0, int H, int W, int crop,
+                                   const float* coarse, const float* weight, float* out, szn_stream_t stream) {
+    int rc = check_up(B, h, w, C, ldc, c0, H, W, crop, coarse, out);
+    if (rc) return rc;
+    if (!weight || C > 4) SZN_FAIL(SZN_ERR_ARG, "deconv64s32_fwd: weight missing or C > 4");
+    hipLaunchKernelGGL(deconv_fwd_kernel, dim3(grid_for((long)B * C * H * W, 1 << 20)), dim3(256), 0, (hipStream_t)stream,
+                       coarse, weight, out, B, h, w, C, ldc, c0, H, W, crop);
+    SZN_CHECK_LAUNCH("deconv_fwd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_deconv64s32_dgrad(int B, int h, int w, int C, int ldc, int c0, int H, int W, int crop,
+                                     const float* dout, const float* weight, float* dcoarse, szn_stream_t stream) {
+    int rc = check_up(B, h, w, C, ldc, c0, H, W, crop, dout, dcoarse);
+    if (rc) return rc;
+    if (!weight || C > 4) SZN_FAIL(SZN_ERR_ARG, "deconv64s32_dgrad: weight missing or C > 4");
+    const long waves = (long)B * h * w * C;
+    hipLaunchKernelGGL(deconv_dgrad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout,
+                       weight, dcoarse, B, h, w, C, ldc, c0, H, W, crop);
+    SZN_CHECK_LAUNCH("deconv_dgrad_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_deconv64s32_wgrad(int B, int h, int w, int C, int ldc, int c0, int H, int W, int crop,
+                                     const float* coarse, const float* dout, float* dweight, int accumulate,
+                                     szn_stream_t stream) {
+    int rc = check_up(B, h, w, C, ldc, c0, H, W, crop, coarse, dout);
+    if (rc) return rc;
+    if (!dweight || C > 4) SZN_FAIL(SZN_ERR_ARG, "deconv64s32_wgrad: dweight missing or C > 4");
+    hipLaunchKernelGGL(deconv_wgrad_kernel, dim3(C * C * 16), dim3(256), 0, (hipStream_t)stream, coarse, dout, dweight, B, h,
+                       w, C, ldc, c0, H, W, crop, accumulate);
+    SZN_CHECK_LAUNCH("deconv_wgrad_kernel");
+    return SZN_OK;
+}
+
+extern "C" size_t szn_loss_workspace_bytes(int B, int H, int W) {
+    const long nblk = ((long)H * W + 255) / 256;
+    return (size_t)B * nblk * 2 * sizeof(double);
+}
+
+namespace {
+template <int MODE>
+int embed_loss_fwd(int B, int E, int H, int W, int K, const float* score, const int64_t* target, const float* embed,
+                   const float* tembed, float* loss, float* stats, void* ws, hipStream_t st, const char* name) {
+    if (!score || !target || !loss || !stats || !ws || B <= 0 || E <= 0 || H <= 0 || W <= 0)
+        SZN_FAIL(SZN_ERR_ARG, "%s: bad argument", name);
+    if (!tembed && (!embed || K <= 0)) SZN_FAIL(SZN_ERR_ARG, "%s: need embed[K][E] or target_embed", name);
+    const size_t lds = tembed ? 0 : (size_t)K * E * sizeof(float);
+    if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "%s: K*E*4 = %zu B exceeds the LDS budget", name, lds);
+    const int HW = H * W, nblk = (HW + 255) / 256;
+    auto kern = embed_loss_fwd_kernel<MODE>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(nblk, B), dim3(256), lds, st, score, target, embed, tembed, (double*)ws, E, HW, K);
+    SZN_CHECK_LAUNCH(name);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, B, nblk, MODE, 0, loss, stats);
+    SZN_CHECK_LAUNCH("loss_finalize_kernel");
+    return SZN_OK;
+}
+template <int MODE>
+int embed_loss_bwd(int B, int E, int H, int W, int K, const float* score, const int64_t* target, const float* embed,
+                   const float* tembed, const float* stats, const float* gout, float* dscore, hipStream_t st,
+                   const char* name) {
+    if (!score || !target || !stats || !dscore || B <= 0 || E <= 0 || H <= 0 || W <= 0)
+        SZN_FAIL(SZN_ERR_ARG, "%s: bad argument", name);
+    if (!tembed && (!embed || K <= 0)) SZN_FAIL(SZN_ERR_ARG, "%s: need embed[K][E] or target_embed", name);
+    const size_t lds = tembed ? 0 : (size_t)K * E * sizeof(float);
+    if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "%s: K*E*4 = %zu B exceeds the LDS budget", name, lds);
+    const int HW = H * W, nblk = (HW + 255) / 256;
+    auto kern = embed_loss_bwd_kernel<MODE>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(nblk, B), dim3(256), lds, st, score, target, embed, tembed, stats, gout, dscore, B, E, HW, K);
+    SZN_CHECK_LAUNCH(name);
+    return SZN_OK;
+}
+}  // namespace
+
+extern "C" int szn_cosine_loss_fwd(int B, int E, int H, int W, int K, const float* score, const int64_t* target,
+                                   const float* embed, const float* target_embed, float* loss, float* stats, void* ws,
+                                   szn_stream_t stream) {
+    return embed_loss_fwd<0>(B, E, H, W, K, score, target, embed, target_embed, loss, stats, ws, (hipStream_t)stream,
+                             "cosine_loss_fwd");
+}
+extern "C" int szn_cosine_loss_bwd(int B, int E, int H, int W, int K, const float* score, const int64_t* target,
+                                   const float* embed, const float* target_embed, const float* stats, const float* gout,
+                                   float* dscore, szn_stream_t stream) {
+    return embed_loss_bwd<0>(B, E, H, W, K, score, target, embed, target_embed, stats, gout, dscore, (hipStream_t)stream,
+                             "cosine_loss_bwd");
+}
+extern "C" int szn_mse_loss_fwd(int B, int E, int H, int W, int K, const float* score, const int64_t* target,
+                                const float* embed, const float* target_embed, float* loss, float* stats, void* ws,
+                                szn_stream_t stream) {
+    return embed_loss_fwd<1>(B, E, H, W, K, score, target, embed, target_embed, loss, stats, ws, (hipStream_t)stream,
+                             "mse_loss_fwd");
+}
+extern "C" int szn_mse_loss_bwd(int B, int E, int H, int W, int K, const float* score, const int64_t* target,
+                                const float* embed, const float* target_embed, const float* stats, const float* gout,
+                                float* dscore, szn_stream_t stream) {
+    return embed_loss_bwd<1>(B, E, H, W, K, score, target, embed, target_embed, stats, gout, dscore, (hipStream_t)stream,
+                             "mse_loss_bwd");
+}
+
+extern "C" int szn_ce2d_fwd(int B, int C, int H, int W, const float* score, const int64_t* target, int size_average,
+                            float* loss, float* stats, int64_t* pred, void* ws, szn_stream_t stream) {
+    if (!score || !target || !loss || !stats || !ws || B <= 0 || C <= 0 || H <= 0 || W <= 0)
+        SZN_FAIL(SZN_ERR_ARG, "ce2d_fwd: bad argument");
+    const int HW = H * W, nblk = (HW + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk, B), dim3(256), 0, st, score, target, (double*)ws, pred, C, HW);
+    SZN_CHECK_LAUNCH("ce_fwd_kernel");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, B, nblk, 2, size_average, loss,
+                       stats);
+    SZN_CHECK_LAUNCH("loss_finalize_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_ce2d_bwd(int B, int C, int H, int W, const float* score, const int64_t* target, int size_average,
+                            const float* stats, const float* gout, float* dscore, szn_stream_t stream) {
+    if (!score || !target || !stats || !dscore || B <= 0 || C <= 0 || H <= 0 || W <= 0)
+        SZN_FAIL(SZN_ERR_ARG, "ce2d_bwd: bad argument");
+    const int HW = H * W, nblk = (HW + 255) / 256;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, score, target, stats, gout, dscore, B,
+                       C, HW, size_average);
+    SZN_CHECK_LAUNCH("ce_bwd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_embed_argmax(int B, int E, int H, int W, int K, const float* score, const float* embed, int mode,
+                                uint64_t unseen_bits, const float* seenmask, const int64_t* target, int64_t* pred,
+                                szn_stream_t stream) {
+    if (!score || !embed || !pred || B <= 0 || E <= 0 || H <= 0 || W <= 0 || K <= 0)
+        SZN_FAIL(SZN_ERR_ARG, "embed_argmax: bad argument");
+    if (K > 64) SZN_FAIL(SZN_ERR_UNSUPPORTED, "embed_argmax: K=%d > 64", K);
+    if (mode != 0 && mode != 1) SZN_FAIL(SZN_ERR_ARG, "embed_argmax: bad mode %d", mode);
+    if (mode == 1 && !seenmask && !target) SZN_FAIL(SZN_ERR_ARG, "embed_argmax: mode 1 needs seenmask or target");
+    const int HW = H * W, nblk = (HW + 255) / 256;
+    const int KP = K <= 24 ? 24 : (K <= 40 ? 40 : 64);
+    const size_t lds = ((size_t)E * KP + KP) * sizeof(float);
+    if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "embed_argmax: E*KP*4 = %zu B exceeds the LDS budget", lds);
+    hipStream_t st = (hipStream_t)stream;
+#define SZN_LAUNCH_AM(KPV)                                                                                             \
+    do {                                                                                                               \
+        auto kern = embed_argmax_kernel<KPV>;                                                                          \
+        if (lds > 48 * 1024)                                                                                           \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL(kern, dim3(nblk, B), dim3(256), lds, st, score, embed, seenmask, target, pred, E, HW, K,    \
+                           mode, unseen_bits);                                                                         \
+    } while (0)
+    if (KP == 24) SZN_LAUNCH_AM(24);
+    else if (KP == 40) SZN_LAUNCH_AM(40);
+    else SZN_LAUNCH_AM(64);
+#undef SZN_LAUNCH_AM
+    SZN_CHECK_LAUNCH("embed_argmax_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_confusion_hist(long npix, int K, const int64_t* label_true, const int64_t* label_pred,
+                                  uint64_t unseen_bits, int64_t* hist, szn_stream_t stream) {
+    if (!label_true || !label_pred || !hist || npix <= 0 || K <= 0 || K > 64)
+        SZN_FAIL(SZN_ERR_ARG, "confusion_hist: bad argument");
+    const int nh = unseen_bits ? 3 : 1;
+    const size_t lds = (size_t)nh * K * K * sizeof(unsigned int);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(hist_kernel, dim3(grid_for(npix, 1024)), dim3(256), lds, (hipStream_t)stream, label_true, label_pred,
+                       npix, K, unseen_bits, (unsigned long long*)hist);
+    SZN_CHECK_LAUNCH("hist_kernel");
+    return SZN_OK;
+}
