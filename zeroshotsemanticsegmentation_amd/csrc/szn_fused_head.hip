@@ -1,7 +1,326 @@
-// placeholder until the fused head lands (replaced in the same round)
+// szn_fused_head.hip -- the SZN head evaluated from the 1/32-resolution projection map without ever
+// materialising the (B,E,H,W) score: bilinear x32 upsample + crop (models.py:146-147), cosine loss
+// (utils.py:75-102), nearest-class-embedding argmax (utils.py:159-185) and the gradient back to the
+// coarse map, per 32x32 output cell.
+//
+// Inside one cell (Y>>5, X>>5 fixed) every pixel's score vector is a blend of the SAME four coarse
+// vectors C_t with per-pixel bilinear weights w_t, so
+//     s . e_k = sum_t w_t (C_t . e_k)            -> per-cell table G[4][K]
+//     |s|^2   = sum_{t,t'} w_t w_t' (C_t . C_t') -> per-cell Gram matrix Q[4][4]
+// and the gradient wrt the coarse vectors collapses to
+//     dC_t = -sum_k A[t][k] e_k + sum_t' Bm[t][t'] C_t',  A[t][k] = sum_{px: label k} w_t / (|s||e_k|),
+//                                                         Bm[t][t'] = sum_px w_t w_t' cos / |s|^2
+// (all scaled by 1/(B N_b)).  HBM traffic: labels in, prediction out (16 B/px) + the coarse map.
+//
+// Kernel 1 (cell kernel): one block per (image, cell): builds G, Q, walks its <= 1024 pixels, writes pred,
+//   the cell's loss partial, A and Bm.  All reductions are fixed-order (bit-reproducible).
+// Kernel 2: loss_finalize (per-image sums, fixed order).  Kernel 3 (gather): one block per coarse
+//   position sums the contributions of the <= 4 cells that use it as a tap and writes dcoarse.
 #include "szn_common.h"
-extern "C" size_t szn_fused_head_workspace_bytes(int, int, int, int, int) { return 0; }
-extern "C" int szn_fused_head(int, int, int, int, int, int, int, int, int, int, const float*, const float*, const int64_t*,
-                              float*, float*, int64_t*, int, void*, void*, szn_stream_t) {
-    SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head: not built yet");
+
+namespace {
+
+__device__ __forceinline__ double bil1d(int t) { return 1.0 - fabs((double)t - 31.5) / 32.0; }
+
+struct FhArgs {
+    const float* coarse; const float* embed; const int64_t* target;
+    int64_t* pred; float* ws_f; double* part;
+    int B, h, w, E, ldc, c0, H, W, crop, K, KP;
+};
+
+// workspace (floats): embT [E][KP] | en [KP] (0 -> 1, for the argmax) | ent [KP] (raw norms, for the loss)
+//                     | per cell: A [4][KP] , Bm [16]
+__host__ __device__ inline size_t ws_cell_off(int E, int KP) { return (size_t)E * KP + 2 * KP; }
+__host__ __device__ inline size_t ws_cell_stride(int KP) { return (size_t)4 * KP + 16; }
+
+__global__ __launch_bounds__(256) void fh_prep_kernel(const float* __restrict__ embed, float* __restrict__ ws, int E,
+                                                      int K, int KP) {
+    float* embT = ws;
+    float* en = ws + (size_t)E * KP;
+    float* ent = en + KP;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < E * KP; i += gridDim.x * 256) {
+        const int k = i % KP, c = i / KP;
+        embT[i] = (k < K) ? embed[(size_t)k * E + c] : 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < KP) {
+        const int k = threadIdx.x;
+        float s = 0.f;
+        if (k < K) for (int c = 0; c < E; ++c) s = fmaf(embed[(size_t)k * E + c], embed[(size_t)k * E + c], s);
+        const float n = sqrtf(s);
+        en[k] = (n == 0.f) ? 1.f : n;
+        ent[k] = n;
+    }
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) void fh_cell_kernel(FhArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ct = sm;                       // [4][E]
+    float* G = Ct + 4 * a.E;              // [4][KP]
+    float* Q = G + 4 * KP;                // [16]
+    float* Aw = Q + 16;                   // [4 waves][4][KP]
+    float* red = Aw + 16 * KP;            // [4 waves][16]
+    double* dred = (double*)(red + 64);   // [4 waves][2]   (offset is a multiple of 8 B: all terms are multiples of 4 floats... see host check)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cells_w = a.w + 1, cells = (a.h + 1) * cells_w;
+    const int b = blockIdx.x / cells, cell = blockIdx.x % cells;
+    const int I = cell / cells_w, J = cell % cells_w;
+
+    const float* embT = a.ws_f;
+    const float* en = a.ws_f + (size_t)a.E * KP;
+    const float* ent = en + KP;
+
+    // ---- the four tap vectors (missing taps are zero) ----
+    for (int i = tid; i < 4 * a.E; i += 256) {
+        const int t = i / a.E, c = i - t * a.E;
+        const int ci = I - 1 + (t >> 1), cj = J - 1 + (t & 1);
+        float v = 0.f;
+        if (ci >= 0 && ci < a.h && cj >= 0 && cj < a.w)
+            v = a.coarse[(((size_t)b * a.h + ci) * a.w + cj) * a.ldc + a.c0 + c];
+        Ct[i] = v;
+    }
+    for (int i = tid; i < 16 * KP; i += 256) Aw[i] = 0.f;
+    __syncthreads();
+    // G[t][k]: wave t, lane k (KP <= 64)
+    if (lane < KP) {
+        float g = 0.f;
+        const float* ct = Ct + wave * a.E;
+        for (int c = 0; c < a.E; ++c) g = fmaf(ct[c], embT[(size_t)c * KP + lane], g);
+        G[wave * KP + lane] = g;
+    }
+    // Q[t][t']: wave t computes its row; lanes stride over c, fixed-order wave reduction
+    {
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* ct = Ct + wave * a.E;
+        for (int c = lane; c < a.E; c += 64) {
+            const float v = ct[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = fmaf(v, Ct[u * a.E + c], q[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float s = wave_sum(q[u]);
+            if (lane == 0) Q[wave * 4 + u] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- pixels of this cell: Y in [32I, 32I+32) x X in [32J, 32J+32), image coords y = Y - crop ----
+    float bm[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bm[u] = 0.f;
+    double cos_sum = 0.0, cnt = 0.0;
+    float* myA = Aw + wave * 4 * KP;
+    for (int q = tid; q < 1024; q += 256) {          // q>>5 = row in cell, q&31 = col: a wave covers 2 rows
+        const int ty = q >> 5, tx = q & 31;
+        const int y = 32 * I + ty - a.crop, x = 32 * J + tx - a.crop;
+        const bool inside = (y >= 0 && y < a.H && x >= 0 && x < a.W);
+        long lbl = -1;
+        float wt[4] = {0.f, 0.f, 0.f, 0.f};
+        float aco = 0.f;
+        if (inside) {
+            const double fy1 = bil1d(ty), fy0 = bil1d(ty + 32), fx1 = bil1d(tx), fx0 = bil1d(tx + 32);
+            wt[0] = (float)(fy0 * fx0); wt[1] = (float)(fy0 * fx1); wt[2] = (float)(fy1 * fx0); wt[3] = (float)(fy1 * fx1);
+            float ss = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ss = fmaf(wt[t] * wt[u], Q[t * 4 + u], ss);
+            const float sn = sqrtf(ss);
+            const size_t pix = ((size_t)b * a.H + y) * a.W + x;
+            lbl = a.target ? a.target[pix] : -1;
+            if (a.pred) {
+                int best = 0;
+                float bv = 0.f;
+                for (int k = 0; k < a.K; ++k) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) d = fmaf(wt[t], G[t * KP + k], d);
+                    const float sim = d / (sn * en[k]);
+                    if (k == 0 || sim > bv) { bv = sim; best = k; }
+                }
+                a.pred[pix] = best;
+            }
+            if (lbl >= 0) {
+                const int kl = lbl < a.K ? (int)lbl : 0;
+                float d = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d = fmaf(wt[t], G[t * KP + kl], d);
+                const float nt = ent[kl];
+                const float cosv = d / (sn * nt);
+                cos_sum += (double)cosv;
+                cnt += 1.0;
+                aco = 1.f / (sn * nt);
+                const float bco = cosv / ss;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bm[t * 4 + u] = fmaf(wt[t] * wt[u], bco, bm[t * 4 + u]);
+            }
+        }
+        // A[t][label] += w_t * aco, label by label in a fixed order (wave-uniform loop)
+        unsigned long long todo = __ballot(lbl >= 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const int kl = (int)__shfl((int)(lbl < a.K ? lbl : 0), src, 64);
+            const bool mine = (lbl >= 0) && ((int)(lbl < a.K ? lbl : 0) == kl);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float s = wave_sum(mine ? wt[t] * aco : 0.f);
+                if (lane == 0) myA[t * KP + kl] += s;
+            }
+            todo &= ~__ballot(mine);
+        }
+    }
+    // ---- block reductions (fixed order) ----
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const float s = wave_sum(bm[u]);
+        if (lane == 0) red[wave * 16 + u] = s;
+    }
+    cos_sum = wave_sum_d(cos_sum); cnt = wave_sum_d(cnt);
+    if (lane == 0) { dred[wave * 2] = cos_sum; dred[wave * 2 + 1] = cnt; }
+    __syncthreads();
+    float* wc = a.ws_f + ws_cell_off(a.E, KP) + (size_t)blockIdx.x * ws_cell_stride(KP);
+    for (int i = tid; i < 4 * KP; i += 256) wc[i] = (Aw[i] + Aw[4 * KP + i]) + (Aw[8 * KP + i] + Aw[12 * KP + i]);
+    if (tid < 16) wc[4 * KP + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+    if (tid == 0) {
+        a.part[(size_t)blockIdx.x * 2] = (dred[0] + dred[2]) + (dred[4] + dred[6]);
+        a.part[(size_t)blockIdx.x * 2 + 1] = (dred[1] + dred[3]) + (dred[5] + dred[7]);
+    }
+}
+
+// loss = mean_b (N_b - S_b)/N_b ; stats[b] = {S_b, N_b}
+__global__ void fh_finalize_kernel(const double* __restrict__ part, int B, int cells, float* __restrict__ loss,
+                                   float* __restrict__ stats) {
+    const int lane = threadIdx.x;
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s = 0.0, n = 0.0;
+        for (int k = lane; k < cells; k += 64) { s += part[((size_t)b * cells + k) * 2]; n += part[((size_t)b * cells + k) * 2 + 1]; }
+        s = wave_sum_d(s); n = wave_sum_d(n);
+        if (lane == 0) { stats[2 * b] = (float)s; stats[2 * b + 1] = (float)n; }
+        acc += (n - s) / n;
+    }
+    if (lane == 0) loss[0] = (float)(acc / B);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fh_gather_kernel(const float* __restrict__ coarse, const float* __restrict__ embed,
+                                                        const float* __restrict__ ws, const float* __restrict__ stats,
+                                                        T* __restrict__ dcoarse, int B, int h, int w, int E, int ldc,
+                                                        int c0, int K, int KP) {
+    __shared__ float Al[4][64];      // A of the 4 cells, row = the tap index this position has in that cell
+    __shared__ float Bl[4][4];       // matching rows of Bm
+    const int pos = blockIdx.x;
+    const int b = pos / (h * w), r = pos % (h * w);
+    const int i = r / w, j = r % w;
+    const int cells_w = w + 1, cells = (h + 1) * cells_w;
+    const float* cellbase = ws + ws_cell_off(E, KP);
+    // cell u = (a, bb): this position is tap t = (a, bb) of cell (i + 1 - a, j + 1 - bb)
+    for (int idx = threadIdx.x; idx < 4 * KP + 16; idx += 256) {
+        if (idx < 4 * KP) {
+            const int u = idx / KP, k = idx % KP;
+            const int I = i + 1 - (u >> 1), J = j + 1 - (u & 1);
+            const float* wc = cellbase + ((size_t)b * cells + I * cells_w + J) * ws_cell_stride(KP);
+            Al[u][k] = wc[u * KP + k];
+        } else {
+            const int q = idx - 4 * KP, u = q >> 2, t2 = q & 3;
+            const int I = i + 1 - (u >> 1), J = j + 1 - (u & 1);
+            const float* wc = cellbase + ((size_t)b * cells + I * cells_w + J) * ws_cell_stride(KP);
+            Bl[u][t2] = wc[4 * KP + u * 4 + t2];
+        }
+    }
+    __syncthreads();
+    const float scale = 1.f / ((float)B * stats[2 * b + 1]);
+    for (int c = threadIdx.x; c < E; c += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float au = 0.f;
+            for (int k = 0; k < K; ++k) au = fmaf(Al[u][k], embed[(size_t)k * E + c], au);
+            float bu = 0.f;
+            const int I = i + 1 - (u >> 1), J = j + 1 - (u & 1);
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                const int ci = I - 1 + (t2 >> 1), cj = J - 1 + (t2 & 1);
+                if (ci >= 0 && ci < h && cj >= 0 && cj < w)
+                    bu = fmaf(Bl[u][t2], coarse[(((size_t)b * h + ci) * w + cj) * ldc + c0 + c], bu);
+            }
+            acc += bu - au;
+        }
+        elem<T>::st(dcoarse + ((size_t)pos) * ldc + c0 + c, acc * scale);
+    }
+}
+
+inline int kp_of(int K) { return K <= 24 ? 24 : (K <= 40 ? 40 : 64); }
+
+}  // namespace
+
+extern "C" size_t szn_fused_head_workspace_bytes(int B, int h, int w, int E, int K) {
+    if (B <= 0 || h <= 0 || w <= 0 || E <= 0 || K <= 0 || K > 64) return 0;
+    const int KP = kp_of(K);
+    const size_t cells = (size_t)B * (h + 1) * (w + 1);
+    size_t fl = ws_cell_off(E, KP) + cells * ws_cell_stride(KP);
+    fl = (fl + 1) / 2 * 2;                                   // keep the double region 8-B aligned
+    return fl * sizeof(float) + cells * 2 * sizeof(double);
+}
+
+extern "C" int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
+                              const float* coarse, const float* embed, const int64_t* target, float* loss, float* stats,
+                              int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace, szn_stream_t stream) {
+    if (!coarse || !embed || !workspace || B <= 0 || h <= 0 || w <= 0 || E <= 0 || c0 < 0 || ldc < c0 + E || H <= 0 ||
+        W <= 0 || crop < 0 || K <= 0)
+        SZN_FAIL(SZN_ERR_ARG, "fused_head: bad argument");
+    if (K > 64) SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head: K=%d > 64", K);
+    if (H + crop > 32 * h + 32 || W + crop > 32 * w + 32) SZN_FAIL(SZN_ERR_ARG, "fused_head: crop window exceeds the deconv output");
+    if ((target == nullptr) != (loss == nullptr) || (loss && !stats)) SZN_FAIL(SZN_ERR_ARG, "fused_head: target/loss/stats go together");
+    if (dcoarse && !target) SZN_FAIL(SZN_ERR_ARG, "fused_head: dcoarse needs target");
+    if (((uintptr_t)workspace) & 15) SZN_FAIL(SZN_ERR_ARG, "fused_head: workspace must be 16-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int KP = kp_of(K);
+    const int cells = (h + 1) * (w + 1);
+    float* ws_f = (float*)workspace;
+    size_t fl = ws_cell_off(E, KP) + (size_t)B * cells * ws_cell_stride(KP);
+    fl = (fl + 1) / 2 * 2;
+    double* part = (double*)(ws_f + fl);
+    hipLaunchKernelGGL(fh_prep_kernel, dim3(szn_div_up((long)E * KP, 256)), dim3(256), 0, st, embed, ws_f, E, K, KP);
+    SZN_CHECK_LAUNCH("fh_prep_kernel");
+    FhArgs a;
+    a.coarse = coarse; a.embed = embed; a.target = target; a.pred = pred; a.ws_f = ws_f; a.part = part;
+    a.B = B; a.h = h; a.w = w; a.E = E; a.ldc = ldc; a.c0 = c0; a.H = H; a.W = W; a.crop = crop; a.K = K; a.KP = KP;
+    // LDS floats: Ct 4E | G 4KP | Q 16 | Aw 16KP | red 64 | dred 8 doubles; 4E + 20KP + 80 must be even for the doubles
+    size_t lfl = (size_t)4 * E + 20 * KP + 16 + 64;
+    const size_t lds = lfl * sizeof(float) + 8 * sizeof(double);
+    if (lds > 150 * 1024) SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head: E=%d too large for LDS", E);
+#define SZN_FH_LAUNCH(KPV)                                                                                           \
+    do {                                                                                                             \
+        auto kern = fh_cell_kernel<KPV>;                                                                             \
+        if (lds > 48 * 1024)                                                                                         \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(kern, dim3(B * cells), dim3(256), lds, st, a);                                            \
+    } while (0)
+    if (KP == 24) SZN_FH_LAUNCH(24);
+    else if (KP == 40) SZN_FH_LAUNCH(40);
+    else SZN_FH_LAUNCH(64);
+#undef SZN_FH_LAUNCH
+    SZN_CHECK_LAUNCH("fh_cell_kernel");
+    if (loss) {
+        hipLaunchKernelGGL(fh_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)part, B, cells, loss, stats);
+        SZN_CHECK_LAUNCH("fh_finalize_kernel");
+    }
+    if (dcoarse) {
+        if (dcoarse_dtype == SZN_F32)
+            hipLaunchKernelGGL(fh_gather_kernel<float>, dim3(B * h * w), dim3(256), 0, st, coarse, embed, (const float*)ws_f,
+                               (const float*)stats, (float*)dcoarse, B, h, w, E, ldc, c0, K, KP);
+        else if (dcoarse_dtype == SZN_BF16)
+            hipLaunchKernelGGL(fh_gather_kernel<bf16_raw>, dim3(B * h * w), dim3(256), 0, st, coarse, embed,
+                               (const float*)ws_f, (const float*)stats, (bf16_raw*)dcoarse, B, h, w, E, ldc, c0, K, KP);
+        else
+            SZN_FAIL(SZN_ERR_ARG, "fused_head: bad dcoarse_dtype %d", dcoarse_dtype);
+        SZN_CHECK_LAUNCH("fh_gather_kernel");
+    }
+    return SZN_OK;
 }

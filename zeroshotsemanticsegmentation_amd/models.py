@@ -1,0 +1,511 @@
+"""models.py -- MI355X-native FCN32s with the reference's module surface.
+
+Mirrors /root/reference/models.py: `get_upsampling_weight` (:11-24), `FCN32s` (:27-193) with the same layer
+attribute names / parameter shapes / state_dict keys, `forward(x, mode)` (:114-160) and
+`copy_params_from_vgg16` (:162-193), `VGG16` (:195-203).  Underneath, every operation is a hand-written
+HIP kernel reached through the C-ABI of include/szn.h (no torch.nn.functional compute, no CPU fallback):
+
+  * activations live in HBM as NHWC in the compute dtype (fp32 parity path or bf16 throughput path),
+  * conv weights are kept as fp32 masters in OHWI memory order (torch channels_last of the (O,I,KH,KW)
+    parameter), with a compute-dtype image and a flipped/transposed image for dgrad refreshed whenever a
+    parameter changes,
+  * score_fr and seenmask_score run as ONE projection GEMM with N = n_class + 2 (padded to 64).
+
+The layer objects subclass torch.nn.Conv2d / ConvTranspose2d / ReLU / MaxPool2d / Dropout2d purely as typed
+parameter containers so that `train.get_parameters` (reference train.py:302-331) classifies them the same way.
+"""
+import ctypes as C
+import math
+import os.path as osp
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import synth
+
+CROP = 19            # models.py:147
+PAD1 = 100           # models.py:43
+
+
+def get_upsampling_weight(in_channels, out_channels, kernel_size):
+    """2-D bilinear kernel on the channel diagonal, float64 -> float32 (reference models.py:11-24)."""
+    return torch.from_numpy(synth.bilinear_weight(in_channels, out_channels, kernel_size))
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+# (name, pad) in forward order; "P" = MaxPool2d(2,2,ceil)   (reference models.py:116-137)
+_BACKBONE = [("conv1_1", PAD1), ("conv1_2", 1), "P", ("conv2_1", 1), ("conv2_2", 1), "P",
+             ("conv3_1", 1), ("conv3_2", 1), ("conv3_3", 1), "P", ("conv4_1", 1), ("conv4_2", 1), ("conv4_3", 1), "P",
+             ("conv5_1", 1), ("conv5_2", 1), ("conv5_3", 1), "P"]
+_TRUNK = [n for n, _, _, _ in synth.CONV_LAYERS]          # conv1_1 .. fc7
+_OPT_LAYERS = _TRUNK + ["score_fr"]                        # the layers train.get_parameters yields (train.py:302-331)
+
+
+class _Ctx(object):
+    """what one forward pass leaves behind for its backward"""
+    __slots__ = ("x", "acts", "pools", "relu6", "relu7", "masks", "coarse", "B", "H", "W", "h", "w", "train")
+
+
+class _Engine(object):
+    """Owns device-side weight images and runs the kernel sequence for one FCN32s instance."""
+
+    def __init__(self, model):
+        self.model = model
+        self.dtype = torch.float32
+        self._versions = None
+        self._images = {}
+        self.dropout_seed = 1337
+        self.dropout_calls = 0
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def set_precision(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise L.SznError("compute dtype must be float32 or bfloat16")
+        if dtype != self.dtype:
+            self.dtype = dtype
+            self._versions = None
+
+    def mark_dirty(self):
+        self._versions = None
+
+    def _param_versions(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def _ohwi(self, p):
+        """fp32 OHWI-contiguous storage of an (O,I,KH,KW) parameter (zero-copy when already channels_last)"""
+        t = p.detach()
+        if t.dtype != torch.float32:
+            t = t.float()
+        return t.permute(0, 2, 3, 1).contiguous()
+
+    def sync_weights(self):
+        """refresh compute-dtype / dgrad weight images if any parameter changed since the last call"""
+        v = self._param_versions()
+        if v == self._versions:
+            return
+        m = self.model
+        dev = m.conv1_1.weight.device
+        if dev.type != "cuda":
+            raise L.SznError("FCN32s parameters live on %s: the HIP path needs them on the GPU (model.cuda())" % dev)
+        dt, code = self.dtype, L.dtype_code(self.dtype)
+        img = {}
+        st = L.stream_ptr()
+        for name, co, ci, k in synth.CONV_LAYERS:
+            layer = getattr(m, name)
+            w32 = self._ohwi(layer.weight)
+            img[name + ".b"] = layer.bias.detach().float().contiguous()
+            if name == "conv1_1":
+                img[name + ".w"] = w32                       # conv1_1 kernel reads fp32 weights
+                continue
+            wc = w32 if dt == torch.float32 else w32.to(dt)
+            img[name + ".w"] = wc
+            wt = torch.empty(ci, k, k, co, device=dev, dtype=dt)
+            L.call("szn_pack_weight_dgrad", code, co, k, k, ci, L.ptr(wc), L.ptr(wt), st)
+            img[name + ".wT"] = wt
+        # fused projection head: rows [0,E) = score_fr, [E,E+2) = seenmask_score, zero rows up to CP
+        E, CP, F = m.n_class, m.head_width, m.fc7.out_channels
+        wh = torch.zeros(CP, F, device=dev, dtype=torch.float32)
+        bh = torch.zeros(CP, device=dev, dtype=torch.float32)
+        wh[:E] = m.score_fr.weight.detach().float().reshape(E, F)
+        wh[E:E + 2] = m.seenmask_score.weight.detach().float().reshape(2, F)
+        bh[:E] = m.score_fr.bias.detach().float()
+        bh[E:E + 2] = m.seenmask_score.bias.detach().float()
+        whc = wh if dt == torch.float32 else wh.to(dt)
+        wht = torch.empty(F, CP, device=dev, dtype=dt)
+        L.call("szn_pack_weight_dgrad", code, CP, 1, 1, F, L.ptr(whc), L.ptr(wht), st)
+        img["head.w"], img["head.b"], img["head.wT"] = whc.view(CP, 1, 1, F), bh, wht.view(F, 1, 1, CP)
+        img["up.w"] = m.seenmask_upscore.weight.detach().float().contiguous()
+        self._images = img
+        self._versions = v
+
+    # ---- kernels ---------------------------------------------------------------------------------
+    def _conv(self, x, name, pad, relu=True, scale=None, out_f32=False, w=None, b=None, co=None, k=None):
+        B, Hi, Wi, Ci = x.shape
+        img = self._images
+        w = img[name + ".w"] if w is None else w
+        b = img[name + ".b"] if b is None else b
+        co = w.shape[0] if co is None else co
+        k = w.shape[1] if k is None else k
+        Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
+        out = torch.empty(B, Ho, Wo, co, device=x.device, dtype=torch.float32 if out_f32 else self.dtype)
+        d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, co, k, k, pad, Ci, co, 0, int(relu), int(out_f32))
+        L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), None, L.ptr(scale), L.ptr(out), L.stream_ptr())
+        return out
+
+    def _pool(self, x):
+        B, Hi, Wi, Cc = x.shape
+        out = torch.empty(B, (Hi + 1) // 2, (Wi + 1) // 2, Cc, device=x.device, dtype=self.dtype)
+        L.call("szn_maxpool2x2_ceil_fwd", L.dtype_code(self.dtype), B, Hi, Wi, Cc, L.ptr(x), L.ptr(out), L.stream_ptr())
+        return out
+
+    def make_masks(self, B, F, device):
+        """Dropout2d factors (B,F) in {0, 2} for drop6 / drop7 (models.py:86,91; p = 0.5)"""
+        masks = []
+        for _ in range(2):
+            mk = torch.empty(B, F, device=device, dtype=torch.float32)
+            L.call("szn_dropout2d_mask", B * F, 0.5, self.dropout_seed, self.dropout_calls * (1 << 24), L.ptr(mk),
+                   L.stream_ptr())
+            self.dropout_calls += 1
+            masks.append(mk)
+        return masks
+
+    def forward(self, x, train=False, masks=None):
+        """x (B,3,H,W) f32 NCHW on the GPU -> ctx with ctx.coarse (B,h,w,CP) f32: projection-head output at 1/32"""
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise L.SznError("FCN32s expects (B,3,H,W) input, got %s" % (tuple(x.shape),))
+        if not x.is_cuda:
+            raise L.SznError("FCN32s input must live on the GPU (no CPU fallback in the product path)")
+        self.sync_weights()
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        m = self.model
+        code = L.dtype_code(self.dtype)
+        ctx = _Ctx()
+        ctx.x, ctx.B, ctx.H, ctx.W, ctx.train = x, B, H, W, train
+        H1, W1 = H + 2 * PAD1 - 2, W + 2 * PAD1 - 2
+        a = torch.empty(B, H1, W1, 64, device=x.device, dtype=self.dtype)
+        L.call("szn_conv1_1_fwd", code, B, H, W, PAD1, L.ptr(x), L.ptr(self._images["conv1_1.w"]),
+               L.ptr(self._images["conv1_1.b"]), L.ptr(a), L.stream_ptr())
+        acts, pools = {"conv1_1": a}, []
+        for item in _BACKBONE[1:]:
+            if item == "P":
+                pin = a
+                a = self._pool(a)
+                pools.append((pin, a))
+            else:
+                name, pad = item
+                a = self._conv(a, name, pad)
+                acts[name] = a
+        if train and masks is None:
+            masks = self.make_masks(B, m.fc6.out_channels, x.device)
+        ctx.masks = masks if train else None
+        s6 = ctx.masks[0] if ctx.masks is not None else None
+        s7 = ctx.masks[1] if ctx.masks is not None else None
+        ctx.relu6 = self._conv(a, "fc6", 0, scale=s6)            # relu -> dropout factor, fused epilogue
+        ctx.relu7 = self._conv(ctx.relu6, "fc7", 0, scale=s7)
+        ctx.acts, ctx.pools = acts, pools
+        ctx.coarse = self._conv(ctx.relu7, "head", 0, relu=False, out_f32=True)
+        ctx.h, ctx.w = ctx.coarse.shape[1:3]
+        return ctx
+
+    def upscore(self, ctx):
+        """coarse -> f (B,E,H,W) f32 NCHW: fixed bilinear ConvTranspose2d + crop (models.py:146-147)"""
+        m = self.model
+        f = torch.empty(ctx.B, m.n_class, ctx.H, ctx.W, device=ctx.coarse.device, dtype=torch.float32)
+        L.call("szn_bilinear_up32_crop_fwd", ctx.B, ctx.h, ctx.w, m.n_class, m.head_width, 0, ctx.H, ctx.W, CROP,
+               L.ptr(ctx.coarse), L.ptr(f), L.stream_ptr())
+        return f
+
+    def seenmask_upscore(self, ctx):
+        """coarse -> s (B,2,H,W): learned dense ConvTranspose2d + crop (models.py:150-151)"""
+        m = self.model
+        s = torch.empty(ctx.B, 2, ctx.H, ctx.W, device=ctx.coarse.device, dtype=torch.float32)
+        L.call("szn_deconv64s32_fwd", ctx.B, ctx.h, ctx.w, 2, m.head_width, m.n_class, ctx.H, ctx.W, CROP,
+               L.ptr(ctx.coarse), L.ptr(self._images["up.w"]), L.ptr(s), L.stream_ptr())
+        return s
+
+    # ---- backward --------------------------------------------------------------------------------
+    def head_backward(self, ctx, df=None, ds=None, dcoarse=None):
+        """(df, ds) gradients of the two full-resolution outputs -> dcoarse (B,h,w,CP) f32 (+ d seenmask_upscore.weight)"""
+        m = self.model
+        dev = ctx.coarse.device
+        if dcoarse is None:
+            dcoarse = torch.zeros(ctx.B, ctx.h, ctx.w, m.head_width, device=dev, dtype=torch.float32)
+        dup = None
+        if df is not None:
+            df = df.contiguous().float()
+            L.call("szn_bilinear_up32_crop_bwd", ctx.B, ctx.h, ctx.w, m.n_class, m.head_width, 0, ctx.H, ctx.W, CROP,
+                   L.ptr(df), L.ptr(dcoarse), L.stream_ptr())
+        if ds is not None:
+            ds = ds.contiguous().float()
+            L.call("szn_deconv64s32_dgrad", ctx.B, ctx.h, ctx.w, 2, m.head_width, m.n_class, ctx.H, ctx.W, CROP,
+                   L.ptr(ds), L.ptr(self._images["up.w"]), L.ptr(dcoarse), L.stream_ptr())
+            dup = torch.empty(2, 2, 64, 64, device=dev, dtype=torch.float32)
+            L.call("szn_deconv64s32_wgrad", ctx.B, ctx.h, ctx.w, 2, m.head_width, m.n_class, ctx.H, ctx.W, CROP,
+                   L.ptr(ctx.coarse), L.ptr(ds), L.ptr(dup), 0, L.stream_ptr())
+        return dcoarse, dup
+
+    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None):
+        B, Hi, Wi, _ = x.shape
+        Ho, Wo = dout.shape[1:3]
+        ldo = dout.shape[3] if ldo is None else ldo
+        code = L.dtype_code(self.dtype)
+        d = L.ConvDesc(code, B, Hi, Wi, ci, Ho, Wo, co, k, k, pad, ci, ldo, 0, 0, 0)
+        st = L.stream_ptr()
+        L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
+        if db is not None:
+            L.call("szn_bias_grad", code, B * Ho * Wo, co, ldo, L.ptr(dout), L.ptr(db), 0, st)
+
+    def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None):
+        B, Hi, Wi, Ci = in_shape
+        Ho, Wo, Co = dout.shape[1:]
+        wT = self._images[name + ".wT"]
+        k = wT.shape[1]
+        din = torch.empty(B, Hi, Wi, Ci, device=dout.device, dtype=self.dtype)
+        d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, Ci, 0, 0)
+        L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
+        return din
+
+    def backward(self, ctx, dcoarse, grads, backbone=True):
+        """dcoarse (B,h,w,CP) f32 or compute dtype -> fills grads[name] = (dw OHWI f32, db f32) for every layer
+        present in `grads` ('head' holds the fused score_fr||seenmask_score gradient, CP rows)."""
+        m = self.model
+        dt = self.dtype
+        code = L.dtype_code(dt)
+        st = L.stream_ptr()
+        dc = dcoarse if dcoarse.dtype == dt else dcoarse.to(dt)      # tiny (B*h*w*CP)
+        feat = ctx.relu7
+        F = m.fc7.out_channels
+        if "head" in grads:
+            dwh, dbh = grads["head"]
+            self._wgrad(feat, dc, dwh, dbh, F, m.head_width, 1, 0)
+        if not backbone:
+            return
+        s6 = ctx.masks[0] if ctx.masks is not None else None
+        s7 = ctx.masks[1] if ctx.masks is not None else None
+        # d(fc7 pre-activation): ReLU gate (feat > 0) and dropout factor fused into the dgrad epilogue
+        d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7)
+        self._wgrad(ctx.relu6, d, grads["fc7"][0], grads["fc7"][1], F, F, 1, 0)
+        d = self._dgrad(d, "fc7", ctx.relu6.shape, 0, gate=ctx.relu6, scale=s6)
+        pool5 = ctx.pools[4][1]
+        self._wgrad(pool5, d, grads["fc6"][0], grads["fc6"][1], pool5.shape[3], F, 7, 0)
+        d = self._dgrad(d, "fc6", pool5.shape, 0)
+        pi = 4
+        prev_out = None
+        items = _BACKBONE
+        for idx in range(len(items) - 1, -1, -1):
+            item = items[idx]
+            if item == "P":
+                pin, pout = ctx.pools[pi]
+                pi -= 1
+                B, Hi, Wi, Cc = pin.shape
+                dn = torch.empty_like(pin)
+                L.call("szn_maxpool2x2_ceil_bwd", code, B, Hi, Wi, Cc, L.ptr(pin), L.ptr(pout), L.ptr(d), L.ptr(dn), st)
+                d = dn
+                continue
+            name, pad = item
+            if name == "conv1_1":
+                dw, db = grads[name]
+                L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), L.ptr(db), 0, st)
+                break
+            prev = items[idx - 1]
+            xin = ctx.pools[pi][1] if prev == "P" else ctx.acts[prev[0]]
+            layer = getattr(m, name)
+            self._wgrad(xin, d, grads[name][0], grads[name][1], layer.in_channels, layer.out_channels, 3, pad)
+            # next d: wrt this conv's input; gate by the ReLU of the producing conv unless a pool sits in between
+            d = self._dgrad(d, name, xin.shape, pad, gate=None if prev == "P" else xin)
+
+
+class _Backbone(torch.autograd.Function):
+    """autograd bridge: parameters -> coarse projection map; backward runs the HIP dgrad/wgrad chain"""
+
+    @staticmethod
+    def forward(ctx, model, x, train, masks, *params):
+        eng = model._engine
+        c = eng.forward(x, train=train, masks=masks)
+        ctx.model, ctx.c = model, c
+        model._last_ctx = c
+        return c.coarse
+
+    @staticmethod
+    def backward(ctx, dcoarse):
+        model, c = ctx.model, ctx.c
+        eng = model._engine
+        dev = dcoarse.device
+        need = ctx.needs_input_grad[4:]
+        names = [n for n, _ in model.named_parameters()]
+        need_of = dict(zip(names, need))
+        backbone = any(need_of.get(n + ".weight", False) for n in _TRUNK)
+        grads = {}
+        for name, co, ci, k in synth.CONV_LAYERS:
+            if backbone:
+                grads[name] = (torch.empty(co, k, k, ci, device=dev), torch.empty(co, device=dev))
+        CP, F, E = model.head_width, model.fc7.out_channels, model.n_class
+        grads["head"] = (torch.empty(CP, 1, 1, F, device=dev), torch.empty(CP, device=dev))
+        eng.backward(c, dcoarse.contiguous(), grads, backbone=backbone)
+        out = []
+        for n in names:
+            layer, kind = n.rsplit(".", 1)
+            if not need_of[n] or layer in ("upscore", "seenmask_upscore"):
+                out.append(None)
+            elif layer == "score_fr":
+                g = grads["head"][0][:E].reshape(E, F, 1, 1) if kind == "weight" else grads["head"][1][:E]
+                out.append(g.clone())
+            elif layer == "seenmask_score":
+                g = grads["head"][0][E:E + 2].reshape(2, F, 1, 1) if kind == "weight" else grads["head"][1][E:E + 2]
+                out.append(g.clone())
+            elif layer in grads:
+                out.append(grads[layer][0].permute(0, 3, 1, 2) if kind == "weight" else grads[layer][1])
+            else:
+                out.append(None)
+        return (None, None, None, None) + tuple(out)
+
+
+class _Upscore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, coarse):
+        c = model._last_ctx
+        ctx.model, ctx.c = model, c
+        return model._engine.upscore(c)
+
+    @staticmethod
+    def backward(ctx, df):
+        dcoarse, _ = ctx.model._engine.head_backward(ctx.c, df=df)
+        return None, dcoarse
+
+
+class _SeenmaskUpscore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, coarse, weight):
+        c = model._last_ctx
+        ctx.model, ctx.c = model, c
+        return model._engine.seenmask_upscore(c)
+
+    @staticmethod
+    def backward(ctx, ds):
+        dcoarse, dup = ctx.model._engine.head_backward(ctx.c, ds=ds)
+        return None, dcoarse, dup
+
+
+class FCN32s(nn.Module):
+    """Reference models.py:27-193.  n_class = embedding dimension E (train.py:102-105)."""
+
+    pretrained_model = 'data/fcn32s_from_caffe.pth'
+
+    def __init__(self, n_class=21):
+        super(FCN32s, self).__init__()
+        self.n_class = n_class
+        self.head_width = _round_up(n_class + 2, 64)
+        chans = {n: (ci, co, k) for n, co, ci, k in synth.CONV_LAYERS}
+
+        def conv(name, pad):
+            ci, co, k = chans[name]
+            return nn.Conv2d(ci, co, k, padding=pad)
+
+        # conv1
+        self.conv1_1 = conv("conv1_1", PAD1); self.relu1_1 = nn.ReLU(inplace=True)
+        self.conv1_2 = conv("conv1_2", 1); self.relu1_2 = nn.ReLU(inplace=True)
+        self.pool1 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
+        # conv2
+        self.conv2_1 = conv("conv2_1", 1); self.relu2_1 = nn.ReLU(inplace=True)
+        self.conv2_2 = conv("conv2_2", 1); self.relu2_2 = nn.ReLU(inplace=True)
+        self.pool2 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
+        # conv3
+        self.conv3_1 = conv("conv3_1", 1); self.relu3_1 = nn.ReLU(inplace=True)
+        self.conv3_2 = conv("conv3_2", 1); self.relu3_2 = nn.ReLU(inplace=True)
+        self.conv3_3 = conv("conv3_3", 1); self.relu3_3 = nn.ReLU(inplace=True)
+        self.pool3 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
+        # conv4
+        self.conv4_1 = conv("conv4_1", 1); self.relu4_1 = nn.ReLU(inplace=True)
+        self.conv4_2 = conv("conv4_2", 1); self.relu4_2 = nn.ReLU(inplace=True)
+        self.conv4_3 = conv("conv4_3", 1); self.relu4_3 = nn.ReLU(inplace=True)
+        self.pool4 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
+        # conv5
+        self.conv5_1 = conv("conv5_1", 1); self.relu5_1 = nn.ReLU(inplace=True)
+        self.conv5_2 = conv("conv5_2", 1); self.relu5_2 = nn.ReLU(inplace=True)
+        self.conv5_3 = conv("conv5_3", 1); self.relu5_3 = nn.ReLU(inplace=True)
+        self.pool5 = nn.MaxPool2d(2, stride=2, ceil_mode=True)
+        # fc6 / fc7
+        self.fc6 = nn.Conv2d(512, 4096, 7); self.relu6 = nn.ReLU(inplace=True); self.drop6 = nn.Dropout2d()
+        self.fc7 = nn.Conv2d(4096, 4096, 1); self.relu7 = nn.ReLU(inplace=True); self.drop7 = nn.Dropout2d()
+        # heads
+        self.score_fr = nn.Conv2d(4096, n_class, 1)
+        self.upscore = nn.ConvTranspose2d(n_class, n_class, 64, stride=32, bias=False)
+        self.seenmask_score = nn.Conv2d(4096, 2, 1)
+        self.seenmask_upscore = nn.ConvTranspose2d(2, 2, 64, stride=32, bias=False)
+        self._initialize_weights()
+        # OHWI memory order for every k > 1 conv weight (== channels_last): the kernels read the masters in place
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                mod.weight.data = mod.weight.data.contiguous(memory_format=torch.channels_last)
+        object.__setattr__(self, "_engine", _Engine(self))
+        object.__setattr__(self, "_last_ctx", None)
+
+    def _initialize_weights(self):
+        # only the transposed convolutions are (re)initialised -- bilinear kernels (models.py:102-112)
+        for mod in self.modules():
+            if isinstance(mod, nn.ConvTranspose2d):
+                assert mod.kernel_size[0] == mod.kernel_size[1]
+                mod.weight.data.copy_(get_upsampling_weight(mod.in_channels, mod.out_channels, mod.kernel_size[0]))
+
+    # ---- precision / synthetic init ----------------------------------------------------------------
+    def set_precision(self, dtype):
+        """compute dtype of the HIP path: torch.float32 (parity) or torch.bfloat16 (throughput)"""
+        self._engine.set_precision(dtype)
+        return self
+
+    def load_synthetic(self, seed=1337):
+        """deterministic He-uniform weights (no VGG16 download available): synth.make_params"""
+        sd = self.state_dict()
+        for k, v in synth.make_params(self.n_class, seed).items():
+            sd[k].copy_(torch.from_numpy(v))
+        self._engine.mark_dirty()
+        return self
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, x, mode='fcn', dropout_masks=None):
+        if mode not in ('fcn', 'seenmask', 'both'):
+            raise Exception('model given unexpected forward mode')
+        params = [p for _, p in self.named_parameters()]
+        coarse = _Backbone.apply(self, x, self.training, dropout_masks, *params)
+        # only the requested head is evaluated (the reference computes both and discards one, models.py:145-160)
+        f = _Upscore.apply(self, coarse) if mode in ('fcn', 'both') else None
+        s = _SeenmaskUpscore.apply(self, coarse, self.seenmask_upscore.weight) if mode in ('seenmask', 'both') else None
+        if mode == 'fcn':
+            return f
+        if mode == 'seenmask':
+            return s
+        return f, s
+
+    def copy_params_from_vgg16(self, vgg16):
+        """reference models.py:162-193: zip vgg16.features with our conv list; fc6/fc7 from classifier[0], [3]"""
+        features = []
+        for item in _BACKBONE:
+            if item == "P":
+                features.append(None)
+            else:
+                features += [getattr(self, item[0]), None]
+        for l1, l2 in zip(vgg16.features, features):
+            if isinstance(l1, nn.Conv2d) and isinstance(l2, nn.Conv2d):
+                assert l1.weight.size() == l2.weight.size()
+                assert l1.bias.size() == l2.bias.size()
+                l2.weight.data.copy_(l1.weight.data)
+                l2.bias.data.copy_(l1.bias.data)
+        for i, name in zip([0, 3], ['fc6', 'fc7']):
+            l1 = vgg16.classifier[i]
+            l2 = getattr(self, name)
+            l2.weight.data.copy_(l1.weight.data.view(l2.weight.size()))
+            l2.bias.data.copy_(l1.bias.data.view(l2.bias.size()))
+        self._engine.mark_dirty()
+
+
+def VGG16(pretrained=False, data_dir='data'):
+    """reference models.py:195-210 builds torchvision's VGG16 and downloads caffe weights (no network here).
+    Accepts a local `<data_dir>/models/vgg16_from_caffe.pth` state dict; otherwise raises."""
+    class _VGG(nn.Module):
+        def __init__(self):
+            super(_VGG, self).__init__()
+            layers, cin = [], 3
+            for v in [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']:
+                if v == 'M':
+                    layers.append(nn.MaxPool2d(2, 2))
+                else:
+                    layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                    cin = v
+            self.features = nn.Sequential(*layers)
+            self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(),
+                                            nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 1000))
+    model = _VGG()
+    if not pretrained:
+        return model
+    model_path = osp.join(data_dir, 'models/vgg16_from_caffe.pth')
+    if not osp.exists(model_path):
+        raise IOError("pretrained VGG16 weights not found at %s (no network access to download them); "
+                      "use FCN32s.load_synthetic() or place the file there" % model_path)
+    model.load_state_dict(torch.load(model_path))
+    return model

@@ -84,10 +84,10 @@ def bilinear_filter_1d(k=64):
 def bilinear_weight(cin, cout, k=64):
     """(cin, cout, k, k) float32: the filter on the channel diagonal, zeros elsewhere (models.py:21-24)."""
     f = bilinear_filter_1d(k)
-    filt = f[:, None] * f[None, :]
-    w = np.zeros((cin, cout, k, k), dtype=np.float64)
+    filt = (f[:, None] * f[None, :]).astype(np.float32)      # float64 product, then float32 (models.py:24)
+    w = np.zeros((cin, cout, k, k), dtype=np.float32)
     w[range(min(cin, cout)), range(min(cin, cout))] = filt
-    return w.astype(np.float32)
+    return w
 
 
 def make_images(B, H, W, seed=1337):
