@@ -1,0 +1,59 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient exchange (engine.GradBuckets) used by TrainStep over RCCL."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zeroshotsemanticsegmentation_amd.engine import GradBuckets
+    layers, off = [], 0
+    for i, n in enumerate([27, 5000, 120, 9000, 64, 7]):            # forward-order layer sizes
+        layers.append(("L%d" % i, off, n))
+        off += n
+    flat = torch.arange(off, dtype=torch.float32) * (rank + 1)
+    bias = torch.full((11,), float(rank + 1))
+    gb = GradBuckets(flat, layers, bucket_elems=4000, extra=[bias])
+    # buckets are contiguous, cover everything once, in backward order, each >= 4000 elems except the last
+    spans = [(o, e) for o, e, _ in gb.buckets]
+    assert spans[0][1] == off and spans[-1][0] == 0
+    assert all(spans[i][0] == spans[i + 1][1] for i in range(len(spans) - 1))
+    assert all(e - o >= 4000 for o, e in spans[:-1])
+    for name, _, _ in reversed(layers):                               # backward completion order
+        gb.layer_done(name)
+    gb.finish()
+    want = torch.arange(off, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = torch.equal(flat, want) and torch.equal(bias, torch.full((11,), float(sum(r + 1 for r in range(world)))))
+    # the optimizer applies grad_scale = 1/world: mean of the rank gradients
+    ok = ok and torch.allclose(flat / world, torch.arange(off, dtype=torch.float32) * 1.5)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_single_process_is_noop():
+    from zeroshotsemanticsegmentation_amd.engine import GradBuckets
+    flat = torch.ones(10)
+    gb = GradBuckets(flat, [("a", 0, 4), ("b", 4, 6)], bucket_elems=1)
+    gb.layer_done("b"); gb.layer_done("a"); gb.finish()
+    assert torch.equal(flat, torch.ones(10)) and gb.world == 1

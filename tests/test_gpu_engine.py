@@ -1,0 +1,140 @@
+"""GPU tests of the fused training step (engine.TrainStep) and the fused-from-coarse head (szn_fused_head):
+the fused path must reproduce the unfused kernel sequence / the golden train step of the reference.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import szn_oracle as O  # noqa: E402
+from zeroshotsemanticsegmentation_amd import _lib as L  # noqa: E402
+from zeroshotsemanticsegmentation_amd import engine, models, synth, utils  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("case", [(2, 3, 4, 20, 33, 70, 101), (1, 17, 17, 300, 21, 512, 512), (1, 1, 1, 20, 21, 1, 1),
+                                  (2, 2, 2, 20, 59, 32, 32)])
+def test_fused_head_matches_unfused(case):
+    B, h, w, E, K, H, W = case
+    CP = (E + 2 + 63) // 64 * 64
+    emb = synth.make_embeddings(K, E, seed=5)
+    coarse = np.zeros((B, h, w, CP), np.float32)
+    coarse[..., :E + 2] = synth.uniform(31 + E, (B, h, w, E + 2), -2, 2)
+    target = synth.make_labels(B, H, W, K, seed=32 + K, block=8, ignore_frac=0.1)
+    c, e, t = cu(coarse), cu(emb), cu(target)
+    st = L.stream_ptr()
+    # unfused reference sequence on the GPU
+    f = torch.empty(B, E, H, W, device="cuda")
+    L.call("szn_bilinear_up32_crop_fwd", B, h, w, E, CP, 0, H, W, 19, L.ptr(c), L.ptr(f), st)
+    fr = f.clone().requires_grad_(True)
+    loss_u = utils.cosine_loss(fr, t, e)
+    loss_u.backward()
+    dc_u = torch.zeros(B, h, w, CP, device="cuda")
+    L.call("szn_bilinear_up32_crop_bwd", B, h, w, E, CP, 0, H, W, 19, L.ptr(fr.grad.contiguous()), L.ptr(dc_u), st)
+    pred_u = utils.infer_lbl_device(f, e)
+    # fused
+    ws = torch.empty(L.load().szn_fused_head_workspace_bytes(B, h, w, E, K), dtype=torch.uint8, device="cuda")
+    loss = torch.empty(1, device="cuda"); stats = torch.empty(B, 2, device="cuda")
+    pred = torch.empty(B, H, W, dtype=torch.int64, device="cuda")
+    dc = torch.zeros(B, h, w, CP, device="cuda")
+    L.call("szn_fused_head", B, h, w, E, CP, 0, H, W, 19, K, L.ptr(c), L.ptr(e), L.ptr(t), L.ptr(loss), L.ptr(stats),
+           L.ptr(pred), L.SZN_F32, L.ptr(dc), L.ptr(ws), st)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_u.item()) < 2e-6 * max(1.0, abs(loss_u.item()))
+    assert int(stats[:, 1].sum().item()) == int((target >= 0).sum())
+    assert rel(dc[..., :E], dc_u[..., :E]) < 1e-4
+    assert float(dc[..., E:].abs().max()) == 0.0
+    # the algebraic evaluation may flip exact near-ties only: compare against the oracle's margins
+    sims_ok = (pred == pred_u)
+    nbad = int((~sims_ok).sum())
+    assert nbad < 2e-3 * sims_ok.numel(), nbad
+    if nbad > 0:
+        fs = f.permute(0, 2, 3, 1).reshape(-1, E).double()
+        ee = e.double()
+        sim = (fs @ ee.t()) / (fs.norm(dim=1, keepdim=True) * ee.norm(dim=1)[None])
+        top = sim.sort(dim=1).values
+        margin = (top[:, -1] - top[:, -2]).reshape(B, H, W)
+        assert float(margin[~sims_ok].max()) < 1e-5
+    # bf16 dcoarse output and pred-only / loss-only call forms
+    dcb = torch.zeros(B, h, w, CP, device="cuda", dtype=torch.bfloat16)
+    L.call("szn_fused_head", B, h, w, E, CP, 0, H, W, 19, K, L.ptr(c), L.ptr(e), L.ptr(t), L.ptr(loss), L.ptr(stats),
+           None, L.SZN_BF16, L.ptr(dcb), L.ptr(ws), st)
+    assert rel(dcb.float()[..., :E], dc_u[..., :E]) < 1e-2
+    p2 = torch.empty_like(pred)
+    L.call("szn_fused_head", B, h, w, E, CP, 0, H, W, 19, K, L.ptr(c), L.ptr(e), None, None, None, L.ptr(p2), L.SZN_F32,
+           None, L.ptr(ws), st)
+    torch.cuda.synchronize()
+    assert torch.equal(p2, pred)
+
+
+PROBE_PARAMS = ["conv1_1.weight", "conv1_1.bias", "conv1_2.weight", "conv3_2.weight", "conv5_3.bias", "fc6.weight",
+                "fc7.weight", "fc7.bias", "score_fr.weight", "score_fr.bias"]
+
+
+def probe_idx(n, cnt=64):
+    return (np.arange(cnt, dtype=np.int64) * 2654435761 % n).astype(np.int64)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("optname", ["adam", "sgd"])
+def test_trainstep_matches_golden_g7(fused, optname):
+    g = np.load(os.path.join(G, "g7_train_step_%s.npz" % optname))
+    m = models.FCN32s(20).load_synthetic(1337).cuda().eval()
+    before = {k: v.detach().clone() for k, v in m.named_parameters() if k in PROBE_PARAMS}
+    lr = float(g["lr"])
+    ts = engine.TrainStep(m, g["embed"], optimizer=optname, lr=lr, precision=torch.float32, fused_head=fused)
+    named = dict(m.named_parameters())
+    x, t = cu(g["x"]), cu(g["target"])
+    for it in range(2):
+        loss, pred = ts.step(x, t)
+        assert abs(loss.item() - float(g["loss%d" % it])) < 1e-5
+        if it == 0:
+            safe = g["margin0"][None] > 1e-5
+            assert np.array_equal(pred.cpu().numpy()[safe], g["pred0"][safe])
+            for k in PROBE_PARAMS:
+                gr = named[k].grad
+                tol = 1e-2 if k == "conv1_1.bias" else 1e-3
+                assert rel(gr.flatten()[cu(probe_idx(gr.numel()))], g["grad_probe/" + k]) < tol, k
+        key = "delta_probe/" if it == 0 else "delta2_probe/"
+        for k in PROBE_PARAMS:
+            idx = cu(probe_idx(named[k].numel()))
+            d = (named[k].detach().flatten()[idx].double() - before[k].flatten()[idx].double()).cpu().numpy()
+            ulp = float(before[k].flatten()[idx].abs().max()) * 2.0 ** -23
+            rtol = 2e-2 if k == "conv1_1.bias" else 2e-3
+            assert np.abs(d - g[key + k]).max() < rtol * np.abs(g[key + k]).max() + 2 * ulp, (k, it)
+    acc, acc_cls, miu, fw = ts.metrics()
+    assert 0.0 <= acc <= 1.0
+
+
+def test_trainstep_bf16_runs_and_learns_direction():
+    E, K, H = 20, 33, 64
+    emb = np.load(os.path.join(G, "embeddings_context_20.npy"))
+    m = models.FCN32s(E).load_synthetic(1337).cuda().train()
+    ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=torch.bfloat16, fused_head=True)
+    x = cu(synth.make_images(2, H, H, seed=3)); t = cu(synth.make_labels(2, H, H, K, seed=4, block=16))
+    losses = [float(ts.step(x, t)[0]) for _ in range(4)]
+    assert all(np.isfinite(losses))
+    # fp32 loss of the same initial model within bf16 noise
+    m2 = models.FCN32s(E).load_synthetic(1337).cuda().eval()
+    with torch.no_grad():
+        l32 = utils.cosine_loss(m2(x), t, cu(emb)).item()
+    m.eval()
+    ts0 = engine.TrainStep(models.FCN32s(E).load_synthetic(1337).cuda().eval(), emb, precision=torch.bfloat16)
+    assert abs(float(ts0.step(x, t)[0]) - l32) < 2e-2

@@ -1,0 +1,137 @@
+"""CPU: host-side logic that mirrors the reference's train.py / configs.py / utils.py metrics (no GPU needed)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from zeroshotsemanticsegmentation_amd import configs, synth, train, utils  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_configs_equal_reference():
+    ref = json.load(open(os.path.join(G, "configs.json")))
+    assert {str(k): v for k, v in configs.configurations.items()} == ref
+    assert sorted(configs.configurations) == [1, 2, 4, 14, 15, 16, 17, 18, 19]
+
+
+def args(*argv):
+    return train.build_parser().parse_args(list(argv))
+
+
+def test_update_and_validate_cfg():
+    cfg = train.update_cfg_with_args(configs.configurations[18], args('-c', '18', '-e', '300', '-lr', '0.001', '-tu', '3,4'))
+    assert cfg['embed_dim'] == 300 and cfg['fcn_lr'] == 0.001 and cfg['train_unseen'] == [3, 4]
+    assert cfg['one_hot_embed'] is None and cfg['forced_unseen'] is None and cfg['load_fcn_path'] is None
+    assert configs.configurations[18]['embed_dim'] == 20          # the table itself is not mutated
+    train.validate_cfg(cfg)
+    # reference quirks kept: -ve 0 cannot override (truthiness), -se is parsed but never applied
+    cfg = train.update_cfg_with_args(configs.configurations[18], args('-c', '18', '-ve', '0', '-se', '3'))
+    assert cfg['fcn_epochs'] == 59 and cfg['seenmask_epochs'] == 10
+    with pytest.raises(Exception):      # test mode needs -r
+        train.validate_cfg(train.update_cfg_with_args(configs.configurations[19], args('-c', '19')))
+    with pytest.raises(Exception):      # seenmask phase without train_unseen
+        c = dict(train.update_cfg_with_args(configs.configurations[4], args('-c', '4')), seenmask_epochs=2)
+        train.validate_cfg(c)
+    with pytest.raises(Exception):      # cos loss without an embedding space
+        c = dict(train.update_cfg_with_args(configs.configurations[1], args('-c', '1')), fcn_loss='cos')
+        train.validate_cfg(c)
+    with pytest.raises(SystemExit):     # -e choices as in the reference
+        args('-e', '33')
+
+
+def test_log_dir_name(tmp_path):
+    import datetime
+    cfg = train.update_cfg_with_args(configs.configurations[14], args('-c', '14'))
+    now = datetime.datetime(2018, 4, 21, 16, 37, 51)
+    d = train.get_log_dir('8_2_10', 14, cfg, str(tmp_path), now=now)
+    # the reference's own run name for cfg 14 (configs.py:83, load_fcn_path of cfg 15)
+    assert os.path.basename(d) == configs.configurations[15]['load_fcn_path']
+    assert os.path.isdir(d)
+
+
+def test_get_parameters_groups():
+    from zeroshotsemanticsegmentation_amd import models
+    m = models.FCN32s(n_class=20)
+    ws = list(train.get_parameters(m, bias=False))
+    bs = list(train.get_parameters(m, bias=True))
+    sm = list(train.get_parameters(m, seenmask=True))
+    assert len(ws) == 16 and len(bs) == 16 and len(sm) == 3
+    assert sum(p.numel() for p in ws) + sum(p.numel() for p in bs) == 134342484      # SURVEY A2, E = 20
+    ids = {id(p) for p in ws + bs}
+    assert id(m.upscore.weight) not in ids and id(m.seenmask_score.weight) not in ids
+    assert [tuple(p.shape) for p in sm] == [(2, 4096, 1, 1), (2,), (2, 2, 64, 64)]
+    m.extra = nn.Linear(2, 2)
+    with pytest.raises(ValueError):
+        list(train.get_parameters(m))
+    del m.extra
+    train.freeze_for_seenmask(m)
+    assert [n for n, p in m.named_parameters() if p.requires_grad] == ['seenmask_score.weight', 'seenmask_score.bias',
+                                                                      'seenmask_upscore.weight']
+    # state_dict surface of the reference
+    keys = list(m.state_dict().keys())
+    assert keys[:2] == ['conv1_1.weight', 'conv1_1.bias'] and 'upscore.weight' in keys and len(keys) == 36
+    assert tuple(m.upscore.weight.shape) == (20, 20, 64, 64) and m.upscore.bias is None
+    assert torch.equal(m.upscore.weight[3, 3], m.seenmask_upscore.weight[1, 1]) and float(m.upscore.weight[0, 1].abs().sum()) == 0
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 3, 4, 4), mode='nope')
+
+
+def test_copy_params_from_vgg16():
+    from zeroshotsemanticsegmentation_amd import models
+    vgg = models.VGG16(pretrained=False)
+    m = models.FCN32s(n_class=5)
+    m.copy_params_from_vgg16(vgg)
+    assert torch.equal(m.conv3_2.weight, vgg.features[12].weight)
+    assert torch.equal(m.fc6.weight.reshape(4096, -1), vgg.classifier[0].weight)
+    assert torch.equal(m.fc7.bias, vgg.classifier[3].bias)
+    with pytest.raises(IOError):
+        models.VGG16(pretrained=True, data_dir='/nonexistent')
+
+
+def test_metrics_host_path_against_golden():
+    g = np.load(os.path.join(G, "g6_metrics.npz"))
+    lt, lp = list(g["lt"]), list(g["lp"])
+    np.testing.assert_allclose(utils.label_accuracy_score(lt, lp, 33), g["metrics"], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(np.array(utils.label_accuracy_score(lt, lp, 33, unseen=[16, 18])), g["metrics3"], rtol=1e-12,
+                               equal_nan=True)
+    lt2, lp2 = [g["lt_adv0"], g["lt_adv1"]], [g["lp_adv0"], g["lp_adv1"]]
+    np.testing.assert_allclose(utils.label_accuracy_score(lt2, lp2, 33), g["metrics_adv"], rtol=1e-12, equal_nan=True)
+
+
+def test_synth_is_deterministic_and_shaped():
+    a, b = synth.make_params(20), synth.make_params(20)
+    assert all(np.array_equal(a[k], b[k]) for k in a) and a["fc6.weight"].shape == (4096, 512, 7, 7)
+    x = synth.make_images(2, 8, 9)
+    assert x.shape == (2, 3, 8, 9) and x.dtype == np.float32 and -123.0 <= x.min() and x.max() <= 151.0
+    lbl = synth.make_labels(2, 70, 40, 21)
+    assert lbl.min() == -1 and lbl.max() <= 20 and 0.02 < (lbl == -1).mean() < 0.09
+    e = synth.make_embeddings(59, 300)
+    n = np.linalg.norm(e, axis=1)
+    assert e.shape == (59, 300) and abs(n.max() - 1.0) < 1e-6 and n.min() > 0.62
+    assert synth.unseen_bits([0, 12, 63]) == (1 | (1 << 12) | (1 << 63))
+
+
+def test_seenmask_binary_target_rule():
+    from zeroshotsemanticsegmentation_amd import trainer_seenmask
+    g = np.load(os.path.join(G, "g8_seenmask_step.npz"))
+
+    class DS(object):
+        class_names = ['c%d' % i for i in range(33)]
+
+    class Loader(object):
+        dataset = DS()
+
+    tr = trainer_seenmask.Trainer.__new__(trainer_seenmask.Trainer)
+    tr.n_class, tr.device = 33, torch.device("cpu")
+    seen = [x for x in range(33) if x not in list(g["unseen"])]
+    tr._seen_lut = torch.zeros(34, dtype=torch.int64)
+    tr._seen_lut[torch.tensor(seen)] = 1
+    got = tr.binary_target(torch.from_numpy(g["target"]))
+    assert np.array_equal(got.numpy(), g["bin_target"])          # -1 -> 0 ("unseen"), not ignored

@@ -343,10 +343,20 @@ def g9_embeddings():
             print("embeddings_%s_%d sha256[:16]=%s" % (ds, E, hashlib.sha256(emb.tobytes()).hexdigest()[:16]))
 
 
+def g0_configs():
+    """the numbered experiment dicts (reference configs.py) as data, for the host-side parity test"""
+    import json
+    import configs as ref_configs  # reference
+    with open(os.path.join(OUT, "configs.json"), "w") as f:
+        json.dump({str(k): v for k, v in ref_configs.configurations.items()}, f, indent=1, sort_keys=True)
+    print("wrote configs.json")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     run = lambda tag: not only or tag in only
+    if run("g0"): g0_configs()
     if run("g1"): g1_upsampling()
     if run("g9"): g9_embeddings()
     if run("g4"): g4_losses()

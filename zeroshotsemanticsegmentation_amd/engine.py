@@ -1,0 +1,215 @@
+"""engine.py -- the fused training step of the SZN path (what bench.py measures and the trainers run).
+
+One `TrainStep.step(x, target)` is the reference's hot loop body (trainer_fcn.py:149-180):
+    forward (models.py:114-160, train mode)  ->  cosine loss (utils.py:75-102)  ->  train-time
+    infer_lbl (utils.py:159-185)  ->  backward  ->  [gradient all-reduce over RCCL]  ->  Adam / SGD step
+    (train.py:126-133)  ->  confusion histogram for the running metrics (utils.py:104-154)
+without autograd bookkeeping: parameters, gradients and optimizer moments live in flat fp32 buffers (the
+module's Parameters are channels_last views into them), the head runs fused from the 1/32 map
+(szn_fused_head) and the per-layer gradient buckets are all-reduced on RCCL's stream while the rest of the
+backward pass is still running.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import synth
+from .models import _OPT_LAYERS, CROP
+from .synth import unseen_bits
+
+
+class GradBuckets(object):
+    """Data-parallel exchange of the flat weight gradient: contiguous buckets in BACKWARD completion order.
+
+    `layers` = [(name, offset, count)] in FORWARD order inside `flat`; backward finishes them last-to-first, so the
+    tail of `flat` becomes final first.  A bucket is closed once it holds >= bucket_elems elements (or at the first
+    layer) and its sum all-reduce is issued asynchronously (RCCL's own stream; gloo in the CPU tests) as soon as the
+    bucket's earliest layer reports `layer_done`; `finish` waits for everything.  The 1/world scaling is applied by the
+    optimizer kernel (grad_scale), not here."""
+
+    def __init__(self, flat, layers, bucket_elems, extra=(), group=None):
+        self.flat, self.extra, self.group = flat, list(extra), group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.buckets = []            # (start, end, name of the layer whose completion closes the bucket)
+        end = None
+        for name, off, cnt in reversed(layers):
+            if end is None:
+                end = off + cnt
+            if end - off >= bucket_elems or name == layers[0][0]:
+                self.buckets.append((off, end, name))
+                end = None
+        self.ready_after = {name: (o, e) for o, e, name in self.buckets}
+        self.works = []
+
+    def layer_done(self, name):
+        if self.world > 1 and name in self.ready_after:
+            o, e = self.ready_after[name]
+            self.works.append(dist.all_reduce(self.flat[o:e], group=self.group, async_op=True))
+
+    def finish(self):
+        if self.world > 1:
+            for t in self.extra:
+                self.works.append(dist.all_reduce(t, group=self.group, async_op=True))
+            for wk in self.works:
+                wk.wait()
+        self.works = []
+
+
+class TrainStep(object):
+    def __init__(self, model, embeddings, optimizer="adam", lr=1e-5, momentum=0.99, weight_decay=0.0005,
+                 precision=torch.bfloat16, fused_head=True, loss="cos", process_group=None, bucket_mb=64,
+                 train_metrics=True):
+        if loss not in ("cos", "mse") or (fused_head and loss != "cos"):
+            raise L.SznError("TrainStep: fused head supports the cosine loss; use fused_head=False for mse")
+        self.model = model
+        self.eng = model._engine
+        model.set_precision(precision)
+        self.dev = model.conv1_1.weight.device
+        if self.dev.type != "cuda":
+            raise L.SznError("TrainStep needs the model on the GPU")
+        self.emb = torch.as_tensor(embeddings).to(self.dev, torch.float32).contiguous()
+        self.K, self.E = self.emb.shape
+        if self.E != model.n_class:
+            raise L.SznError("embedding dimension %d != model n_class %d" % (self.E, model.n_class))
+        self.opt, self.lr, self.momentum, self.wd = optimizer, lr, momentum, weight_decay
+        self.fused_head, self.loss_kind = fused_head, loss
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.train_metrics = train_metrics
+        self.nstep = 0
+        self._flatten()
+        self._buckets(bucket_mb)
+        self.hist = torch.zeros(3, self.K, self.K, dtype=torch.int64, device=self.dev)
+        self.loss = torch.zeros(1, device=self.dev)
+        self.stats = None
+        self._ws = None
+
+    # ---- flat parameter / gradient / moment storage ----------------------------------------------------
+    def _flatten(self):
+        m = self.model
+        ws = [getattr(m, n).weight for n in _OPT_LAYERS]
+        bs = [getattr(m, n).bias for n in _OPT_LAYERS]
+        nw, nb = sum(p.numel() for p in ws), sum(p.numel() for p in bs)
+        self.flat_w = torch.empty(nw, device=self.dev)
+        self.flat_b = torch.empty(nb, device=self.dev)
+        self.flat_gw = torch.zeros(nw, device=self.dev)
+        self.flat_gb = torch.zeros(nb, device=self.dev)
+        self.woff, self.boff = {}, {}
+        off = 0
+        for n, p in zip(_OPT_LAYERS, ws):
+            co, ci, kh, kw = p.shape
+            seg = self.flat_w[off:off + p.numel()].view(co, kh, kw, ci)
+            seg.copy_(p.detach().permute(0, 2, 3, 1))
+            p.data = seg.permute(0, 3, 1, 2)                       # channels_last view of the flat master
+            p.grad = self.flat_gw[off:off + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            self.woff[n] = (off, p.numel())
+            off += p.numel()
+        off = 0
+        for n, p in zip(_OPT_LAYERS, bs):
+            seg = self.flat_b[off:off + p.numel()]
+            seg.copy_(p.detach())
+            p.data = seg
+            p.grad = self.flat_gb[off:off + p.numel()]
+            self.boff[n] = (off, p.numel())
+            off += p.numel()
+        self.state = {}
+        for key, flat in (("w", self.flat_w), ("b", self.flat_b)):
+            if self.opt == "adam":
+                self.state[key] = (torch.zeros_like(flat), torch.zeros_like(flat))
+            else:
+                self.state[key] = (torch.zeros_like(flat),)
+        self.eng.mark_dirty()
+        # per-layer gradient targets handed to the engine (OHWI views of the flat gradient)
+        self.grads = {}
+        for n in _OPT_LAYERS[:-1]:
+            p = getattr(m, n).weight
+            co, ci, kh, kw = p.shape
+            o, cnt = self.woff[n]
+            bo, bc = self.boff[n]
+            self.grads[n] = (self.flat_gw[o:o + cnt].view(co, kh, kw, ci), self.flat_gb[bo:bo + bc])
+        CP, F = m.head_width, m.fc7.out_channels
+        self.head_gw = torch.empty(CP, 1, 1, F, device=self.dev)
+        self.head_gb = torch.empty(CP, device=self.dev)
+        self.grads["head"] = (self.head_gw, self.head_gb)
+
+    def _buckets(self, bucket_mb):
+        layers = [(n,) + self.woff[n] for n in _OPT_LAYERS]
+        self.buckets = GradBuckets(self.flat_gw, layers, bucket_mb * (1 << 20) // 4, extra=[self.flat_gb], group=self.pg)
+
+    # ---- one training step -----------------------------------------------------------------------------
+    def step(self, x, target):
+        """x (B,3,H,W) f32 NCHW, target (B,H,W) int64 (-1 ignore), both on the GPU.
+        Returns (loss 0-dim device tensor, pred (B,H,W) int64 device tensor)."""
+        m, eng = self.model, self.eng
+        B, _, H, W = x.shape
+        st = L.stream_ptr()
+        ctx = eng.forward(x, train=m.training)
+        CP, E, K = m.head_width, self.E, self.K
+        code = L.dtype_code(eng.dtype)
+        pred = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
+        stats = torch.empty(B, 2, device=self.dev)
+        dcoarse = torch.zeros(B, ctx.h, ctx.w, CP, device=self.dev, dtype=eng.dtype)
+        if self.fused_head:
+            nbytes = L.load().szn_fused_head_workspace_bytes(B, ctx.h, ctx.w, E, K)
+            if self._ws is None or self._ws.numel() < nbytes:
+                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            L.call("szn_fused_head", B, ctx.h, ctx.w, E, CP, 0, H, W, CROP, K, L.ptr(ctx.coarse), L.ptr(self.emb),
+                   L.ptr(target), L.ptr(self.loss), L.ptr(stats), L.ptr(pred), code, L.ptr(dcoarse), L.ptr(self._ws), st)
+        else:
+            f = eng.upscore(ctx)
+            ws = torch.empty(L.load().szn_loss_workspace_bytes(B, H, W), dtype=torch.uint8, device=self.dev)
+            fwd = "szn_cosine_loss_fwd" if self.loss_kind == "cos" else "szn_mse_loss_fwd"
+            bwd = "szn_cosine_loss_bwd" if self.loss_kind == "cos" else "szn_mse_loss_bwd"
+            L.call(fwd, B, E, H, W, K, L.ptr(f), L.ptr(target), L.ptr(self.emb), None, L.ptr(self.loss), L.ptr(stats),
+                   L.ptr(ws), st)
+            L.call("szn_embed_argmax", B, E, H, W, K, L.ptr(f), L.ptr(self.emb), 0, 0, None, None, L.ptr(pred), st)
+            df = torch.empty_like(f)
+            L.call(bwd, B, E, H, W, K, L.ptr(f), L.ptr(target), L.ptr(self.emb), None, L.ptr(stats), None, L.ptr(df), st)
+            dc32, _ = eng.head_backward(ctx, df=df)
+            dcoarse = dc32
+        self.stats = stats
+        self._backward(ctx, dcoarse, self.buckets.layer_done)
+        self.buckets.finish()
+        self._optimizer_step()
+        if self.train_metrics:
+            L.call("szn_confusion_hist", target.numel(), K, L.ptr(target), L.ptr(pred), 0, L.ptr(self.hist), st)
+        return self.loss.reshape(()), pred
+
+    def _backward(self, ctx, dcoarse, layer_done):
+        eng, m = self.eng, self.model
+        eng.backward(ctx, dcoarse, self.grads, backbone=True, layer_done=layer_done, head_first=self._head_copy(layer_done))
+
+    def _head_copy(self, layer_done):
+        def fn():
+            # rows [0,E) of the fused head gradient are score_fr's (seenmask_score is frozen in phase 1)
+            E, F = self.E, self.model.fc7.out_channels
+            o, cnt = self.woff["score_fr"]
+            self.flat_gw[o:o + cnt].view(E, F).copy_(self.head_gw.view(-1, F)[:E])
+            bo, bc = self.boff["score_fr"]
+            self.flat_gb[bo:bo + bc].copy_(self.head_gb[:E])
+            layer_done("score_fr")
+        return fn
+
+    def _optimizer_step(self):
+        self.nstep += 1
+        st = L.stream_ptr()
+        gs = 1.0 / self.world
+        for key, flat, grad, lr, wd in (("w", self.flat_w, self.flat_gw, self.lr, self.wd),
+                                        ("b", self.flat_b, self.flat_gb, 2 * self.lr, 0.0)):
+            if self.opt == "adam":       # train.py:130-133 (Adam has no weight decay in the reference wiring)
+                m1, m2 = self.state[key]
+                L.call("szn_adam_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr), 0.9, 0.999,
+                       1e-8, 0.0, self.nstep, gs, None, st)
+            else:                        # train.py:126-129
+                (buf,) = self.state[key]
+                L.call("szn_sgd_momentum_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(buf), float(lr),
+                       float(self.momentum), float(wd), int(self.nstep == 1), gs, None, st)
+        self.eng.mark_dirty()
+
+    def metrics(self, reset=True):
+        """running train metrics from the device histogram (trainer_fcn.py:164)"""
+        from .utils import _hist_to_metrics
+        h = self.hist[0].cpu().numpy()
+        if reset:
+            self.hist.zero_()
+        return _hist_to_metrics(h)

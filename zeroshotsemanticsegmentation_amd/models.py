@@ -251,7 +251,7 @@ class _Engine(object):
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
         return din
 
-    def backward(self, ctx, dcoarse, grads, backbone=True):
+    def backward(self, ctx, dcoarse, grads, backbone=True, layer_done=None, head_first=None):
         """dcoarse (B,h,w,CP) f32 or compute dtype -> fills grads[name] = (dw OHWI f32, db f32) for every layer
         present in `grads` ('head' holds the fused score_fr||seenmask_score gradient, CP rows)."""
         m = self.model
@@ -264,16 +264,21 @@ class _Engine(object):
         if "head" in grads:
             dwh, dbh = grads["head"]
             self._wgrad(feat, dc, dwh, dbh, F, m.head_width, 1, 0)
+            if head_first is not None:
+                head_first()
         if not backbone:
             return
+        done = layer_done if layer_done is not None else (lambda name: None)
         s6 = ctx.masks[0] if ctx.masks is not None else None
         s7 = ctx.masks[1] if ctx.masks is not None else None
         # d(fc7 pre-activation): ReLU gate (feat > 0) and dropout factor fused into the dgrad epilogue
         d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7)
         self._wgrad(ctx.relu6, d, grads["fc7"][0], grads["fc7"][1], F, F, 1, 0)
+        done("fc7")
         d = self._dgrad(d, "fc7", ctx.relu6.shape, 0, gate=ctx.relu6, scale=s6)
         pool5 = ctx.pools[4][1]
         self._wgrad(pool5, d, grads["fc6"][0], grads["fc6"][1], pool5.shape[3], F, 7, 0)
+        done("fc6")
         d = self._dgrad(d, "fc6", pool5.shape, 0)
         pi = 4
         prev_out = None
@@ -292,11 +297,13 @@ class _Engine(object):
             if name == "conv1_1":
                 dw, db = grads[name]
                 L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), L.ptr(db), 0, st)
+                done(name)
                 break
             prev = items[idx - 1]
             xin = ctx.pools[pi][1] if prev == "P" else ctx.acts[prev[0]]
             layer = getattr(m, name)
             self._wgrad(xin, d, grads[name][0], grads[name][1], layer.in_channels, layer.out_channels, 3, pad)
+            done(name)
             # next d: wrt this conv's input; gate by the ReLU of the producing conv unless a pool sits in between
             d = self._dgrad(d, name, xin.shape, pad, gate=None if prev == "P" else xin)
 
@@ -439,11 +446,26 @@ class FCN32s(nn.Module):
         self._engine.set_precision(dtype)
         return self
 
-    def load_synthetic(self, seed=1337):
-        """deterministic He-uniform weights (no VGG16 download available): synth.make_params"""
-        sd = self.state_dict()
-        for k, v in synth.make_params(self.n_class, seed).items():
-            sd[k].copy_(torch.from_numpy(v))
+    def load_synthetic(self, seed=1337, device=None):
+        """deterministic He-uniform weights (no VGG16 download available).
+        device=None: the exact counter-based values of synth.make_params (what the oracle / golden use);
+        device given: moves the model there and draws the same distribution with a seeded torch generator on the
+        GPU (fast path for benchmarks; identical on every rank for a given seed)."""
+        if device is None:
+            sd = self.state_dict()
+            for k, v in synth.make_params(self.n_class, seed).items():
+                sd[k].copy_(torch.from_numpy(v))
+        else:
+            self.to(device)
+            g = torch.Generator(device=device)
+            g.manual_seed(seed)
+            with torch.no_grad():
+                for name, mod in self.named_modules():
+                    if isinstance(mod, nn.Conv2d):
+                        fan_in = mod.in_channels * mod.kernel_size[0] * mod.kernel_size[1]
+                        b = math.sqrt(6.0 / fan_in)
+                        mod.weight.copy_((torch.rand(mod.weight.shape, device=device, generator=g) * 2 - 1) * b)
+                        mod.bias.copy_((torch.rand(mod.bias.shape, device=device, generator=g) * 2 - 1) * 0.1)
         self._engine.mark_dirty()
         return self
 

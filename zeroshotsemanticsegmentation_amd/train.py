@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""train.py -- CLI entry point of the SZN training path (mirrors /root/reference/train.py).
+
+Same flags (-n -g -c -dir -tb -m -d -tu -vu -e -ve -lr -loss -o -se -slr -oh -fu -r; reference :20-42), same
+configuration merge / validation (:202-251), same optimizer wiring (two parameter groups, :126-133,302-331) and
+two-phase orchestration (FCN phase, then seen-mask phase with the backbone frozen, :161-194).
+
+Added for this implementation (none change the reference flags):
+  --synthetic N H W    deterministic synthetic dataset (no PASCAL data / network here; real-data loaders are row F1)
+  --batch-size B       images per GPU per step (reference: 1)
+  --precision fp32|bf16
+  --init synthetic|vgg path handling: without the caffe VGG16 file the backbone starts from synth weights
+  torchrun: RANK / LOCAL_RANK / WORLD_SIZE are honoured (one process per GPU, RCCL gradient all-reduce).
+"""
+import argparse
+import datetime
+import os
+import os.path as osp
+
+import torch
+import torch.nn as nn
+import yaml
+
+from . import models, trainer_fcn, trainer_seenmask
+from .configs import configurations
+from .optim import FusedAdam, FusedSGD
+from .synthetic_dataset import SyntheticSegmentation
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    # default value args
+    p.add_argument('-n', '--name', type=str, default=None, help='name of checkpoint folder')
+    p.add_argument('-g', '--gpu', type=int, default=0, help='gpu number')
+    p.add_argument('-c', '--config', type=int, default=1, choices=configurations.keys())
+    p.add_argument('-dir', '--data_dir', type=str, default='data', help='path for storing dataset, logs, and models')
+    p.add_argument('-tb', '--tb_dir', type=str, default=None, help='path to tensorboard directory (optional)')
+    # override cfg args
+    p.add_argument('-m', '--mode', type=str, choices=['train', 'test_fcn', 'test_all'])
+    p.add_argument('-d', '--dataset', type=str, choices=['pascal', 'context'])
+    p.add_argument('-tu', '--train_unseen', type=str, help='comma separated zero-shot train-split unseen classes')
+    p.add_argument('-vu', '--val_unseen', type=str, help='comma separated zero-shot val-split unseen classes')
+    p.add_argument('-e', '--embed_dim', type=int, choices=[2, 5, 10, 20, 21, 50, 100, 200, 300])
+    p.add_argument('-ve', '--fcn_epochs', type=int)
+    p.add_argument('-lr', '--fcn_learning_rate', type=float)
+    p.add_argument('-loss', '--fcn_loss', type=str, choices=['cos', 'mse', 'cross_entropy'])
+    p.add_argument('-o', '--fcn_optim', type=str, choices=['sgd', 'adam'])
+    p.add_argument('-se', '--seenmask_epochs', type=int)
+    p.add_argument('-slr', '--seenmask_learning_rate', type=float)
+    # optional cfg args
+    p.add_argument('-oh', '--one_hot_embed', action='store_true')
+    p.add_argument('-fu', '--forced_unseen', action='store_true')
+    p.add_argument('-r', '--resume', type=str, help='fcn model checkpoint path')
+    # additions
+    p.add_argument('--synthetic', type=int, nargs=3, metavar=('N', 'H', 'W'), help='synthetic dataset: N images of HxW')
+    p.add_argument('--batch-size', type=int, default=1)
+    p.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32')
+    return p
+
+
+def update_cfg_with_args(cfg, args):
+    """reference :202-230 (truthiness rules kept: 0 cannot override; -se is parsed but never applied)"""
+    cfg = dict(cfg)
+    for key, val in (('mode', args.mode), ('dataset', args.dataset), ('embed_dim', args.embed_dim),
+                     ('fcn_epochs', args.fcn_epochs), ('fcn_lr', args.fcn_learning_rate), ('fcn_loss', args.fcn_loss),
+                     ('fcn_optim', args.fcn_optim), ('seenmask_lr', args.seenmask_learning_rate)):
+        if val:
+            cfg[key] = val
+    for key, val in (('train_unseen', args.train_unseen), ('val_unseen', args.val_unseen)):
+        if val:
+            cfg[key] = [int(item) for item in val.split(',')]
+    cfg['one_hot_embed'] = args.one_hot_embed if args.one_hot_embed else cfg.get('one_hot_embed')
+    cfg['forced_unseen'] = args.forced_unseen if args.forced_unseen else cfg.get('forced_unseen')
+    cfg['load_fcn_path'] = args.resume if args.resume else cfg.get('load_fcn_path')
+    return cfg
+
+
+def validate_cfg(cfg):
+    """reference :232-251"""
+    if cfg['one_hot_embed'] and cfg['embed_dim'] != 21 and cfg['dataset'] == "pascal":
+        raise Exception('joint-embedding space must be size of one-hot embedding space')
+    if cfg['one_hot_embed'] and cfg['embed_dim'] != 33 and cfg['dataset'] == "context":
+        raise Exception('joint-embedding space must be size of one-hot embedding space')
+    if cfg['mode'] in ['test_fcn', 'test_all'] and not cfg['load_fcn_path']:
+        raise Exception('must load model path via -r flag for test mode')
+    if cfg['fcn_epochs'] < 1 and not cfg['load_fcn_path']:
+        raise Exception('must load model path via -r flag for test mode')
+    if cfg['seenmask_epochs'] > 0 and len(cfg['train_unseen']) < 1:
+        raise Exception("can't train the seenmask classifier without train_unseen specified")
+    if cfg['embed_dim'] == 0 and cfg['fcn_loss'] in ['cos', 'mse']:
+        raise Exception("invalid loss function because pixel embedding dimensionality not defined")
+
+
+def get_log_dir(model_name, cfg_num, cfg, data_dir, now=None):
+    """<data_dir>/logs/<name>CFG_<n>_<KEY>_<value>_..._TIME_<stamp>_ (reference :253-286)"""
+    os.makedirs(data_dir, exist_ok=True)
+    name = ('%s_' % model_name) if model_name else ''
+    name += "CFG_%d_" % int(cfg_num)
+    for k, v in cfg.items():
+        if k in ['one_hot_embed', 'forced_unseen'] and not v:
+            continue
+        if k == 'load_fcn_path':
+            continue
+        if k in ['train_unseen', 'val_unseen']:
+            name += '%s_%s_' % (k.upper(), str(bool(v)))
+        else:
+            name += '%s_%s_' % (k.upper(), str(v))
+    now = now or datetime.datetime.now(datetime.timezone(datetime.timedelta(hours=-5)))
+    name += 'TIME_%s_' % now.strftime('%Y%m%d-%H%M%S')
+    log_dir = osp.join(data_dir, 'logs', name)
+    os.makedirs(log_dir, exist_ok=True)
+    return log_dir
+
+
+def output_cfg(cfg, log_dir, writer):
+    for k, v in cfg.items():
+        print(k, v)
+    with open(osp.join(log_dir, 'config.yaml'), 'w') as f:
+        yaml.safe_dump(cfg, f, default_flow_style=False)
+    if writer is not None:
+        writer.add_text("cfg", '\n'.join(['%s: %s' % (k, str(v)) for k, v in cfg.items()]))
+
+
+def get_parameters(model, bias=False, seenmask=False):
+    """reference :302-331: Conv2d weights | Conv2d biases (seenmask layers excluded); ConvTranspose2d weights are the
+    frozen bilinear kernels and yield nothing; unknown module types raise."""
+    if seenmask:
+        for p in model.seenmask_score.parameters():
+            yield p
+        for p in model.seenmask_upscore.parameters():
+            yield p
+        return
+    skipped = (nn.ReLU, nn.MaxPool2d, nn.Dropout2d, nn.Sequential, models.FCN32s)
+    for name, m in model.named_modules():
+        if name in ['seenmask_score', 'seenmask_upscore']:
+            continue
+        if isinstance(m, nn.Conv2d):
+            yield m.bias if bias else m.weight
+        elif isinstance(m, nn.ConvTranspose2d):
+            if bias:
+                assert m.bias is None
+        elif isinstance(m, skipped):
+            continue
+        else:
+            raise ValueError('Unexpected module: %s' % str(m))
+
+
+def make_fcn_optimizer(model, cfg):
+    """two parameter groups: conv weights, conv biases at 2x lr (SGD: momentum .99, wd 5e-4 on weights only) :126-133"""
+    if cfg['fcn_optim'] == "sgd":
+        params = [{'params': list(get_parameters(model, bias=False))},
+                  {'params': list(get_parameters(model, bias=True)), 'lr': cfg['fcn_lr'] * 2, 'weight_decay': 0}]
+        return FusedSGD(params, lr=cfg['fcn_lr'], momentum=.99, weight_decay=0.0005)
+    params = [{'params': list(get_parameters(model, bias=False))},
+              {'params': list(get_parameters(model, bias=True)), 'lr': cfg['fcn_lr'] * 2}]
+    return FusedAdam(params, lr=cfg['fcn_lr'])
+
+
+def freeze_for_seenmask(model):
+    """phase 2: everything frozen except seenmask_score (w, b) and seenmask_upscore (w) (reference :166-171)"""
+    for param in model.parameters():
+        param.requires_grad = False
+    for p in model.seenmask_score.parameters():
+        p.requires_grad = True
+    for p in model.seenmask_upscore.parameters():
+        p.requires_grad = True
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    cfg = update_cfg_with_args(configurations[args.config], args)
+    validate_cfg(cfg)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: this implementation has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    torch.manual_seed(1337)
+    torch.cuda.manual_seed(1337)
+
+    log_dir = get_log_dir(args.name, args.config, cfg, args.data_dir)
+    tb_writer = None
+    if args.tb_dir and rank == 0:
+        try:
+            from tensorboardX import SummaryWriter
+            tb_writer = SummaryWriter(osp.join(args.tb_dir, log_dir.split('/')[-1]))
+        except ImportError:
+            print("tensorboardX not installed: tensorboard logging disabled")
+    if rank == 0:
+        output_cfg(cfg, log_dir, tb_writer)
+
+    # 1. dataset
+    if not args.synthetic:
+        raise SystemExit("real PASCAL / PASCAL-Context loading is not part of this round (SURVEY.md 8-f F1): "
+                         "pass --synthetic N H W")
+    n_img, H, W = args.synthetic
+    n_class = 21 if cfg['dataset'] == 'pascal' else 33
+    all_unseen = cfg['train_unseen'] + cfg['val_unseen']
+    mk = lambda split, unseen, n: SyntheticSegmentation(split=split, n_images=n, size=(H, W), n_class=n_class,
+                                                         embed_dim=cfg['embed_dim'], unseen=unseen, seed=1337 + 7919 * rank)
+    train_dataset = mk('train', [], n_img)
+    train_seen_dataset = mk('train_seen', all_unseen, n_img)
+    val_dataset = mk('val', [], max(n_img // 4, 1))
+    kwargs = {'num_workers': 2, 'pin_memory': True}
+    train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True, **kwargs)
+    train_seen_loader = torch.utils.data.DataLoader(train_seen_dataset, batch_size=args.batch_size, shuffle=True, **kwargs)
+    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=1, shuffle=False, **kwargs)
+    label_names = train_dataset.class_names
+    if rank == 0 and not osp.exists(osp.join(log_dir, 'counts.csv')):
+        with open(osp.join(log_dir, 'counts.csv'), 'w') as f:
+            f.write('train_seen,train_unseen,val\n%d,%d,%d\n' % (len(train_seen_loader), len(train_loader) - len(train_seen_loader),
+                                                                 len(val_loader)))
+
+    # 2. model
+    model = models.FCN32s(n_class=cfg['embed_dim'] if cfg['embed_dim'] else 21)
+    start_epoch, start_iteration, checkpoint = 0, 0, None
+    if cfg['load_fcn_path']:
+        checkpoint = torch.load(osp.join(args.data_dir, 'logs', cfg['load_fcn_path'], 'best'), map_location='cpu')
+        model.load_state_dict(checkpoint['model_state_dict'], strict=False)
+        start_epoch, start_iteration = checkpoint['epoch'], checkpoint['iteration']
+    else:
+        try:
+            model.copy_params_from_vgg16(models.VGG16(pretrained=True, data_dir=args.data_dir))
+        except IOError as e:
+            print("%s -> deterministic synthetic initialisation" % e)
+            model.load_synthetic(1337)
+    model = model.to(device)
+    precision = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+    model.set_precision(precision)
+
+    # 3. fcn optimizer and trainer
+    optim = make_fcn_optimizer(model, cfg)
+    if cfg['load_fcn_path'] and checkpoint.get('optim_state_dict'):
+        optim.load_state_dict(checkpoint['optim_state_dict'])
+    fcn_trainer = trainer_fcn.Trainer(
+        cuda=True, model=model, optimizer=optim, train_loader=train_seen_loader, val_loader=val_loader, log_dir=log_dir,
+        dataset=cfg['dataset'], max_epoch=cfg['fcn_epochs'], pixel_embeddings=cfg['embed_dim'], loss_func=cfg['fcn_loss'],
+        tb_writer=tb_writer, unseen=all_unseen, val_unseen=cfg['val_unseen'], label_names=label_names,
+        forced_unseen=cfg['forced_unseen'], precision=precision, rank=rank)
+    fcn_trainer.epoch, fcn_trainer.iteration = start_epoch, start_iteration
+
+    if cfg['mode'] == 'train':
+        if cfg['fcn_epochs'] > 0:
+            fcn_trainer.train()
+        # 4. seen-mask phase
+        if cfg['seenmask_epochs'] > 0:
+            freeze_for_seenmask(model)
+            sm_optim = FusedAdam([{'params': list(get_parameters(model, seenmask=True))}], lr=cfg['seenmask_lr'])
+            if not checkpoint:
+                best = osp.join(log_dir, 'best')
+                checkpoint = torch.load(best, map_location='cpu') if osp.exists(best) else {}
+            seenmask_trainer = trainer_seenmask.Trainer(
+                cuda=True, model=model, optimizer=sm_optim, train_loader=train_loader, val_loader=val_loader,
+                log_dir=log_dir, dataset=cfg['dataset'], max_epoch=cfg['seenmask_epochs'], tb_writer=tb_writer,
+                checkpoint=checkpoint, unseen=cfg['train_unseen'], rank=rank)
+            seenmask_trainer.train()
+    elif cfg['mode'] == 'test_fcn':
+        fcn_trainer.validate(both_fcn_and_seenmask=False)
+    elif cfg['mode'] == 'test_all':
+        fcn_trainer.validate(both_fcn_and_seenmask=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,266 @@
+"""trainer_fcn.py -- phase-1 trainer of the SZN path: FCN backbone + pixel-embedding (or softmax) head.
+
+Same constructor / method surface and return contracts as /root/reference/trainer_fcn.py (Trainer.__init__ :21-81,
+forward :83-120, forward_szn :123-147, train_epoch :149-180, validate :182-292, train :294-306), on top of the
+HIP path: with an embedding loss 'cos' the hot loop runs engine.TrainStep (fused head, flat-buffer optimizer,
+RCCL gradient all-reduce); other losses compose the same kernels through autograd.  Logging (CSV, optional
+tensorboard writer, checkpoints with the reference's dict keys) is host-side and kept format-compatible;
+JPEG tile visualisations (third-party `fcn` package in the reference) are out of scope and skipped.
+"""
+import datetime
+import os
+import os.path as osp
+import shutil
+
+import numpy as np
+import torch
+
+from . import engine as _engine
+from . import utils
+
+_GOLDEN = osp.join(osp.dirname(osp.dirname(osp.abspath(__file__))), "tests", "golden")
+
+
+def load_embeddings(dataset, dim):
+    """K x E class-embedding matrix: `datasets/<ds>/embeddings/norm_embed_arr_<E>.pkl` relative to the CWD exactly
+    like the reference (trainer_fcn.py:49), else the .npy re-saves shipped with this repo's fixtures."""
+    pkl = 'datasets/%s/embeddings/norm_embed_arr_%s' % (dataset, str(dim))
+    if osp.exists(pkl + '.pkl'):
+        return np.asarray(utils.load_obj(pkl), dtype=np.float32)
+    npy = osp.join(_GOLDEN, "embeddings_%s_%s.npy" % (dataset, str(dim)))
+    if osp.exists(npy):
+        return np.load(npy)
+    raise IOError("no embedding matrix for dataset=%s dim=%s (looked for %s.pkl and %s)" % (dataset, dim, pkl, npy))
+
+
+def _now():
+    return datetime.datetime.now(datetime.timezone(datetime.timedelta(hours=-5)))      # 'US/Eastern' (no DST handling)
+
+
+class _NullWriter(object):
+    def add_scalar(self, *a, **k): pass
+    def add_text(self, *a, **k): pass
+    def add_image(self, *a, **k): pass
+
+
+class Trainer(object):
+
+    def __init__(self, cuda, model, optimizer, train_loader, val_loader, log_dir, dataset, max_epoch, tb_writer,
+                 pixel_embeddings=None, loss_func=None, unseen=None, val_unseen=None, label_names=None,
+                 forced_unseen=False, embed_arr=None, precision=torch.float32, fused_step=True, rank=0):
+        if not cuda:
+            raise RuntimeError("this implementation runs on the GPU only (cuda=False has no CPU fallback)")
+        self.cuda = cuda
+        self.model = model
+        self.optim = optimizer
+        self.train_loader = train_loader
+        self.val_loader = val_loader
+        self.log_dir = log_dir
+        self.dataset = dataset
+        self.max_epoch = max_epoch
+        self.tb_writer = tb_writer if tb_writer is not None else _NullWriter()
+        self.pixel_embeddings = pixel_embeddings
+        self.loss_func = loss_func
+        self.unseen = list(unseen or [])            # all unseen classes (train_unseen + val_unseen)
+        self.val_unseen = list(val_unseen or [])
+        self.label_names = label_names
+        self.forced_unseen = forced_unseen
+        self.rank = rank
+
+        self.epoch = 0
+        self.iteration = 0
+        self.best_mean_iu = 0
+        self.n_class = len(self.train_loader.dataset.class_names)
+        self.timestamp_start = _now()
+        self.seen = [x for x in range(self.n_class) if x not in self.unseen]
+        self.device = next(model.parameters()).device
+        self.precision = precision
+        self._step = None
+        self._fused_step = fused_step
+
+        if self.pixel_embeddings:
+            arr = np.asarray(embed_arr, dtype=np.float32) if embed_arr is not None else \
+                load_embeddings(dataset, pixel_embeddings)
+            self.embeddings = torch.from_numpy(arr).to(self.device).float()
+            # zero-masked copies used for forced_unseen / full SZN testing (reference :56-64; built in float64)
+            seen_arr, unseen_arr = np.zeros(arr.shape), np.zeros(arr.shape)
+            seen_arr[self.seen, :] = arr[self.seen, :]
+            unseen_arr[self.unseen, :] = arr[self.unseen, :]
+            self.seen_embeddings = torch.from_numpy(seen_arr).to(self.device).float()
+            self.unseen_embeddings = torch.from_numpy(unseen_arr).to(self.device).float()
+
+        base = ['loss', 'pxl_acc', 'class_acc', 'mean_iu', 'fwavacc']
+        self.train_log_headers = ['epoch', 'iteration'] + ['train/' + b for b in base] + ['elapsed_time']
+        self.val_log_headers = ['epoch', 'iteration'] + ['val/' + b for b in base]
+        if self.unseen:
+            for grp in ('seen', 'unseen'):
+                self.val_log_headers += ['val/%s/%s' % (grp, b) for b in base[1:]]
+        self.val_log_headers += ['elapsed_time']
+        if self.rank == 0:
+            os.makedirs(self.log_dir, exist_ok=True)
+            for fname, hdr in (('train_log.csv', self.train_log_headers), ('val_log.csv', self.val_log_headers)):
+                if not osp.exists(osp.join(self.log_dir, fname)):
+                    with open(osp.join(self.log_dir, fname), 'w') as f:
+                        f.write(','.join(hdr) + '\n')
+
+    # ---- forward passes ------------------------------------------------------------------------------------
+    def _unpack(self, data, target):
+        """targets are (label, label_embedding) tuples when embeddings are on (dataset contract, context_dataset.py:
+        116-141); the dense per-pixel embedding is optional here: the label alone is enough (gathered on the GPU)."""
+        target_embed = None
+        if self.pixel_embeddings and isinstance(target, (tuple, list)):
+            target, target_embed = target
+        data = data.to(self.device, non_blocking=True)
+        target = target.to(self.device, non_blocking=True)
+        if target_embed is not None:
+            target_embed = target_embed.to(self.device, non_blocking=True)
+        return data, target, target_embed
+
+    def _loss(self, score, target, target_embed):
+        te = target_embed if target_embed is not None else (self.embeddings if self.pixel_embeddings else None)
+        if self.loss_func == "cos":
+            return utils.cosine_loss(score, target, te)
+        if self.loss_func == "mse":
+            return utils.mse_loss(score, target, te)
+        if self.loss_func == "cross_entropy":
+            return utils.cross_entropy2d(score, target, size_average=False)
+        raise ValueError("unknown loss_func %r" % (self.loss_func,))
+
+    def forward(self, data, target):
+        """-> (score, loss, lbl_pred numpy int64 (n,h,w), lbl_true cpu tensor)   [reference :83-120]"""
+        data, target, target_embed = self._unpack(data, target)
+        score = self.model(data, mode='fcn')
+        loss = self._loss(score, target, target_embed)
+        if np.isnan(float(loss.item())):
+            raise ValueError('loss is nan while training')
+        if self.pixel_embeddings:
+            if self.forced_unseen:
+                lbl_pred = utils.infer_lbl_forced_unseen(score, target, self.seen_embeddings, self.unseen_embeddings,
+                                                         self.unseen, self.cuda)
+            else:
+                lbl_pred = utils.infer_lbl(score, self.embeddings, self.cuda)
+        else:
+            lbl_pred = utils.channel_argmax(score).cpu().numpy()
+        return score, loss, lbl_pred, target.detach().cpu()
+
+    def forward_szn(self, data, target):
+        """both heads + seen-mask-stitched inference   [reference :123-147]"""
+        data, target, target_embed = self._unpack(data, target)
+        fcn_score, seen_mask_score = self.model(data, mode='both')
+        loss = self._loss(fcn_score, target, target_embed)
+        lbl_pred = utils.infer_lbl_szn(fcn_score, seen_mask_score, self.seen_embeddings, self.unseen_embeddings, self.cuda)
+        return fcn_score, loss, lbl_pred, target.detach().cpu()
+
+    # ---- training --------------------------------------------------------------------------------------------
+    def _fast_step(self):
+        """engine.TrainStep when the configuration allows it (embedding cosine loss, Adam/SGD wiring of train.py)"""
+        if self._step is None and self._fused_step and self.pixel_embeddings and self.loss_func == "cos":
+            from .optim import FusedAdam, FusedSGD
+            if isinstance(self.optim, (FusedAdam, torch.optim.Adam)):
+                kind, extra = "adam", {}
+            elif isinstance(self.optim, (FusedSGD, torch.optim.SGD)):
+                kind = "sgd"
+                extra = dict(momentum=self.optim.param_groups[0].get('momentum', 0.99),
+                             weight_decay=self.optim.param_groups[0].get('weight_decay', 0.0005))
+            else:
+                return None
+            self._step = _engine.TrainStep(self.model, self.embeddings, optimizer=kind, lr=self.optim.param_groups[0]['lr'],
+                                           precision=self.precision, fused_head=True, **extra)
+        return self._step
+
+    def train_epoch(self):
+        self.model.train()
+        step = self._fast_step()
+        for batch_idx, (data, target) in enumerate(self.train_loader):
+            if step is not None:
+                data, target, _ = self._unpack(data, target)
+                loss, pred = step.step(data, target)
+                lossv = float(loss.item())
+                if np.isnan(lossv):
+                    raise ValueError('loss is nan while training')
+                metrics = utils.label_accuracy_score([target], [pred], self.n_class)
+                gsum = float(self.model.score_fr.weight.grad.sum().item())
+                ssum = float('nan')                  # the (B,E,H,W) score is never materialised on this path
+            else:
+                score, loss, lbl_pred, lbl_true = self.forward(data, target)
+                self.optim.zero_grad()
+                loss.backward()
+                self.optim.step()
+                lossv = float(loss.item())
+                metrics = utils.label_accuracy_score(lbl_true.numpy(), lbl_pred, self.n_class)
+                gsum = float(self.model.score_fr.weight.grad.sum().item())
+                ssum = float(score.sum().item())
+            if self.rank == 0:
+                print("FCN Train Epoch {:<5} | Iteration {:<5} | Loss {:5.5f} | score_fr grad sum {:15.0f} | "
+                      "upscore grad sum {:15.0f} | score sum {:10.5f}".format(int(self.epoch), int(batch_idx), lossv, gsum,
+                                                                               0.0, ssum))
+                with open(osp.join(self.log_dir, 'train_log.csv'), 'a') as f:
+                    elapsed = (_now() - self.timestamp_start).total_seconds()
+                    f.write(','.join(map(str, [self.epoch, self.iteration, lossv] + list(metrics) + [elapsed])) + '\n')
+                for name, v in zip(['loss', 'pxl_acc', 'class_acc', 'mean_iu', 'fwavacc'], [lossv] + list(metrics)):
+                    self.tb_writer.add_scalar('fcn/train/' + name, v, self.iteration)
+            self.iteration += 1
+
+    def validate(self, both_fcn_and_seenmask=False):
+        self.model.eval()
+        val_loss = 0
+        lbl_trues, lbl_preds = [], []
+        with torch.no_grad():
+            for batch_idx, (data, target) in enumerate(self.val_loader):
+                fwd = self.forward_szn if both_fcn_and_seenmask else self.forward
+                score, loss, lbl_pred, lbl_true = fwd(data, target)
+                val_loss += float(loss.item())
+                if self.rank == 0:
+                    print("Test Epoch {:<5} | Iteration {:<5} | Loss {:5.5f} | Score Sum {:10.5f}".format(
+                        int(self.epoch), int(batch_idx), float(loss.item()), float(score.sum().item())))
+                for i in range(lbl_pred.shape[0]):
+                    lbl_trues.append(lbl_true[i].numpy())
+                    lbl_preds.append(lbl_pred[i])
+        seen_metrics = unseen_metrics = None
+        if self.unseen:
+            metrics, seen_metrics, unseen_metrics = utils.label_accuracy_score(lbl_trues, lbl_preds, self.n_class,
+                                                                               unseen=self.val_unseen)
+        else:
+            metrics = utils.label_accuracy_score(lbl_trues, lbl_preds, self.n_class)
+        val_loss /= max(len(self.val_loader), 1)        # averaged over images like the reference (:246)
+        names = ['pxl_acc', 'class_acc', 'mean_iu', 'fwavacc']
+        if self.rank == 0:
+            with open(osp.join(self.log_dir, 'val_log.csv'), 'a') as f:
+                row = [self.epoch, self.iteration, val_loss] + list(metrics)
+                if self.unseen:
+                    row += list(seen_metrics) + list(unseen_metrics)
+                row += [_now() - self.timestamp_start]
+                f.write(','.join(map(str, row)) + '\n')
+            self.tb_writer.add_scalar('fcn/val/loss', val_loss, self.epoch)
+            for grp, ms in (('', metrics), ('seen/', seen_metrics), ('unseen/', unseen_metrics)):
+                if ms is None:
+                    continue
+                for n, v in zip(names, ms):
+                    self.tb_writer.add_scalar('fcn/val/%s%s' % (grp, n), v, self.epoch)
+                    print('%s%s: %.3f' % ((grp.replace('/', ' ') or 'overall '), n, v))
+        mean_iu = metrics[2]
+        is_best = mean_iu > self.best_mean_iu
+        if is_best:
+            self.best_mean_iu = mean_iu
+        if self.rank == 0:
+            torch.save({
+                'epoch': self.epoch,
+                'iteration': self.iteration,
+                'arch': self.model.__class__.__name__,
+                'optim_state_dict': self.optim.state_dict(),
+                'model_state_dict': self.model.state_dict(),
+                'best_mean_iu': self.best_mean_iu,
+            }, osp.join(self.log_dir, 'checkpoint'))
+            if is_best:
+                shutil.copy(osp.join(self.log_dir, 'checkpoint'), osp.join(self.log_dir, 'best'))
+        return metrics
+
+    def train(self):
+        for epoch in range(self.max_epoch):
+            self.epoch = epoch
+            self.train_epoch()
+            self.validate()
+            # early stop once as many images were seen as in 50 epochs without zero-shot (reference :300-306)
+            cur_iter = self.epoch * len(self.train_loader)
+            if (self.dataset == 'pascal' and cur_iter > 425000) or (self.dataset == 'context' and cur_iter > 247000):
+                break
