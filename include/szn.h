@@ -56,6 +56,8 @@ typedef struct {
     int ldi, ldo, ldg; /* pixel strides (elements) of in / out / gate                            */
     int relu;         /* epilogue max(v,0)  (nn.ReLU, models.py:44..90)                           */
     int out_f32;      /* store out as float even when dtype == SZN_BF16                           */
+    void* workspace;  /* optional device scratch for split-K (few output tiles, long K: fc6/fc7); */
+    size_t workspace_bytes; /* used when >= B*Ho*Wo*Co*4 bytes (dgrad: B*Hi*Wi*Ci*4); NULL = never split */
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
@@ -98,9 +100,12 @@ int szn_gemm_proj_wgrad(int dtype, long M, int K, int N, int ldd, const void* x,
  * models.py:43,116 (+ ReLU models.py:44).  w is OHWI f32 [64][3][3][3], out NHWC dtype.           */
 int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const float* x_nchw, const float* w,
                     const float* bias, void* out, szn_stream_t stream);
-/* dw[64][3][3][3], db[64] from dout (already ReLU-gated) -- no dgrad: the image needs no gradient */
+/* dw[64][3][3][3], db[64] from dout (already ReLU-gated) -- no dgrad: the image needs no gradient.
+ * Runs as an MFMA wgrad over the im2col image (27 taps padded to 32 columns) held in `workspace`.   */
+size_t szn_conv1_1_wgrad_workspace_bytes(int dtype, int B, int H, int W, int pad);
 int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const float* x_nchw,
-                      const void* dout, float* dw, float* db, int accumulate, szn_stream_t stream);
+                      const void* dout, float* dw, float* db, int accumulate, void* workspace,
+                      szn_stream_t stream);
 
 /* ---- MaxPool2d(2, stride 2, ceil_mode=True): models.py:47,54,63,72,81 ---------------------------- */
 int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out,

@@ -32,6 +32,8 @@ CASES = [
     (3, 5, 7, 192, 302, 1, 0),
     (1, 33, 17, 64, 64, 3, 1),
     (2, 12, 12, 64, 130, 3, 2),
+    (1, 40, 36, 256, 64, 3, 1),          # 64-cout tile variant, several pixel tiles, 4 chunks per tap
+    (2, 8, 8, 512, 128, 7, 0),           # long K (392 chunks bf16), 1 pixel tile: split-K path
 ]
 
 
@@ -60,6 +62,9 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     dt = L.dtype_code(dtype)
     d, Ho, Wo = conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad, relu=1)
     dev = "cuda"
+    # split-K scratch (used by the library only for few-tile / long-K shapes such as case 1)
+    ws = torch.empty(max(B * Ho * Wo * Co, B * Hi * Wi * Ci) * 4, dtype=torch.uint8, device=dev)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     xd = nhwc(x.detach()).to(dev, dtype)
     wd = nhwc(w.detach()).to(dev, dtype)       # OHWI
     bd = bias.to(dev)
@@ -86,6 +91,7 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     torch.cuda.synchronize()
     assert torch.equal(wT.float().cpu(), wT_ref.to(dtype).float())
     dgd, _, _ = conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad, ldg=Ci)
+    dgd.workspace, dgd.workspace_bytes = ws.data_ptr(), ws.numel()
     din = torch.full((B, Hi, Wi, Ci), float("nan"), device=dev, dtype=dtype)
     if Co % (64 if dtype == torch.bfloat16 else 32) == 0:
         L.call("szn_conv2d_dgrad", C.byref(dgd), L.ptr(doutd), L.ptr(wT), L.ptr(xd), None, L.ptr(din), L.stream_ptr())
@@ -148,9 +154,11 @@ def test_conv1_1(dtype):
     pre.backward(dout)
     dw = torch.empty(64, 3, 3, 3, device="cuda"); db = torch.empty(64, device="cuda")
     doutd = nhwc(dout).cuda().to(dtype)
-    L.call("szn_conv1_1_wgrad", dt, B, H, W, pad, L.ptr(xd), L.ptr(doutd), L.ptr(dw), L.ptr(db), 0, L.stream_ptr())
+    ws = torch.empty(L.load().szn_conv1_1_wgrad_workspace_bytes(dt, B, H, W, pad), dtype=torch.uint8, device="cuda")
+    L.call("szn_conv1_1_wgrad", dt, B, H, W, pad, L.ptr(xd), L.ptr(doutd), L.ptr(dw), L.ptr(db), 0, L.ptr(ws), L.stream_ptr())
     torch.cuda.synchronize()
-    assert relerr(dw.cpu().permute(0, 3, 1, 2), w.grad) < 1e-4
+    # bf16 path: the im2col image is bf16 (pixel values up to ~150 keep 8 mantissa bits)
+    assert relerr(dw.cpu().permute(0, 3, 1, 2), w.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
     assert relerr(db.cpu(), dout.sum((0, 2, 3))) < 1e-4
 
 

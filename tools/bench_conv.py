@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the conv kernels through the C-ABI (per-layer TF/s at the bench shapes).
+usage: tools/bench_conv.py [--batch 8] [--dtype bf16] [--layers conv3_2,fc6,...] [--what fwd,dgrad,wgrad] [--iters 5]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zeroshotsemanticsegmentation_amd import _lib as L
+
+# name: (Hi, Ci, Co, K, pad) at 512x512 input
+SHAPES = {
+    "conv1_2": (710, 64, 64, 3, 1), "conv2_1": (355, 64, 128, 3, 1), "conv2_2": (355, 128, 128, 3, 1),
+    "conv3_1": (178, 128, 256, 3, 1), "conv3_2": (178, 256, 256, 3, 1), "conv4_1": (89, 256, 512, 3, 1),
+    "conv4_2": (89, 512, 512, 3, 1), "conv5_1": (45, 512, 512, 3, 1), "fc6": (23, 512, 4096, 7, 0),
+    "fc7": (17, 4096, 4096, 1, 0), "head": (17, 4096, 320, 1, 0),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--layers", default=",".join(SHAPES))
+    ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    code = L.dtype_code(dt)
+    B = a.batch
+    st = L.stream_ptr()
+    for name in a.layers.split(","):
+        Hi, Ci, Co, K, pad = SHAPES[name]
+        Ho = Hi + 2 * pad - K + 1
+        x = torch.randn(B, Hi, Hi, Ci, device="cuda").to(dt)
+        w = (torch.randn(Co, K, K, Ci, device="cuda") / (Ci * K * K) ** 0.5).to(dt)
+        wT = torch.empty(Ci, K, K, Co, device="cuda", dtype=dt)
+        L.call("szn_pack_weight_dgrad", code, Co, K, K, Ci, L.ptr(w), L.ptr(wT), st)
+        bias = torch.randn(Co, device="cuda")
+        out = torch.empty(B, Ho, Ho, Co, device="cuda", dtype=dt)
+        dout = torch.randn(B, Ho, Ho, Co, device="cuda").to(dt)
+        din = torch.empty_like(x)
+        dw = torch.zeros(Co, K, K, Ci, device="cuda")
+        d = L.ConvDesc(code, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, pad, Ci, Co, Ci, 1, 0)
+        flops = 2.0 * B * Ho * Ho * Co * Ci * K * K
+        calls = {
+            "fwd": lambda: L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, None, L.ptr(out), st),
+            "dgrad": lambda: L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(x), None, L.ptr(din), st),
+            "wgrad": lambda: L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 1, st),
+        }
+        res = []
+        for what in a.what.split(","):
+            if what == "dgrad" and Co % (64 if dt == torch.bfloat16 else 32):
+                continue
+            fn = calls[what]
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            res.append("%s %7.3f ms %6.0f TF/s" % (what, ms, flops / ms / 1e9))
+        print("%-8s B=%d %s | %s" % (name, B, a.dtype, " | ".join(res)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,8 @@ class SznError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
-        "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")]
+        "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")] + [
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class DeviceInfo(C.Structure):
@@ -46,7 +47,8 @@ SIGNATURES = {
     "szn_gemm_proj_dgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "szn_gemm_proj_wgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _I, _P]),
     "szn_conv1_1_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "szn_conv1_1_wgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "szn_conv1_1_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "szn_conv1_1_wgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "szn_maxpool2x2_ceil_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
     "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "szn_bilinear_up32_crop_fwd": (_I, [_I] * 9 + [_P, _P, _P]),

@@ -392,21 +392,44 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad(WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// db[n] += sum_m dout[m][n]
+// db[n] += sum_m dout[m][n]: 16-B loads, thread = (16-B channel chunk, row lane), LDS reduce, one atomic per
+// (block, channel)
 template <typename T>
-__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dout, float* __restrict__ db,
-                                                        long M, int Co, int ldd, int rows_per_block) {
-    // thread -> channel (tid % cpb) + row lane (tid / cpb); block covers `rows_per_block` rows
-    const int cpb = min(Co, 256);
-    const int c = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dout, float* __restrict__ db, long M, int Co,
+                                                        int ldd, int rows_per_block) {
+    constexpr int CH = elem<T>::kPer16B;
+    __shared__ float red[256 * CH];
+    const int cpr = (Co + CH - 1) / CH;                  // 16-B chunks per row
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
-    for (int cb = 0; cb < Co; cb += cpb) {
-        const int ch = cb + c;
-        float s = 0.f;
-        if (ch < Co && rl < nrl)
-            for (long r = r0 + rl; r < r1; r += nrl) s += elem<T>::ld(dout + r * ldd + ch);
-        if (ch < Co && rl < nrl && s != 0.f) atomicAdd(db + ch, s);
+    for (int cg = 0; cg < cpr; cg += 256) {              // chunk groups (only Co > 256*CH needs more than one)
+        const int ncg = min(256, cpr - cg);
+        const int rl = 256 / ncg;                        // row lanes
+        const int chunk = threadIdx.x % ncg, lr = threadIdx.x / ncg;
+        float acc[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+        if (lr < rl) {
+            const T* p = dout + (long)(cg + chunk) * CH;
+            for (long r = r0 + lr; r < r1; r += rl) {
+                const u32x4_t v = *(const u32x4_t*)(p + r * ldd);
+                const T* ve = (const T*)&v;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) acc[e] += elem<T>::ld(ve + e);
+            }
+        }
+        __syncthreads();
+        if (lr < rl) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) red[(lr * ncg + chunk) * CH + e] = acc[e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < ncg * CH; i += 256) {
+            float s = 0.f;
+            for (int l = 0; l < rl; ++l) s += red[l * ncg * CH + i];
+            const int n = cg * CH + i;
+            if (n < Co && s != 0.f) atomicAdd(db + n, s);
+        }
     }
 }
 
@@ -438,8 +461,9 @@ int check_desc(const szn_conv_desc_t* d) {
 
 }  // namespace
 
-extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias,
-                              const void* gate, const float* chan_scale, void* out, szn_stream_t stream) {
+// first-generation kernel (register-staged, 128x128 tile): fallback of szn_conv2d_fwd (szn_conv_igemm.hip)
+int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                      const float* chan_scale, void* out, szn_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     const int bke = d->dtype == SZN_BF16 ? 64 : 32;
@@ -532,13 +556,15 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
 extern "C" int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
                              szn_stream_t stream) {
     if (!dout || !db || M <= 0 || Co <= 0 || ldd < Co) SZN_FAIL(SZN_ERR_ARG, "bias_grad: bad argument");
+    if (ldd % (dtype == SZN_BF16 ? 8 : 4) || ((uintptr_t)dout & 15))
+        SZN_FAIL(SZN_ERR_UNSUPPORTED, "bias_grad: rows must be 16-B aligned (ldd multiple of %d)", dtype == SZN_BF16 ? 8 : 4);
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(db, 0, (size_t)Co * sizeof(float), st);
         if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "bias_grad memset: %s", hipGetErrorString(e));
     }
-    long rpb = (M + 1023) / 1024;
-    if (rpb < 64) rpb = 64;
+    long rpb = (M + 2047) / 2048;
+    if (rpb < 32) rpb = 32;
     const int blocks = szn_div_up(M, rpb);
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(bias_grad_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)dout, db, M, Co, ldd,

@@ -1,0 +1,336 @@
+// szn_conv_igemm.hip -- second-generation forward / dgrad implicit-GEMM convolution for gfx950 and the
+// public szn_conv2d_fwd dispatcher.
+//
+// conv_igemm_v2: block = 512 threads = 8 waves (4 along pixels x 2 along couts), tile 256 pixels x BN couts
+// (BN = 128, or 64 for the 64-channel layers), K advanced in 128-byte chunks of one filter tap.
+//   * operands go HBM/L2 -> LDS directly with buffer_load_dwordx4 ... lds (no VGPR round trip); padding /
+//     out-of-image taps / tile edges are out-of-range buffer offsets, which the hardware returns as zeros;
+//   * the per-chunk part of every address (channel offset, tap offset of the weights) rides in the scalar
+//     soffset operand, so a K chunk costs no vector address arithmetic; per-lane offsets change only when the
+//     filter tap changes;
+//   * the LDS image is [row][128 B] with the 16-B chunk index XOR-swizzled by (row & 7): LDS-DMA writes are
+//     lane-linear, so the swizzle is applied to the per-lane SOURCE address (lane -> chunk = pos ^ (row & 7));
+//   * 3-stage LDS ring, loads run two chunks ahead with counted s_waitcnt vmcnt(N) and one raw s_barrier per chunk;
+//   * optional split-K (few output tiles, long K: fc6 dgrad/fwd, fc7): fp32 atomics into a caller workspace and a
+//     second small kernel for the epilogue.
+// Same arithmetic and epilogue as conv_igemm (szn_conv.hip), which remains the fallback for tensors >= 4 GiB.
+#include "szn_common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((address_space(3))) void* ldsptr_t;
+
+int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                      const float* chan_scale, void* out, szn_stream_t stream);
+
+namespace {
+
+template <typename T> struct Mma2;
+template <> struct Mma2<bf16_raw> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
+                                                      0, 0, 0);
+    }
+};
+template <> struct Mma2<float> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+struct Conv2Args {
+    const char* in; const char* w; const float* bias; const char* gate; const float* cscale; char* out;
+    float* ws;                 // split-K accumulator [M][Co] (nsplit > 1)
+    unsigned in_bytes, w_bytes;
+    int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
+    int ldi, ldo, ldg, relu, out_f32;
+    int M, HoWo, mtiles, ntiles, nsplit, chunks_per_split;
+};
+
+__device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+constexpr unsigned kOOB = 0x80000000u;   // any offset >= num_records reads as zero
+
+template <typename T, int WNF>           // WNF = 16-cout fragments per wave: 4 -> BN = 128, 2 -> BN = 64
+__global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type does not exist in the host pass
+    constexpr int ES = sizeof(T);
+    constexpr int BKE = 128 / ES;                 // elements per 128-B K chunk
+    constexpr int BM = 256, BN = 32 * WNF;
+    constexpr int STAGE = (BM + BN) * 128;        // bytes per ring stage
+    constexpr int NB = BN / 64;                   // weight-tile LDS-DMA instructions per wave per chunk (2 or 1)
+    constexpr int LPC = 4 + NB;                   // loads per chunk per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [3][pixels BM x 128 B | weights BN x 128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;            // wave -> 64 pixels x (BN/2) couts
+    const int g = lane >> 4, r16 = lane & 15;
+
+    const int nwg = a.mtiles * a.ntiles;
+    const int lid = xcd_remap2(blockIdx.x, nwg);
+    const int nt = lid % a.ntiles, mt = lid / a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int split = blockIdx.y;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+
+    // ---- LDS-DMA assignment: instruction (w, i) fills pixel rows 32w + 8i .. +7; lane -> (row lane>>3, slot lane&7)
+    const int chunkA = (lane & 7) ^ (lane >> 3);          // source 16-B chunk that lands in this lane's slot
+    unsigned baseA[4];                                     // byte offset of (pixel, tap (0,0), chunkA), wraps mod 2^32
+    int ohw[4];                                            // (oh - pad) << 16 | (ow - pad) & 0xffff ; invalid row: 0x7fff7fff
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 32 * w + 8 * i + (lane >> 3);
+        if (m < a.M) {
+            const int b = m / a.HoWo, r = m - b * a.HoWo;
+            const int oh = r / a.Wo, ow = r - oh * a.Wo;
+            const int ih0 = oh - a.pad, iw0 = ow - a.pad;
+            ohw[i] = (ih0 << 16) | (iw0 & 0xffff);
+            const long px = ((long)(b * a.Hi + ih0) * a.Wi + iw0);
+            baseA[i] = (unsigned)((px * a.ldi + chunkA * (16 / ES)) * ES);
+        } else {
+            ohw[i] = 0x7fff7fff;
+            baseA[i] = 0;
+        }
+    }
+    unsigned voffB[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + (BN / 8) * w + 8 * i + (lane >> 3);     // BN=128: rows 16w+8i+..; BN=64: rows 8w+..
+        voffB[i] = (n < a.Co) ? (unsigned)(((long)n * a.KH * a.KW * a.Ci + chunkA * (16 / ES)) * ES) : kOOB;
+    }
+
+    // issue-side iterator (runs two chunks ahead of the compute side)
+    const int cpt = a.Ci / BKE;                            // chunks per tap
+    const int kbeg = split * a.chunks_per_split;
+    const int kend = min(a.KH * a.KW * cpt, kbeg + a.chunks_per_split);
+    const int nK = kend - kbeg;
+    int itap = kbeg / cpt, ic = kbeg - itap * cpt;         // tap index, chunk within tap
+    unsigned voffA[4];
+    auto set_tap = [&]() {
+        const int kh = itap / a.KW, kw = itap - kh * a.KW;
+        const unsigned tapoff = (unsigned)((kh * a.Wi + kw) * a.ldi * ES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ih = (ohw[i] >> 16) + kh, iw = (int)(short)(ohw[i] & 0xffff) + kw;
+            const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+            voffA[i] = ok ? baseA[i] + tapoff : kOOB;
+        }
+    };
+    auto issue = [&](int stage) {
+        char* sb = smem + stage * STAGE;
+        const int soffA = ic * 128;                                  // channel offset of this chunk (bytes)
+        const int soffB = (itap * a.Ci) * ES + ic * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (32 * w + 8 * i) * 128), 16, voffA[i], soffA, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + BM * 128 + ((BN / 8) * w + 8 * i) * 128), 16, voffB[i],
+                                                     soffB, 0, 0);
+        if (++ic == cpt) { ic = 0; ++itap; set_tap(); }
+    };
+
+    f32x4_t acc[WNF][4];
+#pragma unroll
+    for (int i = 0; i < WNF; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    set_tap();
+    if (nK > 0) issue(0);
+    if (nK > 1) issue(1);
+    const int offs0 = ((g ^ (r16 & 7)) << 4), offs1 = (((4 + g) ^ (r16 & 7)) << 4);
+    int stage = 0;
+    for (int kc = 0; kc < nK; ++kc) {
+        // chunk kc has landed once at most the next chunk's loads are still outstanding
+        if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kc + 2 < nK) issue(stage >= 1 ? stage - 1 : 2);          // (stage + 2) % 3: last read in iteration kc-1
+        const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
+        const char* sw = smem + stage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = s ? offs1 : offs0;
+            u32x4_t wf[WNF], pf[4];
+#pragma unroll
+            for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pf[j] = *(const u32x4_t*)(sp + j * 16 * 128 + off);
+#pragma unroll
+            for (int i = 0; i < WNF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma2<T>::run(acc[i][j], wf[i], pf[j]);
+        }
+        if (++stage == 3) stage = 0;
+    }
+
+    // ---- epilogue: lane holds couts nb..nb+3 of pixel m ----
+    if (a.nsplit > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + r16;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int i = 0; i < WNF; ++i) {
+                const int nb = n0 + wn * (BN / 2) + i * 16 + g * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (nb + e < a.Co) atomicAdd(a.ws + (long)m * a.Co + nb + e, acc[i][j][e]);
+            }
+        }
+        return;
+    }
+    const T* __restrict__ gate = (const T*)a.gate;
+    const bool vec_ok = ((a.ldo & 3) == 0) && (!a.gate || (a.ldg & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + r16;
+        if (m >= a.M) continue;
+        const int b = a.cscale ? (m / a.HoWo) : 0;
+#pragma unroll
+        for (int i = 0; i < WNF; ++i) {
+            const int nb = n0 + wn * (BN / 2) + i * 16 + g * 4;
+            if (nb >= a.Co) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nb + e;
+                float x = acc[i][j][e];
+                if (n < a.Co) {
+                    if (a.bias) x += a.bias[n];
+                    if (a.relu) x = fmaxf(x, 0.f);
+                    if (gate) x = (elem<T>::ld(gate + (long)m * a.ldg + n) > 0.f) ? x : 0.f;
+                    if (a.cscale) x *= a.cscale[(long)b * a.Co + n];
+                }
+                v[e] = x;
+            }
+            if (a.out_f32 || sizeof(T) == 4) {
+                float* o = (float*)a.out + (long)m * a.ldo + nb;
+                if (vec_ok && nb + 3 < a.Co) {
+                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (nb + e < a.Co) o[e] = v[e];
+                }
+            } else {
+                uint16_t* o = (uint16_t*)a.out + (long)m * a.ldo + nb;
+                if (vec_ok && nb + 3 < a.Co) {
+                    u32x2_t pk;
+                    pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+                    *(u32x2_t*)o = pk;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (nb + e < a.Co) o[e] = f32_to_bf16_bits(v[e]);
+                }
+            }
+        }
+    }
+#endif
+}
+
+// epilogue of the split-K path: out = epi(ws + bias)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__ ws, Conv2Args a) {
+    const long total = (long)a.M * a.Co;
+    const T* __restrict__ gate = (const T*)a.gate;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int n = (int)(idx % a.Co);
+        const long m = idx / a.Co;
+        float x = ws[idx];
+        if (a.bias) x += a.bias[n];
+        if (a.relu) x = fmaxf(x, 0.f);
+        if (gate) x = (elem<T>::ld(gate + m * a.ldg + n) > 0.f) ? x : 0.f;
+        if (a.cscale) x *= a.cscale[(m / a.HoWo) * a.Co + n];
+        if (a.out_f32 || sizeof(T) == 4) ((float*)a.out)[m * a.ldo + n] = x;
+        else ((uint16_t*)a.out)[m * a.ldo + n] = f32_to_bf16_bits(x);
+    }
+}
+
+template <typename T, int WNF>
+int launch_v2(const Conv2Args& a, hipStream_t st) {
+    constexpr int BN = 32 * WNF;
+    const size_t lds = 3 * (256 + BN) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_v2<T, WNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_v2<T, WNF>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
+    SZN_CHECK_LAUNCH("conv_igemm_v2");
+    return SZN_OK;
+}
+
+}  // namespace
+
+extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias,
+                              const void* gate, const float* chan_scale, void* out, szn_stream_t stream) {
+    if (!d) SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: null descriptor");
+    const size_t es = d->dtype == SZN_BF16 ? 2 : 4;
+    const size_t in_bytes = (size_t)d->B * d->Hi * d->Wi * d->ldi * es;
+    const size_t w_bytes = (size_t)d->Co * d->KH * d->KW * d->Ci * es;
+    const int bke = (int)(128 / es);
+    const bool v2_ok = (d->dtype == SZN_BF16 || d->dtype == SZN_F32) && d->Ci > 0 && (d->Ci % bke) == 0 &&
+                       in_bytes < 0x7fff0000ul && w_bytes < 0x7fff0000ul && d->Hi < 32000 && d->Wi < 32000 && d->pad < 16000 &&
+                       ((size_t)d->ldi * es) % 16 == 0;
+    if (!v2_ok) return szn_conv2d_fwd_v1(d, in, w, bias, gate, chan_scale, out, stream);
+    // argument validation is shared with the v1 path (same contract)
+    if (d->B <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Co <= 0 || d->KH <= 0 || d->KW <= 0 || d->pad < 0 ||
+        d->Ho != d->Hi + 2 * d->pad - d->KH + 1 || d->Wo != d->Wi + 2 * d->pad - d->KW + 1 || d->Ho <= 0 || d->Wo <= 0 ||
+        d->ldi < d->Ci || d->ldo < d->Co || !in || !w || !out || (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) ||
+        (long)d->B * d->Ho * d->Wo >= (1L << 31))
+        return szn_conv2d_fwd_v1(d, in, w, bias, gate, chan_scale, out, stream);   // reports the precise error
+    hipStream_t st = (hipStream_t)stream;
+    Conv2Args a;
+    a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
+    a.out = (char*)out; a.ws = nullptr;
+    a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
+    a.relu = d->relu; a.out_f32 = d->out_f32;
+    a.M = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo;
+    const bool narrow = d->Co <= 64;
+    const int BN = narrow ? 64 : 128;
+    a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(a.Co, BN);
+    const int nK = d->KH * d->KW * (d->Ci / bke);
+    a.nsplit = 1; a.chunks_per_split = nK;
+    const long tiles = (long)a.mtiles * a.ntiles;
+    const size_t ws_need = (size_t)a.M * a.Co * sizeof(float);
+    if (d->workspace && d->workspace_bytes >= ws_need && tiles < 512 && nK >= 64) {
+        long ns = (1024 + tiles - 1) / tiles;
+        if (ns > nK / 16) ns = nK / 16;
+        if (ns > 1) {
+            a.chunks_per_split = (int)((nK + ns - 1) / ns);
+            a.nsplit = szn_div_up(nK, a.chunks_per_split);
+        }
+    }
+    if (a.nsplit > 1) {
+        a.ws = (float*)d->workspace;
+        hipError_t e = hipMemsetAsync(a.ws, 0, ws_need, st);
+        if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "conv2d_fwd split-K memset: %s", hipGetErrorString(e));
+    }
+    int rc;
+    if (d->dtype == SZN_BF16) rc = narrow ? launch_v2<bf16_raw, 2>(a, st) : launch_v2<bf16_raw, 4>(a, st);
+    else rc = narrow ? launch_v2<float, 2>(a, st) : launch_v2<float, 4>(a, st);
+    if (rc) return rc;
+    if (a.nsplit > 1) {
+        long blocks = ((long)a.M * a.Co + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        if (d->dtype == SZN_BF16)
+            hipLaunchKernelGGL(splitk_epilogue<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a.ws, a);
+        else
+            hipLaunchKernelGGL(splitk_epilogue<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a.ws, a);
+        SZN_CHECK_LAUNCH("splitk_epilogue");
+    }
+    return SZN_OK;
+}

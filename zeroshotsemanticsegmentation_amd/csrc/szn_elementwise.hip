@@ -85,52 +85,44 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
     for (int e = 0; e < 8; ++e) elem<T>::st(o + e, fmaxf(acc[e] + bl[cg * 8 + e], 0.f));
 }
 
-// dw[co][t] += sum over the (H+2)x(W+2) output pixels whose window touches the image.
-// lane = cout; a wave walks pixels; the 27 inputs of a pixel are wave-uniform.
+// conv1_1 wgrad = a 1x1-conv wgrad on the im2col image: xcol[m][t] = x[b][ci][oh+kh-pad][ow+kw-pad], t = (kh*3+kw)*3+ci
+// (27 taps padded to 32 "channels"), so the MFMA wgrad kernel does the reduction over the B*Ho*Wo pixels.
 template <typename T>
-__global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dout,
-                                                            float* __restrict__ dw, int B, int H, int W, int pad,
-                                                            int Ho, int Wo, int pix_per_wave) {
-    __shared__ float red[4][27][64];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int RW = W + 2, RH = H + 2;            // region of outputs with a non-zero window
-    const long nreg = (long)B * RH * RW;
-    long q0 = ((long)blockIdx.x * 4 + wave) * pix_per_wave;
-    const long q1 = min(nreg, q0 + pix_per_wave);
-    float acc[27];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+__global__ __launch_bounds__(256) void im2col_c3_kernel(const float* __restrict__ x, T* __restrict__ xcol, int B, int H,
+                                                        int W, int pad, int Ho, int Wo) {
+    constexpr int CH = elem<T>::kPer16B;
+    constexpr int CPR = 32 / CH;                         // 16-B chunks per row (4 bf16 / 8 f32)
+    const long total = (long)B * Ho * Wo * CPR;
     const long plane = (long)H * W;
-    for (long q = q0; q < q1; ++q) {
-        const int b = (int)(q / ((long)RH * RW));
-        const int r = (int)(q - (long)b * RH * RW);
-        const int oh = r / RW + (pad - 2), ow = r % RW + (pad - 2);
-        if (oh < 0 || ow < 0 || oh >= Ho || ow >= Wo) continue;
-        const float d = elem<T>::ld(dout + (((long)b * Ho + oh) * Wo + ow) * 64 + lane);
+    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+        const int cc = (int)(gid % CPR);
+        const long p = gid / CPR;
+        const int ow = (int)(p % Wo);
+        const long q = p / Wo;
+        const int oh = (int)(q % Ho), b = (int)(q / Ho);
+        u32x4_t o;
+        T* oe = (T*)&o;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int ih = oh + kh - pad;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int iw = ow + kw - pad;
-                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-#pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const float xv = ok ? x[((long)b * 3 + ci) * plane + (long)ih * W + iw] : 0.f;
-                    acc[(kh * 3 + kw) * 3 + ci] = fmaf(d, xv, acc[(kh * 3 + kw) * 3 + ci]);
-                }
+        for (int e = 0; e < CH; ++e) {
+            const int t = cc * CH + e;
+            float v = 0.f;
+            if (t < 27) {
+                const int ci = t % 3, tap = t / 3, kh = tap / 3, kw = tap - kh * 3;
+                const int ih = oh + kh - pad, iw = ow + kw - pad;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[((long)b * 3 + ci) * plane + (long)ih * W + iw];
             }
+            elem<T>::st(oe + e, v);
         }
+        *(u32x4_t*)(xcol + p * 32 + cc * CH) = o;
     }
-#pragma unroll
-    for (int t = 0; t < 27; ++t) red[wave][t][lane] = acc[t];
-    __syncthreads();
-    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-        const int co = i & 63, t = i >> 6;
-        const float s = red[0][t][co] + red[1][t][co] + red[2][t][co] + red[3][t][co];
-        if (s != 0.f) atomicAdd(dw + co * 27 + t, s);
-    }
+}
+
+__global__ void unpack_dw32_kernel(const float* __restrict__ dw32, float* __restrict__ dw, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * 27) return;
+    const int co = i / 27, t = i - co * 27;
+    const float v = dw32[co * 32 + t];
+    dw[i] = accumulate ? dw[i] + v : v;
 }
 
 // ---- MaxPool2d(2,2,ceil_mode=True) on NHWC: thread = (output pixel, 16-B channel chunk) -----------
@@ -300,29 +292,43 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
     return SZN_OK;
 }
 
+extern "C" size_t szn_conv1_1_wgrad_workspace_bytes(int dtype, int B, int H, int W, int pad) {
+    if (B <= 0 || H <= 0 || W <= 0 || pad < 0) return 0;
+    const size_t Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    return (size_t)B * Ho * Wo * 32 * (dtype == SZN_BF16 ? 2 : 4) + 64 * 32 * sizeof(float);
+}
+
 extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw,
-                                 float* db, int accumulate, szn_stream_t stream) {
-    if (!x || !dout || !dw || B <= 0 || H <= 0 || W <= 0 || pad < 2) SZN_FAIL(SZN_ERR_ARG, "conv1_1_wgrad: bad argument");
+                                 float* db, int accumulate, void* workspace, szn_stream_t stream) {
+    if (!x || !dout || !dw || !workspace || B <= 0 || H <= 0 || W <= 0 || pad < 0)
+        SZN_FAIL(SZN_ERR_ARG, "conv1_1_wgrad: bad argument");
+    if ((uintptr_t)workspace & 15) SZN_FAIL(SZN_ERR_ARG, "conv1_1_wgrad: workspace must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
-    if (!accumulate) {
-        hipError_t e = hipMemsetAsync(dw, 0, 64 * 27 * sizeof(float), st);
-        if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "conv1_1_wgrad memset: %s", hipGetErrorString(e));
-    }
-    const long nreg = (long)B * (H + 2) * (W + 2);
-    int ppw = (int)((nreg + 4095) / 4096);
-    if (ppw < 16) ppw = 16;
-    const int blocks = szn_div_up(nreg, (long)ppw * 4);
+    const long M = (long)B * Ho * Wo;
+    if (M >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_wgrad: more than 2^31 pixels");
+    const size_t es = dtype == SZN_BF16 ? 2 : 4;
+    float* dw32 = (float*)workspace;                              // [64][32]
+    char* xcol = (char*)workspace + 64 * 32 * sizeof(float);      // [M][32] of dtype
+    const long chunks = M * (32 / (16 / es));
+    long blocks = (chunks + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
     if (dtype == SZN_BF16)
-        hipLaunchKernelGGL(conv1_1_wgrad_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, x, (const bf16_raw*)dout, dw, B, H,
-                           W, pad, Ho, Wo, ppw);
+        hipLaunchKernelGGL(im2col_c3_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, x, (bf16_raw*)xcol, B, H, W,
+                           pad, Ho, Wo);
     else if (dtype == SZN_F32)
-        hipLaunchKernelGGL(conv1_1_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, x, (const float*)dout, dw, B, H, W,
-                           pad, Ho, Wo, ppw);
+        hipLaunchKernelGGL(im2col_c3_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, x, (float*)xcol, B, H, W, pad, Ho,
+                           Wo);
     else
         SZN_FAIL(SZN_ERR_ARG, "conv1_1_wgrad: bad dtype %d", dtype);
-    SZN_CHECK_LAUNCH("conv1_1_wgrad_kernel");
-    if (db) return szn_bias_grad(dtype, (long)B * Ho * Wo, 64, 64, dout, db, accumulate, stream);
+    SZN_CHECK_LAUNCH("im2col_c3_kernel");
+    // 1x1 "conv" over M rows: in = xcol [M][32], dout [M][64] -> dw32 [64][1][1][32]
+    szn_conv_desc_t d = {dtype, 1, 1, (int)M, 32, 1, (int)M, 64, 1, 1, 0, 32, 64, 0, 0, 0};
+    int rc = szn_conv2d_wgrad(&d, xcol, dout, dw32, 0, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(unpack_dw32_kernel, dim3((64 * 27 + 255) / 256), dim3(256), 0, st, (const float*)dw32, dw, accumulate);
+    SZN_CHECK_LAUNCH("unpack_dw32_kernel");
+    if (db) return szn_bias_grad(dtype, M, 64, 64, dout, db, accumulate, stream);
     return SZN_OK;
 }
 

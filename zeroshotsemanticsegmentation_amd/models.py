@@ -61,6 +61,15 @@ class _Engine(object):
         self._images = {}
         self.dropout_seed = 1337
         self.dropout_calls = 0
+        self._splitk_ws = None
+
+    def _workspace(self, desc, nbytes, device):
+        """split-K scratch handed to the conv kernels (they use it only for few-tile / long-K shapes: fc6, fc7)"""
+        if nbytes > (256 << 20):
+            return
+        if self._splitk_ws is None or self._splitk_ws.numel() < nbytes or self._splitk_ws.device != device:
+            self._splitk_ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        desc.workspace, desc.workspace_bytes = self._splitk_ws.data_ptr(), self._splitk_ws.numel()
 
     # ---- weights ---------------------------------------------------------------------------------
     def set_precision(self, dtype):
@@ -134,6 +143,7 @@ class _Engine(object):
         Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
         out = torch.empty(B, Ho, Wo, co, device=x.device, dtype=torch.float32 if out_f32 else self.dtype)
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, co, k, k, pad, Ci, co, 0, int(relu), int(out_f32))
+        self._workspace(d, B * Ho * Wo * co * 4, x.device)
         L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), None, L.ptr(scale), L.ptr(out), L.stream_ptr())
         return out
 
@@ -248,6 +258,7 @@ class _Engine(object):
         k = wT.shape[1]
         din = torch.empty(B, Hi, Wi, Ci, device=dout.device, dtype=self.dtype)
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, Ci, 0, 0)
+        self._workspace(d, B * Hi * Wi * Ci * 4, dout.device)
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
         return din
 
@@ -296,7 +307,10 @@ class _Engine(object):
             name, pad = item
             if name == "conv1_1":
                 dw, db = grads[name]
-                L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), L.ptr(db), 0, st)
+                nb = L.load().szn_conv1_1_wgrad_workspace_bytes(code, ctx.B, ctx.H, ctx.W, PAD1)
+                ws = torch.empty(nb, dtype=torch.uint8, device=d.device)
+                L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), L.ptr(db), 0,
+                       L.ptr(ws), st)
                 done(name)
                 break
             prev = items[idx - 1]
