@@ -514,8 +514,9 @@ extern "C" int szn_conv2d_dgrad(const szn_conv_desc_t* d, const void* dout, cons
     return szn_conv2d_fwd(&s, dout, wT, nullptr, gate, chan_scale, din, stream);
 }
 
-extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
-                                szn_stream_t stream) {
+// first-generation kernel (register-staged, 128x128 tile): fallback of szn_conv2d_wgrad (szn_conv_wgrad.hip)
+int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
+                        szn_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!in || !dout || !dw) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad: null pointer");

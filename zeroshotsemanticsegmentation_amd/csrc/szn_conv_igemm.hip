@@ -183,9 +183,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
 #pragma unroll
             for (int i = 0; i < WNF; ++i) {
                 const int nb = n0 + wn * (BN / 2) + i * 16 + g * 4;
+                if (nb >= a.Co) continue;
+                float* o = a.ws + ((long)split * a.M + m) * a.Co + nb;      // slab of this split: plain stores
+                if ((a.Co & 3) == 0) {
+                    *(float4*)o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (nb + e < a.Co) atomicAdd(a.ws + (long)m * a.Co + nb + e, acc[i][j][e]);
+                    for (int e = 0; e < 4; ++e) if (nb + e < a.Co) o[e] = acc[i][j][e];
+                }
             }
         }
         return;
@@ -247,7 +252,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int n = (int)(idx % a.Co);
         const long m = idx / a.Co;
-        float x = ws[idx];
+        float x = 0.f;
+        for (int sp = 0; sp < a.nsplit; ++sp) x += ws[(long)sp * total + idx];     // fixed order: bit-reproducible
         if (a.bias) x += a.bias[n];
         if (a.relu) x = fmaxf(x, 0.f);
         if (gate) x = (elem<T>::ld(gate + m * a.ldg + n) > 0.f) ? x : 0.f;
@@ -305,19 +311,17 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     const int nK = d->KH * d->KW * (d->Ci / bke);
     a.nsplit = 1; a.chunks_per_split = nK;
     const long tiles = (long)a.mtiles * a.ntiles;
-    const size_t ws_need = (size_t)a.M * a.Co * sizeof(float);
-    if (d->workspace && d->workspace_bytes >= ws_need && tiles < 512 && nK >= 64) {
-        long ns = (1024 + tiles - 1) / tiles;
-        if (ns > nK / 16) ns = nK / 16;
+    // split-K only where the grid cannot fill the chip AND K is long (fc6 dgrad: 68 tiles x 3136 chunks): every split
+    // writes its own fp32 slab with plain stores, a second kernel sums the slabs in a fixed order + epilogue
+    if (d->workspace && tiles < 128 && nK >= 256) {
+        long ns = (768 + tiles - 1) / tiles;
+        if (ns > nK / 32) ns = nK / 32;
+        while (ns > 1 && (size_t)ns * a.M * a.Co * sizeof(float) > d->workspace_bytes) --ns;
         if (ns > 1) {
             a.chunks_per_split = (int)((nK + ns - 1) / ns);
             a.nsplit = szn_div_up(nK, a.chunks_per_split);
+            a.ws = (float*)d->workspace;
         }
-    }
-    if (a.nsplit > 1) {
-        a.ws = (float*)d->workspace;
-        hipError_t e = hipMemsetAsync(a.ws, 0, ws_need, st);
-        if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "conv2d_fwd split-K memset: %s", hipGetErrorString(e));
     }
     int rc;
     if (d->dtype == SZN_BF16) rc = narrow ? launch_v2<bf16_raw, 2>(a, st) : launch_v2<bf16_raw, 4>(a, st);

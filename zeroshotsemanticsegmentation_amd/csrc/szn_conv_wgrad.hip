@@ -1,0 +1,284 @@
+// szn_conv_wgrad.hip -- second-generation weight-gradient kernel for gfx950 and the public szn_conv2d_wgrad
+// dispatcher.   dw[co][kh][kw][ci] += sum_pixels dout[p][co] * in[p + (kh,kw) - pad][ci]
+//
+// conv_wgrad_v2: per filter tap a GEMM D[co][ci] = A^T B with A = dout [pixel][co], B = shifted in [pixel][ci]; the
+// contraction index (pixels) is the slow one in both operands, so tiles are staged pixel-major and fragments are
+// fetched with ds_read_b64_tr_b16 (bf16, hardware transpose) or ds_read_b32 (f32).
+//   * block = 256 threads = 4 waves (2 x 2), tile (32 FA) couts x (32 FB) cins, FA, FB in {2, 4}: 64-channel layers
+//     (conv1_2, conv2_1, conv1_1's im2col form) no longer pad to 128;
+//   * operands go to LDS with buffer_load ... lds; out-of-image taps / tile edges / split ends are out-of-range
+//     offsets (zeros); the 16-B chunk index of every row is XOR-swizzled on the SOURCE side so that the transpose
+//     reads (4 rows x 32 B per 16-lane group) and the f32 reads are bank-conflict free without row padding;
+//   * pixel coordinates advance incrementally (no integer division in the K loop);
+//   * 3-stage LDS ring (<= 48 KiB, 3 blocks per CU), counted vmcnt, one raw s_barrier per K step;
+//   * split over pixels; partial tiles are added to the fp32 OHWI gradient with global atomics.
+#include "szn_common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((address_space(3))) void* ldsptr_t;
+
+int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
+                        szn_stream_t stream);
+
+namespace {
+
+struct Wg2Args {
+    const char* dout; const char* in; float* dw;
+    unsigned dout_bytes, in_bytes;
+    int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
+    int ldi, ldd;
+    int M;
+    int kspan, nsplit, cotiles, citiles;
+    int plain_store;           // single split and no accumulation: write the tile instead of atomically adding it
+};
+
+constexpr unsigned kOOBw = 0x80000000u;
+
+template <typename T, int FA, int FB>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_v2(Wg2Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ES = sizeof(T);
+    constexpr int CH = 16 / ES;                    // elements per 16-B chunk
+    constexpr int KP = (ES == 2) ? 32 : 16;        // pixels per K step
+    constexpr int CO_T = 32 * FA, CI_T = 32 * FB;  // tile channels
+    constexpr int RBA = CO_T * ES, RBB = CI_T * ES;            // LDS row bytes
+    constexpr int CPRA = RBA / 16, CPRB = RBB / 16;            // 16-B chunks per row
+    constexpr int RPIA = 1024 / RBA, RPIB = 1024 / RBB;        // rows per LDS-DMA instruction
+    constexpr int NA = FA / 2, NBI = FB / 2;                   // LDS-DMA instructions per wave per step
+    constexpr int LPC = NA + NBI;
+    constexpr int STAGE = KP * (RBA + RBB);
+    __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;             // wave -> (16 FA) couts x (16 FB) cins
+    const int g = lane >> 4, r16 = lane & 15;
+
+    int bid = blockIdx.x;
+    const int cit = bid % a.citiles; bid /= a.citiles;
+    const int cot = bid % a.cotiles; bid /= a.cotiles;
+    const int ntap = a.KH * a.KW;
+    const int tap = bid % ntap, split = bid / ntap;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int co0 = cot * CO_T, ci0 = cit * CI_T;
+    const int mbeg = split * a.kspan;
+    const int mend = min(a.M, mbeg + a.kspan);
+    if (mbeg >= mend) return;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, (int)a.dout_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+
+    // row swizzle (XOR on the 16-B chunk index), see header comment
+    auto swz = [](int row, int rowbytes) -> int {
+        if (ES == 2) return rowbytes == 256 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
+        return (row & 1) << 2;
+    };
+
+    // ---- LDS-DMA slots of this thread ----
+    int mA[NA]; unsigned chA[NA];       // pixel index and channel byte offset (or OOB) of the dout slots
+    int mB[NBI], ohB[NBI], owB[NBI], bB[NBI]; unsigned chB[NBI];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (w * NA + i) * RPIA + lane / CPRA, slot = lane % CPRA;
+        const int chunk = slot ^ swz(row, RBA);
+        const int co = co0 + chunk * CH;
+        mA[i] = mbeg + row;
+        chA[i] = (co < a.Co && co + CH <= a.ldd) ? (unsigned)(co * ES) : kOOBw;
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int row = (w * NBI + i) * RPIB + lane / CPRB, slot = lane % CPRB;
+        const int chunk = slot ^ swz(row, RBB);
+        const int ci = ci0 + chunk * CH;
+        const int m = mbeg + row;
+        mB[i] = m;
+        const int b = m / (a.Ho * a.Wo), r = m - b * (a.Ho * a.Wo);
+        bB[i] = b; ohB[i] = r / a.Wo; owB[i] = r - ohB[i] * a.Wo;
+        chB[i] = (ci < a.Ci) ? (unsigned)(ci * ES) : kOOBw;
+    }
+    auto issue = [&](int stage) {
+        char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned v = (mA[i] < mend && chA[i] != kOOBw) ? (unsigned)mA[i] * (unsigned)(a.ldd * ES) + chA[i] : kOOBw;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (w * NA + i) * 1024), 16, v, 0, 0, 0);
+            mA[i] += KP;
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int ih = ohB[i] + kh - a.pad, iw = owB[i] + kw - a.pad;
+            const bool ok = mB[i] < mend && chB[i] != kOOBw && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+            const unsigned v = ok ? (unsigned)((bB[i] * a.Hi + ih) * a.Wi + iw) * (unsigned)(a.ldi * ES) + chB[i] : kOOBw;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + KP * RBA + (w * NBI + i) * 1024), 16, v, 0, 0, 0);
+            mB[i] += KP; owB[i] += KP;
+            while (owB[i] >= a.Wo) { owB[i] -= a.Wo; if (++ohB[i] >= a.Ho) { ohB[i] = 0; ++bB[i]; } }
+        }
+    };
+
+    f32x4_t acc[FA][FB];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane read offsets (bytes within a stage) ----
+    int offA[FA], offB[FB];
+    if constexpr (ES == 2) {
+        const int kk = g * 4 + (r16 >> 2);                 // row supplied by this lane (first read; second is +16 rows)
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int cb = wm * FA * 16 + i * 16;
+            offA[i] = kk * RBA + ((((cb >> 3)) ^ swz(kk, RBA)) << 4) + (r16 & 3) * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+            const int cb = wn * FB * 16 + j * 16;
+            offB[j] = KP * RBA + kk * RBB + ((((cb >> 3)) ^ swz(kk, RBB)) << 4) + (r16 & 3) * 8;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int c = wm * FA * 16 + i * 16 + r16;
+            offA[i] = g * RBA + (((c >> 2) ^ swz(g, RBA)) << 4) + (c & 3) * 4;
+        }
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+            const int c = wn * FB * 16 + j * 16 + r16;
+            offB[j] = KP * RBA + g * RBB + (((c >> 2) ^ swz(g, RBB)) << 4) + (c & 3) * 4;
+        }
+    }
+
+    const int nK = (mend - mbeg + KP - 1) / KP;
+    issue(0);
+    if (nK > 1) issue(1);
+    int stage = 0;
+    for (int kc = 0; kc < nK; ++kc) {
+        if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kc + 2 < nK) issue(stage >= 1 ? stage - 1 : 2);
+        const char* sb = smem + stage * STAGE;
+        if constexpr (ES == 2) {
+            typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+            u32x4_t df[FA], xf[FB];
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offA[i]));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offA[i] + 16 * RBA));
+                const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+                df[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offB[j]));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offB[j] + 16 * RBB));
+                const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+                xf[j] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < FB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, df[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {       // rows 4s + g; the swizzle depends on (row & 1) == (g & 1) only
+                float df[FA], xf[FB];
+#pragma unroll
+                for (int i = 0; i < FA; ++i) df[i] = *(const float*)(sb + offA[i] + 4 * s * RBA);
+#pragma unroll
+                for (int j = 0; j < FB; ++j) xf[j] = *(const float*)(sb + offB[j] + 4 * s * RBB);
+#pragma unroll
+                for (int i = 0; i < FA; ++i)
+#pragma unroll
+                    for (int j = 0; j < FB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(df[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (++stage == 3) stage = 0;
+    }
+
+    // D[co][ci]: lane holds rows co = g*4+e, column ci = r16
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = co0 + wm * FA * 16 + i * 16 + g * 4 + e;
+            if (co >= a.Co) continue;
+            float* row = a.dw + ((long)(co * a.KH + kh) * a.KW + kw) * a.Ci;
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const int ci = ci0 + wn * FB * 16 + j * 16 + r16;
+                if (ci < a.Ci) {
+                    if (a.plain_store) row[ci] = acc[i][j][e];
+                    else atomicAdd(row + ci, acc[i][j][e]);
+                }
+            }
+        }
+    }
+#endif
+}
+
+template <typename T, int FA, int FB>
+void launch_wg2(const Wg2Args& a, long blocks, hipStream_t st) {
+    hipLaunchKernelGGL((conv_wgrad_v2<T, FA, FB>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
+                                szn_stream_t stream) {
+    if (!d) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad: null descriptor");
+    const size_t es = d->dtype == SZN_BF16 ? 2 : 4;
+    const int ch = (int)(16 / es);
+    const size_t in_bytes = (size_t)d->B * d->Hi * d->Wi * d->ldi * es;
+    const size_t dout_bytes = (size_t)d->B * d->Ho * d->Wo * d->ldo * es;
+    const bool ok = (d->dtype == SZN_BF16 || d->dtype == SZN_F32) && in && dout && dw && d->B > 0 && d->Hi > 0 && d->Wi > 0 &&
+                    d->Ci > 0 && d->Co > 0 && d->KH > 0 && d->KW > 0 && d->pad >= 0 &&
+                    d->Ho == d->Hi + 2 * d->pad - d->KH + 1 && d->Wo == d->Wi + 2 * d->pad - d->KW + 1 && d->Ho > 0 && d->Wo > 0 &&
+                    (d->Ci % ch) == 0 && (d->ldi % ch) == 0 && (d->ldo % ch) == 0 && in_bytes < 0x7fff0000ul &&
+                    dout_bytes < 0x7fff0000ul && (long)d->B * d->Ho * d->Wo < (1L << 31) &&
+                    !(((uintptr_t)in | (uintptr_t)dout) & 15);
+    if (!ok) return szn_conv2d_wgrad_v1(d, in, dout, dw, accumulate, stream);     // validates and reports / handles >= 2 GiB
+    hipStream_t st = (hipStream_t)stream;
+    const long nw = (long)d->Co * d->KH * d->KW * d->Ci;
+    Wg2Args a;
+    a.dout = (const char*)dout; a.in = (const char*)in; a.dw = dw;
+    a.dout_bytes = (unsigned)dout_bytes; a.in_bytes = (unsigned)in_bytes;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldd = d->ldo;
+    a.M = d->B * d->Ho * d->Wo;
+    const int FA = d->Co <= 64 ? 2 : 4, FB = d->Ci <= 64 ? 2 : 4;
+    a.cotiles = szn_div_up(d->Co, 32 * FA); a.citiles = szn_div_up(d->Ci, 32 * FB);
+    const long tiles = (long)a.cotiles * a.citiles * d->KH * d->KW;
+    // ~3 blocks per CU x 256 CUs x a few waves of blocks; each split covers a multiple of 64 pixels, at least 1024
+    long want = (3072 + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    long span = (a.M + want - 1) / want;
+    if (span < 1024) span = 1024;
+    span = (span + 63) / 64 * 64;
+    a.kspan = (int)span;
+    a.nsplit = szn_div_up(a.M, span);
+    const long blocks = tiles * a.nsplit;
+    if (blocks >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad: grid too large");
+    a.plain_store = (a.nsplit == 1 && !accumulate) ? 1 : 0;      // fc6: 411 MB written once instead of memset + atomics
+    if (!accumulate && !a.plain_store) {
+        hipError_t e = hipMemsetAsync(dw, 0, nw * sizeof(float), st);
+        if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "conv2d_wgrad memset: %s", hipGetErrorString(e));
+    }
+    if (d->dtype == SZN_BF16) {
+        if (FA == 4 && FB == 4) launch_wg2<bf16_raw, 4, 4>(a, blocks, st);
+        else if (FA == 4) launch_wg2<bf16_raw, 4, 2>(a, blocks, st);
+        else if (FB == 4) launch_wg2<bf16_raw, 2, 4>(a, blocks, st);
+        else launch_wg2<bf16_raw, 2, 2>(a, blocks, st);
+    } else {
+        if (FA == 4 && FB == 4) launch_wg2<float, 4, 4>(a, blocks, st);
+        else if (FA == 4) launch_wg2<float, 4, 2>(a, blocks, st);
+        else if (FB == 4) launch_wg2<float, 2, 4>(a, blocks, st);
+        else launch_wg2<float, 2, 2>(a, blocks, st);
+    }
+    SZN_CHECK_LAUNCH("conv_wgrad_v2");
+    return SZN_OK;
+}
