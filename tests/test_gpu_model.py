@@ -232,8 +232,8 @@ def test_g7_train_step(optname):
             assert np.array_equal(pred, O.infer_lbl(score.detach().cpu().numpy(), g["embed"]))
             for k in PROBE_PARAMS:
                 gr = named[k].grad
-                assert rel(stats(gr), g["grad_stats/" + k]) < 1e-3, k
                 tol = 1e-2 if k == "conv1_1.bias" else 1e-3       # fp32 reduction noise in the reference, see oracle test
+                assert rel(stats(gr), g["grad_stats/" + k]) < tol, k
                 assert rel(gr.flatten()[cu(probe_idx(gr.numel()))], g["grad_probe/" + k]) < tol, k
         else:
             assert abs(loss.item() - float(g["loss1"])) < 1e-5

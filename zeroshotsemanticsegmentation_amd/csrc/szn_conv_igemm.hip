@@ -22,6 +22,9 @@ typedef __attribute__((address_space(3))) void* ldsptr_t;
 
 int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, szn_stream_t stream);
+int szn_conv3x3_halo_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                         const float* chan_scale, void* out, szn_stream_t stream);
+#include <stdlib.h>
 
 namespace {
 
@@ -57,7 +60,9 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
 
 constexpr unsigned kOOB = 0x80000000u;   // any offset >= num_records reads as zero
 
-template <typename T, int WNF>           // WNF = 16-cout fragments per wave: 4 -> BN = 128, 2 -> BN = 64
+// ABL (debug ablation, env SZN_ABLATE, results are then WRONG): 1 = no LDS-DMA issue in the loop, 2 = no waits/barrier,
+// 3 = fragments read once (no ds_read in the loop), 4 = no MFMA
+template <typename T, int WNF, int ABL = 0>   // WNF = 16-cout fragments per wave: 4 -> BN = 128, 2 -> BN = 64
 __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type does not exist in the host pass
     constexpr int ES = sizeof(T);
@@ -152,12 +157,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
     int stage = 0;
     for (int kc = 0; kc < nK; ++kc) {
         // chunk kc has landed once at most the next chunk's loads are still outstanding
-        if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPC) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kc + 2 < nK) issue(stage >= 1 ? stage - 1 : 2);          // (stage + 2) % 3: last read in iteration kc-1
-        const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
-        const char* sw = smem + stage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
+        if (ABL != 2) {
+            if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (ABL != 1 && kc + 2 < nK) issue(stage >= 1 ? stage - 1 : 2);          // (stage + 2) % 3: last read in iteration kc-1
+        const int rstage = (ABL == 3) ? 0 : stage;
+        const char* sp = smem + rstage * STAGE + (wm * 64 + r16) * 128;
+        const char* sw = smem + rstage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int off = s ? offs1 : offs0;
@@ -169,7 +177,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
 #pragma unroll
             for (int i = 0; i < WNF; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Mma2<T>::run(acc[i][j], wf[i], pf[j]);
+                for (int j = 0; j < 4; ++j) {
+                    if (ABL == 4) { acc[i][j][0] += __uint_as_float(wf[i].x ^ pf[j].x); }
+                    else Mma2<T>::run(acc[i][j], wf[i], pf[j]);
+                }
         }
         if (++stage == 3) stage = 0;
     }
@@ -263,6 +274,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__
     }
 }
 
+template <typename T, int WNF, int ABL>
+void launch_abl(const Conv2Args& a, size_t lds, hipStream_t st) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_v2<T, WNF, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv_igemm_v2<T, WNF, ABL>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
+}
+
 template <typename T, int WNF>
 int launch_v2(const Conv2Args& a, hipStream_t st) {
     constexpr int BN = 32 * WNF;
@@ -271,6 +288,16 @@ int launch_v2(const Conv2Args& a, hipStream_t st) {
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_v2<T, WNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
+    }
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("SZN_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (abl && sizeof(T) == 2 && WNF == 4) {          // debug ablations of the bf16 BN=128 kernel (wrong results)
+        if (abl == 1) launch_abl<T, WNF, 1>(a, lds, st);
+        else if (abl == 2) launch_abl<T, WNF, 2>(a, lds, st);
+        else if (abl == 3) launch_abl<T, WNF, 3>(a, lds, st);
+        else launch_abl<T, WNF, 4>(a, lds, st);
+        SZN_CHECK_LAUNCH("conv_igemm_v2(ablation)");
+        return SZN_OK;
     }
     hipLaunchKernelGGL((conv_igemm_v2<T, WNF>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
     SZN_CHECK_LAUNCH("conv_igemm_v2");
@@ -297,6 +324,19 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
         (long)d->B * d->Ho * d->Wo >= (1L << 31))
         return szn_conv2d_fwd_v1(d, in, w, bias, gate, chan_scale, out, stream);   // reports the precise error
     hipStream_t st = (hipStream_t)stream;
+    // 3x3 layers on large feature maps: LDS-resident input patch (szn_conv_halo.hip); SZN_HALO_MIN overrides the
+    // smallest output side for which it is used (0 = always, huge = never)
+    if (d->KH == 3 && d->KW == 3) {
+        static int halo_min = -1;
+        if (halo_min < 0) {
+            const char* e = getenv("SZN_HALO_MIN");
+            halo_min = e ? atoi(e) : 64;
+        }
+        if (d->Ho >= halo_min && d->Wo >= halo_min) {
+            const int rc = szn_conv3x3_halo_try(d, in, w, bias, gate, chan_scale, out, stream);
+            if (rc <= 0) return rc;
+        }
+    }
     Conv2Args a;
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
     a.out = (char*)out; a.ws = nullptr;
