@@ -132,6 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(HaloArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(smem + (w + 8 * p) * 1024), 16, voffP[p], 0, 0, 0);
     issue(0, 0);
     if (nIter > 1) issue(1, 1);
+    if (nIter > 2) issue(2, 2);
 
     // fragment read bases: pixel fragment j = output row 4 wm + j, lane r16 = column; patch row q = (R+kh)*18 + kw + r16
     int qb[4];
@@ -139,43 +140,61 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(HaloArgs a) {
     for (int j = 0; j < 4; ++j) qb[j] = (wm * 4 + j) * PW + r16;
     const int woff0 = ((g ^ (r16 & 7)) << 4), woff1 = (((4 + g) ^ (r16 & 7)) << 4);
 
-    int stage = 0;
-    for (int it = 0; it < nIter; ++it) {
-        if (it + 1 < nIter) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPC) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (it + 2 < nIter) issue(it + 2, stage >= 1 ? stage - 1 : 2);
+    auto mma = [&](const u32x4_t (&wf)[WNF], const u32x4_t (&pf)[4]) {
+#pragma unroll
+        for (int i = 0; i < WNF; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (ES == 2) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, pf[j]), acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].x), __uint_as_float(pf[j].x), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].y), __uint_as_float(pf[j].y), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].z), __uint_as_float(pf[j].z), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].w), __uint_as_float(pf[j].w), acc[i][j], 0, 0, 0);
+                }
+            }
+    };
+    // fragments of half `s` (0/1) of iteration `it` whose weights sit in ring stage `wst`
+    auto fetch = [&](int it, int wst, int s, u32x4_t (&wf)[WNF], u32x4_t (&pf)[4]) {
         const int sl = it / 9, tap = it - sl * 9;
         const int kh = tap / 3, kw = tap - kh * 3;
         const char* pb = smem + (sl & 1) * PATCHB;
-        const char* sw = smem + OFF_W + stage * WSTAGE + (wn * (BN / 2) + r16) * 128;
+        const char* sw = smem + OFF_W + wst * WSTAGE + (wn * (BN / 2) + r16) * 128;
         const int qs = kh * PW + kw;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4_t wf[WNF], pf[4];
+        for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + (s ? woff1 : woff0));
 #pragma unroll
-            for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + (s ? woff1 : woff0));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = qb[j] + qs;
-                pf[j] = *(const u32x4_t*)(pb + q * 128 + (((s * 4 + g) ^ (q & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < WNF; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (ES == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i]),
-                                                                            __builtin_bit_cast(bf16x8_t, pf[j]), acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].x), __uint_as_float(pf[j].x), acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].y), __uint_as_float(pf[j].y), acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].z), __uint_as_float(pf[j].z), acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].w), __uint_as_float(pf[j].w), acc[i][j], 0, 0, 0);
-                    }
-                }
+        for (int j = 0; j < 4; ++j) {
+            const int q = qb[j] + qs;
+            pf[j] = *(const u32x4_t*)(pb + q * 128 + (((s * 4 + g) ^ (q & 7)) << 4));
         }
-        if (++stage == 3) stage = 0;
+    };
+
+    // software-pipelined loop (see conv_igemm_v2 ABL == 5): fragment reads of the next half run under the MFMAs of the
+    // current half, three tap-iterations of LDS-DMA in flight, the barrier sits between the two halves
+    if (nIter > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPC) : "memory");
+    else if (nIter > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    u32x4_t wfA[WNF], pfA[4], wfB[WNF], pfB[4];
+    fetch(0, 0, 0, wfA, pfA);
+    int stage = 0;
+    for (int it = 0; it < nIter; ++it) {
+        fetch(it, stage, 1, wfB, pfB);
+        mma(wfA, pfA);
+        if (it + 1 < nIter) {
+            if (it + 2 < nIter) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 3 < nIter) issue(it + 3, stage);                  // recycles the weight stage just drained
+        const int nstage = (stage == 2) ? 0 : stage + 1;
+        if (it + 1 < nIter) fetch(it + 1, nstage, 0, wfA, pfA);
+        mma(wfB, pfB);
+        stage = nstage;
     }
 
     // ---- epilogue: lane holds couts nb..nb+3 of output pixel (oh0 + 4 wm + j, ow0 + r16) ----

@@ -39,7 +39,9 @@ extern "C" int szn_device_info(int device, szn_device_info_t* out) {
 namespace {
 
 // ---- conv1_1: 3 -> 64, 3x3, pad P, reads NCHW f32, writes NHWC T ---------------------------------
-// thread = (output pixel, group of 8 couts); weights staged in LDS as [tap*3+ci][64 co].
+// thread = (4 consecutive output pixels of one row, group of 8 couts): the 3 x 6 x 3 input window is loaded once and
+// each weight vector (LDS, [tap*3+ci][64 co]) is reused for the 4 pixels.  With pad = 100 almost half of the outputs
+// only see zero padding: those quads skip the arithmetic and store relu(bias).
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, T* __restrict__ out, int B,
@@ -52,37 +54,62 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
     }
     if (threadIdx.x < 64) bl[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
     __syncthreads();
-    const long npix = (long)B * Ho * Wo;
+    const int qpr = (Wo + 3) >> 2;                       // pixel quads per output row
+    const long nquad = (long)B * Ho * qpr;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long p = gid >> 3;
+    const long qd = gid >> 3;
     const int cg = (int)(gid & 7);
-    if (p >= npix) return;
-    const int b = (int)(p / ((long)Ho * Wo));
-    const int r = (int)(p - (long)b * Ho * Wo);
-    const int oh = r / Wo, ow = r - oh * Wo;
-    float acc[8];
+    if (qd >= nquad) return;
+    const int qx = (int)(qd % qpr);
+    const long rowid = qd / qpr;
+    const int oh = (int)(rowid % Ho), b = (int)(rowid / Ho);
+    const int ow0 = qx * 4;
+    float acc[4][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    const long plane = (long)H * W;
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int ih = oh + kh - pad;
+        for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
+    const int ih0 = oh - pad, iw0 = ow0 - pad;
+    const bool touches = (ih0 + 2 >= 0) && (ih0 < H) && (iw0 + 5 >= 0) && (iw0 < W);
+    if (touches) {
+        const long plane = (long)H * W;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int iw = ow + kw - pad;
-            const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = ih0 + kh;
+            const bool rok = (unsigned)ih < (unsigned)H;
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
-                const float xv = ok ? x[((long)b * 3 + ci) * plane + (long)ih * W + iw] : 0.f;
-                const float* wr = &wl[(kh * 3 + kw) * 3 + ci][cg * 8];
+                float xr[6];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(xv, wr[e], acc[e]);
+                for (int c = 0; c < 6; ++c) {
+                    const int iw = iw0 + c;
+                    xr[c] = (rok && (unsigned)iw < (unsigned)W) ? x[((long)b * 3 + ci) * plane + (long)ih * W + iw] : 0.f;
+                }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* wr = &wl[(kh * 3 + kw) * 3 + ci][cg * 8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float wv = wr[e];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[p][e] = fmaf(xr[kw + p], wv, acc[p][e]);
+                    }
+                }
             }
         }
     }
-    T* o = out + p * 64 + cg * 8;
+    const long pbase = ((long)b * Ho + oh) * Wo + ow0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) elem<T>::st(o + e, fmaxf(acc[e] + bl[cg * 8 + e], 0.f));
+    for (int p = 0; p < 4; ++p) {
+        if (ow0 + p >= Wo) break;
+        u32x4_t o4[2];
+        T* oe = (T*)o4;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) elem<T>::st(oe + e, fmaxf(acc[p][e] + bl[cg * 8 + e], 0.f));
+        T* o = out + (pbase + p) * 64 + cg * 8;
+        *(u32x4_t*)o = o4[0];
+        if (sizeof(T) == 4) *(u32x4_t*)(o + 4) = o4[1];
+    }
 }
 
 // conv1_1 wgrad = a 1x1-conv wgrad on the im2col image: xcol[m][t] = x[b][ci][oh+kh-pad][ow+kw-pad], t = (kh*3+kw)*3+ci
@@ -277,7 +304,7 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
     if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || pad < 0) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd: bad argument");
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     if (Ho <= 0 || Wo <= 0) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd: empty output");
-    const long threads = (long)B * Ho * Wo * 8;
+    const long threads = (long)B * Ho * ((Wo + 3) / 4) * 8;
     const long blocks = (threads + 255) / 256;
     if (blocks >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd: grid too large");
     if (dtype == SZN_BF16)

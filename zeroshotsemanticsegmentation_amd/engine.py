@@ -118,6 +118,15 @@ class TrainStep(object):
                 self.state[key] = (torch.zeros_like(flat), torch.zeros_like(flat))
             else:
                 self.state[key] = (torch.zeros_like(flat),)
+        # low-precision weight image written by the optimizer kernel itself (no separate cast pass per step)
+        self.flat_w_lp = None
+        self.eng.lp_views = {}
+        if self.eng.dtype == torch.bfloat16:
+            self.flat_w_lp = self.flat_w.to(torch.bfloat16)
+            for n in _OPT_LAYERS[:-1]:
+                co, ci, kh, kw = getattr(m, n).weight.shape
+                o, cnt = self.woff[n]
+                self.eng.lp_views[n] = self.flat_w_lp[o:o + cnt].view(co, kh, kw, ci)
         self.eng.mark_dirty()
         # per-layer gradient targets handed to the engine (OHWI views of the flat gradient)
         self.grads = {}
@@ -196,14 +205,15 @@ class TrainStep(object):
         gs = 1.0 / self.world
         for key, flat, grad, lr, wd in (("w", self.flat_w, self.flat_gw, self.lr, self.wd),
                                         ("b", self.flat_b, self.flat_gb, 2 * self.lr, 0.0)):
+            lp = L.ptr(self.flat_w_lp) if (key == "w" and self.flat_w_lp is not None) else None
             if self.opt == "adam":       # train.py:130-133 (Adam has no weight decay in the reference wiring)
                 m1, m2 = self.state[key]
                 L.call("szn_adam_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr), 0.9, 0.999,
-                       1e-8, 0.0, self.nstep, gs, None, st)
+                       1e-8, 0.0, self.nstep, gs, lp, st)
             else:                        # train.py:126-129
                 (buf,) = self.state[key]
                 L.call("szn_sgd_momentum_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(buf), float(lr),
-                       float(self.momentum), float(wd), int(self.nstep == 1), gs, None, st)
+                       float(self.momentum), float(wd), int(self.nstep == 1), gs, lp, st)
         self.eng.mark_dirty()
 
     def metrics(self, reset=True):

@@ -62,6 +62,7 @@ class _Engine(object):
         self.dropout_seed = 1337
         self.dropout_calls = 0
         self._splitk_ws = None
+        self.lp_views = {}          # layer -> compute-dtype OHWI weight image maintained by the optimizer kernel (TrainStep)
 
     def _workspace(self, desc, nbytes, device):
         """split-K scratch handed to the conv kernels (they use it only for few-tile / long-K shapes: fc6, fc7)"""
@@ -111,7 +112,12 @@ class _Engine(object):
             if name == "conv1_1":
                 img[name + ".w"] = w32                       # conv1_1 kernel reads fp32 weights
                 continue
-            wc = w32 if dt == torch.float32 else w32.to(dt)
+            if dt == torch.float32:
+                wc = w32
+            elif name in self.lp_views and self.lp_views[name].dtype == dt:
+                wc = self.lp_views[name]                     # already written by szn_adam_step / szn_sgd_momentum_step
+            else:
+                wc = w32.to(dt)
             img[name + ".w"] = wc
             wt = torch.empty(ci, k, k, co, device=dev, dtype=dt)
             L.call("szn_pack_weight_dgrad", code, co, k, k, ci, L.ptr(wc), L.ptr(wt), st)
