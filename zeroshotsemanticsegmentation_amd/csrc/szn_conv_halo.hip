@@ -197,49 +197,90 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(HaloArgs a) {
         stage = nstage;
     }
 
-    // ---- epilogue: lane holds couts nb..nb+3 of output pixel (oh0 + 4 wm + j, ow0 + r16) ----
-    const T* __restrict__ gate = (const T*)a.gate;
-    const bool vec_ok = ((a.ldo & 3) == 0) && (!a.gate || (a.ldg & 3) == 0);
+    // ---- epilogue staged through LDS (same scheme as conv_igemm_v2): fp32 tile -> whole output rows, 16 B per lane ----
+    constexpr int P = BN + 4;
+    float* tile = (float*)smem;
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int oh = oh0 + wm * 4 + j, ow = ow0 + r16;
-        if (oh >= a.Ho || ow >= a.Wo) continue;
-        const long m = ((long)b * a.Ho + oh) * a.Wo + ow;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < WNF; ++i) {
-            const int nb = n0 + wn * (BN / 2) + i * 16 + g * 4;
-            if (nb >= a.Co) continue;
-            float v[4];
+            const int row = (wm * 4 + j) * 16 + r16, col = wn * (BN / 2) + i * 16 + g * 4;
+            *(f32x4_t*)(tile + row * P + col) = acc[i][j];
+        }
+    __syncthreads();
+    const T* __restrict__ gate = (const T*)a.gate;
+    constexpr int CPR = BN / 8;
+    const bool out32 = a.out_f32 || sizeof(T) == 4;
+    const int oes = out32 ? 4 : 2;
+    const bool fast_o = (((long)a.ldo * oes) & 15) == 0;
+    const bool fast_g = gate && ((((long)a.ldg * ES) & 15) == 0);
+    const int cc = tid % CPR, row0 = tid / CPR;
+    const int n = n0 + cc * 8;
+    if (n < a.Co) {
+        const bool full = n + 8 <= a.Co;
+        float bv[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = nb + e;
-                float x = acc[i][j][e];
-                if (n < a.Co) {
-                    if (a.bias) x += a.bias[n];
+        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && n + e < a.Co) ? a.bias[n + e] : 0.f;
+        constexpr int NIT = 256 * CPR / 512;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int row = row0 + k * (512 / CPR);
+            const int oh = oh0 + (row >> 4), ow = ow0 + (row & 15);
+            if (oh < a.Ho && ow < a.Wo) {
+                const long m = ((long)b * a.Ho + oh) * a.Wo + ow;
+                const float* tp = tile + row * P + cc * 8;
+                float v[8];
+                *(f32x4_t*)&v[0] = *(const f32x4_t*)tp;
+                *(f32x4_t*)&v[4] = *(const f32x4_t*)(tp + 4);
+                float gv[8];
+                if (gate) {
+                    const T* gp = gate + m * a.ldg + n;
+                    if (full && fast_g) {
+                        if constexpr (ES == 2) {
+                            const u32x4_t q = *(const u32x4_t*)gp;
+                            const T* qe = (const T*)&q;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) gv[e] = elem<T>::ld(qe + e);
+                        } else {
+                            *(f32x4_t*)&gv[0] = *(const f32x4_t*)gp;
+                            *(f32x4_t*)&gv[4] = *(const f32x4_t*)((const float*)gp + 4);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gv[e] = (n + e < a.Co) ? elem<T>::ld(gp + e) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = v[e] + bv[e];
                     if (a.relu) x = fmaxf(x, 0.f);
-                    if (gate) x = (elem<T>::ld(gate + m * a.ldg + n) > 0.f) ? x : 0.f;
-                    if (a.cscale) x *= a.cscale[(long)b * a.Co + n];
+                    if (gate) x = (gv[e] > 0.f) ? x : 0.f;
+                    if (a.cscale && n + e < a.Co) x *= a.cscale[(long)b * a.Co + n + e];
+                    v[e] = x;
                 }
-                v[e] = x;
-            }
-            if (a.out_f32 || sizeof(T) == 4) {
-                float* o = (float*)a.out + m * a.ldo + nb;
-                if (vec_ok && nb + 3 < a.Co) {
-                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+                if (out32) {
+                    float* o = (float*)a.out + m * a.ldo + n;
+                    if (full && fast_o) {
+                        *(f32x4_t*)o = *(const f32x4_t*)&v[0];
+                        *(f32x4_t*)(o + 4) = *(const f32x4_t*)&v[4];
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (nb + e < a.Co) o[e] = v[e];
-                }
-            } else {
-                uint16_t* o = (uint16_t*)a.out + m * a.ldo + nb;
-                if (vec_ok && nb + 3 < a.Co) {
-                    u32x2_t pk;
-                    pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-                    *(u32x2_t*)o = pk;
+                        for (int e = 0; e < 8; ++e) if (n + e < a.Co) o[e] = v[e];
+                    }
                 } else {
+                    uint16_t* o = (uint16_t*)a.out + m * a.ldo + n;
+                    if (full && fast_o) {
+                        u32x4_t pk;
+                        pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+                        pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
+                        pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+                        *(u32x4_t*)o = pk;
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (nb + e < a.Co) o[e] = f32_to_bf16_bits(v[e]);
+                        for (int e = 0; e < 8; ++e) if (n + e < a.Co) o[e] = f32_to_bf16_bits(v[e]);
+                    }
                 }
             }
         }

@@ -13,6 +13,7 @@
 //   * 3-stage LDS ring (<= 48 KiB, 3 blocks per CU), counted vmcnt, one raw s_barrier per K step;
 //   * split over pixels; partial tiles are added to the fp32 OHWI gradient with global atomics.
 #include "szn_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
@@ -31,6 +32,7 @@ struct Wg2Args {
     int M;
     int kspan, nsplit, cotiles, citiles;
     int plain_store;           // single split and no accumulation: write the tile instead of atomically adding it
+    int ablate;                // debug (env SZN_WG_ABLATE=1): skip the output epilogue (wrong results)
 };
 
 constexpr unsigned kOOBw = 0x80000000u;
@@ -200,21 +202,42 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_v2(Wg2Args a) {
         if (++stage == 3) stage = 0;
     }
 
-    // D[co][ci]: lane holds rows co = g*4+e, column ci = r16
+    if (a.ablate) {
+        float keep = 0.f;
 #pragma unroll
-    for (int i = 0; i < FA; ++i) {
+        for (int i = 0; i < FA; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int co = co0 + wm * FA * 16 + i * 16 + g * 4 + e;
-            if (co >= a.Co) continue;
-            float* row = a.dw + ((long)(co * a.KH + kh) * a.KW + kw) * a.Ci;
+            for (int j = 0; j < FB; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 123.456f) a.dw[0] = keep;
+        return;
+    }
+    // ---- epilogue: D[co][ci] (lane: rows co = g*4+e, column ci = r16) staged through LDS in two co halves so that
+    // every atomic / store instruction covers whole rows of the OHWI gradient (64 consecutive cins = 256 B per wave
+    // instead of 4 x 64 B): the atomic tail was up to half of the kernel time on the 512-channel layers.
+    constexpr int HR = CO_T / 2;                       // rows per half (wm selects the half)
+    constexpr int PT = CI_T + 4;                       // tile pitch in floats
+    static_assert(HR * PT * 4 <= 3 * STAGE, "staging tile must fit in the operand ring");
+    float* tile = (float*)smem;
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                               // ring / previous half fully consumed
+        if (wm == half) {
 #pragma unroll
-            for (int j = 0; j < FB; ++j) {
-                const int ci = ci0 + wn * FB * 16 + j * 16 + r16;
-                if (ci < a.Ci) {
-                    if (a.plain_store) row[ci] = acc[i][j][e];
-                    else atomicAdd(row + ci, acc[i][j][e]);
-                }
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < FB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        tile[(i * 16 + g * 4 + e) * PT + wn * FB * 16 + j * 16 + r16] = acc[i][j][e];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < HR * CI_T; idx += 256) {
+            const int r = idx / CI_T, c = idx - r * CI_T;
+            const int co = co0 + half * HR + r, ci = ci0 + c;
+            if (co < a.Co && ci < a.Ci) {
+                float* dst = a.dw + ((long)(co * a.KH + kh) * a.KW + kw) * a.Ci + ci;
+                const float v = tile[r * PT + c];
+                if (a.plain_store) *dst = v;
+                else atomicAdd(dst, v);
             }
         }
     }
@@ -254,16 +277,22 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
     a.cotiles = szn_div_up(d->Co, 32 * FA); a.citiles = szn_div_up(d->Ci, 32 * FB);
     const long tiles = (long)a.cotiles * a.citiles * d->KH * d->KW;
     // ~3 blocks per CU x 256 CUs x a few waves of blocks; each split covers a multiple of 64 pixels, at least 1024
-    long want = (3072 + tiles - 1) / tiles;
+    static int wg_target = -1;
+    if (wg_target < 0) { const char* e = getenv("SZN_WG_BLOCKS"); wg_target = e ? atoi(e) : 3072; }
+    long want = (wg_target + tiles - 1) / tiles;
     if (want < 1) want = 1;
     long span = (a.M + want - 1) / want;
     if (span < 1024) span = 1024;
     span = (span + 63) / 64 * 64;
+    if (tiles >= 512) span = (a.M + 63) / 64 * 64;       // enough tiles to fill the chip: one split, plain stores (fc6, fc7)
     a.kspan = (int)span;
     a.nsplit = szn_div_up(a.M, span);
     const long blocks = tiles * a.nsplit;
     if (blocks >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad: grid too large");
     a.plain_store = (a.nsplit == 1 && !accumulate) ? 1 : 0;      // fc6: 411 MB written once instead of memset + atomics
+    static int wg_abl = -1;
+    if (wg_abl < 0) { const char* e = getenv("SZN_WG_ABLATE"); wg_abl = e ? atoi(e) : 0; }
+    a.ablate = wg_abl;
     if (!accumulate && !a.plain_store) {
         hipError_t e = hipMemsetAsync(dw, 0, nw * sizeof(float), st);
         if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "conv2d_wgrad memset: %s", hipGetErrorString(e));
