@@ -58,6 +58,8 @@ typedef struct {
     int out_f32;      /* store out as float even when dtype == SZN_BF16                           */
     void* workspace;  /* optional device scratch for split-K (few output tiles, long K: fc6/fc7); */
     size_t workspace_bytes; /* used when >= B*Ho*Wo*Co*4 bytes (dgrad: B*Hi*Wi*Ci*4); NULL = never split */
+    float* colsum;    /* optional f32 [Co] (dgrad: [Ci]): += column sums of the tensor being written, i.e. the
+                         bias gradient of the layer that produced the gated input (saves a pass over it)  */
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
@@ -113,7 +115,8 @@ int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void*
 /* din = relu_bwd(pool_bwd(dout)): the gradient goes to the FIRST maximum of each window (torch
  * scan order) and is then gated by in > 0 (the ReLU that precedes every pool).                    */
 int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void* in,
-                            const void* out, const void* dout, void* din, szn_stream_t stream);
+                            const void* out, const void* dout, void* din, float* colsum /* [C] += sum of din, or NULL */,
+                            szn_stream_t stream);
 
 /* ---- upscore: ConvTranspose2d(E,E,64,stride 32,bias=False) with the fixed bilinear kernel of
  * get_upsampling_weight (models.py:11-24,94,146) fused with the crop [19:19+H] (models.py:147).

@@ -98,6 +98,16 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
         torch.cuda.synchronize()
         got = din.float().cpu().permute(0, 3, 1, 2)
         assert relerr(got, dx_ref) < tol, ("dgrad", relerr(got, dx_ref))
+        # fused column sums (bias gradient of the producer layer); split-K is off on this path
+        cs = torch.zeros(Ci, device=dev)
+        dgc, _, _ = conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad, ldg=Ci)
+        dgc.colsum = cs.data_ptr()
+        din2 = torch.empty_like(din)
+        L.call("szn_conv2d_dgrad", C.byref(dgc), L.ptr(doutd), L.ptr(wT), L.ptr(xd), None, L.ptr(din2), L.stream_ptr())
+        torch.cuda.synchronize()
+        assert relerr(din2.float().cpu().permute(0, 3, 1, 2), dx_ref) < tol
+        # the sums are taken on the fp32 values before the bf16 rounding of din
+        assert relerr(cs.cpu(), dx_ref.sum((0, 2, 3))) < (1e-4 if dtype == torch.float32 else 1e-2)
     dw = torch.full((Co, K, K, Ci), float("nan"), device=dev)
     db = torch.full((Co,), float("nan"), device=dev)
     L.call("szn_conv2d_wgrad", C.byref(dgd), L.ptr(xd), L.ptr(doutd), L.ptr(dw), 0, L.stream_ptr())
@@ -185,6 +195,9 @@ def test_maxpool(dtype, hw):
     dref = x.grad * (x.detach() > 0)
     din = torch.empty(B, Hi, Wi, Cc, device="cuda", dtype=dtype)
     doutd = nhwc(dout).cuda().to(dtype)
-    L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.stream_ptr())
+    cs = torch.zeros(Cc, device="cuda")
+    L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.ptr(cs),
+           L.stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(din.float().cpu().permute(0, 3, 1, 2), dref)
+    assert relerr(cs.cpu(), dref.sum((0, 2, 3))) < 1e-5          # fused bias gradient = column sums of din

@@ -480,7 +480,10 @@ int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.relu = d->relu; a.out_f32 = d->out_f32;
     a.M = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo;
     a.mtiles = szn_div_up(a.M, TILE); a.ntiles = szn_div_up(a.Co, TILE);
-    return d->dtype == SZN_BF16 ? launch_conv<bf16_raw>(a, (hipStream_t)stream) : launch_conv<float>(a, (hipStream_t)stream);
+    rc = d->dtype == SZN_BF16 ? launch_conv<bf16_raw>(a, (hipStream_t)stream) : launch_conv<float>(a, (hipStream_t)stream);
+    if (rc || !d->colsum) return rc;
+    if (d->out_f32 && d->dtype == SZN_BF16) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_fwd(v1): colsum with out_f32 is unsupported");
+    return szn_bias_grad(d->dtype, a.M, d->Co, d->ldo, out, d->colsum, 1, stream);   // fallback path: separate pass
 }
 
 extern "C" int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, const void* w, void* wT,

@@ -47,6 +47,7 @@ template <> struct Mma2<float> {
 struct Conv2Args {
     const char* in; const char* w; const float* bias; const char* gate; const float* cscale; char* out;
     float* ws;                 // split-K accumulator [M][Co] (nsplit > 1)
+    float* colsum;             // optional [Co]: += column sums of the stored tensor (bias gradient of the producer layer)
     unsigned in_bytes, w_bytes;
     int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
     int ldi, ldo, ldg, relu, out_f32;
@@ -296,6 +297,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
     // fully unrolled row loop lets all gate loads go out before the first store
     const int cc = tid % CPR, row0 = tid / CPR;
     const int n = n0 + cc * 8;
+    float cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
     if (n < a.Co) {
         const bool full = n + 8 <= a.Co;
         float bv[8];
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
                     if (gate) x = (gv[e] > 0.f) ? x : 0.f;
                     if (a.cscale && n + e < a.Co) x *= a.cscale[brow + n + e];
                     v[e] = x;
+                    cs[e] += x;
                 }
                 if (out32) {
                     float* o = (float*)a.out + (long)m * a.ldo + n;
@@ -362,6 +367,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
                     }
                 }
             }
+        }
+    }
+    if (a.colsum) {                                    // bias gradient of the producer layer: column sums of this tile
+        __syncthreads();                               // staging tile no longer needed
+        float* red = (float*)smem;                     // [512 / CPR row groups][BN]
+        if (n < a.Co) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[row0 * BN + cc * 8 + e] = cs[e];
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Co) {
+            float t = 0.f;
+            for (int r = 0; r < 512 / CPR; ++r) t += red[r * BN + tid];
+            if (t != 0.f) atomicAdd(a.colsum + n0 + tid, t);
         }
     }
 #endif
@@ -649,7 +668,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     hipStream_t st = (hipStream_t)stream;
     // 3x3 layers on large feature maps: LDS-resident input patch (szn_conv_halo.hip); SZN_HALO_MIN overrides the
     // smallest output side for which it is used (0 = always, huge = never)
-    if (d->KH == 3 && d->KW == 3) {
+    if (d->KH == 3 && d->KW == 3 && !d->colsum) {
         static int halo_min = -1;
         if (halo_min < 0) {
             const char* e = getenv("SZN_HALO_MIN");
@@ -662,7 +681,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     }
     Conv2Args a;
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
-    a.out = (char*)out; a.ws = nullptr;
+    a.out = (char*)out; a.ws = nullptr; a.colsum = d->colsum;
     a.in_bytes = (unsigned)in_bytes; a.w_bytes = (unsigned)w_bytes;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
@@ -676,7 +695,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     const long tiles = (long)a.mtiles * a.ntiles;
     // split-K only where the grid cannot fill the chip AND K is long (fc6 dgrad: 68 tiles x 3136 chunks): every split
     // writes its own fp32 slab with plain stores, a second kernel sums the slabs in a fixed order + epilogue
-    if (d->workspace && tiles < 128 && nK >= 256) {
+    if (d->workspace && tiles < 128 && nK >= 256 && !d->colsum) {
         long ns = (768 + tiles - 1) / tiles;
         if (ns > nK / 32) ns = nK / 32;
         while (ns > 1 && (size_t)ns * a.M * a.Co * sizeof(float) > d->workspace_bytes) --ns;
@@ -692,7 +711,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     if (persist_max < 0) { const char* e = getenv("SZN_PERSIST_MAXK"); persist_max = e ? atoi(e) : 0; }   // +3 % only: off
     static int persist_min_tiles = -1;
     if (persist_min_tiles < 0) { const char* e = getenv("SZN_PERSIST_MINTILES"); persist_min_tiles = e ? atoi(e) : 1024; }
-    const bool persist = a.nsplit == 1 && nK <= persist_max && tiles >= persist_min_tiles;
+    const bool persist = a.nsplit == 1 && nK <= persist_max && tiles >= persist_min_tiles && !d->colsum;
     if (persist) {
         if (d->dtype == SZN_BF16) rc = narrow ? launch_p<bf16_raw, 2>(a, st) : launch_p<bf16_raw, 4>(a, st);
         else rc = narrow ? launch_p<float, 2>(a, st) : launch_p<float, 4>(a, st);

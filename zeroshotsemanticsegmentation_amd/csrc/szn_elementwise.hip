@@ -195,10 +195,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ in, const T* __restrict__ out,
                                                           const T* __restrict__ dout, T* __restrict__ din, int B, int Hi,
-                                                          int Wi, int C, int Ho, int Wo) {
+                                                          int Wi, int C, int Ho, int Wo, float* __restrict__ colsum) {
     constexpr int CH = elem<T>::kPer16B;
+    __shared__ float red[256 * CH];
     const int cpp = C / CH;
     const long total = (long)B * Hi * Wi * cpp;
+    float cs[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) cs[e] = 0.f;
     for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
         const int cc = (int)(gid % cpp);
         const long p = gid / cpp;
@@ -231,9 +235,24 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         for (int e = 0; e < CH; ++e) {
             const float s = elem<T>::ld(se + e);
             const bool win = (s == elem<T>::ld(me + e)) && !earlier[e] && (s > 0.f);
-            elem<T>::st(oe + e, win ? elem<T>::ld(de + e) : 0.f);
+            const float dv = win ? elem<T>::ld(de + e) : 0.f;
+            elem<T>::st(oe + e, dv);
+            cs[e] += elem<T>::ld(oe + e);           // what was actually stored (bf16-rounded in the bf16 path)
         }
         *(u32x4_t*)(din + p * C + cc * CH) = o;
+    }
+    if (colsum) {
+        // bias gradient of the conv in front of this pool: column sums of din.  The launcher makes the grid stride a
+        // multiple of cpp, so a thread keeps one channel chunk (cc = threadIdx.x % cpp) for all its pixels.
+#pragma unroll
+        for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = cs[e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const int cc = c / CH, e = c - cc * CH;
+            float t = 0.f;
+            for (int r = cc; r < 256; r += cpp) t += red[r * CH + e];
+            if (t != 0.f) atomicAdd(colsum + c, t);
+        }
     }
 }
 
@@ -379,20 +398,22 @@ extern "C" int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, 
 }
 
 extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void* in, const void* out,
-                                       const void* dout, void* din, szn_stream_t stream) {
+                                       const void* dout, void* din, float* colsum, szn_stream_t stream) {
     if (!in || !out || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0)
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad argument");
     const int ch = dtype == SZN_BF16 ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd: C must be a multiple of %d", ch);
     const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
     const long total = (long)B * Hi * Wi * (C / ch);
+    if (colsum && (256 % (C / ch)) != 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd: colsum needs C/%d to divide 256", ch);
+    const int grid = grid_for(total, 256, colsum ? 4096 : 65536);
     if (dtype == SZN_BF16)
-        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_raw>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_raw*)in, (const bf16_raw*)out, (const bf16_raw*)dout, (bf16_raw*)din, B, Hi, Wi, C,
-                           Ho, Wo);
+                           Ho, Wo, colsum);
     else if (dtype == SZN_F32)
-        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)in, (const float*)out, (const float*)dout, (float*)din, B, Hi, Wi, C, Ho, Wo);
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)in, (const float*)out, (const float*)dout, (float*)din, B, Hi, Wi, C, Ho, Wo, colsum);
     else
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad dtype %d", dtype);
     SZN_CHECK_LAUNCH("maxpool_bwd_kernel");

@@ -216,6 +216,45 @@ class TrainStep(object):
                        float(self.momentum), float(wd), int(self.nstep == 1), gs, lp, st)
         self.eng.mark_dirty()
 
+    # ---- checkpoint compatibility (reference dict keys: trainer_fcn.py:281-288) ------------------------------
+    def _param_slots(self):
+        m = self.model
+        for n in _OPT_LAYERS:
+            p = getattr(m, n).weight
+            co, ci, kh, kw = p.shape
+            o, cnt = self.woff[n]
+            yield p, "w", lambda t, o=o, cnt=cnt, co=co, ci=ci, kh=kh, kw=kw: t[o:o + cnt].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            b = getattr(m, n).bias
+            bo, bc = self.boff[n]
+            yield b, "b", lambda t, bo=bo, bc=bc: t[bo:bo + bc]
+
+    def export_optimizer_state(self, optim):
+        """expose the flat moments as per-parameter state of a torch-style optimizer object (views, no copies), so that
+        `optim.state_dict()` written into a checkpoint has the layout torch.optim.Adam / SGD would have produced"""
+        for p, key, view in self._param_slots():
+            st = optim.state[p]
+            if self.opt == "adam":
+                st['step'] = torch.tensor(float(self.nstep))
+                st['exp_avg'] = view(self.state[key][0])
+                st['exp_avg_sq'] = view(self.state[key][1])
+            else:
+                st['momentum_buffer'] = view(self.state[key][0]) if self.nstep > 0 else None
+
+    def import_optimizer_state(self, optim):
+        """inverse of export_optimizer_state (resume: train.py:135-136 loads `optim_state_dict` into the optimizer)"""
+        steps = []
+        for p, key, view in self._param_slots():
+            st = optim.state.get(p, {})
+            if self.opt == "adam" and 'exp_avg' in st:
+                view(self.state[key][0]).copy_(st['exp_avg'])
+                view(self.state[key][1]).copy_(st['exp_avg_sq'])
+                steps.append(int(st.get('step', 0)))
+            elif self.opt != "adam" and st.get('momentum_buffer') is not None:
+                view(self.state[key][0]).copy_(st['momentum_buffer'])
+                steps.append(1)
+        if steps:
+            self.nstep = max(steps)
+
     def metrics(self, reset=True):
         """running train metrics from the device histogram (trainer_fcn.py:164)"""
         from .utils import _hist_to_metrics

@@ -257,14 +257,19 @@ class _Engine(object):
         if db is not None:
             L.call("szn_bias_grad", code, B * Ho * Wo, co, ldo, L.ptr(dout), L.ptr(db), 0, st)
 
-    def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None):
+    def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None, colsum=None):
+        """din = conv(dout, flipped weights) with the ReLU gate / dropout factor of the producing layer fused; colsum
+        (f32 [Ci], pre-zeroed) receives the column sums of din = that layer's bias gradient"""
         B, Hi, Wi, Ci = in_shape
         Ho, Wo, Co = dout.shape[1:]
         wT = self._images[name + ".wT"]
         k = wT.shape[1]
         din = torch.empty(B, Hi, Wi, Ci, device=dout.device, dtype=self.dtype)
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, Ci, 0, 0)
-        self._workspace(d, B * Hi * Wi * Ci * 4, dout.device)
+        if colsum is not None:
+            d.colsum = colsum.data_ptr()
+        else:
+            self._workspace(d, B * Hi * Wi * Ci * 4, dout.device)
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
         return din
 
@@ -288,13 +293,18 @@ class _Engine(object):
         done = layer_done if layer_done is not None else (lambda name: None)
         s6 = ctx.masks[0] if ctx.masks is not None else None
         s7 = ctx.masks[1] if ctx.masks is not None else None
+        # bias gradients are produced as column sums by whichever kernel WRITES the pre-activation gradient (the dgrad
+        # of the next layer or the pool backward), so they start from zero here
+        for name in grads:
+            if name != "head":
+                grads[name][1].zero_()
         # d(fc7 pre-activation): ReLU gate (feat > 0) and dropout factor fused into the dgrad epilogue
-        d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7)
-        self._wgrad(ctx.relu6, d, grads["fc7"][0], grads["fc7"][1], F, F, 1, 0)
+        d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7, colsum=grads["fc7"][1])
+        self._wgrad(ctx.relu6, d, grads["fc7"][0], None, F, F, 1, 0)
         done("fc7")
-        d = self._dgrad(d, "fc7", ctx.relu6.shape, 0, gate=ctx.relu6, scale=s6)
+        d = self._dgrad(d, "fc7", ctx.relu6.shape, 0, gate=ctx.relu6, scale=s6, colsum=grads["fc6"][1])
         pool5 = ctx.pools[4][1]
-        self._wgrad(pool5, d, grads["fc6"][0], grads["fc6"][1], pool5.shape[3], F, 7, 0)
+        self._wgrad(pool5, d, grads["fc6"][0], None, pool5.shape[3], F, 7, 0)
         done("fc6")
         d = self._dgrad(d, "fc6", pool5.shape, 0)
         pi = 4
@@ -307,7 +317,9 @@ class _Engine(object):
                 pi -= 1
                 B, Hi, Wi, Cc = pin.shape
                 dn = torch.empty_like(pin)
-                L.call("szn_maxpool2x2_ceil_bwd", code, B, Hi, Wi, Cc, L.ptr(pin), L.ptr(pout), L.ptr(d), L.ptr(dn), st)
+                producer = items[idx - 1][0]                   # the conv whose (ReLU'd) output this pool reads
+                L.call("szn_maxpool2x2_ceil_bwd", code, B, Hi, Wi, Cc, L.ptr(pin), L.ptr(pout), L.ptr(d), L.ptr(dn),
+                       L.ptr(grads[producer][1]), st)
                 d = dn
                 continue
             name, pad = item
@@ -315,17 +327,20 @@ class _Engine(object):
                 dw, db = grads[name]
                 nb = L.load().szn_conv1_1_wgrad_workspace_bytes(code, ctx.B, ctx.H, ctx.W, PAD1)
                 ws = torch.empty(nb, dtype=torch.uint8, device=d.device)
-                L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), L.ptr(db), 0,
-                       L.ptr(ws), st)
+                L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), None, 0,
+                       L.ptr(ws), st)                          # db came from conv1_2's dgrad (colsum)
                 done(name)
                 break
             prev = items[idx - 1]
             xin = ctx.pools[pi][1] if prev == "P" else ctx.acts[prev[0]]
             layer = getattr(m, name)
-            self._wgrad(xin, d, grads[name][0], grads[name][1], layer.in_channels, layer.out_channels, 3, pad)
+            self._wgrad(xin, d, grads[name][0], None, layer.in_channels, layer.out_channels, 3, pad)
             done(name)
             # next d: wrt this conv's input; gate by the ReLU of the producing conv unless a pool sits in between
-            d = self._dgrad(d, name, xin.shape, pad, gate=None if prev == "P" else xin)
+            if prev == "P":
+                d = self._dgrad(d, name, xin.shape, pad)
+            else:
+                d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1])
 
 
 class _Backbone(torch.autograd.Function):

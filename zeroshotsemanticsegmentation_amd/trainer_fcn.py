@@ -166,6 +166,7 @@ class Trainer(object):
                 return None
             self._step = _engine.TrainStep(self.model, self.embeddings, optimizer=kind, lr=self.optim.param_groups[0]['lr'],
                                            precision=self.precision, fused_head=True, **extra)
+            self._step.import_optimizer_state(self.optim)       # resumed runs (train.py:135-136)
         return self._step
 
     def train_epoch(self):
@@ -243,6 +244,8 @@ class Trainer(object):
         if is_best:
             self.best_mean_iu = mean_iu
         if self.rank == 0:
+            if self._step is not None:
+                self._step.export_optimizer_state(self.optim)   # flat moments -> per-parameter torch optimizer state
             torch.save({
                 'epoch': self.epoch,
                 'iteration': self.iteration,
