@@ -221,7 +221,7 @@ def main(argv=None):
     model = models.FCN32s(n_class=cfg['embed_dim'] if cfg['embed_dim'] else 21)
     start_epoch, start_iteration, checkpoint = 0, 0, None
     if cfg['load_fcn_path']:
-        checkpoint = torch.load(osp.join(args.data_dir, 'logs', cfg['load_fcn_path'], 'best'), map_location='cpu')
+        checkpoint = torch.load(osp.join(args.data_dir, 'logs', cfg['load_fcn_path'], 'best'), map_location='cpu', weights_only=False)
         model.load_state_dict(checkpoint['model_state_dict'], strict=False)
         start_epoch, start_iteration = checkpoint['epoch'], checkpoint['iteration']
     else:
@@ -253,8 +253,14 @@ def main(argv=None):
             freeze_for_seenmask(model)
             sm_optim = FusedAdam([{'params': list(get_parameters(model, seenmask=True))}], lr=cfg['seenmask_lr'])
             if not checkpoint:
-                best = osp.join(log_dir, 'best')
-                checkpoint = torch.load(best, map_location='cpu') if osp.exists(best) else {}
+                # the reference reloads <log_dir>/best (train.py:177-179); fall back to the last checkpoint when no
+                # validation improved on best_mean_iu = 0 (tiny synthetic runs)
+                for fname in ('best', 'checkpoint'):
+                    if osp.exists(osp.join(log_dir, fname)):
+                        checkpoint = torch.load(osp.join(log_dir, fname), map_location='cpu', weights_only=False)
+                        break
+                else:
+                    checkpoint = {}
             seenmask_trainer = trainer_seenmask.Trainer(
                 cuda=True, model=model, optimizer=sm_optim, train_loader=train_loader, val_loader=val_loader,
                 log_dir=log_dir, dataset=cfg['dataset'], max_epoch=cfg['seenmask_epochs'], tb_writer=tb_writer,

@@ -113,7 +113,10 @@ class Trainer(object):
         data = data.to(self.device, non_blocking=True)
         target = target.to(self.device, non_blocking=True)
         if target_embed is not None:
-            target_embed = target_embed.to(self.device, non_blocking=True)
+            if target_embed.dim() == 4 and target_embed.is_floating_point():
+                target_embed = target_embed.to(self.device, non_blocking=True)     # the reference's dense (n,E,h,w) volume
+            else:
+                target_embed = None            # label-only datasets: the row of the K x E matrix is gathered on the GPU
         return data, target, target_embed
 
     def _loss(self, score, target, target_embed):
