@@ -172,9 +172,15 @@ def main():
             fl = sum(f for _, _, f in events)
             peak = 2500.0 if dtype == torch.bfloat16 else 157.3
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = None      # HBM bytes per launch from a committed PMC run of this same command (tools/pmc_bench.sh)
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("per_gpu_batch") == B and tj.get("precision") == args.precision and H == 512 and E == 300:
+                    traffic = round(tj["hbm_bytes_per_launch"])
             out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm (all conv/fc fwd + dgrad launches)",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": None, "launches_per_step": len(events) // args.steps,
+                               "traffic": traffic, "launches_per_step": len(events) // args.steps,
                                "avg_launch_ms": round(ms / len(events), 4),
                                "gflop_per_launch": round(fl / len(events) / 1e9, 2),
                                "share_of_step": round(ms / (dt * 1e3), 3)}

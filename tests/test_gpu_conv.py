@@ -34,6 +34,8 @@ CASES = [
     (2, 12, 12, 64, 130, 3, 2),
     (1, 40, 36, 256, 64, 3, 1),          # 64-cout tile variant, several pixel tiles, 4 chunks per tap
     (2, 8, 8, 512, 128, 7, 0),           # long K (392 chunks bf16), 1 pixel tile: split-K path
+    (1, 20, 21, 64, 256, 3, 1),          # 256-cout tiles (szn_conv_wide.hip when SZN_WIDE_MINTILES allows), 2 pixel tiles
+    (2, 10, 9, 128, 512, 1, 0),          # 2 cout tiles of 256
 ]
 
 

@@ -22,6 +22,9 @@ typedef __attribute__((address_space(3))) void* ldsptr_t;
 
 int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, szn_stream_t stream);
+int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                      const float* chan_scale, void* out, unsigned in_bytes, unsigned w_bytes, int min_tiles,
+                      szn_stream_t stream);
 int szn_conv3x3_halo_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                          const float* chan_scale, void* out, szn_stream_t stream);
 #include <stdlib.h>
@@ -706,6 +709,13 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
         }
     }
     int rc;
+    // >= 256 couts and enough tiles to fill the chip: 256 x 256 tiles (1.5x less LDS fill per FLOP), szn_conv_wide.hip
+    if (a.nsplit == 1) {
+        static int wide_min = -1;
+        if (wide_min < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min = e ? atoi(e) : 256; }
+        rc = szn_conv_wide_try(d, in, w, bias, gate, chan_scale, out, a.in_bytes, a.w_bytes, wide_min, stream);
+        if (rc <= 0) return rc;
+    }
     // persistent cross-tile pipelining pays when a tile has few K chunks and there are many tiles per CU
     static int persist_max = -1;
     if (persist_max < 0) { const char* e = getenv("SZN_PERSIST_MAXK"); persist_max = e ? atoi(e) : 0; }   // +3 % only: off

@@ -1,0 +1,284 @@
+// szn_conv_wide.hip -- 256 x 256 tile variant of the forward / dgrad implicit GEMM for layers with >= 256 couts.
+//
+// rocprof + ablations (profiles/r01_ablations.txt) show conv_igemm_v2 (256 px x 128 couts) pinned by the LDS-DMA fill
+// rate of a CU (~44 GB/s): 48 KB of operands per 4.2 MFLOP.  A 256 x 256 tile moves 64 KB per 8.4 MFLOP (1.5x less per
+// FLOP).  Cost: 128 accumulator registers per lane and a 64 KB ring stage, so the ring is 2 stages (one chunk of
+// prefetch) and the LDS-staged epilogue runs in four 64-pixel passes.
+//   * 512 threads = 8 waves (4 x 2): wave (wm, wn) -> 64 pixels x 128 couts (8 weight fragments x 4 pixel fragments);
+//   * otherwise identical to conv_igemm_v2: buffer_load ... lds with source-side XOR swizzle, scalar soffset per chunk,
+//     OOB offsets for padding, bias / ReLU / gate / dropout / column-sum epilogue on whole output rows.
+#include "szn_common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((address_space(3))) void* ldsptr_t;
+
+namespace {
+
+struct WideArgs {
+    const char* in; const char* w; const float* bias; const char* gate; const float* cscale; char* out;
+    float* colsum;
+    unsigned in_bytes, w_bytes;
+    int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
+    int ldi, ldo, ldg, relu, out_f32;
+    int M, HoWo, mtiles, ntiles;
+};
+
+constexpr unsigned kOOBx = 0x80000000u;
+
+__device__ __forceinline__ int xcd_remap_w(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ES = sizeof(T);
+    constexpr int BKE = 128 / ES;
+    constexpr int BM = 256, BN = 256, WNF = 8;
+    constexpr int STAGE = (BM + BN) * 128;        // 64 KiB
+    constexpr int LPC = 8;                        // 4 pixel + 4 weight LDS-DMA instructions per wave per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][pixels 256 x 128 B | weights 256 x 128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int g = lane >> 4, r16 = lane & 15;
+
+    const int nwg = a.mtiles * a.ntiles;
+    const int lid = xcd_remap_w(blockIdx.x, nwg);
+    const int nt = lid % a.ntiles, mt = lid / a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+
+    const int chunkA = (lane & 7) ^ (lane >> 3);
+    unsigned baseA[4], voffA[4], voffB[4];
+    int ohw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 32 * w + 8 * i + (lane >> 3);
+        if (m < a.M) {
+            const int b = m / a.HoWo, r = m - b * a.HoWo;
+            const int oh = r / a.Wo, ow = r - oh * a.Wo;
+            const int ih0 = oh - a.pad, iw0 = ow - a.pad;
+            ohw[i] = (ih0 << 16) | (iw0 & 0xffff);
+            const long px = ((long)(b * a.Hi + ih0) * a.Wi + iw0);
+            baseA[i] = (unsigned)((px * a.ldi + chunkA * (16 / ES)) * ES);
+        } else {
+            ohw[i] = 0x7fff7fff;
+            baseA[i] = 0;
+        }
+        const int n = n0 + 32 * w + 8 * i + (lane >> 3);
+        voffB[i] = (n < a.Co) ? (unsigned)(((long)n * a.KH * a.KW * a.Ci + chunkA * (16 / ES)) * ES) : kOOBx;
+    }
+    const int cpt = a.Ci / BKE;
+    const int nK = a.KH * a.KW * cpt;
+    int itap = 0, ic = 0;
+    auto set_tap = [&]() {
+        const int kh = itap / a.KW, kw = itap - kh * a.KW;
+        const unsigned tapoff = (unsigned)((kh * a.Wi + kw) * a.ldi * ES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ih = (ohw[i] >> 16) + kh, iw = (int)(short)(ohw[i] & 0xffff) + kw;
+            const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+            voffA[i] = ok ? baseA[i] + tapoff : kOOBx;
+        }
+    };
+    auto issue = [&](int stage) {
+        char* sb = smem + stage * STAGE;
+        const int soffA = ic * 128;
+        const int soffB = (itap * a.Ci) * ES + ic * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (32 * w + 8 * i) * 128), 16, voffA[i], soffA, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + BM * 128 + (32 * w + 8 * i) * 128), 16, voffB[i],
+                                                     soffB, 0, 0);
+        if (++ic == cpt) { ic = 0; ++itap; set_tap(); }
+    };
+
+    f32x4_t acc[WNF][4];
+#pragma unroll
+    for (int i = 0; i < WNF; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    set_tap();
+    issue(0);
+    const int offs0 = ((g ^ (r16 & 7)) << 4), offs1 = (((4 + g) ^ (r16 & 7)) << 4);
+    int stage = 0;
+    for (int kc = 0; kc < nK; ++kc) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunk kc landed (the only one outstanding)
+        __builtin_amdgcn_s_barrier();                             // ... for every wave; everyone left the other stage
+        if (kc + 1 < nK) issue(stage ^ 1);
+        const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
+        const char* sw = smem + stage * STAGE + BM * 128 + (wn * 128 + r16) * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = s ? offs1 : offs0;
+            u32x4_t wf[WNF], pf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pf[j] = *(const u32x4_t*)(sp + j * 16 * 128 + off);
+#pragma unroll
+            for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + off);
+#pragma unroll
+            for (int i = 0; i < WNF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (ES == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i]),
+                                                                            __builtin_bit_cast(bf16x8_t, pf[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].x), __uint_as_float(pf[j].x), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].y), __uint_as_float(pf[j].y), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].z), __uint_as_float(pf[j].z), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].w), __uint_as_float(pf[j].w), acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        stage ^= 1;
+    }
+
+    // ---- epilogue staged through LDS in four 64-pixel passes (pass = the wm group that owns those pixels) ----
+    constexpr int P = BN + 4;                          // tile pitch (floats): 64 x 260 x 4 B = 66,560 B per pass
+    constexpr int CPR = BN / 8;                        // 32 8-cout chunks per row
+    float* tile = (float*)smem;
+    const T* __restrict__ gate = (const T*)a.gate;
+    const bool out32 = a.out_f32 || sizeof(T) == 4;
+    const int oes = out32 ? 4 : 2;
+    const bool fast_o = (((long)a.ldo * oes) & 15) == 0;
+    const bool fast_g = gate && ((((long)a.ldg * ES) & 15) == 0);
+    const int cc = tid % CPR, row0 = tid / CPR;        // 16 row groups
+    const int n = n0 + cc * 8;
+    const bool full = n + 8 <= a.Co;
+    float bv[8], cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bv[e] = (a.bias && n + e < a.Co) ? a.bias[n + e] : 0.f; cs[e] = 0.f; }
+    for (int pass = 0; pass < 4; ++pass) {
+        __syncthreads();
+        if (wm == pass) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < WNF; ++i)
+                    *(f32x4_t*)(tile + (j * 16 + r16) * P + wn * 128 + i * 16 + g * 4) = acc[i][j];
+        }
+        __syncthreads();
+        if (n < a.Co) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = row0 + k * 16;
+                const int m = m0 + pass * 64 + row;
+                if (m < a.M) {
+                    const float* tp = tile + row * P + cc * 8;
+                    float v[8];
+                    *(f32x4_t*)&v[0] = *(const f32x4_t*)tp;
+                    *(f32x4_t*)&v[4] = *(const f32x4_t*)(tp + 4);
+                    float gv[8];
+                    if (gate) {
+                        const T* gp = gate + (long)m * a.ldg + n;
+                        if (full && fast_g) {
+                            if constexpr (ES == 2) {
+                                const u32x4_t q = *(const u32x4_t*)gp;
+                                const T* qe = (const T*)&q;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) gv[e] = elem<T>::ld(qe + e);
+                            } else {
+                                *(f32x4_t*)&gv[0] = *(const f32x4_t*)gp;
+                                *(f32x4_t*)&gv[4] = *(const f32x4_t*)((const float*)gp + 4);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) gv[e] = (n + e < a.Co) ? elem<T>::ld(gp + e) : 0.f;
+                        }
+                    }
+                    const long brow = a.cscale ? (long)(m / a.HoWo) * a.Co : 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float x = v[e] + bv[e];
+                        if (a.relu) x = fmaxf(x, 0.f);
+                        if (gate) x = (gv[e] > 0.f) ? x : 0.f;
+                        if (a.cscale && n + e < a.Co) x *= a.cscale[brow + n + e];
+                        v[e] = x;
+                        cs[e] += x;
+                    }
+                    if (out32) {
+                        float* o = (float*)a.out + (long)m * a.ldo + n;
+                        if (full && fast_o) {
+                            *(f32x4_t*)o = *(const f32x4_t*)&v[0];
+                            *(f32x4_t*)(o + 4) = *(const f32x4_t*)&v[4];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) if (n + e < a.Co) o[e] = v[e];
+                        }
+                    } else {
+                        uint16_t* o = (uint16_t*)a.out + (long)m * a.ldo + n;
+                        if (full && fast_o) {
+                            u32x4_t pk;
+                            pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+                            pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+                            pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
+                            pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+                            *(u32x4_t*)o = pk;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) if (n + e < a.Co) o[e] = f32_to_bf16_bits(v[e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (a.colsum) {
+        __syncthreads();
+        float* red = (float*)smem;                     // [16 row groups][256]
+        if (n < a.Co) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[row0 * BN + cc * 8 + e] = cs[e];
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Co) {
+            float t = 0.f;
+            for (int r = 0; r < 16; ++r) t += red[r * BN + tid];
+            if (t != 0.f) atomicAdd(a.colsum + n0 + tid, t);
+        }
+    }
+#endif
+}
+
+template <typename T>
+int launch_wide(const WideArgs& a, hipStream_t st) {
+    const size_t lds = 2 * (256 + 256) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_wide<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_wide<T>), dim3(a.mtiles * a.ntiles), dim3(512), lds, st, a);
+    SZN_CHECK_LAUNCH("conv_igemm_wide");
+    return SZN_OK;
+}
+
+}  // namespace
+
+// Called by szn_conv2d_fwd (which has validated the descriptor).  Returns 1 when the shape is not a good fit.
+int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                      const float* chan_scale, void* out, unsigned in_bytes, unsigned w_bytes, int min_tiles,
+                      szn_stream_t stream) {
+    if (d->Co < 256) return 1;
+    WideArgs a;
+    a.M = d->B * d->Ho * d->Wo;
+    a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(d->Co, 256);
+    if ((long)a.mtiles * a.ntiles < min_tiles) return 1;            // too few tiles to fill the chip: keep 256 x 128
+    if ((long)a.ntiles * 256 - d->Co > 64) return 1;                // would waste > 64 columns of the last tile
+    a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
+    a.out = (char*)out; a.colsum = d->colsum;
+    a.in_bytes = in_bytes; a.w_bytes = w_bytes;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
+    a.relu = d->relu; a.out_f32 = d->out_f32; a.HoWo = d->Ho * d->Wo;
+    return d->dtype == SZN_BF16 ? launch_wide<bf16_raw>(a, (hipStream_t)stream) : launch_wide<float>(a, (hipStream_t)stream);
+}
