@@ -25,7 +25,7 @@ namespace {
 
 struct C64Args {
     const char* in; const char* w; const float* bias; const char* gate; char* out; float* colsum;
-    unsigned in_bytes;
+    unsigned in_bytes, gate_bytes;
     int B, Hi, Wi, Ho, Wo, pad;
     int ldi, ldo, ldg, relu;
     int tiles_x, tiles_y, ntiles;      // ntiles = B * tiles_y * tiles_x
@@ -35,10 +35,19 @@ constexpr unsigned kOOBc = 0x80000000u;
 constexpr int PWc = 18, PROWSc = PWc * PWc;
 constexpr int PATCHBc = 328 * 128;                  // 41 DMA instructions of 8 rows
 constexpr int NBUF = 3;
-constexpr int OFF_DUMPc = NBUF * PATCHBc;           // 8 x 1 KiB dump pages (idle DMA slots)
-constexpr int OFF_REDc = OFF_DUMPc + 8 * 1024;      // bias[64] + colsum reduction [8 waves][4][8]
-constexpr int OFF_CSc = OFF_REDc + 256 + 1024;      // per-lane column-sum accumulators [512 lanes][8 floats]
-constexpr int LDS_C64 = OFF_CSc + 512 * 32;
+constexpr int OFF_GATEc = NBUF * PATCHBc;           // gate tile: [8 waves][4 j][64 lanes][16 B], filled by LDS-DMA per tile
+constexpr int OFF_DUMPc = OFF_GATEc + 8 * 4096;     // 1 KiB dump page (idle DMA slots)
+constexpr int OFF_REDc = OFF_DUMPc + 1024;          // bias[64] + final colsum reduction [4 wm][64]
+constexpr int OFF_CSc = OFF_REDc + 256 + 1024;      // column-sum accumulators [8 waves][4 g][8 floats]
+constexpr int LDS_C64 = OFF_CSc + 1024;
+
+__device__ __forceinline__ float row16_sum(float x) {                      // sum over the 16 lanes of a DPP row
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x140, 0xF, 0xF, true));   // row_mirror
+    return x;
+}
 
 template <bool GATED, bool COLSUM>
 __global__ __launch_bounds__(512) void conv3x3_c64(C64Args a) {
@@ -57,6 +66,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64(C64Args a) {
     if (first >= last) return;
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)(GATED ? a.gate : a.in), 0, (int)(GATED ? a.gate_bytes : 0u), 0x00020000);
 
     // ---- the filter bank of this wave: A fragments W[tap][s][i], lane (g, r16) = cout 32 wn + 16 i + r16, channels
     //      32 s + 8 g .. + 7 (OHWI) ----
@@ -96,16 +106,16 @@ __global__ __launch_bounds__(512) void conv3x3_c64(C64Args a) {
                     v = (unsigned)(((b * a.Hi + ih) * a.Wi + iw) * a.ldi * 2) + chunkoff;
             }
             const int piece = w + 8 * p;
-            char* dst = (piece < 41) ? base + piece * 1024 : smem + OFF_DUMPc + w * 1024;
+            char* dst = (piece < 41) ? base + piece * 1024 : smem + OFF_DUMPc;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)dst, 16, v, 0, 0, 0);
         }
     };
 
-    // column sums accumulate in a private 32-B LDS slot per lane (8 VGPRs too many next to the 144 of the filter bank)
-    float* csl = (float*)(smem + OFF_CSc + tid * 32);
+    // column sums: per tile reduced over the lane's 4 pixels and the 16 lanes of its row, then ds_add_f32 into a slot per
+    // (wave, g) -- 8 loop-carried VGPRs would not fit next to the 144 of the filter bank
+    float* csl = (float*)(smem + OFF_CSc + (w * 4 + g) * 32);
     if constexpr (COLSUM) {
-        *(f32x4_t*)csl = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        *(f32x4_t*)(csl + 4) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (tid < 256) ((float*)(smem + OFF_CSc))[tid] = 0.f;
     }
     const int cstart = wn * 32 + (g & 1) * 16 + (g >> 1) * 8;              // first of this lane's 8 couts after the swap
     const int qb = (wm * 4) * PWc + r16;
@@ -122,6 +132,22 @@ __global__ __launch_bounds__(512) void conv3x3_c64(C64Args a) {
     int buf = 0;
     for (int t = first; t < last; ++t) {
         const bool more = t + 2 < last;
+        int bb = t;
+        const int tx = bb % a.tiles_x; bb /= a.tiles_x;
+        const int ty = bb % a.tiles_y; const int b = bb / a.tiles_y;
+        const int ow = tx * 16 + r16;
+        const int oh0 = ty * 16 + wm * 4;
+        const unsigned m0 = (unsigned)((b * a.Ho + oh0) * a.Wo + ow);       // < 2^31 pixels (checked by the caller)
+        const bool okw = ow < a.Wo;
+        if constexpr (GATED) {
+            // each lane's 16 gate bytes per pixel row j go to its own LDS slot: an asynchronous, register-free prefetch
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = okw && oh0 + j < a.Ho;
+                const unsigned v = ok ? ((m0 + j * a.Wo) * a.ldg + cstart) * 2u : kOOBc;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (ldsptr_t)(smem + OFF_GATEc + w * 4096 + j * 1024), 16, v, 0, 0, 0);
+            }
+        }
         if (more) issue(t + 2, buf == 0 ? 2 : buf - 1);                    // (buf + 2) % 3
 
         f32x4_t acc[2][4];
@@ -161,29 +187,21 @@ __global__ __launch_bounds__(512) void conv3x3_c64(C64Args a) {
         }
 
         // ---- epilogue from registers ----
-        int bb = t;
-        const int tx = bb % a.tiles_x; bb /= a.tiles_x;
-        const int ty = bb % a.tiles_y; const int b = bb / a.tiles_y;
-        const int ow = tx * 16 + r16;
         float bv[8];
         *(f32x4_t*)&bv[0] = *(const f32x4_t*)(smem + OFF_REDc + cstart * 4);
         *(f32x4_t*)&bv[4] = *(const f32x4_t*)(smem + OFF_REDc + cstart * 4 + 16);
-        const int oh0 = ty * 16 + wm * 4;
-        const unsigned m0 = (unsigned)((b * a.Ho + oh0) * a.Wo + ow);       // < 2^31 pixels (checked by the caller)
-        const bool okw = ow < a.Wo;
-        // retire the patch pieces of t + 1 and the stores of t - 1 before anything newer is queued behind them
+        // retire the gate pieces of t, the patch pieces of t + 1 and the stores of t - 1
         if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        u32x4_t gq[4];
-        auto ldG = [&](int j) {
-            const bool ok = okw && oh0 + j < a.Ho;
-            gq[j] = ok ? *(const u32x4_t*)(a.gate + ((size_t)(m0 + j * a.Wo) * a.ldg + cstart) * 2) : u32x4_t{0, 0, 0, 0};
-        };
-        if constexpr (GATED) { ldG(0); ldG(1); }
+        float cs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = okw && oh0 + j < a.Ho;
             float v[8];
+            u32x4_t gq;
+            if constexpr (GATED) gq = *(const u32x4_t*)(smem + OFF_GATEc + w * 4096 + j * 1024 + lane * 16);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][j][c]), __float_as_uint(acc[1][j][c]), false, false);
@@ -195,12 +213,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64(C64Args a) {
                 float x = v[e] + bv[e];
                 if (a.relu) x = fmaxf(x, 0.f);
                 if constexpr (GATED) {
-                    const uint32_t gw = gq[j][e >> 1];
+                    const uint32_t gw = gq[e >> 1];
                     const float gv = __uint_as_float((e & 1) ? (gw & 0xffff0000u) : (gw << 16));
                     x = (gv > 0.f) ? x : 0.f;
                 }
                 v[e] = x;
-                if constexpr (COLSUM) { if (ok) __hip_atomic_fetch_add(csl + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }  // ds_add_f32, private slot
+                if constexpr (COLSUM) cs[e] += ok ? x : 0.f;
             }
             u32x4_t pk;
             pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
@@ -208,9 +226,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64(C64Args a) {
             pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
             pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
             if (ok) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
-            if constexpr (GATED) {
-                if (j + 2 < 4) ldG(j + 2);
-                __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (COLSUM) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = row16_sum(cs[e]);
+                if (r16 == 0) __hip_atomic_fetch_add(csl + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f32
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -219,20 +240,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64(C64Args a) {
     }
 
     if constexpr (COLSUM) {
-        // lanes with the same g hold the same couts: reduce over r16, then over the 4 wm waves through LDS
-        float cs[8];
-        *(f32x4_t*)&cs[0] = *(const f32x4_t*)csl;
-        *(f32x4_t*)&cs[4] = *(const f32x4_t*)(csl + 4);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = cs[e];
-            x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
-            cs[e] = x;
-        }
+        // slot (w, g) holds the sums of couts cstart .. + 7 of that wave: add the 4 wm waves
         float* red = (float*)(smem + OFF_REDc + 256);                      // [wm][64 couts]
         if (r16 == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[wm * 64 + cstart + e] = cs[e];
+            for (int e = 0; e < 8; ++e) red[wm * 64 + cstart + e] = csl[e];
         }
         __syncthreads();
         if (tid < 64) {
@@ -269,6 +281,9 @@ int szn_conv_c64_try(const szn_conv_desc_t* d, const void* in, const void* w, co
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.out = (char*)out;
     a.colsum = d->colsum;
     a.in_bytes = (unsigned)in_bytes;
+    const size_t gate_bytes = gate ? (size_t)d->B * d->Ho * d->Wo * d->ldg * 2 : 0;
+    if (gate_bytes >= 0x7fff0000ul || (size_t)d->B * d->Ho * d->Wo * d->ldo * 2 >= 0xffff0000ul) return 1;
+    a.gate_bytes = (unsigned)gate_bytes;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.pad = d->pad;
     a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg; a.relu = d->relu;
     a.tiles_x = szn_div_up(d->Wo, 16); a.tiles_y = szn_div_up(d->Ho, 16);
