@@ -22,6 +22,9 @@ typedef __attribute__((address_space(3))) void* ldsptr_t;
 int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                         szn_stream_t stream);
 
+int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
+                            int min_tiles_per_block, szn_stream_t stream);
+
 namespace {
 
 struct Wg2Args {
@@ -266,6 +269,14 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
                     !(((uintptr_t)in | (uintptr_t)dout) & 15);
     if (!ok) return szn_conv2d_wgrad_v1(d, in, dout, dw, accumulate, stream);     // validates and reports / handles >= 2 GiB
     hipStream_t st = (hipStream_t)stream;
+    // 3x3 bf16 layers with a workspace: all nine taps from one staged patch, deterministic slab reduction
+    // (szn_conv_wgrad_taps.hip); SZN_WGT_MINTILES = fewest 16x16 tiles per block for which it is used
+    if (d->KH == 3 && d->KW == 3 && d->workspace) {
+        static int taps_min = -1;
+        if (taps_min < 0) { const char* e = getenv("SZN_WGT_MINTILES"); taps_min = e ? atoi(e) : 8; }
+        const int rc = szn_conv_wgrad_taps_try(d, in, dout, dw, accumulate, taps_min, stream);
+        if (rc <= 0) return rc;
+    }
     const long nw = (long)d->Co * d->KH * d->KW * d->Ci;
     Wg2Args a;
     a.dout = (const char*)dout; a.in = (const char*)in; a.dw = dw;

@@ -1,0 +1,242 @@
+// szn_conv_wgrad_taps.hip -- weight gradient of the 3x3 layers, all nine taps from ONE staged input patch (bf16).
+//
+// conv_wgrad_v2 runs one GEMM per filter tap and re-stages both operands for each of them (256 B of LDS fill per MFMA);
+// on the 64/128-channel layers at 710^2 / 355^2 it sits at ~250 TFLOP/s.  Here a persistent block owns a
+// (64 couts) x (64 cins) x (9 taps) slice of dW -- 144 accumulator fragments = 18 per wave, kept in registers for the
+// whole kernel -- and walks a run of 16 x 16 output tiles.  Per tile it stages the dout tile [256 px][64 co] and the
+// input patch [18 x 18 px][64 ci] ONCE (73 KiB per 1152 MFMA = 64 B per MFMA) with LDS-DMA (out-of-range offsets give
+// the zero padding / ragged edges), double-buffered against the MFMAs of the previous tile.
+//   * the contraction index is the pixel: fragments come out of the pixel-major images with ds_read_b64_tr_b16; a K step
+//     is 32 pixels = 2 tile rows.  Tap (kh, kw) of K step p reads patch rows 2p + kh, 2p + kh + 1 at column shift kw: the
+//     4 x 3 (row, shift) reads of a step serve all nine taps, and two of the four rows carry over to the next step,
+//     so a wave issues 4 (dout) + 6 (patch) ds_read_b64_tr per 18 MFMA;
+//   * wave (h, c): couts 32 h .. + 31 (2 fragments) x cins 16 c .. + 15 x 9 taps;
+//   * both images use the row swizzle chunk ^= ((row >> 1) & 3) << 1 (source side of the DMA): any 8 consecutive rows
+//     are conflict-free for the transpose reads, whatever the start row (the patch reads start anywhere);
+//   * every block writes its fp32 partial [64][9][64] into its own slab of the caller's workspace with coalesced
+//     plain stores; wgrad_taps_reduce adds the slabs in a fixed order (deterministic, no atomics, no memset).
+#include "szn_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((address_space(3))) void* ldsptr_t;
+
+namespace {
+
+struct WtArgs {
+    const char* dout; const char* in; float* dw; float* ws;
+    unsigned dout_bytes, in_bytes;
+    int B, Hi, Wi, Ci, Ho, Wo, Co, pad;
+    int ldi, ldd;
+    int tiles_x, tiles_y, ntiles;      // ntiles = B * tiles_y * tiles_x
+    int cotiles, citiles, nsplit;
+    int accumulate;
+};
+
+constexpr unsigned kOOBt = 0x80000000u;
+constexpr int PWt = 18, PROWSt = PWt * PWt;
+constexpr int DOUTB = 256 * 128;
+constexpr int PATCHBt = 328 * 128;
+constexpr int STAGEt = DOUTB + PATCHBt;
+constexpr int OFF_DUMPt = 2 * STAGEt;
+constexpr int LDS_WT = OFF_DUMPt + 1024;
+constexpr int SLAB = 64 * 9 * 64;                   // floats per block partial
+
+__global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = w >> 2, c = w & 3;
+    const int g = lane >> 4, r16 = lane & 15;
+
+    // block -> (pixel split, cout tile, cin slice); the combos of one pixel range are neighbours in launch order
+    int bid = blockIdx.x;
+    const int cit = bid % a.citiles; bid /= a.citiles;
+    const int cot = bid % a.cotiles; const int split = bid / a.cotiles;
+    const int first = (int)((long)a.ntiles * split / a.nsplit), last = (int)((long)a.ntiles * (split + 1) / a.nsplit);
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, (int)a.dout_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+
+    // ---- LDS-DMA slots: 8 rows of 128 B per instruction; lane -> (row = 8 piece + rsub, 16-B slot) ----
+    const int rsub = lane >> 3;
+    const unsigned chunkoff = (unsigned)(((lane & 7) ^ (((rsub >> 1) & 3) << 1)) << 4);      // (row >> 1) & 3 == (rsub >> 1) & 3
+    const unsigned coA = (unsigned)(cot * 128) + chunkoff, coB = (unsigned)(cit * 128) + chunkoff;
+    const int q0 = 8 * w + rsub;
+    auto issue = [&](int t, int stage) {
+        int bb = t;
+        const int tx = bb % a.tiles_x; bb /= a.tiles_x;
+        const int ty = bb % a.tiles_y; const int b = bb / a.tiles_y;
+        char* sb = smem + stage * STAGEt;
+        int q0v = q0;
+        asm volatile("" : "+v"(q0v));               // keep the per-slot coordinates out of loop-carried VGPRs
+        // dout tile: pieces w, w + 8, w + 16, w + 24 (tile pixel pl = 8 piece + rsub: row pl >> 4, column pl & 15)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int pl = q0v + 64 * p;
+            const int oh = ty * 16 + (pl >> 4), ow = tx * 16 + (pl & 15);
+            const unsigned v = (oh < a.Ho && ow < a.Wo) ? (unsigned)(((b * a.Ho + oh) * a.Wo + ow) * a.ldd * 2) + coA : kOOBt;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (w + 8 * p) * 1024), 16, v, 0, 0, 0);
+        }
+        const int ih0 = ty * 16 - a.pad, iw0 = tx * 16 - a.pad;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            unsigned v = kOOBt;
+            const int q = q0v + 64 * p;
+            if (q < PROWSt) {
+                const int pr = (q * 3641) >> 16, pc = q - pr * PWt;           // q / 18 for q < 324
+                const int ih = ih0 + pr, iw = iw0 + pc;
+                if ((unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi)
+                    v = (unsigned)(((b * a.Hi + ih) * a.Wi + iw) * a.ldi * 2) + coB;
+            }
+            const int piece = w + 8 * p;
+            char* dst = (piece < 41) ? sb + DOUTB + piece * 1024 : smem + OFF_DUMPt;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)dst, 16, v, 0, 0, 0);
+        }
+    };
+
+    f32x4_t acc[2][9];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[i][k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane transpose-read coordinates: this lane supplies pixel kk (of 16) and 8 B = 4 channels
+    const int kk = g * 4 + (r16 >> 2);
+    const int sub = (r16 & 3) * 8;
+    // dout image rows are 32 p + kk (+ 16): (row >> 1) & 3 == (kk >> 1) & 3 for both
+    int offA[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) offA[i] = kk * 128 + (((h * 4 + i * 2) ^ (((kk >> 1) & 3) << 1)) << 4) + sub;
+
+    if (first < last) issue(first, 0);
+    int stage = 0;
+    for (int t = first; t < last; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < last) issue(t + 1, stage ^ 1);
+        const char* sd = smem + stage * STAGEt;
+        const char* sp = sd + DOUTB;
+        auto rdA = [&](int p, int i) -> u32x4_t {
+            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sd + p * 4096 + offA[i]));
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sd + p * 4096 + 2048 + offA[i]));
+            const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+            return u32x4_t{l2.x, l2.y, h2.x, h2.y};
+        };
+        auto rdB = [&](int R, int kw) -> u32x2_t {          // patch row R (0..17), column shift kw, 16 pixels
+            const int q = R * PWt + kw + kk;
+            const bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sp + q * 128 + (((c * 2) ^ (((q >> 1) & 3) << 1)) << 4) + sub));
+            return __builtin_bit_cast(u32x2_t, v);
+        };
+        u32x2_t Br[4][3];
+        u32x4_t Af[2];
+#pragma unroll
+        for (int R = 0; R < 2; ++R)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) Br[R][kw] = rdB(R, kw);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            // rows 2p, 2p + 1 are in Br[0], Br[1]; fetch 2p + 2, 2p + 3 and the dout fragments of this step
+#pragma unroll
+            for (int R = 2; R < 4; ++R)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) Br[R][kw] = rdB(2 * p + R, kw);
+            Af[0] = rdA(p, 0); Af[1] = rdA(p, 1);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const u32x4_t xf = u32x4_t{Br[kh][kw].x, Br[kh][kw].y, Br[kh + 1][kw].x, Br[kh + 1][kw].y};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Af[i]),
+                                                                                      __builtin_bit_cast(bf16x8_t, xf), acc[i][kh * 3 + kw], 0, 0, 0);
+                }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) { Br[0][kw] = Br[2][kw]; Br[1][kw] = Br[3][kw]; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage ^= 1;
+    }
+
+    // ---- partial -> slab [wave][fragment f = 9 i + tap][e][lane], 256 contiguous bytes per store instruction ----
+    float* slab = a.ws + (size_t)blockIdx.x * SLAB + (size_t)w * (18 * 256) + lane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) slab[((i * 9 + k) * 4 + e) * 64] = acc[i][k][e];
+#endif
+}
+
+// dw[co][tap][ci] (+)= sum over the pixel splits of one (cot, cit) combo, in split order
+__global__ __launch_bounds__(256) void wgrad_taps_reduce(WtArgs a) {
+    const int ncombo = a.cotiles * a.citiles;
+    const long total = (long)ncombo * SLAB;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int combo = (int)(idx / SLAB), el = (int)(idx - (long)combo * SLAB);
+        const int cit = combo % a.citiles, cot = combo / a.citiles;
+        const float* p = a.ws + (size_t)combo * SLAB + el;            // block id = split * ncombo + combo
+        float s = 0.f;
+        for (int sp = 0; sp < a.nsplit; ++sp) s += p[(size_t)sp * ncombo * SLAB];
+        const int w = el / 4608, f = (el >> 8) % 18, e = (el >> 6) & 3, lane = el & 63;
+        const int h = w >> 2, c = w & 3, i = f / 9, tap = f - i * 9;
+        const int co = cot * 64 + h * 32 + i * 16 + (lane >> 4) * 4 + e, ci = cit * 64 + c * 16 + (lane & 15);
+        float* dst = a.dw + ((long)co * 9 + tap) * a.Ci + ci;
+        *dst = a.accumulate ? *dst + s : s;
+    }
+}
+
+}  // namespace
+
+// Called by szn_conv2d_wgrad after validation.  Returns 1 if the layer / workspace does not fit this kernel.
+int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
+                            int min_tiles_per_block, szn_stream_t stream) {
+    if (d->dtype != SZN_BF16 || d->KH != 3 || d->KW != 3 || (d->Ci & 63) || (d->Co & 63) || d->pad > 2 || !d->workspace)
+        return 1;
+    if ((d->ldi & 7) || (d->ldo & 7)) return 1;
+    WtArgs a;
+    a.cotiles = d->Co / 64; a.citiles = d->Ci / 64;
+    const int ncombo = a.cotiles * a.citiles;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    if (ncombo > ncu) return 1;
+    a.tiles_x = szn_div_up(d->Wo, 16); a.tiles_y = szn_div_up(d->Ho, 16);
+    const long nt = (long)d->B * a.tiles_y * a.tiles_x;
+    if (nt >= (1L << 30)) return 1;
+    a.ntiles = (int)nt;
+    // pixel splits: one block per CU at most, at least min_tiles_per_block tiles each (the slab write + reduction
+    // must amortise), slabs must fit the workspace; too little parallelism left -> conv_wgrad_v2
+    long ns = ncu / ncombo;
+    if (min_tiles_per_block < 1) min_tiles_per_block = 1;
+    if (ns > nt / min_tiles_per_block) ns = nt / min_tiles_per_block;
+    const size_t slab_bytes = (size_t)ncombo * SLAB * sizeof(float);
+    if (ns > (long)(d->workspace_bytes / slab_bytes)) ns = (long)(d->workspace_bytes / slab_bytes);
+    if (ns < 1 || ns * ncombo < 32) return 1;
+    a.nsplit = (int)ns;
+    a.dout = (const char*)dout; a.in = (const char*)in; a.dw = dw; a.ws = (float*)d->workspace;
+    a.dout_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->ldo * 2);
+    a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->ldi * 2);
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.pad = d->pad;
+    a.ldi = d->ldi; a.ldd = d->ldo; a.accumulate = accumulate;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_taps, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WT);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_taps, dim3((unsigned)(ns * ncombo)), dim3(512), LDS_WT, st, a);
+    SZN_CHECK_LAUNCH("conv_wgrad_taps");
+    const long total = (long)ncombo * SLAB;
+    hipLaunchKernelGGL(wgrad_taps_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    SZN_CHECK_LAUNCH("wgrad_taps_reduce");
+    return SZN_OK;
+}

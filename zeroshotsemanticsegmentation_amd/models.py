@@ -252,6 +252,8 @@ class _Engine(object):
         ldo = dout.shape[3] if ldo is None else ldo
         code = L.dtype_code(self.dtype)
         d = L.ConvDesc(code, B, Hi, Wi, ci, Ho, Wo, co, k, k, pad, ci, ldo, 0, 0, 0)
+        if k == 3:      # slabs of the all-taps kernel (szn_conv_wgrad_taps.hip): <= 256 blocks x 64*9*64 fp32
+            self._workspace(d, 256 * 64 * 9 * 64 * 4, x.device)
         st = L.stream_ptr()
         L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
         if db is not None:
