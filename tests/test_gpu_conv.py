@@ -143,9 +143,10 @@ def test_conv_epilogue_scale_and_padded_strides():
     assert float(out[..., Co:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("geom", [(2, 13, 9, 100), (1, 20, 37, 1), (1, 5, 70, 0)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv1_1(dtype):
-    B, H, W, pad = 2, 13, 9, 100
+def test_conv1_1(dtype, geom):
+    B, H, W, pad = geom
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, 3, H, W, generator=g) * 50
     w = torch.randn(64, 3, 3, 3, generator=g) / 5

@@ -45,7 +45,7 @@ def main():
         din = torch.empty_like(x)
         dw = torch.zeros(Co, K, K, Ci, device="cuda")
         d = L.ConvDesc(code, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, pad, Ci, Co, Ci, 1, 0)
-        ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+        ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         flops = 2.0 * B * Ho * Ho * Co * Ci * K * K
         calls = {

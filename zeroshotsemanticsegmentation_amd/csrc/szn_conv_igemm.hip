@@ -57,6 +57,7 @@ struct Conv2Args {
     int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
     int ldi, ldo, ldg, relu, out_f32;
     int M, HoWo, mtiles, ntiles, nsplit, chunks_per_split;
+    int nmajor;                // tile order: 1 = pixel tile fastest (weights larger than activations)
 };
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
@@ -86,7 +87,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
 
     const int nwg = a.mtiles * a.ntiles;
     const int lid = xcd_remap2(blockIdx.x, nwg);
-    const int nt = lid % a.ntiles, mt = lid / a.ntiles;
+    // consecutive ids (= one XCD) walk the cout tiles of a pixel tile, or -- when the filter bank is the larger operand
+    // (fc6, fc7) -- the pixel tiles of a cout tile, so that the big operand is fetched by one L2 only
+    const int nt = a.nmajor ? lid / a.mtiles : lid % a.ntiles, mt = a.nmajor ? lid % a.mtiles : lid / a.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int split = blockIdx.y;
 
@@ -699,20 +702,39 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
     a.relu = d->relu; a.out_f32 = d->out_f32;
     a.M = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo;
+    { static int nm = -1; if (nm < 0) { const char* e = getenv("SZN_NMAJOR"); nm = e ? atoi(e) : 0; } a.nmajor = (nm && w_bytes > in_bytes) ? 1 : 0; }   // measured slower on fc6/fc7: off
     const bool narrow = d->Co <= 64;
     const int BN = narrow ? 64 : 128;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(a.Co, BN);
     const int nK = d->KH * d->KW * (d->Ci / bke);
     a.nsplit = 1; a.chunks_per_split = nK;
     const long tiles = (long)a.mtiles * a.ntiles;
-    // split-K only where the grid cannot fill the chip AND K is long (fc6 dgrad: 68 tiles x 3136 chunks): every split
-    // writes its own fp32 slab with plain stores, a second kernel sums the slabs in a fixed order + epilogue
-    if (d->workspace && tiles < 128 && nK >= 256 && !d->colsum) {
-        long ns = (768 + tiles - 1) / tiles;
-        if (ns > nK / 32) ns = nK / 32;
-        while (ns > 1 && (size_t)ns * a.M * a.Co * sizeof(float) > d->workspace_bytes) --ns;
-        if (ns > 1) {
-            a.chunks_per_split = (int)((nK + ns - 1) / ns);
+    // split-K where K is long and the tile count quantises badly against the CU count (fc6 forward: 320 tiles = 1.25
+    // waves; fc6 dgrad: 68 tiles x 3136 chunks): every split writes its own fp32 slab with plain stores, a second
+    // kernel sums the slabs in a fixed order + epilogue.  ns minimises a simple time model: MFMA time / wave
+    // efficiency + slab traffic.
+    if (d->workspace && nK >= 256 && !d->colsum) {
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0; hipDeviceProp_t p;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+            if (ncu <= 0) ncu = 256;
+        }
+        const double flops = 2.0 * a.M * (double)d->Co * d->Ci * d->KH * d->KW;
+        const double slab = (double)a.M * d->Co * 8.0;                  // fp32 write + read per split
+        long best = 1; double best_t = 0;
+        for (long ns = 1; ns <= 16 && ns <= nK / 32; ++ns) {
+            if (ns > 1 && (size_t)ns * a.M * a.Co * sizeof(float) > d->workspace_bytes) break;
+            const long blocks = tiles * ns;
+            const double eff = (double)blocks / (double)((blocks + ncu - 1) / ncu * ncu);
+            const double t = flops / (1.0e15 * eff) + (ns > 1 ? ns * slab / 3.0e12 + 5e-6 : 0.0);
+            if (ns == 1 || t < best_t * 0.97) { best = ns; best_t = t; }
+        }
+        static int force_ns = -1;                   // tuning knob: SZN_SPLITK_NS=n forces the split count (0 = model)
+        if (force_ns < 0) { const char* e = getenv("SZN_SPLITK_NS"); force_ns = e ? atoi(e) : 0; }
+        if (force_ns > 0 && force_ns <= nK / 32 && (size_t)force_ns * a.M * a.Co * sizeof(float) <= d->workspace_bytes) best = force_ns;
+        if (best > 1) {
+            a.chunks_per_split = (int)((nK + best - 1) / best);
             a.nsplit = szn_div_up(nK, a.chunks_per_split);
             a.ws = (float*)d->workspace;
         }

@@ -20,7 +20,7 @@ struct WideArgs {
     unsigned in_bytes, w_bytes;
     int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
     int ldi, ldo, ldg, relu, out_f32;
-    int M, HoWo, mtiles, ntiles;
+    int M, HoWo, mtiles, ntiles, nmajor;
 };
 
 constexpr unsigned kOOBx = 0x80000000u;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
 
     const int nwg = a.mtiles * a.ntiles;
     const int lid = xcd_remap_w(blockIdx.x, nwg);
-    const int nt = lid % a.ntiles, mt = lid / a.ntiles;
+    const int nt = a.nmajor ? lid / a.mtiles : lid % a.ntiles, mt = a.nmajor ? lid % a.mtiles : lid / a.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
@@ -272,6 +272,7 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     WideArgs a;
     a.M = d->B * d->Ho * d->Wo;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(d->Co, 256);
+    a.nmajor = 0;
     if ((long)a.mtiles * a.ntiles < min_tiles) return 1;            // too few tiles to fill the chip: keep 256 x 128
     if ((long)a.ntiles * 256 - d->Co > 64) return 1;                // would waste > 64 columns of the last tile
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;

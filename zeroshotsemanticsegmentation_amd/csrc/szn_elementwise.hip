@@ -39,77 +39,88 @@ extern "C" int szn_device_info(int device, szn_device_info_t* out) {
 namespace {
 
 // ---- conv1_1: 3 -> 64, 3x3, pad P, reads NCHW f32, writes NHWC T ---------------------------------
-// thread = (4 consecutive output pixels of one row, group of 8 couts): the 3 x 6 x 3 input window is loaded once and
-// each weight vector (LDS, [tap*3+ci][64 co]) is reused for the 4 pixels.  With pad = 100 almost half of the outputs
-// only see zero padding: those quads skip the arithmetic and store relu(bias).
+// fp32 MFMA (v_mfma_f32_16x16x4_f32) on an im2col fragment gathered straight from the image: a wave owns segments of
+// 16 consecutive output pixels of one row; K = 27 taps*channels padded to 28 = 7 MFMA steps, the lane (g, r16) loads
+// tap t = 4 s + g of pixel r16 (64-B coalesced rows of the fp32 image, each im2col element loaded exactly once).  The
+// 64 x 28 filter bank is 28 VGPRs of A fragments.  With pad = 100 almost half of the segments only see zero padding:
+// those skip the loads and the MFMAs and store relu(bias).  Epilogue: v_permlane16_swap pairs two cout fragments so
+// that a lane stores 8 consecutive couts of its pixel (one 16-B piece in bf16, 64 contiguous bytes per pixel per
+// instruction) -- the kernel is bound by the 64-channel output write.
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, T* __restrict__ out, int B,
                                                           int H, int W, int pad, int Ho, int Wo) {
-    __shared__ __attribute__((aligned(16))) float wl[27][64];
-    __shared__ float bl[64];
-    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-        const int co = i & 63, t = i >> 6;   // t = (kh*3+kw)*3+ci, matches OHWI order of w
-        wl[t][co] = w[co * 27 + t];
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
+    float wa[7][4];
+    int toff[7], tdhw[7];                                // image offset of tap t relative to (ci 0, ih0, iw0); kh << 8 | kw, -1 = pad tap
+    const long plane = (long)H * W;
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int t = 4 * s + g;                         // (kh*3+kw)*3+ci, the OHWI order of w
+        const int kh = t / 9, kw = (t / 3) % 3, ci = t % 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wa[s][i] = t < 27 ? w[(16 * i + r16) * 27 + t] : 0.f;
+        toff[s] = (int)(ci * plane + (long)kh * W + kw);
+        tdhw[s] = t < 27 ? ((kh << 8) | kw) : -1;
     }
-    if (threadIdx.x < 64) bl[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
-    __syncthreads();
-    const int qpr = (Wo + 3) >> 2;                       // pixel quads per output row
-    const long nquad = (long)B * Ho * qpr;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long qd = gid >> 3;
-    const int cg = (int)(gid & 7);
-    if (qd >= nquad) return;
-    const int qx = (int)(qd % qpr);
-    const long rowid = qd / qpr;
-    const int oh = (int)(rowid % Ho), b = (int)(rowid / Ho);
-    const int ow0 = qx * 4;
-    float acc[4][8];
+    float bv[2][8];
+    int cst[2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 2; ++p) {
+        cst[p] = 32 * p + (g & 1) * 16 + (g >> 1) * 8;   // first of the 8 consecutive couts this lane holds after the swap
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
-    const int ih0 = oh - pad, iw0 = ow0 - pad;
-    const bool touches = (ih0 + 2 >= 0) && (ih0 < H) && (iw0 + 5 >= 0) && (iw0 < W);
-    if (touches) {
-        const long plane = (long)H * W;
+        for (int e = 0; e < 8; ++e) bv[p][e] = bias ? bias[cst[p] + e] : 0.f;
+    }
+    const int nsx = (Wo + 15) >> 4;
+    const long nseg = (long)B * Ho * nsx;
+    const long nwaves = (long)gridDim.x * 4;
+    for (long seg = (long)blockIdx.x * 4 + (threadIdx.x >> 6); seg < nseg; seg += nwaves) {
+        const int sx = (int)(seg % nsx);
+        const long rowid = seg / nsx;
+        const int oh = (int)(rowid % Ho), b = (int)(rowid / Ho);
+        const int ih0 = oh - pad, iw0 = sx * 16 - pad;
+        f32x4_t acc[4];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int ih = ih0 + kh;
-            const bool rok = (unsigned)ih < (unsigned)H;
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const bool touches = (ih0 + 2 >= 0) && (ih0 < H) && (iw0 + 17 >= 0) && (iw0 < W);      // wave-uniform
+        if (touches) {
+            const float* xb = x + (long)b * 3 * plane + (long)ih0 * W + iw0 + r16;
+            float xv[7];
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                float xr[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const int iw = iw0 + c;
-                    xr[c] = (rok && (unsigned)iw < (unsigned)W) ? x[((long)b * 3 + ci) * plane + (long)ih * W + iw] : 0.f;
-                }
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const float* wr = &wl[(kh * 3 + kw) * 3 + ci][cg * 8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float wv = wr[e];
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) acc[p][e] = fmaf(xr[kw + p], wv, acc[p][e]);
-                    }
-                }
+            for (int s = 0; s < 7; ++s) {
+                const int ih = ih0 + (tdhw[s] >> 8), iw = iw0 + r16 + (tdhw[s] & 255);
+                const bool ok = tdhw[s] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                xv[s] = ok ? xb[toff[s]] : 0.f;
             }
+#pragma unroll
+            for (int s = 0; s < 7; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][i], xv[s], acc[i], 0, 0, 0);
         }
-    }
-    const long pbase = ((long)b * Ho + oh) * Wo + ow0;
+        const int ow = sx * 16 + r16;
+        if (ow < Wo) {
+            T* op = out + (((long)b * Ho + oh) * Wo + ow) * 64;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (ow0 + p >= Wo) break;
-        u32x4_t o4[2];
-        T* oe = (T*)o4;
+            for (int p = 0; p < 2; ++p) {
+                float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) elem<T>::st(oe + e, fmaxf(acc[p][e] + bl[cg * 8 + e], 0.f));
-        T* o = out + (pbase + p) * 64 + cg * 8;
-        *(u32x4_t*)o = o4[0];
-        if (sizeof(T) == 4) *(u32x4_t*)(o + 4) = o4[1];
+                for (int c = 0; c < 4; ++c) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][c]), __float_as_uint(acc[2 * p + 1][c]), false, false);
+                    v[c] = fmaxf(__uint_as_float(r[0]) + bv[p][c], 0.f);
+                    v[4 + c] = fmaxf(__uint_as_float(r[1]) + bv[p][4 + c], 0.f);
+                }
+                u32x4_t o4[2];
+                T* oe = (T*)o4;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) elem<T>::st(oe + e, v[e]);
+                T* o = op + cst[p];
+                *(u32x4_t*)o = o4[0];
+                if (sizeof(T) == 4) *(u32x4_t*)(o + 4) = o4[1];
+            }
+        }   // (swap partners differ in g only: same pixel, same predicate)
     }
+#endif
 }
 
 // conv1_1 wgrad = a 1x1-conv wgrad on the im2col image: xcol[m][t] = x[b][ci][oh+kh-pad][ow+kw-pad], t = (kh*3+kw)*3+ci
@@ -323,9 +334,10 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
     if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || pad < 0) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd: bad argument");
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     if (Ho <= 0 || Wo <= 0) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd: empty output");
-    const long threads = (long)B * Ho * ((Wo + 3) / 4) * 8;
-    const long blocks = (threads + 255) / 256;
-    if (blocks >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd: grid too large");
+    if ((long)3 * H * W >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd: image plane too large");
+    const long nseg = (long)B * Ho * ((Wo + 15) / 16);     // 16-pixel segments, one wave each (grid-stride)
+    long blocks = (nseg + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(conv1_1_fwd_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                            (bf16_raw*)out, B, H, W, pad, Ho, Wo);

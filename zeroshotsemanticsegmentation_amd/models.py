@@ -66,8 +66,9 @@ class _Engine(object):
 
     def _workspace(self, desc, nbytes, device):
         """split-K scratch handed to the conv kernels (they use it only for few-tile / long-K shapes: fc6, fc7)"""
-        if nbytes > (256 << 20):
+        if nbytes > (64 << 20):          # one fp32 slab of the output; layers this large never split
             return
+        nbytes = min(16 * nbytes, 256 << 20)     # room for up to 16 K-splits (the library picks the count)
         if self._splitk_ws is None or self._splitk_ws.numel() < nbytes or self._splitk_ws.device != device:
             self._splitk_ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
         desc.workspace, desc.workspace_bytes = self._splitk_ws.data_ptr(), self._splitk_ws.numel()
@@ -253,7 +254,7 @@ class _Engine(object):
         code = L.dtype_code(self.dtype)
         d = L.ConvDesc(code, B, Hi, Wi, ci, Ho, Wo, co, k, k, pad, ci, ldo, 0, 0, 0)
         if k == 3:      # slabs of the all-taps kernel (szn_conv_wgrad_taps.hip): <= 256 blocks x 64*9*64 fp32
-            self._workspace(d, 256 * 64 * 9 * 64 * 4, x.device)
+            self._workspace(d, 256 * 64 * 9 * 64 * 4 // 16, x.device)    # (_workspace reserves 16x)
         st = L.stream_ptr()
         L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
         if db is not None:
