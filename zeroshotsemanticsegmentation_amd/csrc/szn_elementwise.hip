@@ -202,55 +202,62 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 }
 
 // din[b][ih][iw][c] = (in is the FIRST max of its window, scan order (0,0),(0,1),(1,0),(1,1)) ? dout[win] : 0,
-// then gated by in > 0 (the ReLU in front of every pool).  thread = (input pixel, 16-B chunk).
+// then gated by in > 0 (the ReLU in front of every pool).  thread = (OUTPUT pixel, 16-B chunk): the 2x2 window is
+// loaded once (4 + 1 loads, 4 stores per 4 input pixels; the pooled tensor itself is not needed -- its value is the
+// window maximum).  `out` stays in the signature for the C-ABI.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ in, const T* __restrict__ out,
                                                           const T* __restrict__ dout, T* __restrict__ din, int B, int Hi,
                                                           int Wi, int C, int Ho, int Wo, float* __restrict__ colsum) {
     constexpr int CH = elem<T>::kPer16B;
     __shared__ float red[256 * CH];
+    (void)out;
     const int cpp = C / CH;
-    const long total = (long)B * Hi * Wi * cpp;
+    const long total = (long)B * Ho * Wo * cpp;
     float cs[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) cs[e] = 0.f;
     for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
         const int cc = (int)(gid % cpp);
-        const long p = gid / cpp;
-        const int iw = (int)(p % Wi);
-        const long t = p / Wi;
-        const int ih = (int)(t % Hi), b = (int)(t / Hi);
-        const int oh = ih >> 1, ow = iw >> 1;
-        const long po = ((long)b * Ho + oh) * Wo + ow;
-        const u32x4_t vm = *(const u32x4_t*)(out + po * C + cc * CH);
+        const long po = gid / cpp;
+        const int ow = (int)(po % Wo);
+        const long t = po / Wo;
+        const int oh = (int)(t % Ho), b = (int)(t / Ho);
+        const int ih = 2 * oh, iw = 2 * ow;
+        const bool okw = iw + 1 < Wi, okh = ih + 1 < Hi;
+        const long p00 = ((long)b * Hi + ih) * Wi + iw;
+        const T* ip = in + p00 * C + cc * CH;
+        u32x4_t v[4];
+        const u32x4_t zero = {0, 0, 0, 0};
+        v[0] = *(const u32x4_t*)ip;
+        v[1] = okw ? *(const u32x4_t*)(ip + C) : zero;
+        v[2] = okh ? *(const u32x4_t*)(ip + (long)Wi * C) : zero;
+        v[3] = (okh && okw) ? *(const u32x4_t*)(ip + (long)Wi * C + C) : zero;
         const u32x4_t vd = *(const u32x4_t*)(dout + po * C + cc * CH);
-        const u32x4_t vs = *(const u32x4_t*)(in + p * C + cc * CH);
-        const T* me = (const T*)&vm; const T* de = (const T*)&vd; const T* se = (const T*)&vs;
-        bool earlier[CH];
-#pragma unroll
-        for (int e = 0; e < CH; ++e) earlier[e] = false;
-        const int myidx = (ih & 1) * 2 + (iw & 1);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k >= myidx) break;
-            const int jh = 2 * oh + (k >> 1), jw = 2 * ow + (k & 1);
-            if (jh >= Hi || jw >= Wi) continue;
-            const u32x4_t vo = *(const u32x4_t*)(in + (((long)b * Hi + jh) * Wi + jw) * C + cc * CH);
-            const T* oe = (const T*)&vo;
-#pragma unroll
-            for (int e = 0; e < CH; ++e) earlier[e] = earlier[e] || (elem<T>::ld(oe + e) == elem<T>::ld(me + e));
-        }
-        u32x4_t o;
-        T* oe = (T*)&o;
+        const T* de = (const T*)&vd;
+        const bool ok[4] = {true, okw, okh, okh && okw};
+        u32x4_t o[4];
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
-            const float s = elem<T>::ld(se + e);
-            const bool win = (s == elem<T>::ld(me + e)) && !earlier[e] && (s > 0.f);
-            const float dv = win ? elem<T>::ld(de + e) : 0.f;
-            elem<T>::st(oe + e, dv);
-            cs[e] += elem<T>::ld(oe + e);           // what was actually stored (bf16-rounded in the bf16 path)
+            float s[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] = elem<T>::ld((const T*)&v[k] + e);
+            float m = s[0];
+            int win = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (ok[k] && s[k] > m) { m = s[k]; win = k; }       // strict >: the first maximum keeps the gradient
+            const float dv = (m > 0.f) ? elem<T>::ld(de + e) : 0.f;  // ReLU gate of the winner
+#pragma unroll
+            for (int k = 0; k < 4; ++k) elem<T>::st((T*)&o[k] + e, k == win ? dv : 0.f);
+            cs[e] += elem<T>::ld((const T*)&o[0] + e) + elem<T>::ld((const T*)&o[1] + e) +
+                     elem<T>::ld((const T*)&o[2] + e) + elem<T>::ld((const T*)&o[3] + e);   // what was stored (one non-zero term)
         }
-        *(u32x4_t*)(din + p * C + cc * CH) = o;
+        T* op = din + p00 * C + cc * CH;
+        *(u32x4_t*)op = o[0];
+        if (okw) *(u32x4_t*)(op + C) = o[1];
+        if (okh) *(u32x4_t*)(op + (long)Wi * C) = o[2];
+        if (okh && okw) *(u32x4_t*)(op + (long)Wi * C + C) = o[3];
     }
     if (colsum) {
         // bias gradient of the conv in front of this pool: column sums of din.  The launcher makes the grid stride a
@@ -416,7 +423,7 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
     const int ch = dtype == SZN_BF16 ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd: C must be a multiple of %d", ch);
     const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
-    const long total = (long)B * Hi * Wi * (C / ch);
+    const long total = (long)B * Ho * Wo * (C / ch);
     if (colsum && (256 % (C / ch)) != 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd: colsum needs C/%d to divide 256", ch);
     const int grid = grid_for(total, 256, colsum ? 4096 : 65536);
     if (dtype == SZN_BF16)
