@@ -25,7 +25,7 @@ int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, c
 int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, unsigned in_bytes, unsigned w_bytes, int min_tiles,
                       szn_stream_t stream);
-int szn_conv_c64_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                      const float* chan_scale, void* out, int min_tiles, szn_stream_t stream);
 int szn_conv3x3_halo_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                          const float* chan_scale, void* out, szn_stream_t stream);
@@ -676,11 +676,12 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     hipStream_t st = (hipStream_t)stream;
     // 3x3 layers on large feature maps: LDS-resident input patch (szn_conv_halo.hip); SZN_HALO_MIN overrides the
     // smallest output side for which it is used (0 = always, huge = never)
-    // 64 -> 64 channel 3x3 layers (conv1_2 forward / dgrad): register-resident filter bank, szn_conv_c64.hip
-    if (d->KH == 3 && d->KW == 3 && d->Ci == 64 && d->Co == 64) {
-        static int c64_min = -1;
-        if (c64_min < 0) { const char* e = getenv("SZN_C64_MINTILES"); c64_min = e ? atoi(e) : 512; }
-        const int rc = szn_conv_c64_try(d, in, w, bias, gate, chan_scale, out, c64_min, stream);
+    // 64/128 -> 64/128 channel 3x3 layers (conv1_2, conv2_x forward / dgrad): register-resident filter bank,
+    // szn_conv_regw.hip; SZN_REGW_MINTILES = fewest 256-pixel tiles for which it is used
+    if (d->KH == 3 && d->KW == 3 && d->Ci <= 128 && d->Co <= 128) {
+        static int regw_min = -1;
+        if (regw_min < 0) { const char* e = getenv("SZN_REGW_MINTILES"); regw_min = e ? atoi(e) : 128; }
+        const int rc = szn_conv_regw_try(d, in, w, bias, gate, chan_scale, out, regw_min, stream);
         if (rc <= 0) return rc;
     }
     if (d->KH == 3 && d->KW == 3 && !d->colsum) {

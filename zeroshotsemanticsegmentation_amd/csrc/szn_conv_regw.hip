@@ -1,0 +1,367 @@
+// szn_conv_regw.hip -- 3x3 convolution with the filter bank held in REGISTERS (bf16; 64/128 -> 64/128 channels: conv1_2
+// and conv2_x forward and dgrad, the 710^2 / 355^2 launches of the pad-100 network).
+//
+// A wave holds the MFMA A fragments of 32 couts x 64 cins x 9 taps = 144 VGPRs per lane for the whole kernel, so a
+// block of 8 waves holds up to 128 x 128 x 9 filters.  The block is persistent (one per CU) and walks a contiguous run
+// of output tiles; the only LDS traffic is the input patch, staged ONCE for all nine taps:
+//   * wave = (pixel group pg, cout group cog of 32, cin group cig of 64); COG x CIG x PG = 8.  The tile is 4 PG rows x
+//     16 columns; a wave computes 4 rows (4 pixel fragments) x 32 couts over its 64 cins: 144 MFMA per tile, pixel
+//     fragments reused across the taps that touch them (36 ds_read_b128 per 144 MFMA);
+//   * LDS = NBUF patch buffers [(4 PG + 2) x 18 px][64 CIG bf16] filled by LDS-DMA (raw buffer loads, out-of-range
+//     offsets give the zero padding), 16-B chunk index XOR-swizzled by the pixel row on the DMA source side; the patch
+//     of tile t + NBUF - 1 streams in while tile t computes;
+//   * CIG = 2: the two cin halves of a cout group sit in neighbouring waves; after the MFMAs each wave hands the
+//     partial sums of two of its four pixel fragments to its partner through LDS and finishes the other two;
+//   * epilogue straight from registers: v_permlane16_swap pairs the two cout fragments so that a lane holds 8
+//     consecutive couts of one pixel (16-B store), + bias / ReLU / gate (gate tile prefetched by LDS-DMA into a
+//     private slot per lane) / column sums (bias gradient of the producer layer: DPP row sums + ds_add_f32, one global
+//     atomicAdd per cout per block);
+//   * one s_barrier per tile (two when CIG = 2).  Per-wave vmcnt order inside a tile: gate pieces (t), patch pieces
+//     (t + NBUF - 1) ... MFMAs ... counted wait [=> gate (t), patch (t + 1), stores (t - 1) retired] ... stores (t).
+// Accumulation is fp32; per output the K terms are added tap-major inside 32-channel groups (a different order from
+// conv_igemm_v2, same tolerance against the oracle).
+#include "szn_common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((address_space(3))) void* ldsptr_t;
+
+namespace {
+
+struct RwArgs {
+    const char* in; const char* w; const float* bias; const char* gate; char* out; float* colsum;
+    unsigned in_bytes, gate_bytes;
+    int B, Hi, Wi, Ho, Wo, pad;
+    int ldi, ldo, ldg, relu;
+    int tiles_x, tiles_y, ntiles;      // ntiles = B * tiles_y * tiles_x
+};
+
+constexpr unsigned kOOBr = 0x80000000u;
+constexpr int PWr = 18;
+
+__device__ __forceinline__ float row16_sum(float x) {                      // sum over the 16 lanes of a DPP row
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x140, 0xF, 0xF, true));   // row_mirror
+    return x;
+}
+
+template <int COG, int CIG>
+struct RwGeom {
+    static constexpr int PG = 8 / (COG * CIG);          // pixel groups of 4 output rows
+    static constexpr int TR = 4 * PG;                   // tile rows
+    static constexpr int PROWS = (TR + 2) * PWr;        // patch pixels
+    static constexpr int RB = 128 * CIG;                // bytes per patch pixel
+    static constexpr int CPR = RB / 16;                 // 16-B chunks per patch pixel
+    static constexpr int RPP = 1024 / RB;               // patch pixels per 1-KiB DMA piece
+    static constexpr int NPIECE = (PROWS * RB + 1023) / 1024;
+    static constexpr int SLOTS = (NPIECE + 7) / 8;      // patch DMA instructions per wave per tile
+    static constexpr int PATCHB = NPIECE * 1024;
+    static constexpr int NBUF = CIG == 1 ? 3 : 2;
+    static constexpr int CO = 32 * COG, CI = 64 * CIG;
+    static constexpr int NJ = 4 / CIG;                  // pixel fragments finished (epilogue) by one wave
+    static constexpr int OFF_GATE = NBUF * PATCHB;      // [8 waves][NJ][64 lanes][16 B]
+    static constexpr int OFF_XCH = OFF_GATE + 8 * NJ * 1024;            // CIG = 2: [8 waves][2 jj][2 i][64 lanes][16 B]
+    static constexpr int OFF_DUMP = OFF_XCH + (CIG == 2 ? 8 * 4096 : 0);
+    static constexpr int OFF_BIAS = OFF_DUMP + 1024;
+    static constexpr int OFF_RED = OFF_BIAS + CO * 4;
+    static constexpr int LDS = OFF_RED + CO * 4;
+    static_assert(COG * CIG * PG == 8 && LDS <= 160 * 1024, "wave decomposition / LDS budget");
+};
+
+template <int COG, int CIG, bool GATED, bool COLSUM>
+__global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef RwGeom<COG, CIG> G_;
+    constexpr int PG = G_::PG, TR = G_::TR, PROWS = G_::PROWS, RB = G_::RB, CPR = G_::CPR, RPP = G_::RPP;
+    constexpr int NPIECE = G_::NPIECE, SLOTS = G_::SLOTS, PATCHB = G_::PATCHB, NBUF = G_::NBUF, CO = G_::CO, CI = G_::CI;
+    constexpr int NJ = G_::NJ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cig = w % CIG, cog = (w / CIG) % COG, pg = w / (CIG * COG);
+    const int g = lane >> 4, r16 = lane & 15;
+
+    // contiguous run of tiles per block; blocks of one XCD (blockIdx % 8) own neighbouring runs so that the halo rows
+    // shared by vertically adjacent tiles meet in the same L2
+    const int G = gridDim.x;
+    const int vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int first = (int)((long)a.ntiles * vb / G), last = (int)((long)a.ntiles * (vb + 1) / G);
+    if (first >= last) return;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)(GATED ? a.gate : a.in), 0, (int)(GATED ? a.gate_bytes : 0u), 0x00020000);
+
+    // ---- the filter bank of this wave: A fragments W[tap][s][i], lane (g, r16) = cout 32 cog + 16 i + r16, channels
+    //      64 cig + 32 s + 8 g .. + 7 (OHWI) ----
+    u32x4_t W[9][2][2];
+    {
+        const char* wp = a.w + ((long)(cog * 32 + r16) * 9 * CI + cig * 64 + g * 8) * 2;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    W[tap][s][i] = *(const u32x4_t*)(wp + ((long)(i * 16) * 9 * CI + tap * CI + s * 32) * 2);
+    }
+    if (tid < CO) {
+        ((float*)(smem + G_::OFF_BIAS))[tid] = a.bias ? a.bias[tid] : 0.f;
+        ((float*)(smem + G_::OFF_RED))[tid] = 0.f;
+    }
+
+    // ---- patch DMA slots: instruction p of wave w is piece w + 8 p = patch pixels RPP * piece .. + RPP - 1; the source
+    //      chunk of a lane's slot is slot ^ (pixel & (CPR - 1)), a per-lane constant for both row widths ----
+    const int slot = lane % CPR, psub = lane / CPR;
+    const unsigned chunkoff = (unsigned)((CPR == 8 ? (slot ^ psub) : (slot ^ ((4 * (w & 3) + psub) & 15))) << 4);
+    const int q0 = RPP * w + psub;                                         // patch pixel of slot p: q0 + 8 RPP p
+    auto issue = [&](int t, int buf) {
+        int bb = t;
+        const int tx = bb % a.tiles_x; bb /= a.tiles_x;
+        const int ty = bb % a.tiles_y; const int b = bb / a.tiles_y;
+        const int ih0 = ty * TR - a.pad, iw0 = tx * 16 - a.pad;
+        char* base = smem + buf * PATCHB;
+        int q0v = q0;
+        asm volatile("" : "+v"(q0v));       // opaque per call: keeps the per-slot coordinates out of loop-carried VGPRs
+#pragma unroll
+        for (int p = 0; p < SLOTS; ++p) {
+            unsigned v = kOOBr;
+            const int q = q0v + 8 * RPP * p;
+            if (q < PROWS) {
+                const int pr = (q * 3641) >> 16, pc = q - pr * PWr;           // q / 18 for q < 324
+                const int ih = ih0 + pr, iw = iw0 + pc;
+                if ((unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi)
+                    v = (unsigned)(((b * a.Hi + ih) * a.Wi + iw) * a.ldi * 2) + chunkoff;
+            }
+            const int piece = w + 8 * p;
+            char* dst = (piece < NPIECE) ? base + piece * 1024 : smem + G_::OFF_DUMP;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)dst, 16, v, 0, 0, 0);
+        }
+    };
+
+    const int cstart = cog * 32 + (g & 1) * 16 + (g >> 1) * 8;             // first of this lane's 8 couts after the swap
+    const int qb = (pg * 4) * PWr + r16;
+    const int j0 = CIG == 2 ? 2 * cig : 0;                                 // first pixel fragment this wave finishes
+
+    issue(first, 0);
+    if constexpr (NBUF == 3) {
+        if (first + 1 < last) {
+            issue(first + 1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SLOTS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    int buf = 0;
+    for (int t = first; t < last; ++t) {
+        const bool more = t + NBUF - 1 < last;
+        int bb = t;
+        const int tx = bb % a.tiles_x; bb /= a.tiles_x;
+        const int ty = bb % a.tiles_y; const int b = bb / a.tiles_y;
+        const int ow = tx * 16 + r16;
+        const int oh0 = ty * TR + pg * 4 + j0;                             // output row of this wave's first finished fragment
+        const unsigned m0 = (unsigned)((b * a.Ho + oh0) * a.Wo + ow);       // < 2^31 pixels (checked by the caller)
+        const bool okw = ow < a.Wo;
+        if constexpr (GATED) {
+            // each lane's 16 gate bytes per finished pixel row go to its own LDS slot: an asynchronous, register-free prefetch
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const bool ok = okw && oh0 + jj < a.Ho;
+                const unsigned v = ok ? ((m0 + jj * a.Wo) * a.ldg + cstart) * 2u : kOOBr;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (ldsptr_t)(smem + G_::OFF_GATE + (w * NJ + jj) * 1024), 16, v, 0, 0, 0);
+            }
+        }
+        if (more) issue(t + NBUF - 1, (buf + NBUF - 1) % NBUF);
+
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const char* pb = smem + buf * PATCHB;
+        int qbv = qb;
+        asm volatile("" : "+v"(qbv));               // per-tile opaque: the 36 swizzled read addresses are not hoisted into VGPRs
+        // 18 steps (patch row pr, shift kw), two fragments (channel halves) each; the fragments of step n + 1 are read
+        // while the MFMAs of step n run (sched_barrier keeps the compiler from hoisting all 36 reads: 144 VGPRs)
+        u32x4_t P[2][2];
+        auto ldP = [&](int step, u32x4_t (&dst)[2]) {
+            const int pr = step / 3, kw = step - pr * 3;
+            const int q = qbv + pr * PWr + kw;
+            const char* rowp = pb + q * RB;
+            const int sw = q & (CPR - 1);
+            dst[0] = *(const u32x4_t*)(rowp + (((cig * 8 + g) ^ sw) << 4));
+            dst[1] = *(const u32x4_t*)(rowp + (((cig * 8 + 4 + g) ^ sw) << 4));
+        };
+        ldP(0, P[0]);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            const int pr = step / 3, kw = step - pr * 3;
+            if (step + 1 < 18) ldP(step + 1, P[(step + 1) & 1]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int j = pr - kh;
+                    if (j < 0 || j > 3) continue;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, W[kh * 3 + kw][s][i]),
+                                                                            __builtin_bit_cast(bf16x8_t, P[step & 1][s]), acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        if constexpr (CIG == 2) {
+            // hand two pixel fragments to the partner wave (w ^ 1, the other cin half), take its sums for the other two
+            f32x4_t* xw = (f32x4_t*)(smem + G_::OFF_XCH + w * 4096) + lane;
+            const f32x4_t* xr = (const f32x4_t*)(smem + G_::OFF_XCH + (w ^ 1) * 4096) + lane;
+            if (cig == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) xw[(jj * 2 + i) * 64] = acc[i][2 + jj];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) xw[(jj * 2 + i) * 64] = acc[i][jj];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (cig == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i][jj] += xr[(jj * 2 + i) * 64];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i][jj] = acc[i][2 + jj] + xr[(jj * 2 + i) * 64];   // finished set in [0], [1]
+            }
+        }
+
+        // ---- epilogue from registers: fragments acc[.][0 .. NJ - 1] are output rows oh0 .. oh0 + NJ - 1 ----
+        float bv[8];
+        *(f32x4_t*)&bv[0] = *(const f32x4_t*)(smem + G_::OFF_BIAS + cstart * 4);
+        *(f32x4_t*)&bv[4] = *(const f32x4_t*)(smem + G_::OFF_BIAS + cstart * 4 + 16);
+        // retire the gate pieces of t, the patch pieces of t + 1 and the stores of t - 1
+        if (NBUF == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SLOTS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float cs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool ok = okw && oh0 + j < a.Ho;
+            float v[8];
+            u32x4_t gq;
+            if constexpr (GATED) gq = *(const u32x4_t*)(smem + G_::OFF_GATE + (w * NJ + j) * 1024 + lane * 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][j][c]), __float_as_uint(acc[1][j][c]), false, false);
+                v[c] = __uint_as_float(r[0]);
+                v[4 + c] = __uint_as_float(r[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = v[e] + bv[e];
+                if (a.relu) x = fmaxf(x, 0.f);
+                if constexpr (GATED) {
+                    const uint32_t gw = gq[e >> 1];
+                    const float gv = __uint_as_float((e & 1) ? (gw & 0xffff0000u) : (gw << 16));
+                    x = (gv > 0.f) ? x : 0.f;
+                }
+                v[e] = x;
+                if constexpr (COLSUM) cs[e] += ok ? x : 0.f;
+            }
+            u32x4_t pk;
+            pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+            pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
+            pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+            if (ok) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
+        }
+        if constexpr (COLSUM) {
+            float* red = (float*)(smem + G_::OFF_RED) + cstart;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = row16_sum(cs[e]);
+                if (r16 == 0) __hip_atomic_fetch_add(red + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f32
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf = (buf == NBUF - 1) ? 0 : buf + 1;
+    }
+
+    if constexpr (COLSUM) {
+        if (tid < CO) {
+            const float s = ((const float*)(smem + G_::OFF_RED))[tid];     // complete: behind the last tile's barrier
+            if (s != 0.f) atomicAdd(a.colsum + tid, s);
+        }
+    }
+#endif
+}
+
+template <int COG, int CIG, bool GATED, bool COLSUM>
+int launch_regw(const RwArgs& a, int grid, hipStream_t st) {
+    constexpr int lds = RwGeom<COG, CIG>::LDS;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_regw<COG, CIG, GATED, COLSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_regw<COG, CIG, GATED, COLSUM>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    SZN_CHECK_LAUNCH("conv3x3_regw");
+    return SZN_OK;
+}
+
+template <int COG, int CIG>
+int launch_regw_flags(const RwArgs& a, int grid, hipStream_t st) {
+    if (a.gate) return a.colsum ? launch_regw<COG, CIG, true, true>(a, grid, st) : launch_regw<COG, CIG, true, false>(a, grid, st);
+    return a.colsum ? launch_regw<COG, CIG, false, true>(a, grid, st) : launch_regw<COG, CIG, false, false>(a, grid, st);
+}
+
+}  // namespace
+
+// Called by szn_conv2d_fwd after it has validated the descriptor. Returns 1 if the layer is not this kernel's shape.
+int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                      const float* chan_scale, void* out, int min_tiles, szn_stream_t stream) {
+    if (d->dtype != SZN_BF16 || d->KH != 3 || d->KW != 3 || d->pad > 2 || d->out_f32 || chan_scale) return 1;
+    if ((d->Ci != 64 && d->Ci != 128) || (d->Co != 64 && d->Co != 128)) return 1;
+    if ((d->ldo & 7) || (d->ldi & 7) || (gate && (d->ldg & 7))) return 1;
+    const size_t in_bytes = (size_t)d->B * d->Hi * d->Wi * d->ldi * 2;
+    const size_t gate_bytes = gate ? (size_t)d->B * d->Ho * d->Wo * d->ldg * 2 : 0;
+    if (in_bytes >= 0x7fff0000ul || gate_bytes >= 0x7fff0000ul || (size_t)d->B * d->Ho * d->Wo * d->ldo * 2 >= 0xffff0000ul)
+        return 1;
+    const int cog = d->Co / 32, cig = d->Ci / 64;
+    const int tr = 4 * (8 / (cog * cig));
+    RwArgs a;
+    a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.out = (char*)out;
+    a.colsum = d->colsum;
+    a.in_bytes = (unsigned)in_bytes; a.gate_bytes = (unsigned)gate_bytes;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.pad = d->pad;
+    a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg; a.relu = d->relu;
+    a.tiles_x = szn_div_up(d->Wo, 16); a.tiles_y = szn_div_up(d->Ho, tr);
+    const long nt = (long)a.B * a.tiles_y * a.tiles_x;
+    if (nt >= (1L << 30) || nt * tr * 16 < (long)min_tiles * 256) return 1;      // min_tiles counts 256-pixel tiles
+    a.ntiles = (int)nt;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+        ncu &= ~7;                                   // whole XCD groups
+        if (ncu < 8) ncu = 8;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (cog == 2 && cig == 1) return launch_regw_flags<2, 1>(a, ncu, st);
+    if (cog == 4 && cig == 1) return launch_regw_flags<4, 1>(a, ncu, st);
+    if (cog == 2 && cig == 2) return launch_regw_flags<2, 2>(a, ncu, st);
+    return launch_regw_flags<4, 2>(a, ncu, st);
+}
