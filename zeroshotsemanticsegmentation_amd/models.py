@@ -14,8 +14,10 @@ HIP kernel reached through the C-ABI of include/szn.h (no torch.nn.functional co
 The layer objects subclass torch.nn.Conv2d / ConvTranspose2d / ReLU / MaxPool2d / Dropout2d purely as typed
 parameter containers so that `train.get_parameters` (reference train.py:302-331) classifies them the same way.
 """
+import contextlib
 import ctypes as C
 import math
+import os
 import os.path as osp
 
 import numpy as np
@@ -62,6 +64,8 @@ class _Engine(object):
         self.dropout_seed = 1337
         self.dropout_calls = 0
         self._splitk_ws = None
+        self._wg_ws = None            # slab workspace of the wgrad kernels (they run on their own stream)
+        self._wg_stream = None        # torch.cuda.Stream, or False when disabled (SZN_WGRAD_STREAM=0)
         self.lp_views = {}          # layer -> compute-dtype OHWI weight image maintained by the optimizer kernel (TrainStep)
 
     def _workspace(self, desc, nbytes, device):
@@ -247,18 +251,49 @@ class _Engine(object):
                    L.ptr(ctx.coarse), L.ptr(ds), L.ptr(dup), 0, L.stream_ptr())
         return dcoarse, dup
 
-    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None):
+    @contextlib.contextmanager
+    def _wgrad_stream(self, *tensors):
+        """Weight gradients are leaves of the backward chain: with SZN_WGRAD_STREAM=1 they run on a second HIP stream
+        so that their blocks can fill the CUs left idle by the tail of the concurrent dgrad launch.  Measured on
+        MI355X at B=8: no gain (158.1 vs 158.8 Mpx/s) -- every launch already fills the chip -- so it is off by default.
+        The side stream first waits for everything queued on the current stream (dout is produced there); `tensors`
+        are the operands whose memory must not be recycled before the side stream is done with them."""
+        if self._wg_stream is None:
+            on = os.environ.get("SZN_WGRAD_STREAM", "0") == "1"
+            self._wg_stream = torch.cuda.Stream(device=tensors[0].device) if on else False
+        side = self._wg_stream
+        if side is False:
+            yield
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            yield
+        for t in tensors:
+            t.record_stream(side)
+
+    def _join_wgrad(self):
+        if self._wg_stream:
+            torch.cuda.current_stream().wait_stream(self._wg_stream)
+
+    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None):
+        """dw (OHWI f32) = wgrad of one layer, on the wgrad stream; `after` (e.g. the DDP bucket hook) runs there too"""
         B, Hi, Wi, _ = x.shape
         Ho, Wo = dout.shape[1:3]
         ldo = dout.shape[3] if ldo is None else ldo
         code = L.dtype_code(self.dtype)
         d = L.ConvDesc(code, B, Hi, Wi, ci, Ho, Wo, co, k, k, pad, ci, ldo, 0, 0, 0)
         if k == 3:      # slabs of the all-taps kernel (szn_conv_wgrad_taps.hip): <= 256 blocks x 64*9*64 fp32
-            self._workspace(d, 256 * 64 * 9 * 64 * 4 // 16, x.device)    # (_workspace reserves 16x)
-        st = L.stream_ptr()
-        L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
-        if db is not None:
-            L.call("szn_bias_grad", code, B * Ho * Wo, co, ldo, L.ptr(dout), L.ptr(db), 0, st)
+            nb = 256 * 64 * 9 * 64 * 4
+            if self._wg_ws is None or self._wg_ws.device != x.device:
+                self._wg_ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+            d.workspace, d.workspace_bytes = self._wg_ws.data_ptr(), nb
+        with self._wgrad_stream(x, dout):
+            st = L.stream_ptr()
+            L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
+            if db is not None:
+                L.call("szn_bias_grad", code, B * Ho * Wo, co, ldo, L.ptr(dout), L.ptr(db), 0, st)
+            if after is not None:
+                after()
 
     def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None, colsum=None):
         """din = conv(dout, flipped weights) with the ReLU gate / dropout factor of the producing layer fused; colsum
@@ -288,10 +323,9 @@ class _Engine(object):
         F = m.fc7.out_channels
         if "head" in grads:
             dwh, dbh = grads["head"]
-            self._wgrad(feat, dc, dwh, dbh, F, m.head_width, 1, 0)
-            if head_first is not None:
-                head_first()
+            self._wgrad(feat, dc, dwh, dbh, F, m.head_width, 1, 0, after=head_first)
         if not backbone:
+            self._join_wgrad()
             return
         done = layer_done if layer_done is not None else (lambda name: None)
         s6 = ctx.masks[0] if ctx.masks is not None else None
@@ -303,12 +337,10 @@ class _Engine(object):
                 grads[name][1].zero_()
         # d(fc7 pre-activation): ReLU gate (feat > 0) and dropout factor fused into the dgrad epilogue
         d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7, colsum=grads["fc7"][1])
-        self._wgrad(ctx.relu6, d, grads["fc7"][0], None, F, F, 1, 0)
-        done("fc7")
+        self._wgrad(ctx.relu6, d, grads["fc7"][0], None, F, F, 1, 0, after=lambda: done("fc7"))
         d = self._dgrad(d, "fc7", ctx.relu6.shape, 0, gate=ctx.relu6, scale=s6, colsum=grads["fc6"][1])
         pool5 = ctx.pools[4][1]
-        self._wgrad(pool5, d, grads["fc6"][0], None, pool5.shape[3], F, 7, 0)
-        done("fc6")
+        self._wgrad(pool5, d, grads["fc6"][0], None, pool5.shape[3], F, 7, 0, after=lambda: done("fc6"))
         d = self._dgrad(d, "fc6", pool5.shape, 0)
         pi = 4
         prev_out = None
@@ -330,20 +362,22 @@ class _Engine(object):
                 dw, db = grads[name]
                 nb = L.load().szn_conv1_1_wgrad_workspace_bytes(code, ctx.B, ctx.H, ctx.W, PAD1)
                 ws = torch.empty(nb, dtype=torch.uint8, device=d.device)
-                L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), None, 0,
-                       L.ptr(ws), st)                          # db came from conv1_2's dgrad (colsum)
-                done(name)
+                with self._wgrad_stream(d, ws):
+                    L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), None, 0,
+                           L.ptr(ws), L.stream_ptr())          # db came from conv1_2's dgrad (colsum)
+                    done(name)
                 break
             prev = items[idx - 1]
             xin = ctx.pools[pi][1] if prev == "P" else ctx.acts[prev[0]]
             layer = getattr(m, name)
-            self._wgrad(xin, d, grads[name][0], None, layer.in_channels, layer.out_channels, 3, pad)
-            done(name)
+            self._wgrad(xin, d, grads[name][0], None, layer.in_channels, layer.out_channels, 3, pad,
+                        after=lambda name=name: done(name))
             # next d: wrt this conv's input; gate by the ReLU of the producing conv unless a pool sits in between
             if prev == "P":
                 d = self._dgrad(d, name, xin.shape, pad)
             else:
                 d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1])
+        self._join_wgrad()
 
 
 class _Backbone(torch.autograd.Function):
