@@ -36,6 +36,7 @@ CASES = [
     (2, 8, 8, 512, 128, 7, 0),           # long K (392 chunks bf16), 1 pixel tile: split-K path
     (1, 20, 21, 64, 256, 3, 1),          # 256-cout tiles (szn_conv_wide.hip when SZN_WIDE_MINTILES allows), 2 pixel tiles
     (2, 10, 9, 128, 512, 1, 0),          # 2 cout tiles of 256
+    (1, 260, 260, 64, 300, 1, 0),        # the 300-d projection shape: one 320-wide cout tile (bf16), >= 256 pixel tiles
     (2, 260, 250, 64, 64, 3, 1),         # register-resident filter bank (szn_conv_regw.hip, bf16), ragged edges; wgrad_taps
     (1, 181, 190, 64, 128, 3, 1),        # regw <COG 4, CIG 1>: 8-row tiles
     (1, 190, 181, 128, 64, 3, 1),        # regw <2, 2>: cin halves in partner waves, exchange through LDS

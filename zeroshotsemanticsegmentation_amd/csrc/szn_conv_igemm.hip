@@ -714,7 +714,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     // waves; fc6 dgrad: 68 tiles x 3136 chunks): every split writes its own fp32 slab with plain stores, a second
     // kernel sums the slabs in a fixed order + epilogue.  ns minimises a simple time model: MFMA time / wave
     // efficiency + slab traffic.
-    if (d->workspace && nK >= 256 && !d->colsum) {
+    if (d->workspace && nK >= 64 && !d->colsum) {
         static int ncu = 0;
         if (!ncu) {
             int dev = 0; hipDeviceProp_t p;
@@ -724,7 +724,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
         const double flops = 2.0 * a.M * (double)d->Co * d->Ci * d->KH * d->KW;
         const double slab = (double)a.M * d->Co * 8.0;                  // fp32 write + read per split
         long best = 1; double best_t = 0;
-        for (long ns = 1; ns <= 16 && ns <= nK / 32; ++ns) {
+        for (long ns = 1; ns <= 16 && ns <= nK / 8; ++ns) {
             if (ns > 1 && (size_t)ns * a.M * a.Co * sizeof(float) > d->workspace_bytes) break;
             const long blocks = tiles * ns;
             const double eff = (double)blocks / (double)((blocks + ncu - 1) / ncu * ncu);
@@ -733,7 +733,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
         }
         static int force_ns = -1;                   // tuning knob: SZN_SPLITK_NS=n forces the split count (0 = model)
         if (force_ns < 0) { const char* e = getenv("SZN_SPLITK_NS"); force_ns = e ? atoi(e) : 0; }
-        if (force_ns > 0 && force_ns <= nK / 32 && (size_t)force_ns * a.M * a.Co * sizeof(float) <= d->workspace_bytes) best = force_ns;
+        if (force_ns > 0 && force_ns <= nK / 8 && (size_t)force_ns * a.M * a.Co * sizeof(float) <= d->workspace_bytes) best = force_ns;
         if (best > 1) {
             a.chunks_per_split = (int)((nK + best - 1) / best);
             a.nsplit = szn_div_up(nK, a.chunks_per_split);

@@ -1,4 +1,6 @@
-// szn_conv_wide.hip -- 256 x 256 tile variant of the forward / dgrad implicit GEMM for layers with >= 256 couts.
+// szn_conv_wide.hip -- 256 x 256 (or 256 x 320) tile variant of the forward / dgrad implicit GEMM for layers with >= 256
+// couts; the 320-wide tile (10 weight fragments per wave, 160 accumulator VGPRs) makes the 300-d pixel projection one
+// cout tile with 6 % padding instead of 3 x 128 (22 %).
 //
 // rocprof + ablations (profiles/r01_ablations.txt) show conv_igemm_v2 (256 px x 128 couts) pinned by the LDS-DMA fill
 // rate of a CU (~44 GB/s): 48 KB of operands per 4.2 MFLOP.  A 256 x 256 tile moves 64 KB per 8.4 MFLOP (1.5x less per
@@ -30,14 +32,14 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <typename T>
+template <typename T, int WNF>                    // WNF = 16-cout fragments per wave: 8 -> BN = 256, 10 -> BN = 320
 __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ES = sizeof(T);
     constexpr int BKE = 128 / ES;
-    constexpr int BM = 256, BN = 256, WNF = 8;
-    constexpr int STAGE = (BM + BN) * 128;        // 64 KiB
-    constexpr int LPC = 8;                        // 4 pixel + 4 weight LDS-DMA instructions per wave per chunk
+    constexpr int BM = 256, BN = 32 * WNF;
+    constexpr int NBW = BN / 64;                  // weight LDS-DMA instructions per wave per chunk (4 / 5)
+    constexpr int STAGE = (BM + BN) * 128;        // 64 / 72 KiB
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][pixels 256 x 128 B | weights 256 x 128 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
 
     const int chunkA = (lane & 7) ^ (lane >> 3);
-    unsigned baseA[4], voffA[4], voffB[4];
+    unsigned baseA[4], voffA[4], voffB[NBW];
     int ohw[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -70,7 +72,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
             ohw[i] = 0x7fff7fff;
             baseA[i] = 0;
         }
-        const int n = n0 + 32 * w + 8 * i + (lane >> 3);
+    }
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int n = n0 + (NBW * w + i) * 8 + (lane >> 3);
         voffB[i] = (n < a.Co) ? (unsigned)(((long)n * a.KH * a.KW * a.Ci + chunkA * (16 / ES)) * ES) : kOOBx;
     }
     const int cpt = a.Ci / BKE;
@@ -94,8 +99,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (32 * w + 8 * i) * 128), 16, voffA[i], soffA, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + BM * 128 + (32 * w + 8 * i) * 128), 16, voffB[i],
+        for (int i = 0; i < NBW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + BM * 128 + (NBW * w + i) * 1024), 16, voffB[i],
                                                      soffB, 0, 0);
         if (++ic == cpt) { ic = 0; ++itap; set_tap(); }
     };
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
         __builtin_amdgcn_s_barrier();                             // ... for every wave; everyone left the other stage
         if (kc + 1 < nK) issue(stage ^ 1);
         const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
-        const char* sw = smem + stage * STAGE + BM * 128 + (wn * 128 + r16) * 128;
+        const char* sw = smem + stage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int off = s ? offs1 : offs0;
@@ -144,14 +149,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
 
     // ---- epilogue staged through LDS in four 64-pixel passes (pass = the wm group that owns those pixels) ----
     constexpr int P = BN + 4;                          // tile pitch (floats): 64 x 260 x 4 B = 66,560 B per pass
-    constexpr int CPR = BN / 8;                        // 32 8-cout chunks per row
+    constexpr int CPR = BN / 8;                        // 8-cout chunks per row (32 / 40)
+    constexpr int RG = 512 / CPR;                      // row groups (16 / 12; threads >= RG * CPR idle in the epilogue)
+    constexpr int NIT = (64 + RG - 1) / RG;
     float* tile = (float*)smem;
     const T* __restrict__ gate = (const T*)a.gate;
     const bool out32 = a.out_f32 || sizeof(T) == 4;
     const int oes = out32 ? 4 : 2;
     const bool fast_o = (((long)a.ldo * oes) & 15) == 0;
     const bool fast_g = gate && ((((long)a.ldg * ES) & 15) == 0);
-    const int cc = tid % CPR, row0 = tid / CPR;        // 16 row groups
+    const int cc = tid % CPR, row0 = tid / CPR;
     const int n = n0 + cc * 8;
     const bool full = n + 8 <= a.Co;
     float bv[8], cs[8];
@@ -164,15 +171,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < WNF; ++i)
-                    *(f32x4_t*)(tile + (j * 16 + r16) * P + wn * 128 + i * 16 + g * 4) = acc[i][j];
+                    *(f32x4_t*)(tile + (j * 16 + r16) * P + wn * (BN / 2) + i * 16 + g * 4) = acc[i][j];
         }
         __syncthreads();
-        if (n < a.Co) {
+        if (n < a.Co && row0 < RG) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int row = row0 + k * 16;
+            for (int k = 0; k < NIT; ++k) {
+                const int row = row0 + k * RG;
                 const int m = m0 + pass * 64 + row;
-                if (m < a.M) {
+                if (row < 64 && m < a.M) {
                     const float* tp = tile + row * P + cc * 8;
                     float v[8];
                     *(f32x4_t*)&v[0] = *(const f32x4_t*)tp;
@@ -234,30 +241,30 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
     }
     if (a.colsum) {
         __syncthreads();
-        float* red = (float*)smem;                     // [16 row groups][256]
-        if (n < a.Co) {
+        float* red = (float*)smem;                     // [RG row groups][BN]
+        if (n < a.Co && row0 < RG) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[row0 * BN + cc * 8 + e] = cs[e];
         }
         __syncthreads();
         if (tid < BN && n0 + tid < a.Co) {
             float t = 0.f;
-            for (int r = 0; r < 16; ++r) t += red[r * BN + tid];
+            for (int r = 0; r < RG; ++r) t += red[r * BN + tid];
             if (t != 0.f) atomicAdd(a.colsum + n0 + tid, t);
         }
     }
 #endif
 }
 
-template <typename T>
+template <typename T, int WNF>
 int launch_wide(const WideArgs& a, hipStream_t st) {
-    const size_t lds = 2 * (256 + 256) * 128;
+    const size_t lds = 2 * (256 + 32 * WNF) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_wide<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_wide<T, WNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_wide<T>), dim3(a.mtiles * a.ntiles), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_wide<T, WNF>), dim3(a.mtiles * a.ntiles), dim3(512), lds, st, a);
     SZN_CHECK_LAUNCH("conv_igemm_wide");
     return SZN_OK;
 }
@@ -271,15 +278,19 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     if (d->Co < 256) return 1;
     WideArgs a;
     a.M = d->B * d->Ho * d->Wo;
-    a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(d->Co, 256);
+    // cout tile 256, or 320 (bf16) when that wastes fewer columns: the 300-d projection is one 320-wide tile
+    const int waste256 = szn_div_up(d->Co, 256) * 256 - d->Co, waste320 = szn_div_up(d->Co, 320) * 320 - d->Co;
+    const int bn = (d->dtype == SZN_BF16 && waste320 < waste256) ? 320 : 256;
+    a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(d->Co, bn);
     a.nmajor = 0;
     if ((long)a.mtiles * a.ntiles < min_tiles) return 1;            // too few tiles to fill the chip: keep 256 x 128
-    if ((long)a.ntiles * 256 - d->Co > 64) return 1;                // would waste > 64 columns of the last tile
+    if ((long)a.ntiles * bn - d->Co > 64) return 1;                 // would waste > 64 columns of the last tile
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
     a.out = (char*)out; a.colsum = d->colsum;
     a.in_bytes = in_bytes; a.w_bytes = w_bytes;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
     a.relu = d->relu; a.out_f32 = d->out_f32; a.HoWo = d->Ho * d->Wo;
-    return d->dtype == SZN_BF16 ? launch_wide<bf16_raw>(a, (hipStream_t)stream) : launch_wide<float>(a, (hipStream_t)stream);
+    if (bn == 320) return launch_wide<bf16_raw, 10>(a, (hipStream_t)stream);
+    return d->dtype == SZN_BF16 ? launch_wide<bf16_raw, 8>(a, (hipStream_t)stream) : launch_wide<float, 8>(a, (hipStream_t)stream);
 }
