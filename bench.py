@@ -11,8 +11,9 @@ gradient all-reduce (N > 1) -> Adam step -> confusion histogram.  Workload = BAS
 (The reference has no FCN8s -- SURVEY.md D1 -- so the backbone is its FCN32s.)
 
 Prints ONE JSON line: metric train_Mpixels_per_sec (whole job), plus
-  roofline     -- the dominant kernel (conv_igemm: every conv / fc forward and dgrad launch): algorithmic
-                  FLOPs of its launches / their HIP-event-measured duration, against the dense MFMA peak,
+  roofline     -- the dominant kernel family (every conv / fc forward and dgrad launch behind szn_conv2d_fwd /
+                  szn_conv2d_dgrad: conv_igemm_v2 | conv_igemm_wide | conv3x3_regw): algorithmic FLOPs of its launches
+                  / their HIP-event-measured duration, against the dense MFMA peak,
   cpu_baseline -- the CPU oracle (oracle/, C + OpenMP "port" of the reference algorithm) timed on this
                   host's cores on ONE 512x512 image of the same workload (rank 0, N = 1 only).
 """
@@ -44,7 +45,7 @@ def parse():
 
 
 def conv_flops(d):
-    """algorithmic FLOPs of one conv_igemm launch described by a ConvDesc (forward or dgrad-as-forward)"""
+    """algorithmic FLOPs of one conv launch described by a ConvDesc (forward or dgrad-as-forward)"""
     return 2.0 * d.B * d.Ho * d.Wo * d.Co * d.Ci * d.KH * d.KW
 
 
@@ -113,7 +114,7 @@ def main():
     x = torch.from_numpy(synth.make_images(B, H, H, seed=1337 + rank)).to(dev)
     target = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337 + rank)).to(dev)
 
-    # ---- kernel-level timing of the dominant kernel (conv_igemm) with HIP events on the launch stream ----
+    # ---- kernel-level timing of the dominant kernel family (conv fwd/dgrad) with HIP events on the launch stream ----
     events, flops_per_step = [], [0.0]
     record = [False]
     if not args.no_kernel_events:
@@ -178,7 +179,7 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("per_gpu_batch") == B and tj.get("precision") == args.precision and H == 512 and E == 300:
                     traffic = round(tj["hbm_bytes_per_launch"])
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm (all conv/fc fwd + dgrad launches)",
+            out["roofline"] = {"bound": "mfma", "kernel": "conv fwd + dgrad launches (conv_igemm_v2 | conv_igemm_wide | conv3x3_regw)",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "launches_per_step": len(events) // args.steps,
                                "avg_launch_ms": round(ms / len(events), 4),

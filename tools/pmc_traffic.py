@@ -8,16 +8,21 @@ import json
 import sys
 
 csv.field_size_limit(1 << 30)
-MATCH = ("conv_igemm", "conv3x3_halo")
+MATCH = ("conv_igemm", "conv3x3_regw")     # one kernel launch per szn_conv2d_fwd / szn_conv2d_dgrad call
+EXTRA = ("splitk_epilogue",)               # second kernel of a split-K call: its bytes count, its launch does not
 
 
 def collect(d, counter):
     tot, n = 0.0, 0
     with open(d.rstrip('/') + '/pmc_counter_collection.csv') as f:
         for row in csv.DictReader(f):
-            if row['Counter_Name'] == counter and any(m in row['Kernel_Name'] for m in MATCH):
+            if row['Counter_Name'] != counter:
+                continue
+            if any(m in row['Kernel_Name'] for m in MATCH):
                 tot += float(row['Counter_Value'])
                 n += 1
+            elif any(m in row['Kernel_Name'] for m in EXTRA):
+                tot += float(row['Counter_Value'])
     return tot, n
 
 
@@ -28,7 +33,7 @@ def main():
     f, nf = collect(fd, "FETCH_SIZE")
     w, nw = collect(wd, "WRITE_SIZE")
     per = (2.0 * f * 1024.0 / nf) + (w * 1024.0 / nw)
-    json.dump({"kernel": "conv_igemm (all conv/fc fwd + dgrad launches)", "per_gpu_batch": batch, "precision": prec,
+    json.dump({"kernel": "conv fwd + dgrad launches (conv_igemm_v2 / conv_igemm_wide / conv3x3_regw)", "per_gpu_batch": batch, "precision": prec,
                "launches_sampled": nf, "fetch_kb_per_launch": f / nf, "write_kb_per_launch": w / nw,
                "hbm_bytes_per_launch": per,
                "note": "FETCH_SIZE x2 (gfx950 wide-read under-count) + WRITE_SIZE, KB -> bytes; separate --pmc passes"},

@@ -11,9 +11,13 @@
 //   * the LDS image is [row][128 B] with the 16-B chunk index XOR-swizzled by (row & 7): LDS-DMA writes are
 //     lane-linear, so the swizzle is applied to the per-lane SOURCE address (lane -> chunk = pos ^ (row & 7));
 //   * 3-stage LDS ring, loads run two chunks ahead with counted s_waitcnt vmcnt(N) and one raw s_barrier per chunk;
-//   * optional split-K (few output tiles, long K: fc6 dgrad/fwd, fc7): fp32 atomics into a caller workspace and a
-//     second small kernel for the epilogue.
-// Same arithmetic and epilogue as conv_igemm (szn_conv.hip), which remains the fallback for tensors >= 4 GiB.
+//   * epilogue staged through LDS so that every store covers whole output rows in 16-B pieces (bias / ReLU / gate /
+//     dropout factor / optional column sums = bias gradient of the producer layer);
+//   * optional deterministic split-K (long K and a tile count that quantises badly against the CU count: fc6 forward /
+//     dgrad, the projection head): every split writes an fp32 slab of the caller's workspace, splitk_epilogue adds the
+//     slabs in a fixed order and applies the epilogue.
+// The dispatcher tries the specialised kernels first (szn_conv_regw.hip: 64/128-channel 3x3 layers; szn_conv_wide.hip:
+// >= 256 couts) and falls back to the register-staged kernel of szn_conv.hip for tensors >= 2 GiB / odd strides.
 #include "szn_common.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -27,8 +31,6 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
                       szn_stream_t stream);
 int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                      const float* chan_scale, void* out, int min_tiles, szn_stream_t stream);
-int szn_conv3x3_halo_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
-                         const float* chan_scale, void* out, szn_stream_t stream);
 #include <stdlib.h>
 
 namespace {
@@ -394,216 +396,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// conv_igemm_p: persistent variant of conv_igemm_v2 for layers with FEW K chunks per tile (conv1_2 .. conv3_x: 9-36
-// chunks).  One 8-wave block per CU walks tiles round-robin (tile = blockIdx + round * gridDim, so the blocks resident
-// at any time cover a compact window of the image and share halo rows / weights through L2) and keeps the LDS-DMA
-// stream two chunks ahead ACROSS tile boundaries: the epilogue and address set-up of one tile overlap the first loads
-// of the next instead of exposing a pipeline fill per tile.  All issue-side state is wave-uniform and is forced into
-// SGPRs with readfirstlane (otherwise hipcc wraps every LDS-DMA in a waterfall loop).
-template <typename T, int WNF>
-__global__ __launch_bounds__(512, 2) void conv_igemm_p(Conv2Args a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int ES = sizeof(T);
-    constexpr int BKE = 128 / ES;
-    constexpr int BM = 256, BN = 32 * WNF;
-    constexpr int STAGE = (BM + BN) * 128;
-    constexpr int NB = BN / 64;
-    constexpr int LPC = 4 + NB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-#define SZN_U(x) __builtin_amdgcn_readfirstlane(x)
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = SZN_U(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
-    const int g = lane >> 4, r16 = lane & 15;
-    const int nwg = a.mtiles * a.ntiles;
-    const int G = (int)gridDim.x;
-    const int first = xcd_remap2(blockIdx.x, G);            // position inside a round; consecutive positions share an XCD
-    if (first >= nwg) return;
-
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
-    const int cpt = a.Ci / BKE;
-    const int totalK = a.KH * a.KW * cpt;                    // chunks per tile (no split-K in this kernel)
-    const int chunkA = (lane & 7) ^ (lane >> 3);
-
-    // ---- issue side ----
-    unsigned baseA[4];
-    int ohw[4];
-    unsigned voffA[4], voffB[NB];
-    int it_tile = first, it_left = totalK, itap = 0, ic = 0;   // wave-uniform
-    auto set_tap = [&](int tap) {
-        const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        const unsigned tapoff = (unsigned)((kh * a.Wi + kw) * a.ldi * ES);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ih = (ohw[i] >> 16) + kh, iw = (int)(short)(ohw[i] & 0xffff) + kw;
-            const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-            voffA[i] = ok ? baseA[i] + tapoff : kOOB;
-        }
-    };
-    auto load_tile = [&](int lid) {
-        const int m0 = (lid / a.ntiles) * BM, n0 = (lid % a.ntiles) * BN;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 32 * w + 8 * i + (lane >> 3);
-            if (m < a.M) {
-                const int b = m / a.HoWo, r = m - b * a.HoWo;
-                const int oh = r / a.Wo, ow = r - oh * a.Wo;
-                const int ih0 = oh - a.pad, iw0 = ow - a.pad;
-                ohw[i] = (ih0 << 16) | (iw0 & 0xffff);
-                const long px = ((long)(b * a.Hi + ih0) * a.Wi + iw0);
-                baseA[i] = (unsigned)((px * a.ldi + chunkA * (16 / ES)) * ES);
-            } else {
-                ohw[i] = 0x7fff7fff;
-                baseA[i] = 0;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int n = n0 + (BN / 8) * w + 8 * i + (lane >> 3);
-            voffB[i] = (n < a.Co) ? (unsigned)(((long)n * a.KH * a.KW * a.Ci + chunkA * (16 / ES)) * ES) : kOOB;
-        }
-        set_tap(0);
-    };
-    auto issue = [&](int stage) {
-        char* sb = smem + SZN_U(stage) * STAGE;
-        const int icu = SZN_U(ic), tapu = SZN_U(itap);
-        const int soffA = icu * 128;
-        const int soffB = (tapu * a.Ci) * ES + icu * 128;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (32 * w + 8 * i) * 128), 16, voffA[i], soffA, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + BM * 128 + ((BN / 8) * w + 8 * i) * 128), 16, voffB[i],
-                                                     soffB, 0, 0);
-        it_left = SZN_U(it_left - 1);
-        if (it_left == 0) {                                   // next tile of this block (uniform branch)
-            it_tile = SZN_U(it_tile + G);
-            it_left = totalK; itap = 0; ic = 0;
-            if (it_tile < nwg) load_tile(it_tile);
-        } else {
-            ic = SZN_U(icu + 1);
-            if (ic == cpt) { ic = 0; itap = SZN_U(tapu + 1); set_tap(itap); }
-        }
-    };
-
-    f32x4_t acc[WNF][4];
-#pragma unroll
-    for (int i = 0; i < WNF; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    load_tile(first);
-    int inflight = 0;
-    issue(0); ++inflight;                                     // first < nwg here
-    if (SZN_U(it_tile) < nwg) { issue(1); ++inflight; }
-    const int offs0 = ((g ^ (r16 & 7)) << 4), offs1 = (((4 + g) ^ (r16 & 7)) << 4);
-    const T* __restrict__ gate = (const T*)a.gate;
-    const bool vec_ok = ((a.ldo & 3) == 0) && (!a.gate || (a.ldg & 3) == 0);
-    int stage = 0;
-    for (int lid = first; lid < nwg; lid += G) {
-        const int m0 = (lid / a.ntiles) * BM, n0 = (lid % a.ntiles) * BN;
-        for (int kc = 0; kc < totalK; ++kc) {
-            // the first chunk of a tile also drains the previous tile's epilogue traffic (stores count in vmcnt)
-            if (kc > 0 && SZN_U(inflight) >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPC) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (SZN_U(it_tile) < nwg) { issue(stage >= 1 ? stage - 1 : 2); ++inflight; }
-            const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
-            const char* sw = smem + stage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int off = s ? offs1 : offs0;
-                u32x4_t wf[WNF], pf[4];
-#pragma unroll
-                for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + off);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pf[j] = *(const u32x4_t*)(sp + j * 16 * 128 + off);
-#pragma unroll
-                for (int i = 0; i < WNF; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Mma2<T>::run(acc[i][j], wf[i], pf[j]);
-            }
-            --inflight;
-            if (++stage == 3) stage = 0;
-        }
-        // ---- epilogue of this tile (the next tile's first two chunks are already in flight) ----
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + r16;
-            if (m < a.M) {
-                const int b = a.cscale ? (m / a.HoWo) : 0;
-#pragma unroll
-                for (int i = 0; i < WNF; ++i) {
-                    const int nb = n0 + wn * (BN / 2) + i * 16 + g * 4;
-                    if (nb >= a.Co) continue;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int n = nb + e;
-                        float x = acc[i][j][e];
-                        if (n < a.Co) {
-                            if (a.bias) x += a.bias[n];
-                            if (a.relu) x = fmaxf(x, 0.f);
-                            if (gate) x = (elem<T>::ld(gate + (long)m * a.ldg + n) > 0.f) ? x : 0.f;
-                            if (a.cscale) x *= a.cscale[(long)b * a.Co + n];
-                        }
-                        v[e] = x;
-                    }
-                    if (a.out_f32 || sizeof(T) == 4) {
-                        float* o = (float*)a.out + (long)m * a.ldo + nb;
-                        if (vec_ok && nb + 3 < a.Co) {
-                            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (nb + e < a.Co) o[e] = v[e];
-                        }
-                    } else {
-                        uint16_t* o = (uint16_t*)a.out + (long)m * a.ldo + nb;
-                        if (vec_ok && nb + 3 < a.Co) {
-                            u32x2_t pk;
-                            pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-                            pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-                            *(u32x2_t*)o = pk;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (nb + e < a.Co) o[e] = f32_to_bf16_bits(v[e]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < WNF; ++i) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-#undef SZN_U
-#endif
-}
-
-template <typename T, int WNF>
-int launch_p(const Conv2Args& a, hipStream_t st) {
-    constexpr int BN = 32 * WNF;
-    const size_t lds = 3 * (256 + BN) * 128;
-    static bool attr_done = false;
-    static int ncu = 0;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_p<T, WNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        attr_done = true;
-    }
-    const int nwg = a.mtiles * a.ntiles;
-    const int grid = nwg < ncu ? nwg : ncu;
-    hipLaunchKernelGGL((conv_igemm_p<T, WNF>), dim3(grid), dim3(512), lds, st, a);
-    SZN_CHECK_LAUNCH("conv_igemm_p");
-    return SZN_OK;
-}
-
-// epilogue of the split-K path: out = epi(ws + bias)
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__ ws, Conv2Args a) {
     const long total = (long)a.M * a.Co;
@@ -674,27 +466,6 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
         (long)d->B * d->Ho * d->Wo >= (1L << 31))
         return szn_conv2d_fwd_v1(d, in, w, bias, gate, chan_scale, out, stream);   // reports the precise error
     hipStream_t st = (hipStream_t)stream;
-    // 3x3 layers on large feature maps: LDS-resident input patch (szn_conv_halo.hip); SZN_HALO_MIN overrides the
-    // smallest output side for which it is used (0 = always, huge = never)
-    // 64/128 -> 64/128 channel 3x3 layers (conv1_2, conv2_x forward / dgrad): register-resident filter bank,
-    // szn_conv_regw.hip; SZN_REGW_MINTILES = fewest 256-pixel tiles for which it is used
-    if (d->KH == 3 && d->KW == 3 && d->Ci <= 128 && d->Co <= 128) {
-        static int regw_min = -1;
-        if (regw_min < 0) { const char* e = getenv("SZN_REGW_MINTILES"); regw_min = e ? atoi(e) : 128; }
-        const int rc = szn_conv_regw_try(d, in, w, bias, gate, chan_scale, out, regw_min, stream);
-        if (rc <= 0) return rc;
-    }
-    if (d->KH == 3 && d->KW == 3 && !d->colsum) {
-        static int halo_min = -1;
-        if (halo_min < 0) {
-            const char* e = getenv("SZN_HALO_MIN");
-            halo_min = e ? atoi(e) : (1 << 30);      // measured slower than conv_igemm_v2 on every layer: off by default
-        }
-        if (d->Ho >= halo_min && d->Wo >= halo_min) {
-            const int rc = szn_conv3x3_halo_try(d, in, w, bias, gate, chan_scale, out, stream);
-            if (rc <= 0) return rc;
-        }
-    }
     Conv2Args a;
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
     a.out = (char*)out; a.ws = nullptr; a.colsum = d->colsum;
@@ -747,17 +518,6 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
         if (wide_min < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min = e ? atoi(e) : 256; }
         rc = szn_conv_wide_try(d, in, w, bias, gate, chan_scale, out, a.in_bytes, a.w_bytes, wide_min, stream);
         if (rc <= 0) return rc;
-    }
-    // persistent cross-tile pipelining pays when a tile has few K chunks and there are many tiles per CU
-    static int persist_max = -1;
-    if (persist_max < 0) { const char* e = getenv("SZN_PERSIST_MAXK"); persist_max = e ? atoi(e) : 0; }   // +3 % only: off
-    static int persist_min_tiles = -1;
-    if (persist_min_tiles < 0) { const char* e = getenv("SZN_PERSIST_MINTILES"); persist_min_tiles = e ? atoi(e) : 1024; }
-    const bool persist = a.nsplit == 1 && nK <= persist_max && tiles >= persist_min_tiles && !d->colsum;
-    if (persist) {
-        if (d->dtype == SZN_BF16) rc = narrow ? launch_p<bf16_raw, 2>(a, st) : launch_p<bf16_raw, 4>(a, st);
-        else rc = narrow ? launch_p<float, 2>(a, st) : launch_p<float, 4>(a, st);
-        return rc;
     }
     if (d->dtype == SZN_BF16) rc = narrow ? launch_v2<bf16_raw, 2>(a, st) : launch_v2<bf16_raw, 4>(a, st);
     else rc = narrow ? launch_v2<float, 2>(a, st) : launch_v2<float, 4>(a, st);
