@@ -466,6 +466,14 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
         (long)d->B * d->Ho * d->Wo >= (1L << 31))
         return szn_conv2d_fwd_v1(d, in, w, bias, gate, chan_scale, out, stream);   // reports the precise error
     hipStream_t st = (hipStream_t)stream;
+    // 64/128 -> 64/128 channel 3x3 layers (conv1_2, conv2_x forward / dgrad): register-resident filter bank,
+    // szn_conv_regw.hip; SZN_REGW_MINTILES = fewest 256-pixel tiles for which it is used
+    if (d->KH == 3 && d->KW == 3 && d->Ci <= 128 && d->Co <= 128) {
+        static int regw_min = -1;
+        if (regw_min < 0) { const char* e = getenv("SZN_REGW_MINTILES"); regw_min = e ? atoi(e) : 128; }
+        const int rc = szn_conv_regw_try(d, in, w, bias, gate, chan_scale, out, regw_min, stream);
+        if (rc <= 0) return rc;
+    }
     Conv2Args a;
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
     a.out = (char*)out; a.ws = nullptr; a.colsum = d->colsum;
