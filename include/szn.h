@@ -31,6 +31,10 @@ enum { SZN_F32 = 0, SZN_BF16 = 1 };
 
 /* ---- library -------------------------------------------------------------------------------- */
 const char* szn_last_error(void);
+/* Name of the kernel most recently launched by this thread's last call (e.g. "conv3x3_regw", "conv_igemm_wide",
+ * "wgrad_taps_reduce"): which specialised path the dispatcher took.  Test / profiling aid -- the parity tests assert it
+ * so that a specialised kernel cannot silently fall back to the generic one. */
+const char* szn_last_kernel(void);
 int szn_version(void); /* major*10000 + minor*100 + patch */
 typedef struct {
     char name[128];

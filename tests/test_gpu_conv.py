@@ -44,6 +44,18 @@ CASES = [
 ]
 
 
+# which kernel the dispatcher must pick in bf16 (forward, dgrad, wgrad) for the cases that exist to cover a specialised
+# path: a silent fallback to the generic kernel would still be numerically right, so it is asserted by name
+EXPECT_BF16 = {
+    (2, 260, 250, 64, 64, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
+    (1, 181, 190, 64, 128, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
+    (1, 190, 181, 128, 64, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
+    (1, 183, 187, 128, 128, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
+    (1, 260, 260, 64, 300, 1, 0): ("conv_igemm_wide", None, None),
+    (2, 8, 8, 512, 128, 7, 0): ("splitk_epilogue", None, None),
+}
+
+
 def conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad, relu=0, out_f32=0, ldg=0):
     Ho, Wo = Hi + 2 * pad - K + 1, Wi + 2 * pad - K + 1
     ldo = (Co + 7) // 8 * 8          # padded pixel stride of the output (e.g. 302 -> 304)
@@ -77,6 +89,9 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     bd = bias.to(dev)
     out = torch.full((B, Ho, Wo, d.ldo), float("nan"), device=dev, dtype=dtype)
     L.call("szn_conv2d_fwd", C.byref(d), L.ptr(xd), L.ptr(wd), L.ptr(bd), None, None, L.ptr(out), L.stream_ptr())
+    expect = EXPECT_BF16.get(case, (None, None, None)) if dtype == torch.bfloat16 else (None, None, None)
+    if expect[0]:
+        assert L.last_kernel() == expect[0], ("fwd kernel", L.last_kernel())
     torch.cuda.synchronize()
     got = out[..., :Co].float().cpu().permute(0, 3, 1, 2)
     tol = 1e-5 if dtype == torch.float32 else 1e-2
@@ -102,6 +117,8 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     din = torch.full((B, Hi, Wi, Ci), float("nan"), device=dev, dtype=dtype)
     if Co % (64 if dtype == torch.bfloat16 else 32) == 0:
         L.call("szn_conv2d_dgrad", C.byref(dgd), L.ptr(doutd), L.ptr(wT), L.ptr(xd), None, L.ptr(din), L.stream_ptr())
+        if expect[1]:
+            assert L.last_kernel() == expect[1], ("dgrad kernel", L.last_kernel())
         torch.cuda.synchronize()
         got = din.float().cpu().permute(0, 3, 1, 2)
         assert relerr(got, dx_ref) < tol, ("dgrad", relerr(got, dx_ref))
@@ -118,6 +135,8 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     dw = torch.full((Co, K, K, Ci), float("nan"), device=dev)
     db = torch.full((Co,), float("nan"), device=dev)
     L.call("szn_conv2d_wgrad", C.byref(dgd), L.ptr(xd), L.ptr(doutd), L.ptr(dw), 0, L.stream_ptr())
+    if expect[2]:
+        assert L.last_kernel() == expect[2], ("wgrad kernel", L.last_kernel())
     L.call("szn_bias_grad", dt, B * Ho * Wo, Co, d.ldo, L.ptr(doutd), L.ptr(db), 0, L.stream_ptr())
     torch.cuda.synchronize()
     got = dw.cpu().permute(0, 3, 1, 2)

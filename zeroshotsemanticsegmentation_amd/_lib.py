@@ -36,6 +36,7 @@ _D = C.POINTER(ConvDesc)
 # name -> (restype, argtypes); must list every symbol of include/szn.h (tests/test_abi.py checks that)
 SIGNATURES = {
     "szn_last_error": (C.c_char_p, []),
+    "szn_last_kernel": (C.c_char_p, []),
     "szn_version": (_I, []),
     "szn_device_info": (_I, [_I, C.POINTER(DeviceInfo)]),
     "szn_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
@@ -96,6 +97,11 @@ def load():
 def check(rc, what):
     if rc != 0:
         raise SznError("%s failed (%d): %s" % (what, rc, load().szn_last_error().decode()))
+
+
+def last_kernel():
+    """name of the kernel the library launched last on this thread (which specialised path the dispatcher took)"""
+    return load().szn_last_kernel().decode()
 
 
 def stream_ptr():

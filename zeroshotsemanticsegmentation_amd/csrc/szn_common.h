@@ -17,7 +17,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // ---- error plumbing -------------------------------------------------------------------------
 void szn_set_error(const char* fmt, ...);
 #define SZN_FAIL(code, ...) do { szn_set_error(__VA_ARGS__); return (code); } while (0)
-#define SZN_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); \
+void szn_note_kernel(const char* name);          /* thread-local: the kernel the dispatcher picked (szn_last_kernel) */
+#define SZN_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); szn_note_kernel(name); \
     if (e__ != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); } while (0)
 
 // ---- element type traits --------------------------------------------------------------------
