@@ -36,6 +36,8 @@ CASES = [
     (2, 8, 8, 512, 128, 7, 0),           # long K (392 chunks bf16), 1 pixel tile: split-K path
     (1, 20, 21, 64, 256, 3, 1),          # 256-cout tiles (szn_conv_wide.hip when SZN_WIDE_MINTILES allows), 2 pixel tiles
     (2, 10, 9, 128, 512, 1, 0),          # 2 cout tiles of 256
+    (1, 9, 9, 256, 512, 7, 0),           # wgrad: 256 x 256 tiles (szn_conv_wgrad_wide.hip), 98 tiles, one K step
+    (2, 7, 6, 448, 512, 5, 1),           # wgrad wide with a ragged cin tile (448 = 256 + 192) and padding taps
     (1, 260, 260, 64, 300, 1, 0),        # the 300-d projection shape: one 320-wide cout tile (bf16), >= 256 pixel tiles
     (2, 260, 250, 64, 64, 3, 1),         # register-resident filter bank (szn_conv_regw.hip, bf16), ragged edges; wgrad_taps
     (1, 181, 190, 64, 128, 3, 1),        # regw <COG 4, CIG 1>: 8-row tiles
@@ -52,6 +54,8 @@ EXPECT_BF16 = {
     (1, 190, 181, 128, 64, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
     (1, 183, 187, 128, 128, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
     (1, 260, 260, 64, 300, 1, 0): ("conv_igemm_wide", None, None),
+    (1, 9, 9, 256, 512, 7, 0): (None, None, "conv_wgrad_wide"),
+    (2, 7, 6, 448, 512, 5, 1): (None, None, "conv_wgrad_wide"),
     (2, 8, 8, 512, 128, 7, 0): ("splitk_epilogue", None, None),
 }
 

@@ -25,6 +25,9 @@ int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* do
 int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                             int min_tiles_per_block, szn_stream_t stream);
 
+int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
+                            int min_tiles, szn_stream_t stream);
+
 namespace {
 
 struct Wg2Args {
@@ -275,6 +278,13 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
         static int taps_min = -1;
         if (taps_min < 0) { const char* e = getenv("SZN_WGT_MINTILES"); taps_min = e ? atoi(e) : 8; }
         const int rc = szn_conv_wgrad_taps_try(d, in, dout, dw, accumulate, taps_min, stream);
+        if (rc <= 0) return rc;
+    }
+    // many channels, few pixels (fc6, fc7): 256 x 256 tiles, one pixel split (szn_conv_wgrad_wide.hip)
+    {
+        static int wide_min = -1;
+        if (wide_min < 0) { const char* e = getenv("SZN_WGW_MINTILES"); wide_min = e ? atoi(e) : 96; }
+        const int rc = szn_conv_wgrad_wide_try(d, in, dout, dw, accumulate, wide_min, stream);
         if (rc <= 0) return rc;
     }
     const long nw = (long)d->Co * d->KH * d->KW * d->Ci;

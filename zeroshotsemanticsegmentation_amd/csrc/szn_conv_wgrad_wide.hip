@@ -1,0 +1,208 @@
+// szn_conv_wgrad_wide.hip -- 256 x 256 tile weight-gradient kernel (bf16) for the layers with many channels and few
+// pixels: fc6 (4096 x 49 x 512, 2312 pixels at B = 8) and fc7 (4096 x 4096).
+//
+// conv_wgrad_v2 (128 x 128 tile, 4 waves) stages 256 B of operands per MFMA and sits at 460-640 TFLOP/s on these
+// layers.  Here: 512 threads = 8 waves (2 x 4), wave = 128 couts x 64 cins (8 x 4 accumulator fragments = 128 VGPRs),
+// K step = 64 pixels (two MFMA K blocks) per barrier = 64 MFMA per wave per barrier and 128 B of LDS fill per MFMA.
+//   * per filter tap a GEMM D[co][ci] = A^T B, A = dout [pixel][256 co], B = shifted input [pixel][256 ci]; both
+//     staged pixel-major ([64 px][512 B]) by LDS-DMA into a 2-stage ring, fragments by ds_read_b64_tr_b16;
+//   * 16-B chunk index XOR-swizzled by (row & 7) << 1 on the DMA source side (8 consecutive 512-B rows of a transpose
+//     read land in 8 distinct 32-B bank groups);
+//   * out-of-image taps / tile edges / the pixel tail are out-of-range buffer offsets (zeros); pixel coordinates advance
+//     incrementally;
+//   * one pixel split: a tile is written once (plain stores, or read-add-write when accumulating) through an LDS-staged
+//     epilogue in four 64-row passes -- deterministic, no atomics, no memset.
+#include "szn_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((address_space(3))) void* ldsptr_t;
+
+namespace {
+
+struct WgwArgs {
+    const char* dout; const char* in; float* dw;
+    unsigned dout_bytes, in_bytes;
+    int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
+    int ldi, ldd;
+    int M;
+    int cotiles, citiles;
+    int accumulate;
+};
+
+constexpr unsigned kOOBg = 0x80000000u;
+constexpr int KPg = 64;                              // pixels per stage
+constexpr int STAGEg = KPg * 1024;                   // A rows 512 B + B rows 512 B
+constexpr int LDS_WGW = 2 * STAGEg;                  // 128 KiB
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;               // wave -> couts 128 wm .. + 127, cins 64 wn .. + 63
+    const int g = lane >> 4, r16 = lane & 15;
+
+    int bid = blockIdx.x;
+    const int cit = bid % a.citiles; bid /= a.citiles;
+    const int cot = bid % a.cotiles; const int tap = bid / a.cotiles;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int co0 = cot * 256, ci0 = cit * 256;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, (int)a.dout_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+
+    // ---- LDS-DMA slots: instruction i (0..3) of wave w = piece 4 w + i = image rows 2 piece, 2 piece + 1 (512 B each);
+    //      lane -> row 2 piece + (lane >> 5), 16-B slot lane & 31; source chunk = slot ^ ((row & 7) << 1) ----
+    const int hrow = lane >> 5, slot = lane & 31;
+    int mA[4]; unsigned chA[4];
+    int mB[4], ohB[4], owB[4], bB[4]; unsigned chB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 2 * (4 * w + i) + hrow;
+        const int chunk = slot ^ (((2 * i + hrow) & 7) << 1);            // (row & 7) == (2 i + hrow) & 7
+        const int co = co0 + chunk * 8, ci = ci0 + chunk * 8;
+        mA[i] = row;
+        chA[i] = (co < a.Co && co + 8 <= a.ldd) ? (unsigned)(co * 2) : kOOBg;
+        mB[i] = row;
+        const int b = row / (a.Ho * a.Wo), r = row - b * (a.Ho * a.Wo);
+        bB[i] = b; ohB[i] = r / a.Wo; owB[i] = r - ohB[i] * a.Wo;
+        chB[i] = (ci < a.Ci) ? (unsigned)(ci * 2) : kOOBg;
+    }
+    auto issue = [&](int stage) {
+        char* sb = smem + stage * STAGEg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned v = (mA[i] < a.M && chA[i] != kOOBg) ? (unsigned)mA[i] * (unsigned)(a.ldd * 2) + chA[i] : kOOBg;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (4 * w + i) * 1024), 16, v, 0, 0, 0);
+            mA[i] += KPg;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ih = ohB[i] + kh - a.pad, iw = owB[i] + kw - a.pad;
+            const bool ok = mB[i] < a.M && chB[i] != kOOBg && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+            const unsigned v = ok ? (unsigned)((bB[i] * a.Hi + ih) * a.Wi + iw) * (unsigned)(a.ldi * 2) + chB[i] : kOOBg;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + KPg * 512 + (4 * w + i) * 1024), 16, v, 0, 0, 0);
+            mB[i] += KPg; owB[i] += KPg;
+            while (owB[i] >= a.Wo) { owB[i] -= a.Wo; if (++ohB[i] >= a.Ho) { ohB[i] = 0; ++bB[i]; } }
+        }
+    };
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane transpose-read offsets: this lane supplies row kk (of a 16-row block) and 8 B = 4 channels
+    const int kk = g * 4 + (r16 >> 2);
+    const int sub = (r16 & 3) * 8;
+    const int sw = (kk & 7) << 1;                    // same for kk + 16, + 32, + 48
+    int offA[8], offB[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) offA[i] = kk * 512 + (((wm * 16 + i * 2) ^ sw) << 4) + sub;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offB[j] = KPg * 512 + kk * 512 + (((wn * 8 + j * 2) ^ sw) << 4) + sub;
+
+    const int nK = (a.M + KPg - 1) / KPg;
+    issue(0);
+    int stage = 0;
+    for (int kc = 0; kc < nK; ++kc) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kc + 1 < nK) issue(stage ^ 1);
+        const char* sb = smem + stage * STAGEg;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                 // two 32-pixel MFMA K blocks per stage
+            u32x4_t df[8], xf[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + h * 32 * 512 + offA[i]));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + h * 32 * 512 + 16 * 512 + offA[i]));
+                const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+                df[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + h * 32 * 512 + offB[j]));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + h * 32 * 512 + 16 * 512 + offB[j]));
+                const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+                xf[j] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, df[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage ^= 1;
+    }
+
+    // ---- epilogue: D[co][ci] (lane: rows co = 4 g + e, column ci = r16) staged through LDS in four 64-row passes so that
+    //      every store instruction covers whole 1-KiB rows of the OHWI gradient ----
+    constexpr int PT = 256 + 4;
+    float* tile = (float*)smem;                       // 64 x 260 x 4 B = 66,560 B
+    for (int pass = 0; pass < 4; ++pass) {
+        __syncthreads();
+        if (wm == (pass >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        tile[(ii * 16 + g * 4 + e) * PT + wn * 64 + j * 16 + r16] = acc[(pass & 1) * 4 + ii][j][e];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 64 * 64; idx += 512) {              // 64 rows x 64 float4
+            const int r = idx >> 6, c4 = (idx & 63) * 4;
+            const int co = co0 + pass * 64 + r, ci = ci0 + c4;
+            if (co < a.Co && ci < a.Ci) {
+                float* dst = a.dw + ((long)(co * a.KH + kh) * a.KW + kw) * a.Ci + ci;
+                f32x4_t v = *(const f32x4_t*)(tile + r * PT + c4);
+                if (ci + 4 <= a.Ci && ((((uintptr_t)dst) & 15) == 0)) {
+                    if (a.accumulate) { const f32x4_t o = *(const f32x4_t*)dst; v += o; }
+                    *(f32x4_t*)dst = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (ci + e < a.Ci) dst[e] = a.accumulate ? dst[e] + v[e] : v[e];
+                }
+            }
+        }
+    }
+#endif
+}
+
+}  // namespace
+
+// Called by szn_conv2d_wgrad after validation.  Returns 1 if the layer does not fit this kernel.
+int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
+                            int min_tiles, szn_stream_t stream) {
+    if (d->dtype != SZN_BF16 || d->Co < 256 || d->Ci < 256 || (d->ldi & 7) || (d->ldo & 7) || (d->Ci & 7)) return 1;
+    WgwArgs a;
+    a.cotiles = szn_div_up(d->Co, 256); a.citiles = szn_div_up(d->Ci, 256);
+    const long tiles = (long)a.cotiles * a.citiles * d->KH * d->KW;
+    if (tiles < min_tiles || tiles >= (1L << 31)) return 1;
+    // padding waste of the last tiles must stay small
+    if ((long)a.cotiles * 256 * a.citiles * 256 > (long)d->Co * d->Ci * 5 / 4) return 1;
+    a.dout = (const char*)dout; a.in = (const char*)in; a.dw = dw;
+    a.dout_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->ldo * 2);
+    a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->ldi * 2);
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldd = d->ldo;
+    a.M = d->B * d->Ho * d->Wo;
+    a.accumulate = accumulate;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_wide, dim3((unsigned)tiles), dim3(512), LDS_WGW, (hipStream_t)stream, a);
+    SZN_CHECK_LAUNCH("conv_wgrad_wide");
+    return SZN_OK;
+}
