@@ -3,9 +3,11 @@
 //
 // conv_wgrad_v2 (128 x 128 tile, 4 waves) stages 256 B of operands per MFMA and sits at 460-640 TFLOP/s on these
 // layers.  Here: 512 threads = 8 waves (2 x 4), wave = 128 couts x 64 cins (8 x 4 accumulator fragments = 128 VGPRs),
-// K step = 64 pixels (two MFMA K blocks) per barrier = 64 MFMA per wave per barrier and 128 B of LDS fill per MFMA.
+// K step = 32 pixels per barrier, 128 B of LDS fill per MFMA.  dout / input slices are used by few blocks, so most of
+// the fill misses L2 and sees HBM / MALL latency (~3 us measured): the fill rate is (bytes in flight) / latency, hence a
+// 4-stage ring of 32-KiB stages with THREE stages in flight (96 KiB) rather than two 64-KiB stages with one in flight.
 //   * per filter tap a GEMM D[co][ci] = A^T B, A = dout [pixel][256 co], B = shifted input [pixel][256 ci]; both
-//     staged pixel-major ([64 px][512 B]) by LDS-DMA into a 2-stage ring, fragments by ds_read_b64_tr_b16;
+//     staged pixel-major ([32 px][512 B]) by LDS-DMA into a 4-stage ring (counted vmcnt), fragments by ds_read_b64_tr_b16;
 //   * 16-B chunk index XOR-swizzled by (row & 7) << 1 on the DMA source side (8 consecutive 512-B rows of a transpose
 //     read land in 8 distinct 32-B bank groups);
 //   * out-of-image taps / tile edges / the pixel tail are out-of-range buffer offsets (zeros); pixel coordinates advance
@@ -29,12 +31,14 @@ struct WgwArgs {
     int M;
     int cotiles, citiles;
     int accumulate;
+    int ablate;                // debug (env SZN_WGW_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no reads / MFMA
 };
 
 constexpr unsigned kOOBg = 0x80000000u;
-constexpr int KPg = 64;                              // pixels per stage
+constexpr int KPg = 32;                              // pixels per stage
 constexpr int STAGEg = KPg * 1024;                   // A rows 512 B + B rows 512 B
-constexpr int LDS_WGW = 2 * STAGEg;                  // 128 KiB
+constexpr int NSTg = 4;
+constexpr int LDS_WGW = NSTg * STAGEg;               // 128 KiB
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -54,40 +58,45 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, (int)a.dout_bytes, 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
 
-    // ---- LDS-DMA slots: instruction i (0..3) of wave w = piece 4 w + i = image rows 2 piece, 2 piece + 1 (512 B each);
-    //      lane -> row 2 piece + (lane >> 5), 16-B slot lane & 31; source chunk = slot ^ ((row & 7) << 1) ----
+    // ---- LDS-DMA slots: instruction i (0..1) of wave w = piece 2 w + i = image rows 2 piece, 2 piece + 1 (512 B each);
+    //      lane -> row 4 w + 2 i + (lane >> 5), 16-B slot lane & 31; source chunk = slot ^ ((row & 7) << 1).
+    //      Offsets of a step are PREPARED (pixel -> (b, oh, ow) by reciprocal multiplication, no loops / branches) one
+    //      step ahead, so that behind the barrier only the eight buffer loads remain to be issued. ----
     const int hrow = lane >> 5, slot = lane & 31;
-    int mA[4]; unsigned chA[4];
-    int mB[4], ohB[4], owB[4], bB[4]; unsigned chB[4];
+    const int HW = a.Ho * a.Wo;
+    const float invHW = 1.0f / (float)HW, invW = 1.0f / (float)a.Wo;
+    auto divq = [](int m, int d, float inv) -> int {               // floor(m / d) for 0 <= m < 2^22
+        int q = (int)((float)m * inv);
+        q -= (q * d > m) ? 1 : 0;
+        q += ((q + 1) * d <= m) ? 1 : 0;
+        return q;
+    };
+    unsigned vA[2], vB[2];
+    int mnext = 4 * w + hrow;                                       // pixel of slot 0 in the step being prepared
+    auto prepare = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 2 * (4 * w + i) + hrow;
-        const int chunk = slot ^ (((2 * i + hrow) & 7) << 1);            // (row & 7) == (2 i + hrow) & 7
-        const int co = co0 + chunk * 8, ci = ci0 + chunk * 8;
-        mA[i] = row;
-        chA[i] = (co < a.Co && co + 8 <= a.ldd) ? (unsigned)(co * 2) : kOOBg;
-        mB[i] = row;
-        const int b = row / (a.Ho * a.Wo), r = row - b * (a.Ho * a.Wo);
-        bB[i] = b; ohB[i] = r / a.Wo; owB[i] = r - ohB[i] * a.Wo;
-        chB[i] = (ci < a.Ci) ? (unsigned)(ci * 2) : kOOBg;
-    }
-    auto issue = [&](int stage) {
+        for (int i = 0; i < 2; ++i) {
+            const int m = mnext + 2 * i;
+            const int chunk = slot ^ (((4 * (w & 1) + 2 * i + hrow) & 7) << 1);     // row & 7
+            const int co = co0 + chunk * 8, ci = ci0 + chunk * 8;
+            const bool inm = m < a.M;
+            vA[i] = (inm && co < a.Co && co + 8 <= a.ldd) ? (unsigned)m * (unsigned)(a.ldd * 2) + (unsigned)(co * 2) : kOOBg;
+            const int b = divq(m, HW, invHW), r = m - b * HW;
+            const int oh = divq(r, a.Wo, invW), ow = r - oh * a.Wo;
+            const int ih = oh + kh - a.pad, iw = ow + kw - a.pad;
+            const bool ok = inm && ci < a.Ci && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+            vB[i] = ok ? (unsigned)((b * a.Hi + ih) * a.Wi + iw) * (unsigned)(a.ldi * 2) + (unsigned)(ci * 2) : kOOBg;
+        }
+        mnext += KPg;
+    };
+    auto fire = [&](int stage) {
         char* sb = smem + stage * STAGEg;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned v = (mA[i] < a.M && chA[i] != kOOBg) ? (unsigned)mA[i] * (unsigned)(a.ldd * 2) + chA[i] : kOOBg;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (4 * w + i) * 1024), 16, v, 0, 0, 0);
-            mA[i] += KPg;
-        }
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (2 * w + i) * 1024), 16, vA[i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ih = ohB[i] + kh - a.pad, iw = owB[i] + kw - a.pad;
-            const bool ok = mB[i] < a.M && chB[i] != kOOBg && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-            const unsigned v = ok ? (unsigned)((bB[i] * a.Hi + ih) * a.Wi + iw) * (unsigned)(a.ldi * 2) + chB[i] : kOOBg;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + KPg * 512 + (4 * w + i) * 1024), 16, v, 0, 0, 0);
-            mB[i] += KPg; owB[i] += KPg;
-            while (owB[i] >= a.Wo) { owB[i] -= a.Wo; if (++ohB[i] >= a.Ho) { ohB[i] = 0; ++bB[i]; } }
-        }
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + KPg * 512 + (2 * w + i) * 1024), 16, vB[i], 0, 0, 0);
     };
 
     f32x4_t acc[8][4];
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
     // per-lane transpose-read offsets: this lane supplies row kk (of a 16-row block) and 8 B = 4 channels
     const int kk = g * 4 + (r16 >> 2);
     const int sub = (r16 & 3) * 8;
-    const int sw = (kk & 7) << 1;                    // same for kk + 16, + 32, + 48
+    const int sw = (kk & 7) << 1;                    // same for kk + 16
     int offA[8], offB[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) offA[i] = kk * 512 + (((wm * 16 + i * 2) ^ sw) << 4) + sub;
@@ -107,15 +116,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
     for (int j = 0; j < 4; ++j) offB[j] = KPg * 512 + kk * 512 + (((wn * 8 + j * 2) ^ sw) << 4) + sub;
 
     const int nK = (a.M + KPg - 1) / KPg;
-    issue(0);
+    prepare(); fire(0);
+    prepare(); if (nK > 1) fire(1);
+    prepare(); if (nK > 2) fire(2);
+    prepare();                                        // offsets of step 3
     int stage = 0;
     for (int kc = 0; kc < nK; ++kc) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // four LDS-DMA instructions per wave per stage; stages kc + 1, kc + 2 may stay in flight
+        if (kc + 2 < nK) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kc + 1 < nK) issue(stage ^ 1);
+        if (kc + 3 < nK && a.ablate != 1) fire((stage + 3) & 3);       // the stage drained in step kc - 1
+        prepare();                                    // offsets of step kc + 4: VALU work under this step's MFMAs
         const char* sb = smem + stage * STAGEg;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                 // two 32-pixel MFMA K blocks per stage
+        if (a.ablate != 2) {
+            constexpr int h = 0;
             u32x4_t df[8], xf[4];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -139,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
                                                                         __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stage ^= 1;
+        stage = (stage + 1) & 3;
     }
 
     // ---- epilogue: D[co][ci] (lane: rows co = 4 g + e, column ci = r16) staged through LDS in four 64-row passes so that
@@ -187,7 +203,7 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     WgwArgs a;
     a.cotiles = szn_div_up(d->Co, 256); a.citiles = szn_div_up(d->Ci, 256);
     const long tiles = (long)a.cotiles * a.citiles * d->KH * d->KW;
-    if (tiles < min_tiles || tiles >= (1L << 31)) return 1;
+    if (tiles < min_tiles || tiles >= (1L << 31) || (long)d->B * d->Ho * d->Wo >= (1L << 22)) return 1;
     // padding waste of the last tiles must stay small
     if ((long)a.cotiles * 256 * a.citiles * 256 > (long)d->Co * d->Ci * 5 / 4) return 1;
     a.dout = (const char*)dout; a.in = (const char*)in; a.dw = dw;
@@ -197,6 +213,7 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldd = d->ldo;
     a.M = d->B * d->Ho * d->Wo;
     a.accumulate = accumulate;
+    { static int abl = -1; if (abl < 0) { const char* e = getenv("SZN_WGW_ABLATE"); abl = e ? atoi(e) : 0; } a.ablate = abl; }
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_wide, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW);
