@@ -234,6 +234,34 @@ __global__ void pack_dgrad_kernel(const T* __restrict__ w, T* __restrict__ wT, i
     }
 }
 
+// 16-bit fast path (Co, Ci multiples of 64): 64 x 64 tiles, 16-B global loads and stores on both sides (full 128-B
+// rows), transpose through LDS with 2-B accesses ([64][66] pitch: conflict-free column reads)
+__global__ __launch_bounds__(256) void pack_dgrad16_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ wT, int Co,
+                                                           int KH, int KW, int Ci) {
+    __shared__ uint16_t tile[64][66];
+    const int tap = blockIdx.z, kh = tap / KW, kw = tap - kh * KW;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+    const int c8 = threadIdx.x & 7, r0 = threadIdx.x >> 3;       // 8 x 16-B chunks per 128-B row, 32 rows per pass
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = r0 + 32 * p;
+        const uint4 v = *(const uint4*)(w + ((long)((co0 + r) * KH + kh) * KW + kw) * Ci + ci0 + c8 * 8);
+        uint32_t* d32 = (uint32_t*)&tile[r][c8 * 8];             // row pitch 132 B: 4-B aligned
+        d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
+    }
+    __syncthreads();
+    const int tapT = (KH - 1 - kh) * KW + (KW - 1 - kw);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int ci = r0 + 32 * p;                               // output row = input channel
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (uint32_t)tile[c8 * 8 + 2 * e][ci] | ((uint32_t)tile[c8 * 8 + 2 * e + 1][ci] << 16);
+        *(uint4*)(wT + ((long)(ci0 + ci) * KH * KW + tapT) * Co + co0 + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
     const char* dout; const char* in; float* dw;
@@ -490,6 +518,12 @@ extern "C" int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, 
                                      szn_stream_t stream) {
     if (!w || !wT || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) SZN_FAIL(SZN_ERR_ARG, "pack_weight_dgrad: bad argument");
     dim3 grid(szn_div_up(Ci, 32), szn_div_up(Co, 32), KH * KW);
+    if (dtype == SZN_BF16 && (Co & 63) == 0 && (Ci & 63) == 0 && !(((uintptr_t)w | (uintptr_t)wT) & 15)) {
+        hipLaunchKernelGGL(pack_dgrad16_kernel, dim3(Ci / 64, Co / 64, KH * KW), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)w, (uint16_t*)wT, Co, KH, KW, Ci);
+        SZN_CHECK_LAUNCH("pack_dgrad16_kernel");
+        return SZN_OK;
+    }
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(pack_dgrad_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w,
                            (uint16_t*)wT, Co, KH, KW, Ci);
