@@ -32,6 +32,7 @@ struct WtArgs {
     int tiles_x, tiles_y, ntiles;      // ntiles = B * tiles_y * tiles_x
     int cotiles, citiles, nsplit;
     int accumulate;
+    int ablate;                // debug (env SZN_WGT_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no reads / MFMA
 };
 
 constexpr unsigned kOOBt = 0x80000000u;
@@ -66,36 +67,39 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
     const unsigned chunkoff = (unsigned)(((lane & 7) ^ (((rsub >> 1) & 3) << 1)) << 4);      // (row >> 1) & 3 == (rsub >> 1) & 3
     const unsigned coA = (unsigned)(cot * 128) + chunkoff, coB = (unsigned)(cit * 128) + chunkoff;
     const int q0 = 8 * w + rsub;
-    auto issue = [&](int t, int stage) {
+    // Offsets of a tile = scalar tile base + a per-lane relative part unless out of range (cheap VALU right behind the
+    // barrier; spreading the ten loads over the K steps costs VGPRs the 18 accumulator fragments do not leave).
+    unsigned vA[4], vB[6];
+    auto prepare = [&](int t) {
         int bb = t;
         const int tx = bb % a.tiles_x; bb /= a.tiles_x;
         const int ty = bb % a.tiles_y; const int b = bb / a.tiles_y;
-        char* sb = smem + stage * STAGEt;
         int q0v = q0;
-        asm volatile("" : "+v"(q0v));               // keep the per-slot coordinates out of loop-carried VGPRs
-        // dout tile: pieces w, w + 8, w + 16, w + 24 (tile pixel pl = 8 piece + rsub: row pl >> 4, column pl & 15)
+        asm volatile("" : "+v"(q0v));               // per-call opaque: no per-slot constants in loop-carried VGPRs
+        const unsigned baseA = (unsigned)(((b * a.Ho + ty * 16) * a.Wo + tx * 16) * a.ldd * 2) + coA;
+        const int nrow = a.Ho - ty * 16, ncol = a.Wo - tx * 16;     // valid rows / columns of this tile
+        const int r0 = q0v >> 4, c0 = q0v & 15;                     // tile pixel of slot p: row r0 + 4 p, column c0
+        const bool colok = c0 < ncol;
+        const unsigned rel0 = (unsigned)((r0 * a.Wo + c0) * a.ldd * 2), relstep = (unsigned)(4 * a.Wo * a.ldd * 2);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int pl = q0v + 64 * p;
-            const int oh = ty * 16 + (pl >> 4), ow = tx * 16 + (pl & 15);
-            const unsigned v = (oh < a.Ho && ow < a.Wo) ? (unsigned)(((b * a.Ho + oh) * a.Wo + ow) * a.ldd * 2) + coA : kOOBt;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (w + 8 * p) * 1024), 16, v, 0, 0, 0);
-        }
+        for (int p = 0; p < 4; ++p) vA[p] = (colok && (r0 + 4 * p) < nrow) ? baseA + rel0 + relstep * p : kOOBt;
         const int ih0 = ty * 16 - a.pad, iw0 = tx * 16 - a.pad;
-#pragma unroll
+        const unsigned baseB = (unsigned)(((b * a.Hi + ih0) * a.Wi + iw0) * a.ldi * 2) + coB;   // may wrap below zero:
+#pragma unroll                                                                                  // only used in range
         for (int p = 0; p < 6; ++p) {
-            unsigned v = kOOBt;
             const int q = q0v + 64 * p;
-            if (q < PROWSt) {
-                const int pr = (q * 3641) >> 16, pc = q - pr * PWt;           // q / 18 for q < 324
-                const int ih = ih0 + pr, iw = iw0 + pc;
-                if ((unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi)
-                    v = (unsigned)(((b * a.Hi + ih) * a.Wi + iw) * a.ldi * 2) + coB;
-            }
-            const int piece = w + 8 * p;
-            char* dst = (piece < 41) ? sb + DOUTB + piece * 1024 : smem + OFF_DUMPt;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)dst, 16, v, 0, 0, 0);
+            const int pr = (q * 3641) >> 16, pc = q - pr * PWt;       // q / 18 for q < 384
+            const bool ok = q < PROWSt && (unsigned)(ih0 + pr) < (unsigned)a.Hi && (unsigned)(iw0 + pc) < (unsigned)a.Wi;
+            vB[p] = ok ? baseB + (unsigned)((pr * a.Wi + pc) * a.ldi * 2) : kOOBt;
         }
+    };
+    auto fireA = [&](int p, int stage) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(smem + stage * STAGEt + (w + 8 * p) * 1024), 16, vA[p], 0, 0, 0);
+    };
+    auto fireB = [&](int p, int stage) {
+        const int piece = w + 8 * p;
+        char* dst = (piece < 41) ? smem + stage * STAGEt + DOUTB + piece * 1024 : smem + OFF_DUMPt;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)dst, 16, vB[p], 0, 0, 0);
     };
 
     f32x4_t acc[2][9];
@@ -112,12 +116,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) offA[i] = kk * 128 + (((h * 4 + i * 2) ^ (((kk >> 1) & 3) << 1)) << 4) + sub;
 
-    if (first < last) issue(first, 0);
+    if (first < last) {
+        prepare(first);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) fireA(p, 0);
+#pragma unroll
+        for (int p = 0; p < 6; ++p) fireB(p, 0);
+    }
     int stage = 0;
     for (int t = first; t < last; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + 1 < last) issue(t + 1, stage ^ 1);
+        const bool fill = t + 1 < last && a.ablate != 1;
+        if (fill) {
+            prepare(t + 1);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fireA(p, stage ^ 1);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) fireB(p, stage ^ 1);
+        }
         const char* sd = smem + stage * STAGEt;
         const char* sp = sd + DOUTB;
         auto rdA = [&](int p, int i) -> u32x4_t {
@@ -137,6 +154,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
         for (int R = 0; R < 2; ++R)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) Br[R][kw] = rdB(R, kw);
+        if (a.ablate != 2)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             // rows 2p, 2p + 1 are in Br[0], Br[1]; fetch 2p + 2, 2p + 3 and the dout fragments of this step
@@ -227,6 +245,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->ldi * 2);
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.pad = d->pad;
     a.ldi = d->ldi; a.ldd = d->ldo; a.accumulate = accumulate;
+    { static int abl = -1; if (abl < 0) { const char* e = getenv("SZN_WGT_ABLATE"); abl = e ? atoi(e) : 0; } a.ablate = abl; }
     hipStream_t st = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {
