@@ -83,6 +83,20 @@ int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, const void*
 int szn_conv2d_dgrad(const szn_conv_desc_t* d, const void* dout, const void* wT, const void* gate,
                      const float* chan_scale, void* din, szn_stream_t stream);
 
+/* dgrad of a large-window convolution (models.py:84 fc6 = Conv2d(512, 4096, 7) backward) as GEMM + col2im: as a
+ * convolution over the padded dout map szn_conv2d_dgrad executes 1.83x the algorithmic FLOPs of fc6's dgrad (most taps
+ * of the border pixels are padding); here
+ *   Y[(b,oh,ow)][(kh,kw,ci)] = sum_co dout[(b,oh,ow)][co] * w[co][kh][kw][ci]   (fp32, in d->workspace)
+ *   din[b][ih][iw][ci]       = sum_{kh,kw} Y[(b, ih+pad-kh, iw+pad-kw)][(kh,kw,ci)]
+ * wG = the plain transpose [KH*KW*Ci][Co] of the OHWI filter bank, i.e. szn_pack_weight_dgrad(dtype, Co, 1, 1,
+ * KH*KW*Ci, w, wG).  d = forward geometry (d->ldo = pixel stride of dout, d->ldi of din); d->workspace must hold
+ * szn_conv2d_dgrad_gemm_workspace_bytes(d) = B*Ho*Wo*KH*KW*Ci*4 bytes.  Co must be a multiple of 64 (bf16) / 32
+ * (f32) like every reduction dimension of szn_conv2d_*; Ci a multiple of 4.  No gate / chan_scale / colsum epilogue
+ * (fc6's input is a pooled map: the ReLU gate is applied by szn_maxpool2x2_ceil_bwd).                          */
+size_t szn_conv2d_dgrad_gemm_workspace_bytes(const szn_conv_desc_t* d);
+int szn_conv2d_dgrad_gemm(const szn_conv_desc_t* d, const void* dout, const void* wG, void* din,
+                          szn_stream_t stream);
+
 /* dw[co][kh][kw][ci] (+)= sum_pixels dout[p][co] * in[p shifted by (kh,kw)][ci]   (fp32, OHWI)
  * accumulate != 0 adds into dw (split-K partial sums are added with fp32 atomics; dw must then be
  * zero or hold a running gradient); accumulate == 0 zeroes dw first on the same stream.           */

@@ -152,6 +152,52 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     assert relerr(dw.cpu().permute(0, 3, 1, 2), 2 * dw_ref) < tol
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 512, 128, 7, 0), (2, 7, 6, 448, 512, 5, 1), (1, 9, 9, 128, 200, 7, 0),
+                                  (2, 23, 23, 512, 256, 7, 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_dgrad_gemm_col2im(case, dtype):
+    """szn_conv2d_dgrad_gemm (fc6's backward-data as GEMM + col2im) against torch's conv backward"""
+    B, Hi, Wi, Ci, Co, K, pad = case
+    g = torch.Generator().manual_seed(77 + Ci + Co)
+    x = torch.randn(B, Ci, Hi, Wi, generator=g, requires_grad=True)
+    w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
+    if dtype == torch.bfloat16:
+        w = w.bfloat16().float()
+    out = F.conv2d(x, w, None, padding=pad)
+    Ho, Wo = out.shape[2:]
+    dout = torch.randn(B, Co, Ho, Wo, generator=g)
+    if dtype == torch.bfloat16:
+        dout = dout.bfloat16().float()
+    out.backward(dout)
+    dt = L.dtype_code(dtype)
+    dev = "cuda"
+    wd = nhwc(w).to(dev, dtype)                                   # OHWI
+    wG = torch.empty(K * K * Ci, Co, device=dev, dtype=dtype)
+    L.call("szn_pack_weight_dgrad", dt, Co, 1, 1, K * K * Ci, L.ptr(wd), L.ptr(wG), L.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(wG.float().cpu(), nhwc(w).reshape(Co, -1).t().to(dtype).float())
+    d, _, _ = conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad)
+    nb = L.load().szn_conv2d_dgrad_gemm_workspace_bytes(C.byref(d))
+    assert nb == B * Ho * Wo * K * K * Ci * 4
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nb
+    doutd = pad_c(nhwc(dout), d.ldo).to(dev, dtype)
+    din = torch.full((B, Hi, Wi, Ci), float("nan"), device=dev, dtype=dtype)
+    if Co % (64 if dtype == torch.bfloat16 else 32):          # same channel granularity as szn_conv2d_dgrad: reported
+        with pytest.raises(L.SznError):
+            L.call("szn_conv2d_dgrad_gemm", C.byref(d), L.ptr(doutd), L.ptr(wG), L.ptr(din), L.stream_ptr())
+        return
+    L.call("szn_conv2d_dgrad_gemm", C.byref(d), L.ptr(doutd), L.ptr(wG), L.ptr(din), L.stream_ptr())
+    assert L.last_kernel() == "col2im_kernel"
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert relerr(din.float().cpu().permute(0, 3, 1, 2), x.grad) < tol
+    # too small a workspace is an error, not a silent fallback
+    d.workspace_bytes = nb - 1
+    with pytest.raises(L.SznError):
+        L.call("szn_conv2d_dgrad_gemm", C.byref(d), L.ptr(doutd), L.ptr(wG), L.ptr(din), L.stream_ptr())
+
+
 def test_conv_epilogue_scale_and_padded_strides():
     # chan_scale (Dropout2d factors) and out_f32 with a padded output stride (score buffer layout)
     B, Hi, Wi, Ci, Co, ldo = 2, 4, 5, 64, 22, 32

@@ -42,6 +42,8 @@ SIGNATURES = {
     "szn_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "szn_pack_weight_dgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
     "szn_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "szn_conv2d_dgrad_gemm_workspace_bytes": (C.c_size_t, [_D]),
+    "szn_conv2d_dgrad_gemm": (_I, [_D, _P, _P, _P, _P]),
     "szn_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "szn_bias_grad": (_I, [_I, _L, _I, _I, _P, _P, _I, _P]),
     "szn_gemm_proj_fwd": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P]),

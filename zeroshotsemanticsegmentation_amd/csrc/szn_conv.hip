@@ -551,6 +551,80 @@ extern "C" int szn_conv2d_dgrad(const szn_conv_desc_t* d, const void* dout, cons
     return szn_conv2d_fwd(&s, dout, wT, nullptr, gate, chan_scale, din, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// dgrad of a large-window convolution (fc6: 7x7 valid on a 23x23 map) as GEMM + col2im.  As a convolution over the
+// (K-1)-padded dout map it executes 1.83x its algorithmic FLOPs (most taps of the border pixels are padding); as
+//   Y[m = (b,oh,ow)][(kh,kw,ci)] = sum_co dout[m][co] * w[co][kh][kw][ci]           (one GEMM, N = KH*KW*Ci)
+//   din[b][ih][iw][ci]           = sum_{kh,kw} Y[(b, ih+pad-kh, iw+pad-kw)][(kh,kw,ci)]
+// it executes exactly them; every Y element is read once by col2im (16-B loads along ci).
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ Y, T* __restrict__ din, int B, int Hi, int Wi,
+                                                     int Ci, int Ho, int Wo, int KH, int KW, int pad, int ldi) {
+    const int c4n = Ci >> 2;
+    const long total = (long)B * Hi * Wi * c4n;
+    const long N = (long)KH * KW * Ci;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const long p = idx / c4n;
+        const int iw = (int)(p % Wi);
+        const long t = p / Wi;
+        const int ih = (int)(t % Hi), b = (int)(t / Hi);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < KH; ++kh) {
+            const int oh = ih + pad - kh;
+            if ((unsigned)oh >= (unsigned)Ho) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int ow = iw + pad - kw;
+                if ((unsigned)ow >= (unsigned)Wo) continue;
+                acc += *(const f32x4_t*)(Y + (((long)b * Ho + oh) * Wo + ow) * N + (long)(kh * KW + kw) * Ci + c4 * 4);
+            }
+        }
+        T* o = din + p * ldi + c4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) elem<T>::st(o + e, acc[e]);
+    }
+}
+
+extern "C" size_t szn_conv2d_dgrad_gemm_workspace_bytes(const szn_conv_desc_t* d) {
+    if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->KH <= 0 || d->KW <= 0 || d->Ci <= 0) return 0;
+    return (size_t)d->B * d->Ho * d->Wo * d->KH * d->KW * d->Ci * sizeof(float);
+}
+
+extern "C" int szn_conv2d_dgrad_gemm(const szn_conv_desc_t* d, const void* dout, const void* wG, void* din,
+                                     szn_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dout || !wG || !din) SZN_FAIL(SZN_ERR_ARG, "conv2d_dgrad_gemm: null pointer");
+    if (d->Ci & 3) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_dgrad_gemm: Ci must be a multiple of 4");
+    const size_t need = szn_conv2d_dgrad_gemm_workspace_bytes(d);
+    if (!d->workspace || d->workspace_bytes < need || ((uintptr_t)d->workspace & 15))
+        SZN_FAIL(SZN_ERR_ARG, "conv2d_dgrad_gemm: needs a 16-B aligned workspace of %zu bytes", need);
+    if (d->B * d->Ho >= 32000 || d->Wo >= 32000) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_dgrad_gemm: map too large");
+    const long N = (long)d->KH * d->KW * d->Ci;
+    if (N >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_dgrad_gemm: KH*KW*Ci too large");
+    // Y = dout x wG^T as a 1x1 convolution over the (B*Ho) x Wo pixel grid: "Ci" = Co, "Co" = KH*KW*Ci, f32 output
+    szn_conv_desc_t g = {};
+    g.dtype = d->dtype; g.B = 1; g.Hi = d->B * d->Ho; g.Wi = d->Wo; g.Ci = d->Co;
+    g.Ho = g.Hi; g.Wo = g.Wi; g.Co = (int)N; g.KH = 1; g.KW = 1; g.pad = 0;
+    g.ldi = d->ldo; g.ldo = (int)N; g.ldg = 0; g.relu = 0; g.out_f32 = 1;
+    g.workspace = nullptr; g.workspace_bytes = 0; g.colsum = nullptr;
+    rc = szn_conv2d_fwd(&g, dout, wG, nullptr, nullptr, nullptr, d->workspace, stream);
+    if (rc) return rc;
+    const long total = (long)d->B * d->Hi * d->Wi * (d->Ci >> 2);
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (d->dtype == SZN_BF16)
+        hipLaunchKernelGGL(col2im_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)d->workspace, (bf16_raw*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
+                           d->pad, d->ldi);
+    else
+        hipLaunchKernelGGL(col2im_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)d->workspace, (float*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
+                           d->pad, d->ldi);
+    SZN_CHECK_LAUNCH("col2im_kernel");
+    return SZN_OK;
+}
+
 // first-generation kernel (register-staged, 128x128 tile): fallback of szn_conv2d_wgrad (szn_conv_wgrad.hip)
 int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                         szn_stream_t stream) {

@@ -140,6 +140,7 @@ class TrainStep(object):
         self.head_gw = torch.empty(CP, 1, 1, F, device=self.dev)
         self.head_gb = torch.empty(CP, device=self.dev)
         self.grads["head"] = (self.head_gw, self.head_gb)
+        self.grads["_flat_bias"] = self.flat_gb      # lets the engine zero all bias gradients with one fill
 
     def _buckets(self, bucket_mb):
         layers = [(n,) + self.woff[n] for n in _OPT_LAYERS]

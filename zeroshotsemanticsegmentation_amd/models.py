@@ -64,6 +64,7 @@ class _Engine(object):
         self.dropout_seed = 1337
         self.dropout_calls = 0
         self._splitk_ws = None
+        self._gemm_ws = None          # fp32 Y of the GEMM + col2im dgrad (fc6)
         self._wg_ws = None            # slab workspace of the wgrad kernels (they run on their own stream)
         self._wg_stream = None        # torch.cuda.Stream, or False when disabled (SZN_WGRAD_STREAM=0)
         self.lp_views = {}          # layer -> compute-dtype OHWI weight image maintained by the optimizer kernel (TrainStep)
@@ -124,6 +125,11 @@ class _Engine(object):
             else:
                 wc = w32.to(dt)
             img[name + ".w"] = wc
+            if k >= 5:      # fc6: dgrad runs as GEMM + col2im on the plain transpose [k*k*ci][co] (szn_conv2d_dgrad_gemm)
+                wg = torch.empty(k * k * ci, co, device=dev, dtype=dt)
+                L.call("szn_pack_weight_dgrad", code, co, 1, 1, k * k * ci, L.ptr(wc), L.ptr(wg), st)
+                img[name + ".wG"] = wg
+                continue
             wt = torch.empty(ci, k, k, co, device=dev, dtype=dt)
             L.call("szn_pack_weight_dgrad", code, co, k, k, ci, L.ptr(wc), L.ptr(wt), st)
             img[name + ".wT"] = wt
@@ -300,9 +306,21 @@ class _Engine(object):
         (f32 [Ci], pre-zeroed) receives the column sums of din = that layer's bias gradient"""
         B, Hi, Wi, Ci = in_shape
         Ho, Wo, Co = dout.shape[1:]
+        din = torch.empty(B, Hi, Wi, Ci, device=dout.device, dtype=self.dtype)
+        wG = self._images.get(name + ".wG")
+        if wG is not None:      # large window (fc6): GEMM + col2im, no gate / dropout factor / column sums on this edge
+            if gate is not None or scale is not None or colsum is not None:
+                raise L.SznError("dgrad of %s: the GEMM form has no gate / scale / colsum epilogue" % name)
+            k = int(round((wG.shape[0] // Ci) ** 0.5))
+            d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, 0, 0, 0)
+            nb = L.load().szn_conv2d_dgrad_gemm_workspace_bytes(C.byref(d))
+            if self._gemm_ws is None or self._gemm_ws.numel() < nb or self._gemm_ws.device != dout.device:
+                self._gemm_ws = torch.empty(nb, dtype=torch.uint8, device=dout.device)
+            d.workspace, d.workspace_bytes = self._gemm_ws.data_ptr(), self._gemm_ws.numel()
+            L.call("szn_conv2d_dgrad_gemm", C.byref(d), L.ptr(dout), L.ptr(wG), L.ptr(din), L.stream_ptr())
+            return din
         wT = self._images[name + ".wT"]
         k = wT.shape[1]
-        din = torch.empty(B, Hi, Wi, Ci, device=dout.device, dtype=self.dtype)
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, Ci, 0, 0)
         if colsum is not None:
             d.colsum = colsum.data_ptr()
@@ -321,6 +339,9 @@ class _Engine(object):
         dc = dcoarse if dcoarse.dtype == dt else dcoarse.to(dt)      # tiny (B*h*w*CP)
         feat = ctx.relu7
         F = m.fc7.out_channels
+        flat_bias = grads.get("_flat_bias")          # TrainStep: every bias gradient is a view of one flat buffer:
+        if flat_bias is not None and backbone:       # one fill, BEFORE the head hook copies score_fr's gradient into it
+            flat_bias.zero_()
         if "head" in grads:
             dwh, dbh = grads["head"]
             self._wgrad(feat, dc, dwh, dbh, F, m.head_width, 1, 0, after=head_first)
@@ -332,9 +353,10 @@ class _Engine(object):
         s7 = ctx.masks[1] if ctx.masks is not None else None
         # bias gradients are produced as column sums by whichever kernel WRITES the pre-activation gradient (the dgrad
         # of the next layer or the pool backward), so they start from zero here
-        for name in grads:
-            if name != "head":
-                grads[name][1].zero_()
+        if flat_bias is None:
+            for name in grads:
+                if name != "head":
+                    grads[name][1].zero_()
         # d(fc7 pre-activation): ReLU gate (feat > 0) and dropout factor fused into the dgrad epilogue
         d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7, colsum=grads["fc7"][1])
         self._wgrad(ctx.relu6, d, grads["fc7"][0], None, F, F, 1, 0, after=lambda: done("fc7"))
