@@ -51,7 +51,7 @@ def main():
         calls = {
             "fwd": lambda: L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, None, L.ptr(out), st),
             "dgrad": lambda: L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(x), None, L.ptr(din), st),
-            "wgrad": lambda: L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 1, st),
+            "wgrad": lambda: L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st),
         }
         res = []
         for what in a.what.split(","):
