@@ -121,7 +121,7 @@ def main():
         orig_call = L.call
 
         def timed_call(name, *a):
-            if record[0] and name in ("szn_conv2d_fwd", "szn_conv2d_dgrad"):
+            if record[0] and name in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm"):
                 d = a[0]._obj
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -179,7 +179,7 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("per_gpu_batch") == B and tj.get("precision") == args.precision and H == 512 and E == 300:
                     traffic = round(tj["hbm_bytes_per_launch"])
-            out["roofline"] = {"bound": "mfma", "kernel": "conv fwd + dgrad launches (conv_igemm_v2 | conv_igemm_wide | conv3x3_regw)",
+            out["roofline"] = {"bound": "mfma", "kernel": "conv fwd + dgrad launches (conv_igemm_v2 | conv_igemm_wide | conv3x3_regw; fc6 dgrad = wide GEMM + col2im)",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "launches_per_step": len(events) // args.steps,
                                "avg_launch_ms": round(ms / len(events), 4),

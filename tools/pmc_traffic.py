@@ -9,7 +9,7 @@ import sys
 
 csv.field_size_limit(1 << 30)
 MATCH = ("conv_igemm", "conv3x3_regw")     # one kernel launch per szn_conv2d_fwd / szn_conv2d_dgrad call
-EXTRA = ("splitk_epilogue",)               # second kernel of a split-K call: its bytes count, its launch does not
+EXTRA = ("splitk_epilogue", "col2im_kernel")   # second kernel of a split-K / GEMM-dgrad call: bytes count, launch does not
 
 
 def collect(d, counter):
