@@ -90,8 +90,12 @@ class TrainStep(object):
         ws = [getattr(m, n).weight for n in _OPT_LAYERS]
         bs = [getattr(m, n).bias for n in _OPT_LAYERS]
         nw, nb = sum(p.numel() for p in ws), sum(p.numel() for p in bs)
+        CP, E, F = m.head_width, m.n_class, m.fc7.out_channels
         self.flat_w = torch.empty(nw, device=self.dev)
-        self.flat_b = torch.empty(nb, device=self.dev)
+        # score_fr is the last layer of the flat layout: the (CP - E) rows behind its bias slot complete the fused head's
+        # bias vector (seenmask_score + zero padding), so the engine can use one contiguous view of it
+        self._flat_b_store = torch.zeros(nb + CP - E, device=self.dev)
+        self.flat_b = self._flat_b_store[:nb]
         self.flat_gw = torch.zeros(nw, device=self.dev)
         self.flat_gb = torch.zeros(nb, device=self.dev)
         self.woff, self.boff = {}, {}
@@ -122,11 +126,21 @@ class TrainStep(object):
         self.flat_w_lp = None
         self.eng.lp_views = {}
         if self.eng.dtype == torch.bfloat16:
-            self.flat_w_lp = self.flat_w.to(torch.bfloat16)
+            # (CP - E) x F extra elements behind score_fr's slot: the fused head's weight image [CP][F] is then a view
+            store = torch.zeros(nw + (CP - E) * F, device=self.dev, dtype=torch.bfloat16)
+            store[:nw].copy_(self.flat_w)
+            self._flat_w_lp_store = store
+            self.flat_w_lp = store[:nw]
             for n in _OPT_LAYERS[:-1]:
                 co, ci, kh, kw = getattr(m, n).weight.shape
                 o, cnt = self.woff[n]
                 self.eng.lp_views[n] = self.flat_w_lp[o:o + cnt].view(co, kh, kw, ci)
+            assert _OPT_LAYERS[-1] == "score_fr"
+            o, cnt = self.woff["score_fr"]
+            bo, bc = self.boff["score_fr"]
+            assert o + cnt == nw and bo + bc == nb
+            self.eng.lp_views["head"] = (store[o:o + CP * F].view(CP, F), self._flat_b_store[bo:bo + CP])
+            self.eng._seen_versions = None
         self.eng.mark_dirty()
         # per-layer gradient targets handed to the engine (OHWI views of the flat gradient)
         self.grads = {}

@@ -68,6 +68,7 @@ class _Engine(object):
         self._wg_ws = None            # slab workspace of the wgrad kernels (they run on their own stream)
         self._wg_stream = None        # torch.cuda.Stream, or False when disabled (SZN_WGRAD_STREAM=0)
         self.lp_views = {}          # layer -> compute-dtype OHWI weight image maintained by the optimizer kernel (TrainStep)
+        self._seen_versions = None    # versions of seenmask_score mirrored into the TrainStep-owned head image
 
     def _workspace(self, desc, nbytes, device):
         """split-K scratch handed to the conv kernels (they use it only for few-tile / long-K shapes: fc6, fc7)"""
@@ -135,13 +136,24 @@ class _Engine(object):
             img[name + ".wT"] = wt
         # fused projection head: rows [0,E) = score_fr, [E,E+2) = seenmask_score, zero rows up to CP
         E, CP, F = m.n_class, m.head_width, m.fc7.out_channels
-        wh = torch.zeros(CP, F, device=dev, dtype=torch.float32)
-        bh = torch.zeros(CP, device=dev, dtype=torch.float32)
-        wh[:E] = m.score_fr.weight.detach().float().reshape(E, F)
-        wh[E:E + 2] = m.seenmask_score.weight.detach().float().reshape(2, F)
-        bh[:E] = m.score_fr.bias.detach().float()
-        bh[E:E + 2] = m.seenmask_score.bias.detach().float()
-        whc = wh if dt == torch.float32 else wh.to(dt)
+        hv = self.lp_views.get("head")
+        if hv is not None and hv[0].dtype == dt:
+            # TrainStep keeps the image itself: score_fr's rows are written by the optimizer kernel, the rows behind them
+            # hold seenmask_score (refreshed only when that parameter changes) and zeros -- nothing to assemble per step
+            whc, bh = hv
+            sv = (m.seenmask_score.weight._version, m.seenmask_score.bias._version)
+            if sv != self._seen_versions:
+                whc[E:E + 2].copy_(m.seenmask_score.weight.detach().reshape(2, F))
+                bh[E:E + 2].copy_(m.seenmask_score.bias.detach())
+                self._seen_versions = sv
+        else:
+            wh = torch.zeros(CP, F, device=dev, dtype=torch.float32)
+            bh = torch.zeros(CP, device=dev, dtype=torch.float32)
+            wh[:E] = m.score_fr.weight.detach().float().reshape(E, F)
+            wh[E:E + 2] = m.seenmask_score.weight.detach().float().reshape(2, F)
+            bh[:E] = m.score_fr.bias.detach().float()
+            bh[E:E + 2] = m.seenmask_score.bias.detach().float()
+            whc = wh if dt == torch.float32 else wh.to(dt)
         wht = torch.empty(F, CP, device=dev, dtype=dt)
         L.call("szn_pack_weight_dgrad", code, CP, 1, 1, F, L.ptr(whc), L.ptr(wht), st)
         img["head.w"], img["head.b"], img["head.wT"] = whc.view(CP, 1, 1, F), bh, wht.view(F, 1, 1, CP)
