@@ -35,6 +35,7 @@ const char* szn_last_error(void);
  * "wgrad_taps_reduce"): which specialised path the dispatcher took.  Test / profiling aid -- the parity tests assert it
  * so that a specialised kernel cannot silently fall back to the generic one. */
 const char* szn_last_kernel(void);
+const char* szn_prev_kernel(void);   /* the launch before it (e.g. the GEMM kernel in front of a split-K epilogue) */
 int szn_version(void); /* major*10000 + minor*100 + patch */
 typedef struct {
     char name[128];

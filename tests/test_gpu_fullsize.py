@@ -126,6 +126,35 @@ def test_fullsize_conv_scaling_and_determinism(name):
     assert torch.isfinite(w1).all() and float(w1.abs().max()) > 0
 
 
+def test_fullsize_fc6_forward_parity_split_k():
+    """fc6 at the bench's batch (2312 pixels x 4096 couts x 25088): 1.25 waves of tiles unsplit, so the library runs it
+    as a deterministic split-K on the 256 x 256 tile kernel; parity against torch's fp32 convolution of the same
+    bf16-rounded operands"""
+    import torch.nn.functional as F
+    B, Hi, Ci, Co, K = 8, 23, 512, 4096, 7
+    dt = torch.bfloat16
+    code = L.dtype_code(dt)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Ci, Hi, Hi, generator=g).bfloat16().float()
+    w = (torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5).bfloat16().float()
+    bias = torch.randn(Co, generator=g)
+    ref = F.relu(F.conv2d(x, w, bias))
+    Ho = Hi - K + 1
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda().to(dt)
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda().to(dt)
+    bd = bias.cuda()
+    out = torch.empty(B, Ho, Ho, Co, device="cuda", dtype=dt)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    d = L.ConvDesc(code, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, 0, Ci, Co, 0, 1, 0)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.call("szn_conv2d_fwd", C.byref(d), L.ptr(xd), L.ptr(wd), L.ptr(bd), None, None, L.ptr(out), L.stream_ptr())
+    assert L.last_kernel() == "splitk_epilogue" and L.prev_kernel() == "conv_igemm_wide", (L.prev_kernel(), L.last_kernel())
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, err
+
+
 def test_fullsize_forward_batch_permutation():
     E = 300
     m = models.FCN32s(E).load_synthetic(1337).cuda().eval()

@@ -39,6 +39,8 @@ def main():
         w = (torch.randn(Co, K, K, Ci, device="cuda") / (Ci * K * K) ** 0.5).to(dt)
         wT = torch.empty(Ci, K, K, Co, device="cuda", dtype=dt)
         L.call("szn_pack_weight_dgrad", code, Co, K, K, Ci, L.ptr(w), L.ptr(wT), st)
+        wG = torch.empty(K * K * Ci, Co, device="cuda", dtype=dt)
+        L.call("szn_pack_weight_dgrad", code, Co, 1, 1, K * K * Ci, L.ptr(w), L.ptr(wG), st)
         bias = torch.randn(Co, device="cuda")
         out = torch.empty(B, Ho, Ho, Co, device="cuda", dtype=dt)
         dout = torch.randn(B, Ho, Ho, Co, device="cuda").to(dt)
@@ -50,7 +52,9 @@ def main():
         flops = 2.0 * B * Ho * Ho * Co * Ci * K * K
         calls = {
             "fwd": lambda: L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, None, L.ptr(out), st),
-            "dgrad": lambda: L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(x), None, L.ptr(din), st),
+            # large windows (fc6) run as GEMM + col2im in the product path (models._dgrad)
+            "dgrad": (lambda: L.call("szn_conv2d_dgrad_gemm", C.byref(d), L.ptr(dout), L.ptr(wG), L.ptr(din), st)) if K >= 5 else
+                     (lambda: L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(x), None, L.ptr(din), st)),
             "wgrad": lambda: L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st),
         }
         res = []

@@ -37,6 +37,7 @@ _D = C.POINTER(ConvDesc)
 SIGNATURES = {
     "szn_last_error": (C.c_char_p, []),
     "szn_last_kernel": (C.c_char_p, []),
+    "szn_prev_kernel": (C.c_char_p, []),
     "szn_version": (_I, []),
     "szn_device_info": (_I, [_I, C.POINTER(DeviceInfo)]),
     "szn_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
@@ -104,6 +105,11 @@ def check(rc, what):
 def last_kernel():
     """name of the kernel the library launched last on this thread (which specialised path the dispatcher took)"""
     return load().szn_last_kernel().decode()
+
+
+def prev_kernel():
+    """the launch before last_kernel() (e.g. the GEMM kernel in front of a split-K epilogue)"""
+    return load().szn_prev_kernel().decode()
 
 
 def stream_ptr():

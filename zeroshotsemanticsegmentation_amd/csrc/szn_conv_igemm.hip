@@ -28,7 +28,7 @@ int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, c
                       const float* chan_scale, void* out, szn_stream_t stream);
 int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, unsigned in_bytes, unsigned w_bytes, int min_tiles,
-                      szn_stream_t stream);
+                      float* ws, int nsplit, int chunks_per_split, szn_stream_t stream);
 int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                      const float* chan_scale, void* out, int min_tiles, szn_stream_t stream);
 #include <stdlib.h>
@@ -493,6 +493,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     // waves; fc6 dgrad: 68 tiles x 3136 chunks): every split writes its own fp32 slab with plain stores, a second
     // kernel sums the slabs in a fixed order + epilogue.  ns minimises a simple time model: MFMA time / wave
     // efficiency + slab traffic.
+    bool use_wide = false;                            // split-K on the 256 x 256 tile kernel (szn_conv_wide.hip)
     if (d->workspace && nK >= 64 && !d->colsum) {
         static int ncu = 0;
         if (!ncu) {
@@ -502,13 +503,22 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
         }
         const double flops = 2.0 * a.M * (double)d->Co * d->Ci * d->KH * d->KW;
         const double slab = (double)a.M * d->Co * 8.0;                  // fp32 write + read per split
-        long best = 1; double best_t = 0;
-        for (long ns = 1; ns <= 16 && ns <= nK / 8; ++ns) {
-            if (ns > 1 && (size_t)ns * a.M * a.Co * sizeof(float) > d->workspace_bytes) break;
-            const long blocks = tiles * ns;
-            const double eff = (double)blocks / (double)((blocks + ncu - 1) / ncu * ncu);
-            const double t = flops / (1.0e15 * eff) + (ns > 1 ? ns * slab / 3.0e12 + 5e-6 : 0.0);
-            if (ns == 1 || t < best_t * 0.97) { best = ns; best_t = t; }
+        // two candidate tilings: 256 x 128 (this file, ~0.95 PF sustained) and 256 x 256 (wide, ~1.15 PF, bf16 / f32 with
+        // >= 256 couts and <= 64 wasted columns)
+        const long wtiles = (long)a.mtiles * szn_div_up(d->Co, 256);
+        const bool wide_ok = d->Co >= 256 && (long)szn_div_up(d->Co, 256) * 256 - d->Co <= 64;
+        long best = 1; double best_t = 0; bool best_wide = false;
+        for (int cand = 0; cand < (wide_ok ? 2 : 1); ++cand) {
+            const long tl = cand ? wtiles : tiles;
+            const double rate = cand ? 1.15e15 : 0.95e15;
+            for (long ns = 1; ns <= 16 && ns <= nK / 8; ++ns) {
+                if (ns > 1 && (size_t)ns * a.M * a.Co * sizeof(float) > d->workspace_bytes) break;
+                if (cand && ns == 1) continue;              // unsplit wide tiles are handled below (SZN_WIDE_MINTILES)
+                const long blocks = tl * ns;
+                const double eff = (double)blocks / (double)((blocks + ncu - 1) / ncu * ncu);
+                const double t = flops / (rate * eff) + (ns > 1 ? ns * slab / 3.0e12 + 5e-6 : 0.0);
+                if ((cand == 0 && ns == 1) || t < best_t * 0.97) { best = ns; best_t = t; best_wide = cand != 0; }
+            }
         }
         static int force_ns = -1;                   // tuning knob: SZN_SPLITK_NS=n forces the split count (0 = model)
         if (force_ns < 0) { const char* e = getenv("SZN_SPLITK_NS"); force_ns = e ? atoi(e) : 0; }
@@ -517,19 +527,23 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
             a.chunks_per_split = (int)((nK + best - 1) / best);
             a.nsplit = szn_div_up(nK, a.chunks_per_split);
             a.ws = (float*)d->workspace;
+            use_wide = best_wide;
         }
     }
-    int rc;
+    int rc = 1;
     // >= 256 couts and enough tiles to fill the chip: 256 x 256 tiles (1.5x less LDS fill per FLOP), szn_conv_wide.hip
-    if (a.nsplit == 1) {
+    if (a.nsplit == 1 || use_wide) {
         static int wide_min = -1;
         if (wide_min < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min = e ? atoi(e) : 256; }
-        rc = szn_conv_wide_try(d, in, w, bias, gate, chan_scale, out, a.in_bytes, a.w_bytes, wide_min, stream);
-        if (rc <= 0) return rc;
+        rc = szn_conv_wide_try(d, in, w, bias, gate, chan_scale, out, a.in_bytes, a.w_bytes, use_wide ? 1 : wide_min, a.ws,
+                               a.nsplit, a.chunks_per_split, stream);
+        if (rc < 0 || (rc == 0 && a.nsplit == 1)) return rc;
     }
-    if (d->dtype == SZN_BF16) rc = narrow ? launch_v2<bf16_raw, 2>(a, st) : launch_v2<bf16_raw, 4>(a, st);
-    else rc = narrow ? launch_v2<float, 2>(a, st) : launch_v2<float, 4>(a, st);
-    if (rc) return rc;
+    if (rc != 0) {                                    // (rc == 0: the wide kernel wrote the slabs)
+        if (d->dtype == SZN_BF16) rc = narrow ? launch_v2<bf16_raw, 2>(a, st) : launch_v2<bf16_raw, 4>(a, st);
+        else rc = narrow ? launch_v2<float, 2>(a, st) : launch_v2<float, 4>(a, st);
+        if (rc) return rc;
+    }
     if (a.nsplit > 1) {
         long blocks = ((long)a.M * a.Co + 255) / 256;
         if (blocks > 8192) blocks = 8192;

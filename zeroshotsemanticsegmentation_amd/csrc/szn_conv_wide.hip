@@ -23,6 +23,8 @@ struct WideArgs {
     int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
     int ldi, ldo, ldg, relu, out_f32;
     int M, HoWo, mtiles, ntiles, nmajor;
+    float* ws;                 // split-K: fp32 slabs [nsplit][M][Co] (plain stores, no epilogue); nullptr = single pass
+    int nsplit, chunks_per_split;
 };
 
 constexpr unsigned kOOBx = 0x80000000u;
@@ -79,8 +81,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
         voffB[i] = (n < a.Co) ? (unsigned)(((long)n * a.KH * a.KW * a.Ci + chunkA * (16 / ES)) * ES) : kOOBx;
     }
     const int cpt = a.Ci / BKE;
-    const int nK = a.KH * a.KW * cpt;
-    int itap = 0, ic = 0;
+    const int split = blockIdx.y;
+    const int kbeg = split * a.chunks_per_split;
+    const int nK = min(a.KH * a.KW * cpt, kbeg + a.chunks_per_split);          // end of this split's chunk range
+    int itap = kbeg / cpt, ic = kbeg - itap * cpt;
     auto set_tap = [&]() {
         const int kh = itap / a.KW, kw = itap - kh * a.KW;
         const unsigned tapoff = (unsigned)((kh * a.Wi + kw) * a.ldi * ES);
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
     issue(0);
     const int offs0 = ((g ^ (r16 & 7)) << 4), offs1 = (((4 + g) ^ (r16 & 7)) << 4);
     int stage = 0;
-    for (int kc = 0; kc < nK; ++kc) {
+    for (int kc = kbeg; kc < nK; ++kc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunk kc landed (the only one outstanding)
         __builtin_amdgcn_s_barrier();                             // ... for every wave; everyone left the other stage
         if (kc + 1 < nK) issue(stage ^ 1);
@@ -174,6 +178,28 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
                     *(f32x4_t*)(tile + (j * 16 + r16) * P + wn * (BN / 2) + i * 16 + g * 4) = acc[i][j];
         }
         __syncthreads();
+        if (a.ws) {                                        // split-K slab: raw fp32 partial sums, whole rows
+            if (n < a.Co && row0 < RG) {
+                float* slab = a.ws + (size_t)split * a.M * a.Co;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int row = row0 + k * RG;
+                    const int m = m0 + pass * 64 + row;
+                    if (row < 64 && m < a.M) {
+                        const float* tp = tile + row * P + cc * 8;
+                        float* o = slab + (size_t)m * a.Co + n;
+                        if (full && (a.Co & 3) == 0) {
+                            *(f32x4_t*)o = *(const f32x4_t*)tp;
+                            *(f32x4_t*)(o + 4) = *(const f32x4_t*)(tp + 4);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) if (n + e < a.Co) o[e] = tp[e];
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         if (n < a.Co && row0 < RG) {
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
@@ -239,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
             }
         }
     }
-    if (a.colsum) {
+    if (a.colsum && !a.ws) {
         __syncthreads();
         float* red = (float*)smem;                     // [RG row groups][BN]
         if (n < a.Co && row0 < RG) {
@@ -264,7 +290,7 @@ int launch_wide(const WideArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_wide<T, WNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_wide<T, WNF>), dim3(a.mtiles * a.ntiles), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_wide<T, WNF>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
     SZN_CHECK_LAUNCH("conv_igemm_wide");
     return SZN_OK;
 }
@@ -274,16 +300,18 @@ int launch_wide(const WideArgs& a, hipStream_t st) {
 // Called by szn_conv2d_fwd (which has validated the descriptor).  Returns 1 when the shape is not a good fit.
 int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, unsigned in_bytes, unsigned w_bytes, int min_tiles,
-                      szn_stream_t stream) {
+                      float* ws, int nsplit, int chunks_per_split, szn_stream_t stream) {
     if (d->Co < 256) return 1;
     WideArgs a;
+    a.ws = nsplit > 1 ? ws : nullptr; a.nsplit = nsplit > 1 ? nsplit : 1;
+    a.chunks_per_split = nsplit > 1 ? chunks_per_split : (1 << 30);
     a.M = d->B * d->Ho * d->Wo;
     // cout tile 256, or 320 (bf16) when that wastes fewer columns: the 300-d projection is one 320-wide tile
     const int waste256 = szn_div_up(d->Co, 256) * 256 - d->Co, waste320 = szn_div_up(d->Co, 320) * 320 - d->Co;
     const int bn = (d->dtype == SZN_BF16 && waste320 < waste256) ? 320 : 256;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(d->Co, bn);
     a.nmajor = 0;
-    if ((long)a.mtiles * a.ntiles < min_tiles) return 1;            // too few tiles to fill the chip: keep 256 x 128
+    if ((long)a.mtiles * a.ntiles * a.nsplit < min_tiles) return 1; // too few blocks to fill the chip: keep 256 x 128
     if ((long)a.ntiles * bn - d->Co > 64) return 1;                 // would waste > 64 columns of the last tile
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
     a.out = (char*)out; a.colsum = d->colsum;

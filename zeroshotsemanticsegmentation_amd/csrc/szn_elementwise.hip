@@ -20,8 +20,10 @@ void szn_set_error(const char* fmt, ...) {
 }
 extern "C" const char* szn_last_error(void) { return g_err; }
 static thread_local const char* g_last_kernel = "";
-void szn_note_kernel(const char* name) { g_last_kernel = name; }
+static thread_local const char* g_prev_kernel = "";
+void szn_note_kernel(const char* name) { g_prev_kernel = g_last_kernel; g_last_kernel = name; }
 extern "C" const char* szn_last_kernel(void) { return g_last_kernel; }
+extern "C" const char* szn_prev_kernel(void) { return g_prev_kernel; }
 extern "C" int szn_version(void) { return 100; /* 0.1.0 */ }
 extern "C" int szn_device_info(int device, szn_device_info_t* out) {
     if (!out) SZN_FAIL(SZN_ERR_ARG, "device_info: null output");
