@@ -122,7 +122,8 @@ int szn_gemm_proj_wgrad(int dtype, long M, int K, int N, int ldd, const void* x,
 int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const float* x_nchw, const float* w,
                     const float* bias, void* out, szn_stream_t stream);
 /* dw[64][3][3][3], db[64] from dout (already ReLU-gated) -- no dgrad: the image needs no gradient.
- * Runs as an MFMA wgrad over the im2col image (27 taps padded to 32 columns) held in `workspace`.   */
+ * bf16: a fused MFMA kernel (taps gathered from the image in registers, padding-only pixels skipped, fp32 slabs in
+ * `workspace`, deterministic); f32: an MFMA wgrad over the im2col image (27 taps padded to 32) in `workspace`.  */
 size_t szn_conv1_1_wgrad_workspace_bytes(int dtype, int B, int H, int W, int pad);
 int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const float* x_nchw,
                       const void* dout, float* dw, float* db, int accumulate, void* workspace,

@@ -243,6 +243,8 @@ def test_conv1_1(dtype, geom):
     doutd = nhwc(dout).cuda().to(dtype)
     ws = torch.empty(L.load().szn_conv1_1_wgrad_workspace_bytes(dt, B, H, W, pad), dtype=torch.uint8, device="cuda")
     L.call("szn_conv1_1_wgrad", dt, B, H, W, pad, L.ptr(xd), L.ptr(doutd), L.ptr(dw), L.ptr(db), 0, L.ptr(ws), L.stream_ptr())
+    if dtype == torch.bfloat16:     # fused kernel (no im2col image), then the bias-gradient kernel
+        assert L.prev_kernel() == "conv1_1_wgrad_reduce", L.prev_kernel()
     torch.cuda.synchronize()
     # bf16 path: the im2col image is bf16 (pixel values up to ~150 keep 8 mantissa bits)
     assert relerr(dw.cpu().permute(0, 3, 1, 2), w.grad) < (1e-4 if dtype == torch.float32 else 1e-2)

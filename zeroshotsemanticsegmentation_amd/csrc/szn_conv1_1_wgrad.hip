@@ -1,0 +1,221 @@
+// szn_conv1_1_wgrad.hip -- weight gradient of conv1_1 (3 -> 64 channels, 3x3, pad P) for bf16 gradients, without an
+// im2col image.
+//
+//   dw[co][t] = sum_pixels dout[p][co] * xcol[p][t],   t = (kh*3 + kw)*3 + ci (27 taps*channels, padded to 32)
+// The im2col route writes and re-reads a [pixels][32] bf16 image (258 MB at B = 8) and reads all of dout (516 MB).  With
+// pad = 100 only 52 % of the output pixels see the image at all: every other pixel has xcol = 0 and contributes
+// nothing, so neither its dout row nor its taps are touched here.
+//   * a K step is a segment of 32 consecutive output pixels of one row; only segments whose 3x3 windows overlap the
+//     image are enumerated; a WAVE owns segments (no block barriers): its dout rows (32 x 128 B) stream into a private
+//     3-deep LDS ring by LDS-DMA, A fragments (dout^T) come out with ds_read_b64_tr_b16;
+//   * the B operand (xcol^T, 2 fragments of 16 taps) is gathered straight from the f32 NCHW image into registers with
+//     buffer loads (out-of-range offsets = the zero padding), rounded to bf16 like the im2col path did, one segment
+//     ahead of its use;
+//   * 8 MFMA 16x16x32 per segment into 8 accumulator fragments per wave; at the end the 4 waves of a block add up in
+//     LDS and write one fp32 slab [64][32] per block; conv1_1_wgrad_reduce sums the slabs in a fixed order
+//     (deterministic) into dw[64][27].
+#include "szn_common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((address_space(3))) void* ldsptr_t;
+
+namespace {
+
+struct C11Args {
+    const char* dout; const float* x; float* ws;
+    unsigned dout_bytes, x_bytes;
+    int B, H, W, pad, Ho, Wo;
+    int oh_lo, nrows, seg_lo, nsegx;       // touching rows [oh_lo, oh_lo + nrows), segments [seg_lo, seg_lo + nsegx) of 32 px
+    long nseg;                             // B * nrows * nsegx
+};
+
+constexpr unsigned kOOB1 = 0x80000000u;
+constexpr int RING1 = 3;
+
+__global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(C11Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+    __shared__ __attribute__((aligned(16))) char smem[4 * RING1 * 4096];      // per wave: 3 stages of 32 px x 128 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, r16 = lane & 15;
+    char* ring = smem + w * RING1 * 4096;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, (int)a.dout_bytes, 0x00020000);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+
+    // dout DMA: instruction j (0..3) = rows 8 j .. 8 j + 7; lane -> row 8 j + (lane >> 3), slot lane & 7, source chunk
+    // slot ^ (((row >> 1) & 3) << 1) (transpose-read swizzle, see szn_conv_wgrad_taps.hip)
+    const int rsub = lane >> 3;
+    const unsigned chunkoff = (unsigned)(((lane & 7) ^ (((rsub >> 1) & 3) << 1)) << 4);
+    // transpose reads: this lane supplies pixel row kk (and kk + 16) and 8 B = 4 couts
+    const int kk = g * 4 + (r16 >> 2);
+    const int sw = ((kk >> 1) & 3) << 1;
+    int offA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offA[i] = kk * 128 + (((i * 2) ^ sw) << 4) + (r16 & 3) * 8;
+
+    // B operand taps of this lane: fragment f covers t = r16 + 16 f; element e of the MFMA K index 8 g + e is pixel
+    // pix(e) = (e < 4 ? 4 g + e : 16 + 4 g + e - 4) -- the pixel order the transpose reads give the A operand
+    int tkh[2], tkw[2]; unsigned tci[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int t = r16 + 16 * f;
+        tkh[f] = t < 27 ? t / 9 : -100000;                         // pad taps never hit the image
+        tkw[f] = (t / 3) % 3;
+        tci[f] = (unsigned)(t % 3);
+    }
+    const unsigned plane = (unsigned)(a.H * a.W);
+
+    auto seg_coords = [&](long s, int& b, int& oh, int& ow0) {
+        const int sx = (int)(s % a.nsegx);
+        const long r = s / a.nsegx;
+        oh = a.oh_lo + (int)(r % a.nrows);
+        b = (int)(r / a.nrows);
+        ow0 = (a.seg_lo + sx) * 32;
+    };
+    auto issue_dma = [&](long s, int stage) {
+        int b, oh, ow0;
+        seg_coords(s, b, oh, ow0);
+        char* sb = ring + stage * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ow = ow0 + 8 * j + rsub;
+            const unsigned v = ow < a.Wo ? (unsigned)(((b * a.Ho + oh) * a.Wo + ow) * 128) + chunkoff : kOOB1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + j * 1024), 16, v, 0, 0, 0);
+        }
+    };
+    auto gather = [&](long s, float (&xv)[2][8]) {
+        int b, oh, ow0;
+        seg_coords(s, b, oh, ow0);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int ih = oh + tkh[f] - a.pad;
+            const bool rok = (unsigned)ih < (unsigned)a.H;
+            const unsigned rowoff = ((unsigned)(b * 3) + tci[f]) * plane + (unsigned)(ih * a.W);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int pix = e < 4 ? 4 * g + e : 16 + 4 * g + e - 4;
+                const int iw = ow0 + pix + tkw[f] - a.pad;
+                const unsigned off = (rok && (unsigned)iw < (unsigned)a.W) ? (rowoff + (unsigned)iw) * 4u : kOOB1;
+                xv[f][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, off, 0, 0));
+            }
+        }
+    };
+
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const long nwaves = (long)gridDim.x * 4;
+    const long s0 = (long)blockIdx.x * 4 + w;
+    // software pipeline per wave: DMA two segments ahead, gather one segment ahead
+    float xn[2][8];
+    if (s0 < a.nseg) { issue_dma(s0, 0); gather(s0, xn); }
+    if (s0 + nwaves < a.nseg) issue_dma(s0 + nwaves, 1);
+    int stage = 0;
+    for (long s = s0; s < a.nseg; s += nwaves) {
+        // pack the gathered taps of this segment (forces the wait for its loads), then start the next gather
+        u32x4_t xf[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            xf[f].x = (uint32_t)f32_to_bf16_bits(xn[f][0]) | ((uint32_t)f32_to_bf16_bits(xn[f][1]) << 16);
+            xf[f].y = (uint32_t)f32_to_bf16_bits(xn[f][2]) | ((uint32_t)f32_to_bf16_bits(xn[f][3]) << 16);
+            xf[f].z = (uint32_t)f32_to_bf16_bits(xn[f][4]) | ((uint32_t)f32_to_bf16_bits(xn[f][5]) << 16);
+            xf[f].w = (uint32_t)f32_to_bf16_bits(xn[f][6]) | ((uint32_t)f32_to_bf16_bits(xn[f][7]) << 16);
+        }
+        const bool more1 = s + nwaves < a.nseg, more2 = s + 2 * nwaves < a.nseg;
+        // gather first, DMA second: the compiler's wait for the gathered values at the top of the next iteration then
+        // leaves the DMA in flight
+        if (more1) gather(s + nwaves, xn);
+        if (more2) issue_dma(s + 2 * nwaves, stage >= 1 ? stage - 1 : 2);      // (stage + 2) % 3: drained last iteration
+        // dout rows of THIS segment: newer in flight = this iteration's DMA (4) + gather (16) and last iteration's DMA (4)
+        if (more2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (more1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* sb = ring + stage * 4096;
+        u32x4_t df[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offA[i]));
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + 2048 + offA[i]));
+            const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+            df[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, df[i]),
+                                                                    __builtin_bit_cast(bf16x8_t, xf[f]), acc[i][f], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // stage drained before it is refilled
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+
+    // ---- block partial: D[co = 16 i + 4 g + e][t = 16 f + r16], waves added in a fixed order ----
+    __syncthreads();
+    float* red = (float*)smem;                                       // [4 waves][64][32] = 32 KiB <= 48 KiB ring
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(w * 64 + 16 * i + 4 * g + e) * 32 + 16 * f + r16] = acc[i][f][e];
+    __syncthreads();
+    float* slab = a.ws + (size_t)blockIdx.x * 2048;
+    for (int idx = tid; idx < 2048; idx += 256)
+        slab[idx] = (red[idx] + red[2048 + idx]) + (red[4096 + idx] + red[6144 + idx]);
+#endif
+}
+
+// dw[co][t] (+)= sum over the block slabs: 8 outputs per block, 32 lanes each striding over the slabs, then a fixed-order
+// shuffle tree (deterministic)
+__global__ __launch_bounds__(256) void conv1_1_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int nblocks,
+                                                            int accumulate) {
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    const bool ok = i < 64 * 27;
+    const int co = ok ? i / 27 : 0, t = ok ? i - co * 27 : 0;
+    float s = 0.f;
+    if (ok)
+        for (int b = l; b < nblocks; b += 32) s += ws[(size_t)b * 2048 + co * 32 + t];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);
+    if (ok && l == 0) dw[i] = accumulate ? dw[i] + s : s;
+}
+
+}  // namespace
+
+// bf16 path of szn_conv1_1_wgrad (szn_elementwise.hip).  workspace: >= nblocks * 8 KiB.  Returns 1 if not applicable.
+int szn_conv1_1_wgrad_fused_try(int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
+                                void* workspace, size_t workspace_bytes, szn_stream_t stream) {
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const size_t dout_bytes = (size_t)B * Ho * Wo * 128, x_bytes = (size_t)B * 3 * H * W * 4;
+    if (dout_bytes >= 0x7fff0000ul || x_bytes >= 0x7fff0000ul) return 1;
+    C11Args a;
+    a.dout = (const char*)dout; a.x = x; a.ws = (float*)workspace;
+    a.dout_bytes = (unsigned)dout_bytes; a.x_bytes = (unsigned)x_bytes;
+    a.B = B; a.H = H; a.W = W; a.pad = pad; a.Ho = Ho; a.Wo = Wo;
+    // output pixel (oh, ow) sees the image iff oh - pad + kh in [0, H) for some kh in 0..2, same for columns
+    int oh_lo = pad - 2; if (oh_lo < 0) oh_lo = 0;
+    int oh_hi = pad + H; if (oh_hi > Ho) oh_hi = Ho;                  // exclusive
+    int ow_lo = pad - 2; if (ow_lo < 0) ow_lo = 0;
+    int ow_hi = pad + W; if (ow_hi > Wo) ow_hi = Wo;
+    if (oh_hi <= oh_lo || ow_hi <= ow_lo) return 1;
+    a.oh_lo = oh_lo; a.nrows = oh_hi - oh_lo;
+    a.seg_lo = ow_lo / 32; a.nsegx = (ow_hi + 31) / 32 - a.seg_lo;
+    a.nseg = (long)B * a.nrows * a.nsegx;
+    long blocks = (a.nseg + 4 * 16 - 1) / (4 * 16);                   // >= 16 segments per wave
+    if (blocks > 768) blocks = 768;
+    if (blocks < 1) blocks = 1;
+    if (workspace_bytes < (size_t)blocks * 2048 * sizeof(float)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv1_1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    SZN_CHECK_LAUNCH("conv1_1_wgrad_kernel");
+    hipLaunchKernelGGL(conv1_1_wgrad_reduce, dim3(64 * 27 / 8), dim3(256), 0, st, (const float*)workspace, dw,
+                       (int)blocks, accumulate);
+    SZN_CHECK_LAUNCH("conv1_1_wgrad_reduce");
+    return SZN_OK;
+}

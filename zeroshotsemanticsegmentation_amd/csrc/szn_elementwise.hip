@@ -362,6 +362,9 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
     return SZN_OK;
 }
 
+int szn_conv1_1_wgrad_fused_try(int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
+                                void* workspace, size_t workspace_bytes, szn_stream_t stream);
+
 extern "C" size_t szn_conv1_1_wgrad_workspace_bytes(int dtype, int B, int H, int W, int pad) {
     if (B <= 0 || H <= 0 || W <= 0 || pad < 0) return 0;
     const size_t Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
@@ -378,6 +381,12 @@ extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const 
     const long M = (long)B * Ho * Wo;
     if (M >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_wgrad: more than 2^31 pixels");
     const size_t es = dtype == SZN_BF16 ? 2 : 4;
+    if (dtype == SZN_BF16) {        // fused kernel: no im2col image, padding-only pixels skipped (szn_conv1_1_wgrad.hip)
+        const int rc = szn_conv1_1_wgrad_fused_try(B, H, W, pad, x, dout, dw, accumulate, workspace,
+                                                   szn_conv1_1_wgrad_workspace_bytes(dtype, B, H, W, pad), stream);
+        if (rc < 0) return rc;
+        if (rc == 0) return db ? szn_bias_grad(dtype, M, 64, 64, dout, db, accumulate, stream) : SZN_OK;
+    }
     float* dw32 = (float*)workspace;                              // [64][32]
     char* xcol = (char*)workspace + 64 * 32 * sizeof(float);      // [M][32] of dtype
     const long chunks = M * (32 / (16 / es));
