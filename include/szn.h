@@ -65,6 +65,10 @@ typedef struct {
     size_t workspace_bytes; /* used when >= B*Ho*Wo*Co*4 bytes (dgrad: B*Hi*Wi*Ci*4); NULL = never split */
     float* colsum;    /* optional f32 [Co] (dgrad: [Ci]): += column sums of the tensor being written, i.e. the
                          bias gradient of the layer that produced the gated input (saves a pass over it)  */
+    void* pool_out;   /* szn_conv2d_fwd only, optional: ALSO write MaxPool2d(2, 2, ceil_mode=True) of the output
+                         (models.py:47,54,63,72,81 follow a ReLU'd conv): [B][ceil(Ho/2)][ceil(Wo/2)][Co], same element
+                         type as out, dense (needs ldo == Co, relu != 0).  Fused into the conv epilogue where the
+                         kernel supports it (the 710^2 / 355^2 layers), else szn_maxpool2x2_ceil_fwd runs behind it */
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )

@@ -101,6 +101,22 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     tol = 1e-5 if dtype == torch.float32 else 1e-2
     assert relerr(got, ref) < tol, ("fwd", relerr(got, ref))
 
+    # ---- fused MaxPool2d(2,2,ceil) of the output (descriptor.pool_out): exactly the pool of the stored tensor
+    if d.ldo == Co:
+        pooled = torch.full((B, (Ho + 1) // 2, (Wo + 1) // 2, Co), float("nan"), device=dev, dtype=dtype)
+        out2 = torch.full_like(out, float("nan"))
+        d.pool_out = pooled.data_ptr()
+        L.call("szn_conv2d_fwd", C.byref(d), L.ptr(xd), L.ptr(wd), L.ptr(bd), None, None, L.ptr(out2), L.stream_ptr())
+        if expect[0] == "conv3x3_regw":
+            assert L.last_kernel() == "conv3x3_regw", L.last_kernel()      # pooled inside the conv epilogue
+        else:
+            assert L.last_kernel() == "maxpool_fwd_kernel", L.last_kernel()
+        d.pool_out = None
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out)
+        pref = F.max_pool2d(out.float().permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
+        assert torch.equal(pooled.float(), pref)
+
     # ---- backward: dout random, gate = x > 0 is applied by the dgrad epilogue
     dout = torch.randn(B, Co, Ho, Wo, generator=g)
     if dtype == torch.bfloat16:

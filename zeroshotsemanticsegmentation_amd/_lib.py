@@ -21,7 +21,7 @@ class SznError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")] + [
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p)]
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p)]
 
 
 class DeviceInfo(C.Structure):

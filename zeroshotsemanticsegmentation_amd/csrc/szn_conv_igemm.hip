@@ -448,9 +448,25 @@ int launch_v2(const Conv2Args& a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out, szn_stream_t stream);
+static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                               const float* chan_scale, void* out, szn_stream_t stream, int* pooled);
+
 extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias,
                               const void* gate, const float* chan_scale, void* out, szn_stream_t stream) {
     if (!d) SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: null descriptor");
+    if (d->pool_out && (!d->relu || d->ldo != d->Co || gate || chan_scale))
+        SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: pool_out needs relu, ldo == Co and no gate / chan_scale");
+    int pooled = 0;
+    const int rc = conv2d_fwd_dispatch(d, in, w, bias, gate, chan_scale, out, stream, &pooled);
+    if (rc || !d->pool_out || pooled) return rc;
+    // the kernel that ran has no fused pooling: pool the tensor it wrote
+    return szn_maxpool2x2_ceil_fwd((d->out_f32 || d->dtype == SZN_F32) ? SZN_F32 : SZN_BF16, d->B, d->Ho, d->Wo, d->Co, out,
+                                   d->pool_out, stream);
+}
+
+static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                               const float* chan_scale, void* out, szn_stream_t stream, int* pooled) {
     const size_t es = d->dtype == SZN_BF16 ? 2 : 4;
     const size_t in_bytes = (size_t)d->B * d->Hi * d->Wi * d->ldi * es;
     const size_t w_bytes = (size_t)d->Co * d->KH * d->KW * d->Ci * es;
@@ -472,6 +488,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
         static int regw_min = -1;
         if (regw_min < 0) { const char* e = getenv("SZN_REGW_MINTILES"); regw_min = e ? atoi(e) : 128; }
         const int rc = szn_conv_regw_try(d, in, w, bias, gate, chan_scale, out, regw_min, stream);
+        if (rc == 0 && d->pool_out) *pooled = 1;        // conv3x3_regw pools in its epilogue
         if (rc <= 0) return rc;
     }
     Conv2Args a;

@@ -29,7 +29,9 @@ namespace {
 
 struct RwArgs {
     const char* in; const char* w; const float* bias; const char* gate; char* out; float* colsum;
+    char* pool;                        // optional: MaxPool2d(2,2,ceil) of the (ReLU'd) output, [B][Hp][Wp][Co] dense
     unsigned in_bytes, gate_bytes;
+    int Hp, Wp;
     int B, Hi, Wi, Ho, Wo, pad;
     int ldi, ldo, ldg, relu;
     int tiles_x, tiles_y, ntiles;      // ntiles = B * tiles_y * tiles_x
@@ -253,8 +255,9 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
         if (NBUF == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SLOTS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float cs[8];
+        float pm[8];                                                       // pooling: the even row of the current row pair
 #pragma unroll
-        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+        for (int e = 0; e < 8; ++e) { cs[e] = 0.f; pm[e] = 0.f; }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const bool ok = okw && oh0 + j < a.Ho;
@@ -285,6 +288,33 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
             pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
             if (ok) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
+            if constexpr (!GATED) {
+                // fused MaxPool2d(2,2,ceil): rows (j, j + 1) pair up in this lane (oh0 is even), columns (ow, ow ^ 1) in
+                // neighbouring lanes; post-ReLU values are >= 0, so out-of-range window members count as 0
+                if (a.pool) {
+                    if ((j & 1) == 0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pm[e] = ok ? v[e] : 0.f;
+                    } else {
+                        float mx[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float m2 = fmaxf(pm[e], ok ? v[e] : 0.f);
+                            const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(m2), 0xB1, 0xF, 0xF, true));
+                            mx[e] = fmaxf(m2, nb);                         // quad_perm [1,0,3,2]: the lane of column ow ^ 1
+                        }
+                        const int poh = (oh0 + j) >> 1, pw = ow >> 1;
+                        if ((r16 & 1) == 0 && okw && poh < a.Hp) {
+                            u32x4_t pq;
+                            pq.x = (uint32_t)f32_to_bf16_bits(mx[0]) | ((uint32_t)f32_to_bf16_bits(mx[1]) << 16);
+                            pq.y = (uint32_t)f32_to_bf16_bits(mx[2]) | ((uint32_t)f32_to_bf16_bits(mx[3]) << 16);
+                            pq.z = (uint32_t)f32_to_bf16_bits(mx[4]) | ((uint32_t)f32_to_bf16_bits(mx[5]) << 16);
+                            pq.w = (uint32_t)f32_to_bf16_bits(mx[6]) | ((uint32_t)f32_to_bf16_bits(mx[7]) << 16);
+                            *(u32x4_t*)(a.pool + ((size_t)((b * a.Hp + poh) * a.Wp + pw) * (32 * COG) + cstart) * 2) = pq;
+                        }
+                    }
+                }
+            }
         }
         if constexpr (COLSUM) {
             float* red = (float*)(smem + G_::OFF_RED) + cstart;
@@ -335,6 +365,7 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     if (d->dtype != SZN_BF16 || d->KH != 3 || d->KW != 3 || d->pad > 2 || d->out_f32 || chan_scale) return 1;
     if ((d->Ci != 64 && d->Ci != 128) || (d->Co != 64 && d->Co != 128)) return 1;
     if ((d->ldo & 7) || (d->ldi & 7) || (gate && (d->ldg & 7))) return 1;
+    if (d->pool_out && (gate || (size_t)d->B * ((d->Ho + 1) / 2) * ((d->Wo + 1) / 2) * d->Co * 2 >= 0xffff0000ul)) return 1;
     const size_t in_bytes = (size_t)d->B * d->Hi * d->Wi * d->ldi * 2;
     const size_t gate_bytes = gate ? (size_t)d->B * d->Ho * d->Wo * d->ldg * 2 : 0;
     if (in_bytes >= 0x7fff0000ul || gate_bytes >= 0x7fff0000ul || (size_t)d->B * d->Ho * d->Wo * d->ldo * 2 >= 0xffff0000ul)
@@ -344,6 +375,7 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     RwArgs a;
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.out = (char*)out;
     a.colsum = d->colsum;
+    a.pool = (char*)d->pool_out; a.Hp = (d->Ho + 1) / 2; a.Wp = (d->Wo + 1) / 2;
     a.in_bytes = (unsigned)in_bytes; a.gate_bytes = (unsigned)gate_bytes;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.pad = d->pad;
     a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg; a.relu = d->relu;

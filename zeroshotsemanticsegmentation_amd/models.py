@@ -162,7 +162,9 @@ class _Engine(object):
         self._versions = v
 
     # ---- kernels ---------------------------------------------------------------------------------
-    def _conv(self, x, name, pad, relu=True, scale=None, out_f32=False, w=None, b=None, co=None, k=None):
+    def _conv(self, x, name, pad, relu=True, scale=None, out_f32=False, w=None, b=None, co=None, k=None, pool=False):
+        """conv (+ bias, ReLU, dropout factor) through szn_conv2d_fwd; pool=True also returns MaxPool2d(2,2,ceil) of the
+        output (the descriptor's pool_out: fused into the epilogue of the kernels that support it)"""
         B, Hi, Wi, Ci = x.shape
         img = self._images
         w = img[name + ".w"] if w is None else w
@@ -173,14 +175,12 @@ class _Engine(object):
         out = torch.empty(B, Ho, Wo, co, device=x.device, dtype=torch.float32 if out_f32 else self.dtype)
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, co, k, k, pad, Ci, co, 0, int(relu), int(out_f32))
         self._workspace(d, B * Ho * Wo * co * 4, x.device)
+        pooled = None
+        if pool:
+            pooled = torch.empty(B, (Ho + 1) // 2, (Wo + 1) // 2, co, device=x.device, dtype=out.dtype)
+            d.pool_out = pooled.data_ptr()
         L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), None, L.ptr(scale), L.ptr(out), L.stream_ptr())
-        return out
-
-    def _pool(self, x):
-        B, Hi, Wi, Cc = x.shape
-        out = torch.empty(B, (Hi + 1) // 2, (Wi + 1) // 2, Cc, device=x.device, dtype=self.dtype)
-        L.call("szn_maxpool2x2_ceil_fwd", L.dtype_code(self.dtype), B, Hi, Wi, Cc, L.ptr(x), L.ptr(out), L.stream_ptr())
-        return out
+        return (out, pooled) if pool else out
 
     def make_masks(self, B, F, device):
         """Dropout2d factors (B,F) in {0, 2} for drop6 / drop7 (models.py:86,91; p = 0.5)"""
@@ -211,13 +211,16 @@ class _Engine(object):
         L.call("szn_conv1_1_fwd", code, B, H, W, PAD1, L.ptr(x), L.ptr(self._images["conv1_1.w"]),
                L.ptr(self._images["conv1_1.b"]), L.ptr(a), L.stream_ptr())
         acts, pools = {"conv1_1": a}, []
-        for item in _BACKBONE[1:]:
+        items = _BACKBONE[1:]
+        for i, item in enumerate(items):
             if item == "P":
-                pin = a
-                a = self._pool(a)
+                continue                                  # pooled by the conv in front of it (pool_out)
+            name, pad = item
+            if i + 1 < len(items) and items[i + 1] == "P":
+                pin, a = self._conv(a, name, pad, pool=True)
+                acts[name] = pin
                 pools.append((pin, a))
             else:
-                name, pad = item
                 a = self._conv(a, name, pad)
                 acts[name] = a
         if train and masks is None:
