@@ -57,7 +57,7 @@ class GradBuckets(object):
 
 class TrainStep(object):
     def __init__(self, model, embeddings, optimizer="adam", lr=1e-5, momentum=0.99, weight_decay=0.0005,
-                 precision=torch.bfloat16, fused_head=True, loss="cos", process_group=None, bucket_mb=64,
+                 precision=torch.bfloat16, fused_head=True, loss="cos", process_group=None, bucket_mb=25,
                  train_metrics=True):
         if loss not in ("cos", "mse") or (fused_head and loss != "cos"):
             raise L.SznError("TrainStep: fused head supports the cosine loss; use fused_head=False for mse")
