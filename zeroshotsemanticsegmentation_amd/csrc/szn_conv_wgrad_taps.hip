@@ -124,17 +124,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
         for (int p = 0; p < 6; ++p) fireB(p, 0);
     }
     int stage = 0;
+    long long tw = 0, ti = 0, tc = 0, c0 = 0, c1 = 0, c2 = 0;   // SZN_WGT_ABLATE=9: cycles in wait+barrier / issue / compute
     for (int t = first; t < last; ++t) {
+        if (a.ablate == 9) c0 = clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (a.ablate == 9) { c1 = clock64(); tw += c1 - c0; }
         const bool fill = t + 1 < last && a.ablate != 1;
-        if (fill) {
-            prepare(t + 1);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) fireA(p, stage ^ 1);
-#pragma unroll
-            for (int p = 0; p < 6; ++p) fireB(p, stage ^ 1);
-        }
+        if (a.ablate == 9) { c2 = clock64(); ti += c2 - c1; }
         const char* sd = smem + stage * STAGEt;
         const char* sp = sd + DOUTB;
         auto rdA = [&](int p, int i) -> u32x4_t {
@@ -157,6 +154,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
         if (a.ablate != 2)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
+            // The fill of tile t + 1 is issued by wave pair p at K step p (p < 4): ten 1-KiB LDS-DMA loads stall their wave
+            // at VMEM issue for ~1800 cycles (SZN_WGT_ABLATE=9), so the waves take turns and the other waves of the
+            // CU -- in particular the SIMD partner w +- 4 -- keep the MFMA pipe busy meanwhile.
+            if (p < 4 && fill && (w >> 1) == p) {
+                prepare(t + 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fireA(q, stage ^ 1);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) fireB(q, stage ^ 1);
+            }
             // rows 2p, 2p + 1 are in Br[0], Br[1]; fetch 2p + 2, 2p + 3 and the dout fragments of this step
 #pragma unroll
             for (int R = 2; R < 4; ++R)
@@ -177,6 +184,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
             for (int kw = 0; kw < 3; ++kw) { Br[0][kw] = Br[2][kw]; Br[1][kw] = Br[3][kw]; }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (a.ablate == 9) tc += clock64() - c2;
         stage ^= 1;
     }
 
@@ -188,6 +196,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
         for (int k = 0; k < 9; ++k)
 #pragma unroll
             for (int e = 0; e < 4; ++e) slab[((i * 9 + k) * 4 + e) * 64] = acc[i][k][e];
+    if (a.ablate == 9 && tid == 0) {                  // debug: the block's cycle split replaces the head of its slab
+        float* dbg = a.ws + (size_t)blockIdx.x * SLAB;
+        dbg[0] = (float)tw; dbg[1] = (float)ti; dbg[2] = (float)tc; dbg[3] = (float)(last - first);
+    }
 #endif
 }
 
