@@ -60,6 +60,7 @@ struct Conv2Args {
     int ldi, ldo, ldg, relu, out_f32;
     int M, HoWo, mtiles, ntiles, nsplit, chunks_per_split;
     int nmajor;                // tile order: 1 = pixel tile fastest (weights larger than activations)
+    int stagger;               // 1: wave pairs take turns issuing a chunk's LDS-DMA loads (SZN_IGEMM_STAGGER=0: all at once)
 };
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
@@ -229,7 +230,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        if (ABL != 1 && kc + 2 < nK) issue(stage >= 1 ? stage - 1 : 2);          // (stage + 2) % 3: last read in iteration kc-1
+        // (stage + 2) % 3 was last read in iteration kc - 1.  Wave pair k issues its LDS-DMA loads behind its k-th weight
+        // fragment: all eight waves stalled at VMEM issue at once (a CU ingests ~64 B of LDS-DMA per clock) would idle the
+        // MFMA pipe for most of a chunk's fill time
+        const bool fill = ABL != 1 && kc + 2 < nK;
+        const int turn = a.stagger ? (w >> 1) : 0;
+        if (fill && turn == 0) issue(stage >= 1 ? stage - 1 : 2);
         const int rstage = (ABL == 3) ? 0 : stage;
         const char* sp = smem + rstage * STAGE + (wm * 64 + r16) * 128;
         const char* sw = smem + rstage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
@@ -242,12 +248,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) pf[j] = *(const u32x4_t*)(sp + j * 16 * 128 + off);
 #pragma unroll
-            for (int i = 0; i < WNF; ++i)
+            for (int i = 0; i < WNF; ++i) {
+                if (s * WNF + i > 0 && s * WNF + i < 4 && fill && turn == s * WNF + i) issue(stage >= 1 ? stage - 1 : 2);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (ABL == 4) { acc[i][j][0] += __uint_as_float(wf[i].x ^ pf[j].x); }
                     else Mma2<T>::run(acc[i][j], wf[i], pf[j]);
                 }
+            }
         }
         if (++stage == 3) stage = 0;
     }
@@ -499,6 +507,7 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
     a.relu = d->relu; a.out_f32 = d->out_f32;
     a.M = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo;
+    { static int stg = -1; if (stg < 0) { const char* e = getenv("SZN_IGEMM_STAGGER"); stg = e ? atoi(e) : 1; } a.stagger = stg; }
     { static int nm = -1; if (nm < 0) { const char* e = getenv("SZN_NMAJOR"); nm = e ? atoi(e) : 0; } a.nmajor = (nm && w_bytes > in_bytes) ? 1 : 0; }   // measured slower on fc6/fc7: off
     const bool narrow = d->Co <= 64;
     const int BN = narrow ? 64 : 128;

@@ -10,6 +10,7 @@
 //   * otherwise identical to conv_igemm_v2: buffer_load ... lds with source-side XOR swizzle, scalar soffset per chunk,
 //     OOB offsets for padding, bias / ReLU / gate / dropout / column-sum epilogue on whole output rows.
 #include "szn_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((address_space(3))) void* ldsptr_t;
@@ -25,6 +26,7 @@ struct WideArgs {
     int M, HoWo, mtiles, ntiles, nmajor;
     float* ws;                 // split-K: fp32 slabs [nsplit][M][Co] (plain stores, no epilogue); nullptr = single pass
     int nsplit, chunks_per_split;
+    int stagger;               // 1: wave pairs take turns issuing the LDS-DMA loads of a chunk (SZN_WIDE_STAGGER=0: all at once)
 };
 
 constexpr unsigned kOOBx = 0x80000000u;
@@ -122,7 +124,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
     for (int kc = kbeg; kc < nK; ++kc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunk kc landed (the only one outstanding)
         __builtin_amdgcn_s_barrier();                             // ... for every wave; everyone left the other stage
-        if (kc + 1 < nK) issue(stage ^ 1);
+        // The eight LDS-DMA loads of a wave stall it at VMEM issue (a CU ingests ~64 B of LDS-DMA per clock: 64 KiB = ~1000
+        // cycles per chunk, half of the chunk's MFMA time): wave pair k issues behind its k-th pair of weight fragments of
+        // the first K half, so the eight waves are never all stalled at once and their SIMD partners keep the MFMA pipe busy.
+        const bool fill = kc + 1 < nK;
+        // turn = the weight-fragment index (of the first K half) behind which this wave issues: stagger 1 -> pairs at
+        // 0, 2, 4, 6; stagger 2 -> every wave its own slot
+        const int turn = a.stagger == 2 ? w : (a.stagger ? 2 * (w >> 1) : 0);
+        if (fill && turn == 0) issue(stage ^ 1);
         const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
         const char* sw = smem + stage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
 #pragma unroll
@@ -134,7 +143,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
 #pragma unroll
             for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + off);
 #pragma unroll
-            for (int i = 0; i < WNF; ++i)
+            for (int i = 0; i < WNF; ++i) {
+                if (s == 0 && i > 0 && i < 8 && fill && turn == i) issue(stage ^ 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if constexpr (ES == 2) {
@@ -147,6 +157,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].w), __uint_as_float(pf[j].w), acc[i][j], 0, 0, 0);
                     }
                 }
+            }
         }
         stage ^= 1;
     }
@@ -304,6 +315,7 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     if (d->Co < 256) return 1;
     WideArgs a;
     a.ws = nsplit > 1 ? ws : nullptr; a.nsplit = nsplit > 1 ? nsplit : 1;
+    { static int stg = -1; if (stg < 0) { const char* e = getenv("SZN_WIDE_STAGGER"); stg = e ? atoi(e) : 1; } a.stagger = stg; }
     a.chunks_per_split = nsplit > 1 ? chunks_per_split : (1 << 30);
     a.M = d->B * d->Ho * d->Wo;
     // cout tile 256, or 320 (bf16) when that wastes fewer columns: the 300-d projection is one 320-wide tile
