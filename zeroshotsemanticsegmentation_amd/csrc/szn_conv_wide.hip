@@ -36,7 +36,8 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <typename T, int WNF>                    // WNF = 16-cout fragments per wave: 8 -> BN = 256, 10 -> BN = 320
+// ABL (debug, SZN_WIDE_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no fragment reads / MFMA
+template <typename T, int WNF, int ABL = 0>       // WNF = 16-cout fragments per wave: 8 -> BN = 256, 10 -> BN = 320
 __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ES = sizeof(T);
@@ -127,13 +128,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
         // The eight LDS-DMA loads of a wave stall it at VMEM issue (a CU ingests ~64 B of LDS-DMA per clock: 64 KiB = ~1000
         // cycles per chunk, half of the chunk's MFMA time): wave pair k issues behind its k-th pair of weight fragments of
         // the first K half, so the eight waves are never all stalled at once and their SIMD partners keep the MFMA pipe busy.
-        const bool fill = kc + 1 < nK;
+        const bool fill = ABL != 1 && kc + 1 < nK;
         // turn = the weight-fragment index (of the first K half) behind which this wave issues: stagger 1 -> pairs at
         // 0, 2, 4, 6; stagger 2 -> every wave its own slot
         const int turn = a.stagger == 2 ? w : (a.stagger ? 2 * (w >> 1) : 0);
         if (fill && turn == 0) issue(stage ^ 1);
         const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
         const char* sw = smem + stage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
+        if constexpr (ABL == 2) { if (fill && turn != 0) issue(stage ^ 1); } else
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int off = s ? offs1 : offs0;
@@ -300,6 +302,19 @@ int launch_wide(const WideArgs& a, hipStream_t st) {
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_wide<T, WNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
+    }
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("SZN_WIDE_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (abl && sizeof(T) == 2 && WNF == 8) {          // debug ablations of the bf16 256 x 256 kernel (wrong results)
+        if (abl == 1) {
+            (void)hipFuncSetAttribute((const void*)conv_igemm_wide<T, WNF, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((conv_igemm_wide<T, WNF, 1>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)conv_igemm_wide<T, WNF, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((conv_igemm_wide<T, WNF, 2>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
+        }
+        SZN_CHECK_LAUNCH("conv_igemm_wide(ablation)");
+        return SZN_OK;
     }
     hipLaunchKernelGGL((conv_igemm_wide<T, WNF>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
     SZN_CHECK_LAUNCH("conv_igemm_wide");
