@@ -245,7 +245,12 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     a.ntiles = (int)nt;
     // pixel splits: one block per CU at most, at least min_tiles_per_block tiles each (the slab write + reduction
     // must amortise), slabs must fit the workspace; too little parallelism left -> conv_wgrad_v2
-    long ns = ncu / ncombo;
+    // SZN_WGT_OVERSUB = k (default 1): k blocks per CU instead of one.  One block per CU is fastest on an idle GPU but its
+    // static partition has a full-kernel tail whenever another queue (an RCCL all-reduce running under the backward
+    // pass) holds CUs: the data-parallel trainer sets k = 2 so that the late blocks are half as long.
+    static int oversub = 0;
+    if (!oversub) { const char* e = getenv("SZN_WGT_OVERSUB"); oversub = e ? atoi(e) : 1; if (oversub < 1) oversub = 1; }
+    long ns = (long)ncu * oversub / ncombo;
     if (min_tiles_per_block < 1) min_tiles_per_block = 1;
     if (ns > nt / min_tiles_per_block) ns = nt / min_tiles_per_block;
     const size_t slab_bytes = (size_t)ncombo * SLAB * sizeof(float);
