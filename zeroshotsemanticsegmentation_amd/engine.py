@@ -9,8 +9,6 @@ module's Parameters are channels_last views into them), the head runs fused from
 (szn_fused_head) and the per-layer gradient buckets are all-reduced on RCCL's stream while the rest of the
 backward pass is still running.
 """
-import os
-
 import torch
 import torch.distributed as dist
 
@@ -77,10 +75,6 @@ class TrainStep(object):
         self.fused_head, self.loss_kind = fused_head, loss
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        if self.world > 1:
-            # the all-reduce kernels of the fc6 bucket hold CUs for ~3 ms of the backward pass: give the persistent
-            # all-taps wgrad kernel two blocks per CU so that its late blocks are half as long (read once by the library)
-            os.environ.setdefault("SZN_WGT_OVERSUB", "2")
         self.train_metrics = train_metrics
         self.nstep = 0
         self._flatten()
