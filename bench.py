@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--embed-dim", type=int, default=300)
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--unfused-head", action="store_true", help="materialise the (B,E,H,W) score like the reference")
+    ap.add_argument("--phase", choices=["fcn", "seenmask"], default="fcn",
+                    help="fcn = phase 1 (the headline train step); seenmask = phase 2 (BASELINE configs[2]: frozen backbone, "
+                         "seen-mask head + 2-class cross entropy, trainer_seenmask.py:72-102)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     return ap.parse_args()
@@ -110,9 +113,38 @@ def main():
     model = models.FCN32s(n_class=E)
     model.load_synthetic(1337, device=dev)
     model.train()
-    ts = engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=not args.unfused_head)
     x = torch.from_numpy(synth.make_images(B, H, H, seed=1337 + rank)).to(dev)
     target = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337 + rank)).to(dev)
+    if args.phase == "fcn":
+        ts = engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=not args.unfused_head)
+    else:
+        # phase 2 (train.py:164-175): everything frozen except seenmask_score (w, b) and seenmask_upscore (w); binary target
+        # "label is a seen class" with unlabelled pixels = 0 (trainer_seenmask.py:55-56); 2-class CE, size_average=True
+        from zeroshotsemanticsegmentation_amd import optim as szn_optim, utils as szn_utils
+        if world > 1:
+            raise SystemExit("--phase seenmask is a single-GPU line (98 KB of gradients)")
+        model.set_precision(dtype)
+        for p in model.parameters():
+            p.requires_grad = False
+        head = [model.seenmask_score.weight, model.seenmask_score.bias, model.seenmask_upscore.weight]
+        for p in head:
+            p.requires_grad = True
+        opt2 = szn_optim.FusedAdam(head, lr=1e-5)
+        unseen = (16, 18)                                             # cfg 18 split of the pascal classes
+        lut = torch.ones(K + 1, dtype=torch.int64, device=dev)
+        lut[list(unseen)] = 0
+        lut[K] = 0
+        bin_target = lut[torch.where(target >= 0, target, torch.full_like(target, K))]
+
+        class _Phase2(object):
+            def step(self, xx, tt):
+                score = model(xx, mode="seenmask")
+                loss = szn_utils.cross_entropy2d(score, bin_target, size_average=True)
+                opt2.zero_grad()
+                loss.backward()
+                opt2.step()
+                return loss.detach(), szn_utils.channel_argmax(score)
+        ts = _Phase2()
 
     # ---- kernel-level timing of the dominant kernel family (conv fwd/dgrad) with HIP events on the launch stream ----
     events, flops_per_step = [], [0.0]
@@ -163,9 +195,12 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: FCN32s (the reference has no FCN8s) + %d-d pixel projection, "
-                                   "%dx%d, K=%d, Adam lr 1e-5, train step fwd+cosine loss+infer_lbl+bwd+optimizer" % (E, H, H, K),
-                       "per_gpu_batch": B, "global_batch": B * world, "head": "unfused" if args.unfused_head else "fused-from-coarse",
+            "config": {"workload": ("BASELINE configs[1]: FCN32s (the reference has no FCN8s) + %d-d pixel projection, "
+                                    "%dx%d, K=%d, Adam lr 1e-5, train step fwd+cosine loss+infer_lbl+bwd+optimizer" % (E, H, H, K))
+                       if args.phase == "fcn" else
+                       ("BASELINE configs[2] (phase 2): seen-mask head on the frozen FCN32s backbone, %dx%d, K=%d, 2-class CE, "
+                        "train step fwd+CE+argmax+head bwd+Adam" % (H, H, K)),
+                       "per_gpu_batch": B, "global_batch": B * world, "head": ("unfused" if args.unfused_head else "fused-from-coarse") if args.phase == "fcn" else "seenmask_score + learned 64x64 s32 deconv",
                        "parallelism": "dp%d" % world, "final_loss": round(lossv, 5)},
         }
         if events:
@@ -177,7 +212,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
-                if tj.get("per_gpu_batch") == B and tj.get("precision") == args.precision and H == 512 and E == 300:
+                if tj.get("per_gpu_batch") == B and tj.get("precision") == args.precision and H == 512 and E == 300 and args.phase == "fcn":
                     traffic = round(tj["hbm_bytes_per_launch"])
             out["roofline"] = {"bound": "mfma", "kernel": "conv fwd + dgrad launches (conv_igemm_v2 | conv_igemm_wide | conv3x3_regw; fc6 dgrad = wide GEMM + col2im)",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -186,7 +221,7 @@ def main():
                                "gflop_per_launch": round(fl / len(events) / 1e9, 2),
                                "share_of_step": round(ms / (dt * 1e3), 3)}
             # whole-step MFMA-class algorithmic FLOPs (4.342 MFLOP/px at 512^2, E=300)
-            if H == 512 and E == 300:
+            if H == 512 and E == 300 and args.phase == "fcn":
                 out["roofline"]["step_mfma_frac"] = round(4.342e6 * B * H * H * args.steps / dt / 1e12 / peak, 4)
         if world == 1 and not args.no_cpu_baseline:
             try:
