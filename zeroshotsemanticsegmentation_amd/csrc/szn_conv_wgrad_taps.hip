@@ -203,21 +203,37 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
 #endif
 }
 
-// dw[co][tap][ci] (+)= sum over the pixel splits of one (cot, cit) combo, in split order
+// dw[co][tap][ci] (+)= sum over the pixel splits of one (cot, cit) combo.  A thread owns 4 consecutive slab elements
+// (= 4 consecutive cins) and adds the splits with four independent running sums (fixed order: bit-reproducible), so
+// that enough 16-B loads are in flight to stream the slabs at HBM rate.
 __global__ __launch_bounds__(256) void wgrad_taps_reduce(WtArgs a) {
     const int ncombo = a.cotiles * a.citiles;
-    const long total = (long)ncombo * SLAB;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int combo = (int)(idx / SLAB), el = (int)(idx - (long)combo * SLAB);
+    const long total4 = (long)ncombo * (SLAB / 4);
+    const size_t stride = (size_t)ncombo * SLAB;                     // block id = split * ncombo + combo
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int combo = (int)(idx / (SLAB / 4)), el = (int)(idx - (long)combo * (SLAB / 4)) * 4;
         const int cit = combo % a.citiles, cot = combo / a.citiles;
-        const float* p = a.ws + (size_t)combo * SLAB + el;            // block id = split * ncombo + combo
-        float s = 0.f;
-        for (int sp = 0; sp < a.nsplit; ++sp) s += p[(size_t)sp * ncombo * SLAB];
-        const int w = el / 4608, f = (el >> 8) % 18, e = (el >> 6) & 3, lane = el & 63;
+        const float* p = a.ws + (size_t)combo * SLAB + el;
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        int sp = 0;
+        for (; sp + 4 <= a.nsplit; sp += 4) {
+            s0 += *(const f32x4_t*)(p + (size_t)sp * stride);
+            s1 += *(const f32x4_t*)(p + (size_t)(sp + 1) * stride);
+            s2 += *(const f32x4_t*)(p + (size_t)(sp + 2) * stride);
+            s3 += *(const f32x4_t*)(p + (size_t)(sp + 3) * stride);
+        }
+        for (; sp < a.nsplit; ++sp) s0 += *(const f32x4_t*)(p + (size_t)sp * stride);
+        const f32x4_t s = (s0 + s1) + (s2 + s3);
+        const int w = el / 4608, f = (el >> 8) % 18, e = (el >> 6) & 3, lane = el & 63;      // lane .. lane + 3: same row g
         const int h = w >> 2, c = w & 3, i = f / 9, tap = f - i * 9;
         const int co = cot * 64 + h * 32 + i * 16 + (lane >> 4) * 4 + e, ci = cit * 64 + c * 16 + (lane & 15);
         float* dst = a.dw + ((long)co * 9 + tap) * a.Ci + ci;
-        *dst = a.accumulate ? *dst + s : s;
+        if (a.accumulate) {
+            const f32x4_t o = *(const f32x4_t*)dst;
+            *(f32x4_t*)dst = o + s;
+        } else {
+            *(f32x4_t*)dst = s;
+        }
     }
 }
 
@@ -228,7 +244,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
                             int min_tiles_per_block, szn_stream_t stream) {
     if (d->dtype != SZN_BF16 || d->KH != 3 || d->KW != 3 || (d->Ci & 63) || (d->Co & 63) || d->pad > 2 || !d->workspace)
         return 1;
-    if ((d->ldi & 7) || (d->ldo & 7)) return 1;
+    if ((d->ldi & 7) || (d->ldo & 7) || ((uintptr_t)dw & 15) || ((uintptr_t)d->workspace & 15)) return 1;
     WtArgs a;
     a.cotiles = d->Co / 64; a.citiles = d->Ci / 64;
     const int ncombo = a.cotiles * a.citiles;
@@ -271,8 +287,8 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     }
     hipLaunchKernelGGL(conv_wgrad_taps, dim3((unsigned)(ns * ncombo)), dim3(512), LDS_WT, st, a);
     SZN_CHECK_LAUNCH("conv_wgrad_taps");
-    const long total = (long)ncombo * SLAB;
-    hipLaunchKernelGGL(wgrad_taps_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    const long total4 = (long)ncombo * (SLAB / 4);
+    hipLaunchKernelGGL(wgrad_taps_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a);
     SZN_CHECK_LAUNCH("wgrad_taps_reduce");
     return SZN_OK;
 }
