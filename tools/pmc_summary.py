@@ -21,7 +21,7 @@ def main():
         with open(d.rstrip('/') + '/pmc_counter_collection.csv') as f:
             for row in csv.DictReader(f):
                 k = short(row['Kernel_Name'])
-                if not any(t in k for t in ('conv_', 'bias_grad', 'maxpool', 'adam', 'fh_', 'im2col', 'pack_dgrad')):
+                if not any(t in k for t in ('conv_', 'conv3x3', 'conv1_1', 'col2im', 'bias_grad', 'maxpool', 'adam', 'fh_', 'im2col', 'pack_dgrad')):
                     continue
                 key = (k, int(row['Grid_Size']))
                 acc[key][row['Counter_Name']].append(float(row['Counter_Value']))
