@@ -48,6 +48,7 @@ def lib():
         _lib.szo_cosine_loss.restype = C.c_double
         _lib.szo_mse_loss.restype = C.c_double
         _lib.szo_ce2d.restype = C.c_double
+        _lib.szo_fused_head.restype = C.c_double
     return _lib
 
 
@@ -336,6 +337,24 @@ def infer_lbl_forced_unseen(score, target, embed, unseen):
     pred = np.empty((B, H, W), np.int64)
     lib().szo_embed_argmax(B, E, H * W, embed.shape[0], _p(score), _p(embed), 1, C.c_uint64(bits(unseen)), None, _p(t), _p(pred))
     return pred
+
+
+def fused_head(coarse, embed, target, H, W, n_class=None, c0=0, crop=19, want_grad=True, want_pred=True):
+    """The fused-from-coarse head of the training step (csrc/szn_fused_head.hip) restated: coarse (B,h,w,ldc) f32
+    NHWC projection map -> (loss, stats (B,2), pred (B,H,W) int64, dcoarse (B,h,w,ldc) f32 with channels [c0,c0+E) filled).
+    Same math as deconv_fwd(diag) -> cosine_loss -> infer_lbl (models.py:146-147, utils.py:75-102,159-185), different
+    rounding order; pred follows the kernel's arithmetic contract bit for bit (see szn_oracle_head.c)."""
+    coarse, embed = _c(coarse), _c(embed)
+    B, h, w, ldc = coarse.shape
+    K, E = embed.shape
+    if n_class is not None:
+        assert n_class == E
+    t = None if target is None else _c(target, np.int64)
+    stats = np.zeros((B, 2), np.float32)
+    pred = np.empty((B, H, W), np.int64) if want_pred else None
+    dc = np.zeros_like(coarse) if (want_grad and t is not None) else None
+    loss = lib().szo_fused_head(B, h, w, E, ldc, c0, H, W, crop, K, _p(coarse), _p(embed), _p(t), _p(stats), _p(pred), _p(dc))
+    return np.float32(loss), stats, pred, dc
 
 
 def confusion_hist(label_trues, label_preds, n_class, unseen=None):

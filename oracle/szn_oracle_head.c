@@ -201,3 +201,142 @@ void szo_confusion_hist(long n, int K, const int64_t* lt, const int64_t* lp, uin
         if (unseen_bits) hist[(size_t)(((unseen_bits >> t) & 1ull) ? 2 : 1) * K * K + t * K + p] += 1;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * szo_fused_head: CPU restatement of the fused-from-coarse head the training step runs
+ * (csrc/szn_fused_head.hip): bilinear x32 upsample + crop (models.py:146-147), cosine loss (utils.py:75-102),
+ * infer_lbl (utils.py:159-185), evaluated per 32x32 output cell from the four coarse vectors C_t that every
+ * pixel of the cell blends:   s.e_k = sum_t w_t (C_t.e_k) = sum_t w_t G[t][k],   |s|^2 = sum_tu w_t w_u Q[t][u].
+ *
+ * Arithmetic contract for the class assignment (bit-exact with the kernel):
+ *   G[t][k]  fmaf chain over the channel index, ascending, from 0.f
+ *   Q[t][u]  64 strided partial chains (channel c goes to partial c % 64, ascending) combined by the
+ *            xor-butterfly 32,16,8,4,2,1 (what a 64-lane wave reduction computes in lane 0)
+ *   w_t      float( double(1-|ty-31.5|/32 ...) products ), ss = fmaf chain over (t,u) of (w_t*w_u) * Q[t][u],
+ *            sim_k = (fmaf chain over t of w_t*G[t][k]) / (sqrtf(ss) * en_k), en_k = ||e_k|| with 0 -> 1, first index
+ *            wins ties.
+ * The loss / gradient reductions are done here in double (the kernel uses fixed-order float / double trees):
+ * compared with tolerances, not bit-exactly.
+ * dcoarse: (B,h,w,ldc) float, only channels [c0, c0+E) written (others left untouched), may be NULL.          */
+static float wave_tree64(float* v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        float n[64];
+        for (int i = 0; i < 64; ++i) n[i] = v[i] + v[i ^ o];
+        memcpy(v, n, sizeof(n));
+    }
+    return v[0];
+}
+
+static double fh_bil1d(int t) { return 1.0 - fabs((double)t - 31.5) / 32.0; }
+
+double szo_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K, const float* coarse,
+                      const float* embed, const int64_t* target, float* stats, int64_t* pred, float* dcoarse) {
+    float* en = (float*)malloc((size_t)K * sizeof(float));
+    float* ent = (float*)malloc((size_t)K * sizeof(float));
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (int c = 0; c < E; ++c) s = fmaf(embed[(size_t)k * E + c], embed[(size_t)k * E + c], s);
+        ent[k] = sqrtf(s);
+        en[k] = (ent[k] == 0.f) ? 1.f : ent[k];
+    }
+    const int cells_w = w + 1, cells = (h + 1) * cells_w;
+    double* cs = (double*)calloc((size_t)B * cells * 2, sizeof(double));          /* per cell: sum cos, count */
+    double* dC = dcoarse ? (double*)calloc((size_t)B * cells * 4 * E, sizeof(double)) : NULL;   /* per cell, per tap */
+#pragma omp parallel for collapse(2) schedule(dynamic)
+    for (int b = 0; b < B; ++b)
+        for (int cell = 0; cell < cells; ++cell) {
+            const int I = cell / cells_w, J = cell % cells_w;
+            float* Ct = (float*)calloc((size_t)4 * E, sizeof(float));
+            float G[4][64], Q[16];
+            for (int t = 0; t < 4; ++t) {
+                const int ci = I - 1 + (t >> 1), cj = J - 1 + (t & 1);
+                if (ci >= 0 && ci < h && cj >= 0 && cj < w)
+                    for (int c = 0; c < E; ++c) Ct[t * E + c] = coarse[(((size_t)b * h + ci) * w + cj) * ldc + c0 + c];
+            }
+            for (int t = 0; t < 4; ++t)
+                for (int k = 0; k < K; ++k) {
+                    float g = 0.f;
+                    for (int c = 0; c < E; ++c) g = fmaf(Ct[t * E + c], embed[(size_t)k * E + c], g);
+                    G[t][k] = g;
+                }
+            for (int t = 0; t < 4; ++t)
+                for (int u = 0; u < 4; ++u) {
+                    float part[64];
+                    for (int l = 0; l < 64; ++l) {
+                        float q = 0.f;
+                        for (int c = l; c < E; c += 64) q = fmaf(Ct[t * E + c], Ct[u * E + c], q);
+                        part[l] = q;
+                    }
+                    Q[t * 4 + u] = wave_tree64(part);
+                }
+            double* dc = dC ? dC + ((size_t)b * cells + cell) * 4 * E : NULL;
+            double csum = 0.0, cnt = 0.0;
+            for (int ty = 0; ty < 32; ++ty)
+                for (int tx = 0; tx < 32; ++tx) {
+                    const int y = 32 * I + ty - crop, x = 32 * J + tx - crop;
+                    if (y < 0 || y >= H || x < 0 || x >= W) continue;
+                    const double fy1 = fh_bil1d(ty), fy0 = fh_bil1d(ty + 32), fx1 = fh_bil1d(tx), fx0 = fh_bil1d(tx + 32);
+                    const float wt[4] = {(float)(fy0 * fx0), (float)(fy0 * fx1), (float)(fy1 * fx0), (float)(fy1 * fx1)};
+                    float ss = 0.f;
+                    for (int t = 0; t < 4; ++t)
+                        for (int u = 0; u < 4; ++u) ss = fmaf(wt[t] * wt[u], Q[t * 4 + u], ss);
+                    const float sn = sqrtf(ss);
+                    const size_t pix = ((size_t)b * H + y) * W + x;
+                    if (pred) {
+                        int best = 0;
+                        float bv = 0.f;
+                        for (int k = 0; k < K; ++k) {
+                            float d = 0.f;
+                            for (int t = 0; t < 4; ++t) d = fmaf(wt[t], G[t][k], d);
+                            const float sim = d / (sn * en[k]);
+                            if (k == 0 || sim > bv) { bv = sim; best = k; }
+                        }
+                        pred[pix] = best;
+                    }
+                    const int64_t lbl = target ? target[pix] : -1;
+                    if (lbl < 0) continue;
+                    const int kl = lbl < K ? (int)lbl : 0;
+                    float d = 0.f;
+                    for (int t = 0; t < 4; ++t) d = fmaf(wt[t], G[t][kl], d);
+                    const float nt = ent[kl];
+                    const float cosv = d / (sn * nt);
+                    csum += (double)cosv;
+                    cnt += 1.0;
+                    if (dc) {
+                        /* d(-cos)/ds = cos * s/|s|^2 - e/(|s||e|), s = sum_t w_t C_t; dC_t += w_t * that */
+                        const double aco = 1.0 / ((double)sn * (double)nt), bco = (double)cosv / (double)ss;
+                        for (int c = 0; c < E; ++c) {
+                            double s = 0.0;
+                            for (int t = 0; t < 4; ++t) s += (double)wt[t] * (double)Ct[t * E + c];
+                            const double gs = bco * s - aco * (double)embed[(size_t)kl * E + c];
+                            for (int t = 0; t < 4; ++t) dc[t * E + c] += (double)wt[t] * gs;
+                        }
+                    }
+                }
+            cs[((size_t)b * cells + cell) * 2] = csum;
+            cs[((size_t)b * cells + cell) * 2 + 1] = cnt;
+            free(Ct);
+        }
+    double total = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s = 0.0, n = 0.0;
+        for (int cell = 0; cell < cells; ++cell) { s += cs[((size_t)b * cells + cell) * 2]; n += cs[((size_t)b * cells + cell) * 2 + 1]; }
+        if (stats) { stats[2 * b] = (float)s; stats[2 * b + 1] = (float)n; }
+        total += (n - s) / n;
+        if (dcoarse) {
+            const double scale = 1.0 / ((double)B * n);
+            for (int i = 0; i < h; ++i)
+                for (int j = 0; j < w; ++j)
+                    for (int c = 0; c < E; ++c) {
+                        double acc = 0.0;
+                        for (int u = 0; u < 4; ++u) {      /* position (i,j) is tap u of cell (i+1-(u>>1), j+1-(u&1)) */
+                            const int I = i + 1 - (u >> 1), J = j + 1 - (u & 1);
+                            acc += dC[(((size_t)b * cells + I * cells_w + J) * 4 + u) * E + c];
+                        }
+                        dcoarse[(((size_t)b * h + i) * w + j) * ldc + c0 + c] = (float)(acc * scale);
+                    }
+        }
+    }
+    free(en); free(ent); free(cs); free(dC);
+    return target ? total / B : 0.0;
+}

@@ -1,0 +1,479 @@
+"""Parity of the HIP path at BASELINE's full sizes and on every BASELINE configuration (GPU box).
+
+  configs[0]  cfg 1: PASCAL-VOC 21-class softmax FCN32s, 256x256, CE-sum + SGD lr 1e-10 (reference configs.py:4-16,
+              train.py:126-129)                                          -> test_cfg1_*
+  configs[1]  512x512, E = 300, K = 21 pascal matrix                      -> test_fused_head_bit_exact_vs_oracle, bf16 layers
+  configs[2]  PASCAL-Context 59 classes (49 seen / 10 unseen, synthetic 59 x 300 matrix of SURVEY 8-d), 512x512:
+              phase 1 and the seen-mask phase (trainer_seenmask.py:50-70) -> test_k59_*, test_fullsize_train_step_*,
+                                                                             test_fullsize_seenmask_step_*
+  configs[4]  768x768 (fp32 forward vs oracle, bf16 train step)           -> test_768_*
+
+What is compared with what:
+  * the fused-from-coarse head the training step runs (szn_fused_head) against its CPU restatement oracle.fused_head:
+    class assignment BIT-EXACT, loss / gradient to rounding; and against the reference-shaped oracle sequence
+    (upsample -> infer_lbl): differing pixels are reported and must all be near-ties (top-2 cosine margin < 1e-5);
+  * one full fp32 training step at 512x512, E = 300 against FCN32sOracle.forward/backward: every layer's weight and
+    bias gradient (sum / abs-sum / square-sum statistics and a 64-element probe), tolerance 1e-3 (north star);
+  * every BASELINE layer shape in bf16 (the throughput path): forward, dgrad and wgrad against torch's fp32 CPU
+    convolution of the same bf16-rounded operands (independent of both the HIP code and the oracle).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import szn_oracle as O  # noqa: E402
+from zeroshotsemanticsegmentation_amd import _lib as L  # noqa: E402
+from zeroshotsemanticsegmentation_amd import engine, models, optim, synth, utils  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+SEEN59, UNSEEN59 = list(range(49)), list(range(49, 59))            # seen 0..48, unseen 49..58
+TRAIN_UNSEEN59 = [49, 50]                                          # phase-2 split of the unseen classes
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+def stats(a):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    return np.array([a.sum(), np.abs(a).sum(), (a * a).sum()])
+
+
+def probe_idx(n, cnt=64):
+    return (np.arange(cnt, dtype=np.int64) * 2654435761 % n).astype(np.int64)
+
+
+def cosine_margins(f, emb):
+    """top-2 cosine margin per pixel of an (1,E,H,W) score, float64 (zero rows -> norm 1 like utils.py:175)"""
+    E = f.shape[1]
+    sc = f[0].reshape(E, -1).T.astype(np.float64)
+    en = np.linalg.norm(emb.astype(np.float64), axis=1)
+    en[en == 0] = 1.0
+    sim = sc @ emb.astype(np.float64).T / (np.linalg.norm(sc, axis=1, keepdims=True) * en[None, :])
+    top2 = np.sort(sim, axis=1)[:, -2:]
+    return (top2[:, 1] - top2[:, 0]).reshape(f.shape[2:])
+
+
+def oracle_params(m):
+    return {k: v.detach().cpu().numpy() for k, v in m.named_parameters() if k.split(".")[0] != "upscore"}
+
+
+# ----------------------------------------------------------------------------------------------- fused head vs oracle
+@pytest.mark.parametrize("case", [(1, 17, 17, 300, 21, 512, 512), (1, 17, 17, 300, 59, 512, 512),
+                                  (2, 3, 4, 20, 33, 70, 101), (2, 2, 2, 20, 59, 32, 32), (1, 25, 25, 300, 59, 768, 768)])
+def test_fused_head_bit_exact_vs_oracle(case):
+    B, h, w, E, K, H, W = case
+    CP = (E + 2 + 63) // 64 * 64
+    emb = np.load(os.path.join(G, "embeddings_pascal_300.npy")) if (K, E) == (21, 300) else synth.make_embeddings(K, E)
+    coarse = np.zeros((B, h, w, CP), np.float32)
+    coarse[..., :E + 2] = synth.uniform(71 + K, (B, h, w, E + 2), -2, 2)
+    target = synth.make_labels(B, H, W, K, seed=72 + K)
+    c, e, t = cu(coarse), cu(emb), cu(target)
+    ws = torch.empty(L.load().szn_fused_head_workspace_bytes(B, h, w, E, K), dtype=torch.uint8, device="cuda")
+    loss = torch.empty(1, device="cuda"); st = torch.empty(B, 2, device="cuda")
+    pred = torch.empty(B, H, W, dtype=torch.int64, device="cuda")
+    dc = torch.zeros(B, h, w, CP, device="cuda")
+    L.call("szn_fused_head", B, h, w, E, CP, 0, H, W, 19, K, L.ptr(c), L.ptr(e), L.ptr(t), L.ptr(loss), L.ptr(st),
+           L.ptr(pred), L.SZN_F32, L.ptr(dc), L.ptr(ws), L.stream_ptr())
+    torch.cuda.synchronize()
+    oloss, ost, opred, odc = O.fused_head(coarse, emb, target, H, W)
+    got = pred.cpu().numpy()
+    assert np.array_equal(got, opred), "fused head class assignment differs from its CPU restatement on %d px" % int((got != opred).sum())
+    assert abs(loss.item() - float(oloss)) < 1e-6 * max(1.0, abs(float(oloss)))
+    assert np.array_equal(st[:, 1].cpu().numpy(), ost[:, 1])
+    assert rel(dc[..., :E], odc[..., :E]) < 1e-4
+    # against the reference-shaped sequence (materialised score -> infer_lbl): near-ties only
+    if B == 1:
+        cf = np.ascontiguousarray(coarse[..., :E].transpose(0, 3, 1, 2))
+        f = O.deconv_fwd(cf, np.broadcast_to(O.get_upsampling_weight(1, 1, 64)[0, 0], (E, 64, 64)), H, W, diag=True)
+        pref = O.infer_lbl(f, emb)
+        bad = got != pref
+        rate = float(bad.mean())
+        print("fused vs unfused oracle argmax: %d / %d px differ (%.2e)" % (int(bad.sum()), bad.size, rate))
+        assert rate < 1e-3
+        if bad.any():
+            assert cosine_margins(f, emb)[bad[0]].max() < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- K = 59 at 512 x 512
+@pytest.fixture(scope="module")
+def score59():
+    """a realistic (1,300,512,512) score: bilinear x32 of a random 17x17 projection map, made by the HIP kernel"""
+    E, K, H = 300, 59, 512
+    CP = 320
+    emb = synth.make_embeddings(K, E)
+    coarse = np.zeros((1, 17, 17, CP), np.float32)
+    coarse[..., :E] = synth.uniform(501, (1, 17, 17, E), -2, 2)
+    f = torch.empty(1, E, H, H, device="cuda")
+    L.call("szn_bilinear_up32_crop_fwd", 1, 17, 17, E, CP, 0, H, H, 19, L.ptr(cu(coarse)), L.ptr(f), L.stream_ptr())
+    torch.cuda.synchronize()
+    target = synth.make_labels(1, H, H, K, seed=502)
+    seenmask = synth.uniform(503, (1, 2, H, H), -1, 1)
+    seenmask[0, :, ::7, ::5] = 0.25                                  # exact two-channel ties (the !(s1 > s0) rule)
+    return emb, f, target, seenmask
+
+
+def test_k59_embed_argmax_modes_bit_exact(score59):
+    emb, f, target, seenmask = score59
+    fn = f.cpu().numpy()
+    cf = np.ascontiguousarray(synth.uniform(501, (1, 17, 17, 300), -2, 2).transpose(0, 3, 1, 2))
+    assert rel(fn, O.deconv_fwd(cf, np.broadcast_to(O.get_upsampling_weight(1, 1, 64)[0, 0], (300, 64, 64)), 512, 512,
+                                diag=True)) < 1e-5
+
+    def masked(rows):
+        m = np.zeros_like(emb)
+        m[rows] = emb[rows]
+        return m
+
+    e = cu(emb)
+    se, ue = cu(masked(SEEN59)), cu(masked(UNSEEN59))
+    checks = [
+        ("all", utils.infer_lbl(f, e, True), O.infer_lbl(fn, emb)),
+        ("seen_only", utils.infer_lbl(f, se, True), O.infer_lbl(fn, masked(SEEN59))),
+        ("unseen_only", utils.infer_lbl(f, ue, True), O.infer_lbl(fn, masked(UNSEEN59))),
+        ("szn", utils.infer_lbl_szn(f, cu(seenmask), se, ue, True), O.infer_lbl_szn(fn, seenmask, emb, UNSEEN59)),
+        ("forced", utils.infer_lbl_forced_unseen(f, cu(target), se, ue, UNSEEN59, True),
+         O.infer_lbl_forced_unseen(fn, target, emb, UNSEEN59)),
+    ]
+    for key, got, want in checks:
+        assert got.dtype == np.int64 and got.shape == want.shape
+        assert np.array_equal(got, want), "%s: %d px differ" % (key, int((got != want).sum()))
+    # the stitched prediction really uses both groups
+    szn = checks[3][1]
+    assert (szn >= 49).any() and (szn < 49).any()
+
+
+def test_k59_cosine_loss_fullsize(score59):
+    emb, f, target, _ = score59
+    s = f.clone().requires_grad_(True)
+    loss = utils.cosine_loss(s, cu(target), cu(emb))
+    loss.backward()
+    oloss, ods, _ = O.cosine_loss(f.cpu().numpy(), target, embed=emb)
+    assert abs(loss.item() - float(oloss)) < 1e-5 * max(1.0, abs(float(oloss)))
+    assert rel(s.grad, ods) < 1e-5
+    # histogram of the K = 59 prediction with the seen / unseen split
+    pred = utils.infer_lbl_device(f, cu(emb))
+    h = utils.confusion_hist_device(cu(target), pred, 59, unseen=UNSEEN59).cpu().numpy()
+    assert np.array_equal(h, O.confusion_hist(target, pred.cpu().numpy(), 59, unseen=UNSEEN59))
+
+
+# ----------------------------------------------------------------------------------------------- full train steps vs oracle
+class _Full(object):
+    pass
+
+
+@pytest.fixture(scope="module")
+def full512():
+    """one oracle forward (both heads) at 512x512, E = 300, with Dropout2d masks, shared by the phase-1 and phase-2 tests"""
+    E, K, H = 300, 59, 512
+    S = _Full()
+    S.E, S.K, S.H = E, K, H
+    S.emb = synth.make_embeddings(K, E)
+    S.x = synth.make_images(1, H, H, seed=31)
+    S.target = synth.make_labels(1, H, H, K, seed=32, classes=SEEN59)      # phase 1 trains on seen-only images
+    S.target_all = synth.make_labels(1, H, H, K, seed=33)                    # phase 2 sees every class
+    m = models.FCN32s(E)
+    m.load_synthetic(1337, device=torch.device("cuda"))                      # seeded on-device init (fast)
+    S.state = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.startswith("upscore")}
+    S.m = m
+    eng = m._engine
+    calls = eng.dropout_calls
+    mk = eng.make_masks(1, 4096, torch.device("cuda"))
+    eng.dropout_calls = calls                                                # the next train-mode forward redraws exactly these
+    S.masks = [t.cpu().numpy() for t in mk]
+    S.om = O.FCN32sOracle(oracle_params(m), E)
+    S.of, S.os = S.om.forward(S.x, "both", masks=S.masks, keep=True)
+    return S
+
+
+def _restore(S):
+    sd = S.m.state_dict()
+    with torch.no_grad():
+        for k, v in S.state.items():
+            sd[k].copy_(v)
+    S.m._engine.mark_dirty()
+
+
+def test_fullsize_seenmask_step_vs_oracle(full512):
+    """BASELINE configs[2], phase 2 (trainer_seenmask.py:50-70, train.py:164-175) at 512x512 with the 59-class split"""
+    S = full512
+    m = S.m
+    _restore(S)
+    m.train()
+    for p in m.parameters():
+        p.requires_grad = False
+    head = list(m.seenmask_score.parameters()) + list(m.seenmask_upscore.parameters())
+    for p in head:
+        p.requires_grad = True
+    try:
+        seen = [k for k in range(S.K) if k not in TRAIN_UNSEEN59]
+        bin_t = np.isin(S.target_all, seen).astype(np.int64)                 # -1 -> 0 ("unseen"), not ignored (:55-56)
+        assert bin_t[S.target_all < 0].sum() == 0 and 0.8 < bin_t.mean() < 0.99
+        score = m(cu(S.x), mode="seenmask", dropout_masks=[cu(a) for a in S.masks])
+        assert rel(score, S.os) < 1e-3
+        loss = utils.cross_entropy2d(score, cu(bin_t), size_average=True)
+        oloss, ods, opred = O.cross_entropy2d(S.os, bin_t, size_average=True)
+        assert abs(loss.item() - float(oloss)) < 1e-4 * abs(float(oloss))
+        # channel argmax: bit-exact against the oracle applied to the SAME score
+        _, _, opred_same = O.cross_entropy2d(score.detach().cpu().numpy(), bin_t, size_average=True, want_grad=False)
+        assert np.array_equal(utils.channel_argmax(score).cpu().numpy(), opred_same)
+        for p in head:
+            p.grad = None
+        loss.backward()
+        assert m.conv5_3.weight.grad is None and m.score_fr.weight.grad is None
+        og = S.om.backward(ds=ods, backbone=False)
+        assert rel(m.seenmask_score.weight.grad, og["seenmask_score.weight"]) < 1e-3
+        assert rel(m.seenmask_score.bias.grad, og["seenmask_score.bias"]) < 1e-3
+        assert rel(m.seenmask_upscore.weight.grad, og["seenmask_upscore.weight"]) < 1e-3
+        # Adam on the head only (seenmask_lr 1e-3): first step moves every touched element by ~lr
+        opt = optim.FusedAdam(head, lr=1e-3)
+        w0 = m.seenmask_score.weight.detach().clone()
+        opt.step()
+        d = (m.seenmask_score.weight.detach() - w0).abs()
+        g = m.seenmask_score.weight.grad.abs()
+        assert float(d[g > 1e-6].min()) > 0.9e-3 and float(d.max()) < 1.1e-3
+    finally:
+        for p in m.parameters():
+            p.requires_grad = True
+        for p in m.parameters():
+            p.grad = None
+        m.eval()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_fullsize_train_step_vs_oracle(full512, fused):
+    """BASELINE configs[2] phase 1 / configs[1] geometry: ONE fp32 training step at 512x512, E = 300, K = 59, Dropout2d on,
+    against the oracle: projection map, loss, class assignment, and the gradient of every one of the 16 layers"""
+    S = full512
+    m = S.m
+    _restore(S)
+    m.train()
+    eng = m._engine
+    calls = eng.dropout_calls
+    ts = engine.TrainStep(m, S.emb, optimizer="adam", lr=1e-5, precision=torch.float32, fused_head=fused)
+    try:
+        # redraw the fixture's masks: same seed, same call counter
+        mk = eng.make_masks(1, 4096, torch.device("cuda"))
+        eng.dropout_calls = calls
+        S2 = [t.cpu().numpy() for t in mk]
+        om, of = S.om, S.of
+        if not all(np.array_equal(a, b) for a, b in zip(S2, S.masks)):     # counter moved on (test order): redo the oracle forward
+            om = O.FCN32sOracle(oracle_params(m), S.E)
+            of = om.forward(S.x, "fcn", masks=S2, keep=True)
+        before = {n: getattr(m, n).weight.detach().flatten()[cu(probe_idx(getattr(m, n).weight.numel()))].clone()
+                  for n in ("conv1_1", "conv3_2", "fc6", "score_fr")}
+        loss, pred = ts.step(cu(S.x), cu(S.target))
+        torch.cuda.synchronize()
+        oloss, odf, _ = O.cosine_loss(of, S.target, embed=S.emb)
+        assert abs(loss.item() - float(oloss)) < 1e-4 * max(1.0, abs(float(oloss)))
+        opred = O.infer_lbl(of, S.emb)
+        clear = cosine_margins(of, S.emb)[None] > 1e-5
+        assert clear.mean() > 0.99
+        assert np.array_equal(pred.cpu().numpy()[clear], opred[clear])
+        og = om.backward(df=odf)
+        worst = {}
+        for name in models._OPT_LAYERS:
+            for kind in ("weight", "bias"):
+                key = "%s.%s" % (name, kind)
+                gr = getattr(getattr(m, name), kind).grad
+                ref = og[key]
+                tol = 1e-2 if key == "conv1_1.bias" else 1e-3          # 5e5 mixed-sign terms reduced in fp32 on both sides
+                idx = probe_idx(ref.size)
+                e1 = np.abs(gr.flatten()[cu(idx)].cpu().numpy().astype(np.float64) - ref.reshape(-1)[idx]).max() / np.abs(ref).max()
+                s_got, s_ref = stats(gr), stats(ref)
+                e2 = max(abs(s_got[1] - s_ref[1]) / s_ref[1], abs(s_got[2] - s_ref[2]) / s_ref[2],
+                         abs(s_got[0] - s_ref[0]) / s_ref[1])
+                worst[key] = (e1, e2)
+                assert e1 < tol and e2 < tol, (key, e1, e2)
+        print("worst full-size gradient errors (probe, stats):", max(v[0] for v in worst.values()), max(v[1] for v in worst.values()))
+        # Adam, first step: |delta| ~= lr (weights), 2 lr (biases) wherever the gradient is not negligible
+        for n, b in before.items():
+            p = getattr(m, n).weight
+            idx = cu(probe_idx(p.numel()))
+            d = (p.detach().flatten()[idx] - b).abs()
+            g = p.grad.flatten()[idx].abs()
+            big = g > 1e-5 * float(g.max()) + 1e-12
+            if big.any():
+                assert float((d[big] - 1e-5).abs().max()) < 2e-6 + float(b.abs().max()) * 2.0 ** -22, n
+    finally:
+        m.eval()
+
+
+# ----------------------------------------------------------------------------------------------- cfg 1 (configs[0])
+def test_cfg1_softmax_fcn_step_vs_oracle():
+    """cfg 1: n_class = 21 softmax head, 256x256, B = 1, CE with size_average=False, SGD lr 1e-10 momentum .99 wd 5e-4 with
+    the bias group at 2x lr / wd 0 (configs.py:4-16, train.py:126-129, trainer_fcn.py:105): two steps vs the oracle"""
+    from zeroshotsemanticsegmentation_amd.configs import configurations
+    from zeroshotsemanticsegmentation_amd.train import make_fcn_optimizer
+    cfg = configurations[1]
+    assert cfg["fcn_loss"] == "cross_entropy" and cfg["fcn_optim"] == "sgd" and cfg["fcn_lr"] == 1e-10 and cfg["embed_dim"] == 0
+    Cn, H = 21, 256
+    m = models.FCN32s(Cn)
+    m.load_synthetic(1337, device=torch.device("cuda"))
+    m.eval()
+    x = synth.make_images(1, H, H, seed=41)
+    target = synth.make_labels(1, H, H, Cn, seed=42)
+    om = O.FCN32sOracle(oracle_params(m), Cn)
+    opt = make_fcn_optimizer(m, cfg)
+    assert [g["lr"] for g in opt.param_groups] == [1e-10, 2e-10] and [g["weight_decay"] for g in opt.param_groups] == [0.0005, 0]
+    osgd = O.SGD(1e-10, 0.99)
+    for it in range(2):
+        score = m(cu(x), mode="fcn")
+        of = om.forward(x, "fcn", keep=True)
+        assert rel(score, of) < 1e-3
+        loss = utils.cross_entropy2d(score, cu(target), size_average=False)
+        oloss, ods, _ = O.cross_entropy2d(of, target, size_average=False)
+        assert abs(loss.item() - float(oloss)) < 1e-4 * abs(float(oloss))
+        _, _, opred = O.cross_entropy2d(score.detach().cpu().numpy(), target, want_grad=False)
+        assert np.array_equal(utils.channel_argmax(score).cpu().numpy(), opred)
+        opt.zero_grad()
+        loss.backward()
+        og = om.backward(df=ods)
+        og = {k: v for k, v in og.items() if k.split(".")[0] in O.WEIGHT_GROUP}
+        for key, ref in og.items():
+            name, kind = key.split(".")
+            gr = getattr(getattr(m, name), kind).grad
+            tol = 1e-2 if key == "conv1_1.bias" else 1e-3
+            idx = probe_idx(ref.size)
+            e1 = np.abs(gr.flatten()[cu(idx)].cpu().numpy().astype(np.float64) - ref.reshape(-1)[idx]).max() / np.abs(ref).max()
+            assert e1 < tol, (key, it, e1)
+        opt.step()
+        osgd.step(om.p, og, lambda k: 1e-10 * (2 if k.endswith(".bias") else 1), lambda k: 0.0 if k.endswith(".bias") else 0.0005)
+        for key in ("conv1_1.weight", "conv3_2.weight", "fc6.weight", "fc7.bias", "score_fr.weight", "score_fr.bias"):
+            name, kind = key.split(".")
+            p = getattr(getattr(m, name), kind).detach()
+            idx = probe_idx(p.numel())
+            got = p.flatten()[cu(idx)].cpu().numpy().astype(np.float64)
+            want = om.p[key].reshape(-1)[idx].astype(np.float64)
+            ulp = np.abs(want).max() * 2.0 ** -23
+            assert np.abs(got - want).max() <= 2 * ulp, (key, it)
+
+
+def test_cfg1_cli_end_to_end(tmp_path):
+    """`train.py -c 1` on the synthetic dataset at 256x256: the softmax / SGD plumbing of configs[0] end to end"""
+    import glob
+    from zeroshotsemanticsegmentation_amd import train
+    d = str(tmp_path)
+    train.main(['-c', '1', '-ve', '1', '-dir', d, '-n', 'cfg1', '--synthetic', '2', '256', '256'])
+    log = glob.glob(os.path.join(d, 'logs', 'cfg1_CFG_1_*'))[0]
+    rows = open(os.path.join(log, 'train_log.csv')).read().strip().split('\n')
+    assert len(rows) == 3
+    losses = [float(r.split(',')[2]) for r in rows[1:]]
+    assert all(np.isfinite(losses)) and all(l > 1e4 for l in losses)        # sum-reduced CE over 65,536 pixels
+    ck = torch.load(os.path.join(log, 'checkpoint'), map_location='cpu', weights_only=False)
+    assert tuple(ck['model_state_dict']['score_fr.weight'].shape) == (21, 4096, 1, 1)
+    assert all('momentum_buffer' in v for v in ck['optim_state_dict']['state'].values())
+
+
+# ----------------------------------------------------------------------------------------------- 768 x 768 (configs[4])
+def test_768_fp32_forward_and_bf16_step():
+    E, K, H = 300, 59, 768
+    emb = synth.make_embeddings(K, E)
+    m = models.FCN32s(E)
+    m.load_synthetic(1337, device=torch.device("cuda"))
+    m.eval()
+    x = synth.make_images(1, H, H, seed=51)
+    target = synth.make_labels(1, H, H, K, seed=52, classes=SEEN59)
+    with torch.no_grad():
+        f, s = m(cu(x), mode="both")
+    om = O.FCN32sOracle(oracle_params(m), E)
+    of, os_ = om.forward(x, "both")
+    assert tuple(f.shape) == (1, E, H, H) and m._last_ctx.coarse.shape[1:3] == (25, 25)
+    assert rel(f, of) < 1e-3 and rel(s, os_) < 1e-3
+    fn = f.cpu().numpy()
+    assert np.array_equal(utils.infer_lbl(f, cu(emb), True), O.infer_lbl(fn, emb))
+    oloss, _, _ = O.cosine_loss(of, target, embed=emb, want_grad=False)
+    del f, s
+    # bf16 throughput path at B = 2: loss of the first step within bf16 noise of the fp32 oracle, then decreasing
+    ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=torch.bfloat16, fused_head=True)
+    xb = cu(np.concatenate([x, x]))
+    tb = cu(np.concatenate([target, target]))
+    losses = [float(ts.step(xb, tb)[0]) for _ in range(3)]
+    assert abs(losses[0] - float(oloss)) < 2e-2, (losses, float(oloss))
+    assert all(np.isfinite(losses)) and losses[2] < losses[0]
+
+
+# ----------------------------------------------------------------------------------------------- bf16 layers vs torch fp32
+# name: (Hi, Ci, Co, K, pad), batch -- the layer shapes of a 512x512 step
+BF16_LAYERS = {
+    "conv1_2": ((710, 64, 64, 3, 1), 2), "conv2_1": ((355, 64, 128, 3, 1), 2), "conv2_2": ((355, 128, 128, 3, 1), 2),
+    "conv3_1": ((178, 128, 256, 3, 1), 4), "conv3_2": ((178, 256, 256, 3, 1), 4), "conv4_1": ((89, 256, 512, 3, 1), 8),
+    "conv4_2": ((89, 512, 512, 3, 1), 8), "conv5_1": ((45, 512, 512, 3, 1), 8), "fc6": ((23, 512, 4096, 7, 0), 8),
+    "fc7": ((17, 4096, 4096, 1, 0), 8),
+}
+
+
+@pytest.mark.parametrize("name", list(BF16_LAYERS))
+def test_fullsize_bf16_layer_vs_torch_fp32(name):
+    import torch.nn.functional as F
+    (Hi, Ci, Co, K, pad), B = BF16_LAYERS[name]
+    dt = torch.bfloat16
+    code = L.dtype_code(dt)
+    Ho = Hi + 2 * pad - K + 1
+    g = torch.Generator().manual_seed(17)
+    x = torch.relu(torch.randn(B, Ci, Hi, Hi, generator=g)).bfloat16().float()          # post-ReLU activations (half zeros)
+    w = (torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5).bfloat16().float()
+    bias = torch.randn(Co, generator=g)
+    dout = torch.randn(B, Co, Ho, Ho, generator=g).bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.relu(F.conv2d(xr, wr, bias, padding=pad))
+    pre = F.conv2d(xr, wr, None, padding=pad)
+    pre.backward(dout)
+    ref_din = xr.grad * (x > 0)                     # the dgrad epilogue applies the producer's ReLU gate
+    ref_dw = wr.grad
+
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda().to(dt)
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda().to(dt)
+    dd = dout.permute(0, 2, 3, 1).contiguous().cuda().to(dt)
+    wT = torch.empty(Ci, K, K, Co, device="cuda", dtype=dt)
+    st = L.stream_ptr()
+    L.call("szn_pack_weight_dgrad", code, Co, K, K, Ci, L.ptr(wd), L.ptr(wT), st)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    d = L.ConvDesc(code, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, pad, Ci, Co, Ci, 1, 0)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    out = torch.empty(B, Ho, Ho, Co, device="cuda", dtype=dt)
+    L.call("szn_conv2d_fwd", C.byref(d), L.ptr(xd), L.ptr(wd), L.ptr(bias.cuda()), None, None, L.ptr(out), st)
+    kf = L.last_kernel()
+    din = torch.empty(B, Hi, Hi, Ci, device="cuda", dtype=dt)
+    L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dd), L.ptr(wT), L.ptr(xd), None, L.ptr(din), st)
+    kd = L.last_kernel()
+    dw = torch.empty(Co, K, K, Ci, device="cuda")
+    d2 = L.ConvDesc(code, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, pad, Ci, Co, 0, 0, 0)
+    if K == 3:                                      # slab workspace of the all-taps kernel, as models._Engine._wgrad sizes it
+        ws2 = torch.empty(2 * 256 * 64 * 9 * 64 * 4, dtype=torch.uint8, device="cuda")
+        d2.workspace, d2.workspace_bytes = ws2.data_ptr(), ws2.numel()
+    L.call("szn_conv2d_wgrad", C.byref(d2), L.ptr(xd), L.ptr(dd), L.ptr(dw), 0, st)
+    kw = L.last_kernel()
+    if K >= 5:          # fc6: the training step runs this edge as GEMM + col2im on the plain transpose (no gate on this edge)
+        wG = torch.empty(K * K * Ci, Co, device="cuda", dtype=dt)
+        L.call("szn_pack_weight_dgrad", code, Co, 1, 1, K * K * Ci, L.ptr(wd), L.ptr(wG), st)
+        d3 = L.ConvDesc(code, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, pad, Ci, Co, 0, 0, 0)
+        gws = torch.empty(L.load().szn_conv2d_dgrad_gemm_workspace_bytes(C.byref(d3)), dtype=torch.uint8, device="cuda")
+        d3.workspace, d3.workspace_bytes = gws.data_ptr(), gws.numel()
+        din2 = torch.empty(B, Hi, Hi, Ci, device="cuda", dtype=dt)
+        L.call("szn_conv2d_dgrad_gemm", C.byref(d3), L.ptr(dd), L.ptr(wG), L.ptr(din2), st)
+        torch.cuda.synchronize()
+        e_g = rel(din2.float().cpu().permute(0, 3, 1, 2), xr.grad)
+        assert e_g < 1e-2, e_g
+    torch.cuda.synchronize()
+    e_f = rel(out.float().cpu().permute(0, 3, 1, 2), ref)
+    e_d = rel(din.float().cpu().permute(0, 3, 1, 2), ref_din)
+    e_w = rel(dw.cpu().permute(0, 3, 1, 2), ref_dw)
+    print("%s B=%d: fwd %s %.2e | dgrad %s %.2e | wgrad %s %.2e" % (name, B, kf, e_f, kd, e_d, kw, e_w))
+    assert e_f < 1e-2 and e_d < 1e-2, (e_f, e_d)          # bf16 outputs: 2^-8 relative rounding of the stored value
+    assert e_w < 2e-3, e_w                                 # fp32 output, fp32 accumulation of exact bf16 products

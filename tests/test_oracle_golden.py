@@ -230,3 +230,38 @@ def test_g8_seenmask_step():
     assert np.abs(d - g["delta_W_score_probe"]).max() < 2e-3 * np.abs(g["delta_W_score_probe"]).max() + 1e-9
     du = (m.p["seenmask_upscore.weight"].astype(np.float64) - u0)[:, :, ::9, ::9]
     assert np.abs(du - g["delta_W_up_probe"]).max() < 2e-3 * np.abs(g["delta_W_up_probe"]).max() + 1e-7
+
+
+@pytest.mark.parametrize("case", [(2, 3, 4, 20, 33, 70, 101), (1, 2, 2, 300, 59, 40, 37), (1, 1, 1, 20, 21, 1, 1)])
+def test_fused_head_restatement_matches_unfused_oracle(case):
+    """oracle.fused_head (the algebraic per-cell evaluation the training step's kernel uses) against the golden-pinned
+    sequence deconv_fwd(bilinear) -> cosine_loss -> infer_lbl -> deconv_dgrad: same loss / gradient to rounding, same
+    class assignment except on pixels whose top-2 cosine margin is below 1e-5"""
+    B, h, w, E, K, H, W = case
+    CP = (E + 2 + 63) // 64 * 64
+    emb = synth.make_embeddings(K, E, seed=5)
+    coarse = np.zeros((B, h, w, CP), np.float32)
+    coarse[..., :E + 2] = synth.uniform(31 + E, (B, h, w, E + 2), -2, 2)
+    target = synth.make_labels(B, H, W, K, seed=32 + K, block=8, ignore_frac=0.1)
+    loss, st, pred, dc = O.fused_head(coarse, emb, target, H, W)
+    cf = np.ascontiguousarray(coarse[..., :E].transpose(0, 3, 1, 2))
+    filt = np.broadcast_to(O.get_upsampling_weight(1, 1, 64)[0, 0], (E, 64, 64))
+    f = O.deconv_fwd(cf, filt, H, W, diag=True)
+    loss_u, df, st_u = O.cosine_loss(f, target, embed=emb)
+    dc_u = O.deconv_dgrad(df, filt, cf.shape, diag=True).transpose(0, 2, 3, 1)
+    pred_u = O.infer_lbl(f, emb)
+    assert abs(float(loss) - float(loss_u)) < 2e-6 * max(1.0, abs(float(loss_u)))
+    assert np.array_equal(st[:, 1], st_u[:, 1])
+    assert rel(dc[..., :E], dc_u) < 1e-4
+    assert not dc[..., E:].any()
+    bad = pred != pred_u
+    assert bad.mean() < 2e-3
+    if bad.any():
+        fs = f.transpose(0, 2, 3, 1).reshape(-1, E).astype(np.float64)
+        en = np.linalg.norm(emb.astype(np.float64), axis=1); en[en == 0] = 1
+        sim = fs @ emb.astype(np.float64).T / (np.linalg.norm(fs, axis=1, keepdims=True) * en[None])
+        top = np.sort(sim, axis=1)
+        assert (top[:, -1] - top[:, -2]).reshape(bad.shape)[bad].max() < 1e-5
+    # pred-only form
+    _, _, p2, _ = O.fused_head(coarse, emb, None, H, W)
+    assert np.array_equal(p2, pred)
