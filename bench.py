@@ -1,21 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- train-step throughput of the SZN pixel-embedding path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|fp32] [--size 512]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|fp32] [--size 512] [--classes 59]
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-One "step" = the reference's hot-loop body (trainer_fcn.py:149-180) on one synthetic batch already resident
-in HBM: FCN32s forward (train mode, Dropout2d on) -> cosine loss -> train-time infer_lbl -> backward ->
-gradient all-reduce (N > 1) -> Adam step -> confusion histogram.  Workload = BASELINE.json configs[1]:
-512x512, E = 300 (pascal 21 x 300 embedding matrix), bf16 operands / fp32 accumulate / fp32 master weights.
-(The reference has no FCN8s -- SURVEY.md D1 -- so the backbone is its FCN32s.)
+One "step" = the reference's hot-loop body (trainer_fcn.py:149-180) on one synthetic batch already resident in HBM:
+FCN32s forward (train mode, Dropout2d on) -> cosine loss -> train-time infer_lbl -> backward -> gradient all-reduce
+(N > 1) -> Adam step -> confusion histogram.  Default workload = the configuration BASELINE.json's metric is quoted on:
+PASCAL-Context 512x512, K = 59 classes (49 seen / 10 unseen; synthetic 59 x 300 embedding matrix of SURVEY 8-d, labels
+drawn from the seen classes), E = 300, bf16 operands / fp32 accumulate / fp32 master weights, 8 images per GPU.
+(`--classes 21` = BASELINE configs[1], the PASCAL-VOC matrix.  The reference has no FCN8s -- SURVEY D1 -- the backbone
+is its FCN32s.)
 
-Prints ONE JSON line: metric train_Mpixels_per_sec (whole job), plus
-  roofline     -- the dominant kernel family (every conv / fc forward and dgrad launch behind szn_conv2d_fwd /
-                  szn_conv2d_dgrad: conv_igemm_v2 | conv_igemm_wide | conv3x3_regw): algorithmic FLOPs of its launches
-                  / their HIP-event-measured duration, against the dense MFMA peak,
-  cpu_baseline -- the CPU oracle (oracle/, C + OpenMP "port" of the reference algorithm) timed on this
-                  host's cores on ONE 512x512 image of the same workload (rank 0, N = 1 only).
+Prints ONE JSON line: metric train_Mpixels_per_sec (whole job) plus
+  roofline      the dominant kernel (conv_igemm_wide: conv3_x / conv4_x forward + dgrad, fc6 GEMMs): algorithmic FLOPs of
+                its launches / their HIP-event-measured duration INSIDE the timed region, against the dense MFMA peak;
+                `traffic` = HBM bytes per launch from the committed PMC passes (source file named; null if none matches)
+  kernels       per kernel family, MFMA-class and HBM-class, from 3 extra instrumented steps after the timed region
+                (HIP events around every C-ABI call): ms per step, algorithmic FLOPs or bytes, fraction of the peak
+  projection    the three labelled MFMA numbers SURVEY 8-d asks for (true shape, step aggregate, nominal shape)
+  phase2        BASELINE configs[2]: the seen-mask step (frozen backbone, 2-class CE, head-only backward + Adam)
+  cpu_baseline  the same train step on this host's cores (rank 0, N = 1 only): torch-CPU restatement (what the reference
+                executes; primary) and the C + OpenMP oracle beside it; one 512x512 image each.
 """
 import argparse
 import json
@@ -28,6 +34,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_BF16, PEAK_F32, PEAK_HBM = 2500.0, 157.3, 8000.0       # TFLOP/s dense MFMA, GB/s (MI355X_MICROARCH.md)
+STEP_MFLOP_PER_PX = {512: 4.342, 768: 3.678}                # SURVEY 8-d, E = 300, phase-1 train step
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -37,51 +46,148 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (weak scaling)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--embed-dim", type=int, default=300)
+    ap.add_argument("--classes", type=int, default=59, help="59 = PASCAL-Context (synthetic matrix), 21 = PASCAL-VOC matrix")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--unfused-head", action="store_true", help="materialise the (B,E,H,W) score like the reference")
     ap.add_argument("--phase", choices=["fcn", "seenmask"], default="fcn",
-                    help="fcn = phase 1 (the headline train step); seenmask = phase 2 (BASELINE configs[2]: frozen backbone, "
-                         "seen-mask head + 2-class cross entropy, trainer_seenmask.py:72-102)")
+                    help="fcn = phase 1 (headline; phase 2 is reported as a sub-record); seenmask = phase 2 as the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the kernels / projection / phase2 sub-records")
     return ap.parse_args()
 
 
-def conv_flops(d):
-    """algorithmic FLOPs of one conv launch described by a ConvDesc (forward or dgrad-as-forward)"""
+# ---- algorithmic work of one C-ABI call (what `achieved` is computed from; formulas in DESIGN.md section 4) -------------
+def _esize(code):
+    return 4 if code == 0 else 2
+
+
+def _conv_flops(d):
     return 2.0 * d.B * d.Ho * d.Wo * d.Co * d.Ci * d.KH * d.KW
 
 
+def call_work(name, a):
+    """-> (bound, work) with work in FLOP (mfma) or bytes (hbm); None for calls that are not accounted"""
+    if name in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm", "szn_conv2d_wgrad"):
+        return "mfma", _conv_flops(a[0]._obj)
+    if name == "szn_conv1_1_fwd":          # reads the f32 image once, writes B x (H+198)^2 x 64 activations
+        code, B, H, W, pad = a[:5]
+        return "hbm", B * 3 * H * W * 4.0 + B * (H + 2 * pad - 2) * (W + 2 * pad - 2) * 64.0 * _esize(code)
+    if name == "szn_conv1_1_wgrad":        # reads dout once + the image
+        code, B, H, W, pad = a[:5]
+        return "hbm", B * 3 * H * W * 4.0 + B * (H + 2 * pad - 2) * (W + 2 * pad - 2) * 64.0 * _esize(code)
+    if name == "szn_maxpool2x2_ceil_fwd":
+        code, B, Hi, Wi, Cc = a[:5]
+        return "hbm", B * Cc * _esize(code) * (Hi * Wi + ((Hi + 1) // 2) * ((Wi + 1) // 2))
+    if name == "szn_maxpool2x2_ceil_bwd":  # pool input + pooled + d(pooled) in, d(input) out
+        code, B, Hi, Wi, Cc = a[:5]
+        return "hbm", B * Cc * _esize(code) * (2.0 * Hi * Wi + 2.0 * ((Hi + 1) // 2) * ((Wi + 1) // 2))
+    if name == "szn_adam_step":            # p, g, m, v in; p, m, v out (+ the bf16 weight image when asked for)
+        return "hbm", a[0] * (28.0 + (2.0 if a[12] is not None else 0.0))
+    if name == "szn_sgd_momentum_step":
+        return "hbm", a[0] * (20.0 + (2.0 if a[9] is not None else 0.0))
+    if name == "szn_fused_head":           # label in, prediction out, coarse map in, dcoarse out
+        B, h, w, E, ldc, c0, H, W = a[:8]
+        return "hbm", B * H * W * 16.0 + 2.0 * B * h * w * E * 4.0
+    if name == "szn_pack_weight_dgrad":
+        code, co, kh, kw, ci = a[:5]
+        return "hbm", 2.0 * co * kh * kw * ci * _esize(code)
+    if name == "szn_confusion_hist":
+        return "hbm", a[0] * 16.0
+    if name == "szn_embed_argmax":         # SURVEY 8-d: E*s read + 8 B written per pixel
+        B, E, H, W, K = a[:5]
+        return "hbm", B * H * W * (E * 4.0 + 8.0)
+    if name in ("szn_cosine_loss_fwd", "szn_mse_loss_fwd"):
+        B, E, H, W, K = a[:5]
+        return "hbm", B * H * W * (E * 4.0 + 8.0)
+    if name in ("szn_cosine_loss_bwd", "szn_mse_loss_bwd"):
+        B, E, H, W, K = a[:5]
+        return "hbm", B * H * W * (2.0 * E * 4.0 + 8.0)
+    if name in ("szn_bilinear_up32_crop_fwd", "szn_bilinear_up32_crop_bwd"):
+        B, h, w, E, ldc, c0, H, W = a[:8]
+        return "hbm", B * H * W * E * 4.0
+    return None
+
+
 def cpu_baseline(E, K, H, emb):
-    """time the CPU oracle on ONE image of the same workload (forward + loss + infer + backward + Adam)"""
+    """the train step on ONE image on this host's cores: torch-CPU restatement (primary) and the C + OpenMP oracle"""
     from oracle import szn_oracle as O
+    from oracle import torch_ref as T
     from zeroshotsemanticsegmentation_amd import synth
-    rng = np.random.default_rng(1337)
-    params = {}
-    for name, co, ci, k in synth.layer_table(E):
-        b = np.sqrt(6.0 / (ci * k * k))
-        params[name + ".weight"] = ((rng.random((co, ci, k, k), dtype=np.float32) * 2 - 1) * b).astype(np.float32)
-        params[name + ".bias"] = ((rng.random((co,), dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32)
-    m = O.FCN32sOracle(params, E)
+    import torch
     x = synth.make_images(1, H, H)
     tgt = synth.make_labels(1, H, H, K)
-    opt = O.Adam(1e-5)
-    t0 = time.time()
-    f = m.forward(x, "fcn", keep=True)
-    t1 = time.time()
-    loss, df, _ = O.cosine_loss(f, tgt, embed=emb)
-    t2 = time.time()
-    O.infer_lbl(f, emb)
-    t3 = time.time()
-    g = m.backward(df=df)
-    t4 = time.time()
-    g = {k: v for k, v in g.items() if k.split(".")[0] in O.WEIGHT_GROUP}
-    opt.step(m.p, g, lambda k: 1e-5 * (2 if k.endswith(".bias") else 1))
-    t5 = time.time()
-    total = t5 - t0
-    return {"value": round(H * H / total / 1e6, 6), "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "1 image %dx%d, E=%d, K=%d, fp32: fwd %.1fs loss %.1fs infer %.1fs bwd %.1fs adam %.1fs (C+OpenMP oracle)"
-                      % (H, H, E, K, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)}
+    cores = os.cpu_count()
+    out = {"unit": "Mpixels/s", "cores": cores, "kind": "port"}
+    t = T.timed_train_step(E, K, H, emb, x, tgt, steps=2)            # second step timed (first pays allocation / mkldnn setup)
+    out["value"] = round(H * H / t["total"] / 1e6, 6)
+    out["threads"] = torch.get_num_threads()
+    out["sample"] = ("torch-CPU restatement of the reference step (oracle/torch_ref.py; depthwise upscore), 1 image %dx%d, "
+                     "E=%d, K=%d, fp32, 2nd of 2 steps: fwd %.2fs loss %.2fs infer %.2fs bwd %.2fs adam %.2fs"
+                     % (H, H, E, K, t["fwd"], t["loss"], t["infer"], t["bwd"], t["adam"]))
+    try:
+        rng = np.random.default_rng(1337)
+        params = {}
+        for name, co, ci, k in synth.layer_table(E):
+            b = np.sqrt(6.0 / (ci * k * k))
+            params[name + ".weight"] = ((rng.random((co, ci, k, k), dtype=np.float32) * 2 - 1) * b).astype(np.float32)
+            params[name + ".bias"] = ((rng.random((co,), dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32)
+        m = O.FCN32sOracle(params, E)
+        opt = O.Adam(1e-5)
+        t0 = time.time()
+        f = m.forward(x, "fcn", keep=True)
+        t1 = time.time()
+        loss, df, _ = O.cosine_loss(f, tgt, embed=emb)
+        t2 = time.time()
+        O.infer_lbl(f, emb)
+        t3 = time.time()
+        g = m.backward(df=df)
+        t4 = time.time()
+        g = {k: v for k, v in g.items() if k.split(".")[0] in O.WEIGHT_GROUP}
+        opt.step(m.p, g, lambda k: 1e-5 * (2 if k.endswith(".bias") else 1))
+        t5 = time.time()
+        out["c_oracle"] = {"value": round(H * H / (t5 - t0) / 1e6, 6), "unit": "Mpixels/s", "cores": cores,
+                           "sample": "C+OpenMP oracle, same image: fwd %.1fs loss %.1fs infer %.1fs bwd %.1fs adam %.1fs"
+                                     % (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)}
+    except Exception as ex:
+        out["c_oracle"] = {"value": None, "sample": "failed: %r" % (ex,)}
+    return out
+
+
+def projection_report(L, torch, step_frac, iters=10):
+    """(1) true shape M = B*289, (2) step aggregate, (3) nominal full-resolution shape; bf16, K=4096, N=300"""
+    import ctypes as C
+
+    def run(B, H, W, N=300, K=4096):
+        dt = torch.bfloat16
+        ldo = (N + 7) // 8 * 8
+        x = torch.randn(B, H, W, K, device="cuda").to(dt)
+        w = (torch.randn(N, 1, 1, K, device="cuda") / K ** 0.5).to(dt)
+        bias = torch.randn(N, device="cuda")
+        out = torch.empty(B, H, W, ldo, device="cuda", dtype=dt)
+        ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+        d = L.ConvDesc(L.SZN_BF16, B, H, W, K, H, W, N, 1, 1, 0, K, ldo, 0, 0, 0)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        st = L.stream_ptr()
+        fn = lambda: L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, None, L.ptr(out), st)
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        tf = 2.0 * B * H * W * K * N / (ms * 1e-3) / 1e12
+        return {"M": B * H * W, "K": K, "N": N, "ms": round(ms, 4), "TF": round(tf, 1), "frac": round(tf / PEAK_BF16, 4),
+                "kernel": L.last_kernel()}
+    return {"peak_TF": PEAK_BF16,
+            "true_shape": [run(B, 17, 17) for B in (1, 8, 64)],
+            "step_aggregate_frac": step_frac,
+            "nominal_shape": run(1, 512, 512),
+            "note": "true = what score_fr executes (17x17 map, before the x32 upsampling); nominal = a full-resolution "
+                    "H*W x 4096 x 300 projection the path never runs (AI = 300 FLOP/B: HBM-bound at N = 300)"}
 
 
 def main():
@@ -89,7 +195,7 @@ def main():
     import torch
     import torch.distributed as dist
     from zeroshotsemanticsegmentation_amd import _lib as L
-    from zeroshotsemanticsegmentation_amd import engine, models, synth
+    from zeroshotsemanticsegmentation_amd import engine, models, synth, trainer_fcn
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -103,38 +209,47 @@ def main():
         dist.init_process_group("nccl", device_id=dev)       # backend "nccl" is RCCL on ROCm
     L.load()
 
-    E, H, B = args.embed_dim, args.size, args.batch
-    emb_np = np.load(os.path.join(ROOT, "tests", "golden", "embeddings_pascal_300.npy")) if E == 300 else \
-        synth.make_embeddings(21, E)
-    K = emb_np.shape[0]
+    E, H, B, K = args.embed_dim, args.size, args.batch, args.classes
+    if K == 21 and E in (20, 21, 300):
+        emb_np, seen, unseen = trainer_fcn.load_embeddings("pascal", E), list(range(21)), [16, 18]
+    elif K == 33 and E in (20, 300):
+        emb_np, seen, unseen = trainer_fcn.load_embeddings("context", E), list(range(33)), [16, 18]
+    else:
+        emb_np = synth.make_embeddings(K, E)
+        n_unseen = 10 if K == 59 else max(K // 6, 1)
+        seen, unseen = list(range(K - n_unseen)), list(range(K - n_unseen, K))     # K = 59: seen 0..48, unseen 49..58
     dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    peak = PEAK_BF16 if dtype == torch.bfloat16 else PEAK_F32
 
     torch.manual_seed(1337)                                   # identical initial weights on every rank
     model = models.FCN32s(n_class=E)
     model.load_synthetic(1337, device=dev)
     model.train()
+    model._engine.dropout_seed = 1337 + 7919 * rank           # ranks draw different Dropout2d masks
     x = torch.from_numpy(synth.make_images(B, H, H, seed=1337 + rank)).to(dev)
-    target = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337 + rank)).to(dev)
-    if args.phase == "fcn":
-        ts = engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=not args.unfused_head)
-    else:
-        # phase 2 (train.py:164-175): everything frozen except seenmask_score (w, b) and seenmask_upscore (w); binary target
+    # phase-1 batches contain seen classes only (the reference's train_seen split, context_dataset.py:75-94)
+    target = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337 + rank, classes=seen)).to(dev)
+    target_all = torch.from_numpy(synth.make_labels(B, H, H, K, seed=4337 + rank)).to(dev)
+
+    def make_phase1():
+        return engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=not args.unfused_head)
+
+    def make_phase2():
+        # train.py:164-175: everything frozen except seenmask_score (w, b) and seenmask_upscore (w); binary target
         # "label is a seen class" with unlabelled pixels = 0 (trainer_seenmask.py:55-56); 2-class CE, size_average=True
         from zeroshotsemanticsegmentation_amd import optim as szn_optim, utils as szn_utils
-        if world > 1:
-            raise SystemExit("--phase seenmask is a single-GPU line (98 KB of gradients)")
         model.set_precision(dtype)
         for p in model.parameters():
             p.requires_grad = False
         head = [model.seenmask_score.weight, model.seenmask_score.bias, model.seenmask_upscore.weight]
         for p in head:
             p.requires_grad = True
-        opt2 = szn_optim.FusedAdam(head, lr=1e-5)
-        unseen = (16, 18)                                             # cfg 18 split of the pascal classes
+        opt2 = szn_optim.FusedAdam(head, lr=1e-3)
+        train_unseen = unseen[:2]                                        # phase 2 trains on train_unseen vs everything else
         lut = torch.ones(K + 1, dtype=torch.int64, device=dev)
-        lut[list(unseen)] = 0
+        lut[train_unseen] = 0
         lut[K] = 0
-        bin_target = lut[torch.where(target >= 0, target, torch.full_like(target, K))]
+        bin_target = lut[torch.where(target_all >= 0, target_all, torch.full_like(target_all, K))]
 
         class _Phase2(object):
             def step(self, xx, tt):
@@ -144,26 +259,36 @@ def main():
                 loss.backward()
                 opt2.step()
                 return loss.detach(), szn_utils.channel_argmax(score)
-        ts = _Phase2()
+        return _Phase2()
 
-    # ---- kernel-level timing of the dominant kernel family (conv fwd/dgrad) with HIP events on the launch stream ----
-    events, flops_per_step = [], [0.0]
-    record = [False]
+    if args.phase == "seenmask" and world > 1:
+        raise SystemExit("--phase seenmask is a single-GPU line (98 KB of gradients)")
+    ts = make_phase1() if args.phase == "fcn" else make_phase2()
+
+    # ---- HIP events on the launch stream around C-ABI calls (torch's current stream IS the stream handed to the C-ABI) ----
+    CONV_ENTRIES = ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm")
+    events = []                      # (e0, e1, entry, kernel, bound, work)
+    mode = ["off"]                   # off | dominant (timed region: conv fwd/dgrad calls only) | all (instrumented pass)
+    orig_call = L.call
+
+    def timed_call(name, *a):
+        if mode[0] == "off" or (mode[0] == "dominant" and name not in CONV_ENTRIES):
+            return orig_call(name, *a)
+        wk = call_work(name, a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_call(name, *a)
+        e1.record()
+        kern = L.last_kernel()
+        if kern == "splitk_epilogue":
+            kern = L.prev_kernel() + "+splitk"
+        elif kern == "col2im_kernel":
+            kern = L.prev_kernel() + "+col2im"
+        events.append((e0, e1, name, kern, wk[0] if wk else None, wk[1] if wk else 0.0))
     if not args.no_kernel_events:
-        orig_call = L.call
-
-        def timed_call(name, *a):
-            if record[0] and name in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm"):
-                d = a[0]._obj
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                orig_call(name, *a)
-                e1.record()
-                events.append((e0, e1, conv_flops(d)))
-            else:
-                orig_call(name, *a)
         L.call = timed_call
-        models.L.call = timed_call
+        for mod in (models, engine):
+            mod.L.call = timed_call
 
     def sync():
         if world > 1:
@@ -173,13 +298,13 @@ def main():
     for _ in range(args.warmup):
         loss, pred = ts.step(x, target)
     sync()
-    record[0] = True
+    mode[0] = "dominant"
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, pred = ts.step(x, target)
     sync()
     dt = time.perf_counter() - t0
-    record[0] = False
+    mode[0] = "off"
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -187,42 +312,120 @@ def main():
     lossv = float(loss.item())
     if not np.isfinite(lossv):
         raise SystemExit("loss is not finite: %r" % lossv)
+    timed_events, events = events, []
 
+    out = None
     if rank == 0:
         mpx = world * B * H * H * args.steps / dt / 1e6
+        workload = ("PASCAL-Context 512x512 phase 1" if (K == 59 and H == 512) else "BASELINE configs[1]" if K == 21 else "custom")
         out = {
             "metric": "train_Mpixels_per_sec", "value": round(mpx, 3), "unit": "Mpixels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: FCN32s (the reference has no FCN8s) + %d-d pixel projection, "
-                                    "%dx%d, K=%d, Adam lr 1e-5, train step fwd+cosine loss+infer_lbl+bwd+optimizer" % (E, H, H, K))
-                       if args.phase == "fcn" else
+            "config": {"workload": ("%s: FCN32s (the reference has no FCN8s) + %d-d pixel projection, %dx%d, K=%d (%d seen / %d "
+                                    "unseen), Adam lr 1e-5, train step fwd+cosine loss+infer_lbl+bwd+optimizer"
+                                    % (workload, E, H, H, K, len(seen), len(unseen))) if args.phase == "fcn" else
                        ("BASELINE configs[2] (phase 2): seen-mask head on the frozen FCN32s backbone, %dx%d, K=%d, 2-class CE, "
                         "train step fwd+CE+argmax+head bwd+Adam" % (H, H, K)),
-                       "per_gpu_batch": B, "global_batch": B * world, "head": ("unfused" if args.unfused_head else "fused-from-coarse") if args.phase == "fcn" else "seenmask_score + learned 64x64 s32 deconv",
+                       "per_gpu_batch": B, "global_batch": B * world,
+                       "head": ("unfused" if args.unfused_head else "fused-from-coarse") if args.phase == "fcn"
+                       else "seenmask_score + learned 64x64 s32 deconv",
                        "parallelism": "dp%d" % world, "final_loss": round(lossv, 5)},
         }
-        if events:
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
-            fl = sum(f for _, _, f in events)
-            peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+        if timed_events:
+            by = {}
+            for e0, e1, name, kern, bound, work in timed_events:
+                r = by.setdefault(kern, [0.0, 0.0, 0])
+                r[0] += e0.elapsed_time(e1); r[1] += work; r[2] += 1
+            dom = max(by, key=lambda k: by[k][0])
+            ms, fl, n = by[dom]
             ach = fl / (ms * 1e-3) / 1e12
-            traffic = None      # HBM bytes per launch from a committed PMC run of this same command (tools/pmc_bench.sh)
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("per_gpu_batch") == B and tj.get("precision") == args.precision and H == 512 and E == 300 and args.phase == "fcn":
-                    traffic = round(tj["hbm_bytes_per_launch"])
-            out["roofline"] = {"bound": "mfma", "kernel": "conv fwd + dgrad launches (conv_igemm_v2 | conv_igemm_wide | conv3x3_regw; fc6 dgrad = wide GEMM + col2im)",
-                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": traffic, "launches_per_step": len(events) // args.steps,
-                               "avg_launch_ms": round(ms / len(events), 4),
-                               "gflop_per_launch": round(fl / len(events) / 1e9, 2),
-                               "share_of_step": round(ms / (dt * 1e3), 3)}
-            # whole-step MFMA-class algorithmic FLOPs (4.342 MFLOP/px at 512^2, E=300)
-            if H == 512 and E == 300 and args.phase == "fcn":
-                out["roofline"]["step_mfma_frac"] = round(4.342e6 * B * H * H * args.steps / dt / 1e12 / peak, 4)
+            traffic, tsrc = None, None
+            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if fn.endswith("_traffic.json"):
+                    tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    rec = tj.get("kernels", {}).get(dom)
+                    if rec and tj.get("per_gpu_batch") == B and tj.get("precision") == args.precision and tj.get("size") == H \
+                            and tj.get("classes", K) == K:
+                        traffic, tsrc = round(rec["hbm_bytes_per_launch"]), "profiles/" + fn
+                        break
+            fam_ms = sum(v[0] for v in by.values())
+            fam_fl = sum(v[1] for v in by.values())
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                               "launches_per_step": n // args.steps, "avg_launch_ms": round(ms / n, 4),
+                               "gflop_per_launch": round(fl / n / 1e9, 2), "share_of_step": round(ms / (dt * 1e3), 3),
+                               "conv_fwd_dgrad_family": {"achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 2),
+                                                         "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / peak, 4),
+                                                         "launches_per_step": len(timed_events) // args.steps,
+                                                         "share_of_step": round(fam_ms / (dt * 1e3), 3)}}
+            if H in STEP_MFLOP_PER_PX and E == 300 and args.phase == "fcn":
+                out["roofline"]["step_mfma_frac"] = round(STEP_MFLOP_PER_PX[H] * 1e6 * B * H * H * args.steps / dt / 1e12 / peak, 4)
+
+    # ---- instrumented pass: every C-ABI call of 3 more steps (same state, not part of `value`) ----
+    if not args.no_kernel_events and not args.no_extras and world == 1:
+        NI = 3
+        mode[0] = "all"
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        for _ in range(NI):
+            ts.step(x, target)
+        torch.cuda.synchronize()
+        dti = (time.perf_counter() - ti) / NI * 1e3
+        mode[0] = "off"
+        by = {}
+        for e0, e1, name, kern, bound, work in events:
+            key = (kern or name, bound)
+            r = by.setdefault(key, [0.0, 0.0, 0, name])
+            r[0] += e0.elapsed_time(e1); r[1] += work; r[2] += 1
+        rows = []
+        for (kern, bound), (ms, work, n, entry) in sorted(by.items(), key=lambda kv: -kv[1][0]):
+            row = {"kernel": kern, "entry": entry, "calls_per_step": round(n / NI, 2), "ms_per_step": round(ms / NI, 4)}
+            if bound == "mfma":
+                a = work / (ms * 1e-3) / 1e12
+                row.update({"bound": "mfma", "gflop_per_step": round(work / NI / 1e9, 1), "achieved": round(a, 1),
+                            "unit": "TFLOP/s", "frac": round(a / peak, 4)})
+            elif bound == "hbm":
+                a = work / (ms * 1e-3) / 1e9
+                row.update({"bound": "hbm", "mbytes_per_step": round(work / NI / 1e6, 1), "achieved": round(a, 1),
+                            "unit": "GB/s", "frac": round(a / PEAK_HBM, 4)})
+            rows.append(row)
+        tot = sum(r["ms_per_step"] for r in rows)
+        out["kernels"] = {"note": "HIP events around every C-ABI call of %d extra steps after the timed region; a call = the "
+                                  "named kernel plus its small helpers (reduce / epilogue)" % NI,
+                          "instrumented_ms_per_step": round(dti, 3), "c_abi_ms_per_step": round(tot, 3),
+                          "torch_glue_ms_per_step": round(max(dti - tot, 0.0), 3),
+                          "mfma_class_ms": round(sum(r["ms_per_step"] for r in rows if r.get("bound") == "mfma"), 3),
+                          "hbm_class_ms": round(sum(r["ms_per_step"] for r in rows if r.get("bound") == "hbm"), 3),
+                          "rows": rows}
+        events = []
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        if dtype == torch.bfloat16:
+            try:
+                out["projection"] = projection_report(L, torch, out.get("roofline", {}).get("step_mfma_frac"))
+            except Exception as ex:
+                out["projection"] = {"error": repr(ex)}
+        if args.phase == "fcn":
+            try:
+                p2 = make_phase2()
+                n2 = max(args.steps // 2, 3)
+                for _ in range(2):
+                    l2, _ = p2.step(x, target_all)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(n2):
+                    l2, _ = p2.step(x, target_all)
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t2
+                out["phase2"] = {"workload": "BASELINE configs[2]: seen-mask head on the frozen backbone, %dx%d, K=%d (train_unseen "
+                                             "= 2 classes), 2-class CE, fwd + head bwd + Adam lr 1e-3" % (H, H, K),
+                                 "value": round(B * H * H * n2 / d2 / 1e6, 3), "unit": "Mpixels/s", "steps": n2,
+                                 "ms_per_step": round(d2 / n2 * 1e3, 3), "final_loss": round(float(l2.item()), 5)}
+            except Exception as ex:
+                out["phase2"] = {"error": repr(ex)}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(E, K, H, emb_np)

@@ -37,10 +37,6 @@ const char* szn_last_error(void);
 const char* szn_last_kernel(void);
 const char* szn_prev_kernel(void);   /* the launch before it (e.g. the GEMM kernel in front of a split-K epilogue) */
 int szn_version(void); /* major*10000 + minor*100 + patch */
-/* Debug aid: `blocks` workgroups x 256 threads spinning for `cycles` shader clocks on `stream` (a stand-in for another
- * queue's kernel -- an RCCL all-reduce -- holding CUs under the training step: tools/contention.py); blocks < 0: |blocks|
- * workgroups of a ~100-VGPR variant that cannot share a SIMD with the persistent conv kernels.  sink: any 4 device bytes. */
-int szn_debug_spin(int blocks, long long cycles, void* sink, szn_stream_t stream);
 typedef struct {
     char name[128];
     char arch[32];

@@ -51,6 +51,47 @@ def test_grad_buckets_world2_gloo():
     assert res == [(0, True), (1, True)]
 
 
+def _worker2(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zeroshotsemanticsegmentation_amd.engine import GradBuckets, allreduce_param_grads
+    # bf16 wire format: sums agree with the fp32 sum to bf16 rounding, staging buffer leaves `flat` fp32
+    layers = [("a", 0, 3000), ("b", 3000, 5000)]
+    g = torch.Generator().manual_seed(7 + rank)
+    flat = torch.randn(8000, generator=g)
+    mine = flat.clone()
+    gb = GradBuckets(flat, layers, bucket_elems=4000, comm_dtype=torch.bfloat16)
+    for name in ("b", "a"):
+        gb.layer_done(name)
+    gb.finish()
+    others = [torch.randn(8000, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+    want = sum(o.bfloat16().float() for o in others)
+    ok = flat.dtype == torch.float32 and torch.allclose(flat, want, rtol=1e-2, atol=1e-2) and not torch.equal(flat, mine)
+    # explicit parameter list (autograd trainer paths): mean of the rank gradients, parameters without a gradient skipped
+    ps = [torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+    ps[0].grad = torch.full((4, 3), float(rank + 1))
+    ps[1].grad = torch.arange(5, dtype=torch.float32) * (rank + 1)
+    allreduce_param_grads(ps)
+    ok = ok and torch.equal(ps[0].grad, torch.full((4, 3), 1.5)) and torch.equal(ps[1].grad, torch.arange(5, dtype=torch.float32) * 1.5)
+    ok = ok and ps[2].grad is None
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_and_param_list_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker2, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
 def test_single_process_is_noop():
     from zeroshotsemanticsegmentation_amd.engine import GradBuckets
     flat = torch.ones(10)

@@ -31,8 +31,14 @@ def test_bench_line_phase1_with_cpu_baseline():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c and "c_oracle" in c
+    assert "workload" in d["config"] and "model" not in d["config"] and "K=59" in d["config"]["workload"]
+    # per-kernel table (MFMA- and HBM-class), projection report and the phase-2 sub-record travel in the same line
+    rows = d["kernels"]["rows"]
+    assert any(x.get("bound") == "mfma" for x in rows) and any(x.get("bound") == "hbm" for x in rows)
+    assert all(abs(x["frac"] - x["achieved"] / (r["peak"] if x["bound"] == "mfma" else 8000.0)) < 1e-3 for x in rows if "frac" in x)
+    assert len(d["projection"]["true_shape"]) == 3 and d["projection"]["nominal_shape"]["M"] == 262144
+    assert d["phase2"]["value"] > 0 and "configs[2]" in d["phase2"]["workload"]
 
 
 def test_bench_line_phase2():

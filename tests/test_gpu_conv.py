@@ -296,3 +296,49 @@ def test_maxpool(dtype, hw):
     torch.cuda.synchronize()
     assert torch.equal(din.float().cpu().permute(0, 3, 1, 2), dref)
     assert relerr(cs.cpu(), dref.sum((0, 2, 3))) < 1e-5          # fused bias gradient = column sums of din
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_proj_aliases_and_cast(dt):
+    """the "pixel projection" entry points of the C-ABI (szn_gemm_proj_fwd / dgrad / wgrad: score_fr as a plain
+    (M x 4096) x (4096 x N) GEMM, models.py:93,145) and szn_cast, against torch matmul on the same rounded operands"""
+    M, K, N = 2 * 17 * 17, 4096, 300
+    ldo = 304
+    code = L.dtype_code(dt)
+    g = torch.Generator(device="cuda").manual_seed(23)
+    x32 = torch.randn(M, K, device="cuda", generator=g)
+    w32 = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    bias = torch.randn(N, device="cuda", generator=g)
+    x = torch.empty(M, K, device="cuda", dtype=dt)
+    w = torch.empty(N, K, device="cuda", dtype=dt)
+    st = L.stream_ptr()
+    L.call("szn_cast", L.SZN_F32, code, M * K, L.ptr(x32), L.ptr(x), st)
+    L.call("szn_cast", L.SZN_F32, code, N * K, L.ptr(w32), L.ptr(w), st)
+    assert torch.equal(x, x32.to(dt)) and torch.equal(w, w32.to(dt))           # round-to-nearest-even like torch
+    back = torch.empty(M, K, device="cuda")
+    L.call("szn_cast", code, L.SZN_F32, M * K, L.ptr(x), L.ptr(back), st)
+    assert torch.equal(back, x.float())
+    tol = 1e-4 if dt == torch.float32 else 2e-3
+    out = torch.zeros(M, ldo, device="cuda")
+    L.call("szn_gemm_proj_fwd", code, M, K, N, ldo, L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(out), st)
+    ref = x.double() @ w.double().t() + bias.double()
+    assert float((out[:, :N].double() - ref).abs().max() / ref.abs().max()) < tol
+    # wgrad: dW = dout^T @ x (dout rows padded to ldo)
+    dout = torch.zeros(M, ldo, device="cuda", dtype=dt)
+    dout[:, :N] = torch.randn(M, N, device="cuda", generator=g).to(dt)
+    dw = torch.empty(N, K, device="cuda")
+    L.call("szn_gemm_proj_wgrad", code, M, K, N, ldo, L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
+    ref_dw = dout[:, :N].double().t() @ x.double()
+    assert float((dw.double() - ref_dw).abs().max() / ref_dw.abs().max()) < tol
+    # dgrad: dx = dout @ W with the ReLU gate of x, on the 64-padded head width the engine uses (zero rows behind N)
+    NP = 320
+    wp = torch.zeros(NP, K, device="cuda", dtype=dt)
+    wp[:N] = w
+    dp = torch.zeros(M, NP, device="cuda", dtype=dt)
+    dp[:, :N] = dout[:, :N]
+    wT = torch.empty(K, NP, device="cuda", dtype=dt)
+    L.call("szn_pack_weight_dgrad", code, NP, 1, 1, K, L.ptr(wp), L.ptr(wT), st)
+    dx = torch.empty(M, K, device="cuda", dtype=dt)
+    L.call("szn_gemm_proj_dgrad", code, M, K, NP, NP, L.ptr(dp), L.ptr(wT), L.ptr(x), None, L.ptr(dx), st)
+    ref_dx = (dout[:, :N].double() @ w.double()) * (x.double() > 0)
+    assert float((dx.double() - ref_dx).abs().max() / ref_dx.abs().max()) < (1e-4 if dt == torch.float32 else 1e-2)

@@ -138,3 +138,26 @@ def test_trainstep_bf16_runs_and_learns_direction():
     m.eval()
     ts0 = engine.TrainStep(models.FCN32s(E).load_synthetic(1337).cuda().eval(), emb, precision=torch.bfloat16)
     assert abs(float(ts0.step(x, t)[0]) - l32) < 2e-2
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+def test_fused_optimizer_resumes_from_nchw_contiguous_state(kind):
+    """a reference torch.optim checkpoint carries NCHW-contiguous moments; the parameters here are channels_last and the
+    kernels walk raw storage: load_state_dict + step must pair every moment with ITS weight element"""
+    from zeroshotsemanticsegmentation_amd import optim
+    g = torch.Generator().manual_seed(3)
+    w0 = torch.randn(8, 6, 3, 3, generator=g)
+    grads = [torch.randn(8, 6, 3, 3, generator=g) for _ in range(3)]
+    pr = torch.nn.Parameter(w0.clone())                                   # the reference: plain torch on the CPU
+    ref = torch.optim.Adam([pr], lr=1e-3) if kind == "adam" else torch.optim.SGD([pr], lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    pr.grad = grads[0].clone(); ref.step()
+    sd = ref.state_dict()                                                 # contiguous (NCHW) state tensors
+    assert all(v.is_contiguous() for st in sd["state"].values() for v in st.values() if torch.is_tensor(v) and v.dim() == 4)
+    p = torch.nn.Parameter(pr.detach().clone().cuda().contiguous(memory_format=torch.channels_last))
+    opt = optim.FusedAdam([p], lr=1e-3) if kind == "adam" else optim.FusedSGD([p], lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    opt.load_state_dict(sd)
+    for gr in grads[1:]:
+        pr.grad = gr.clone(); ref.step()
+        p.grad = gr.cuda().contiguous(memory_format=torch.channels_last); opt.step()
+    torch.cuda.synchronize()
+    assert float((p.detach().cpu() - pr.detach()).abs().max()) < 1e-6

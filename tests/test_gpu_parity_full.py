@@ -29,7 +29,9 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import szn_oracle as O  # noqa: E402
+from helpers_parity import adopt_forward  # noqa: E402
 from zeroshotsemanticsegmentation_amd import _lib as L  # noqa: E402
 from zeroshotsemanticsegmentation_amd import engine, models, optim, synth, utils  # noqa: E402
 
@@ -70,6 +72,10 @@ def cosine_margins(f, emb):
 
 def oracle_params(m):
     return {k: v.detach().cpu().numpy() for k, v in m.named_parameters() if k.split(".")[0] != "upscore"}
+
+
+def oracle_params_from(S):
+    return {k: v.detach().cpu().numpy() for k, v in S.state.items()}
 
 
 # ----------------------------------------------------------------------------------------------- fused head vs oracle
@@ -254,10 +260,26 @@ def test_fullsize_seenmask_step_vs_oracle(full512):
         m.eval()
 
 
+def grad_errors(m, og, keys):
+    """per parameter: max |got - ref| / max |ref| over the WHOLE tensor"""
+    out = {}
+    for key in keys:
+        name, kind = key.split(".")
+        g = getattr(getattr(m, name), kind).grad.detach().cpu().numpy().astype(np.float64)
+        r = og[key].astype(np.float64)
+        out[key] = float(np.abs(g - r).max() / np.abs(r).max())
+    return out
+
+
+OPT_KEYS = ["%s.%s" % (n, k) for n in models._OPT_LAYERS for k in ("weight", "bias")]
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_fullsize_train_step_vs_oracle(full512, fused):
     """BASELINE configs[2] phase 1 / configs[1] geometry: ONE fp32 training step at 512x512, E = 300, K = 59, Dropout2d on,
-    against the oracle: projection map, loss, class assignment, and the gradient of every one of the 16 layers"""
+    against the oracle.  Forward: loss and class assignment against the oracle's own forward pass.  Backward: every element
+    of every layer's gradient against the oracle's backward run on the SAME forward state (tests/helpers_parity.py explains
+    why a backward comparison between two independent fp32 forwards cannot be tight at this size: ReLU-gate / pooling flips)."""
     S = full512
     m = S.m
     _restore(S)
@@ -265,51 +287,55 @@ def test_fullsize_train_step_vs_oracle(full512, fused):
     eng = m._engine
     calls = eng.dropout_calls
     ts = engine.TrainStep(m, S.emb, optimizer="adam", lr=1e-5, precision=torch.float32, fused_head=fused)
+    ts.keep_ctx = True
     try:
-        # redraw the fixture's masks: same seed, same call counter
-        mk = eng.make_masks(1, 4096, torch.device("cuda"))
+        mk = eng.make_masks(1, 4096, torch.device("cuda"))      # what the step is going to draw: same seed, same call counter
         eng.dropout_calls = calls
-        S2 = [t.cpu().numpy() for t in mk]
-        om, of = S.om, S.of
-        if not all(np.array_equal(a, b) for a, b in zip(S2, S.masks)):     # counter moved on (test order): redo the oracle forward
-            om = O.FCN32sOracle(oracle_params(m), S.E)
-            of = om.forward(S.x, "fcn", masks=S2, keep=True)
+        masks = [t.cpu().numpy() for t in mk]
+        same_masks = all(np.array_equal(a, b) for a, b in zip(masks, S.masks))
+        of = S.of if same_masks else O.FCN32sOracle(oracle_params(m), S.E).forward(S.x, "fcn", masks=masks)
         before = {n: getattr(m, n).weight.detach().flatten()[cu(probe_idx(getattr(m, n).weight.numel()))].clone()
                   for n in ("conv1_1", "conv3_2", "fc6", "score_fr")}
         loss, pred = ts.step(cu(S.x), cu(S.target))
         torch.cuda.synchronize()
+        # ---- forward side, against the oracle's independent forward pass
         oloss, odf, _ = O.cosine_loss(of, S.target, embed=S.emb)
         assert abs(loss.item() - float(oloss)) < 1e-4 * max(1.0, abs(float(oloss)))
         opred = O.infer_lbl(of, S.emb)
         clear = cosine_margins(of, S.emb)[None] > 1e-5
         assert clear.mean() > 0.99
         assert np.array_equal(pred.cpu().numpy()[clear], opred[clear])
-        og = om.backward(df=odf)
-        worst = {}
-        for name in models._OPT_LAYERS:
-            for kind in ("weight", "bias"):
-                key = "%s.%s" % (name, kind)
-                gr = getattr(getattr(m, name), kind).grad
-                ref = og[key]
-                tol = 1e-2 if key == "conv1_1.bias" else 1e-3          # 5e5 mixed-sign terms reduced in fp32 on both sides
-                idx = probe_idx(ref.size)
-                e1 = np.abs(gr.flatten()[cu(idx)].cpu().numpy().astype(np.float64) - ref.reshape(-1)[idx]).max() / np.abs(ref).max()
-                s_got, s_ref = stats(gr), stats(ref)
-                e2 = max(abs(s_got[1] - s_ref[1]) / s_ref[1], abs(s_got[2] - s_ref[2]) / s_ref[2],
-                         abs(s_got[0] - s_ref[0]) / s_ref[1])
-                worst[key] = (e1, e2)
-                assert e1 < tol and e2 < tol, (key, e1, e2)
-        print("worst full-size gradient errors (probe, stats):", max(v[0] for v in worst.values()), max(v[1] for v in worst.values()))
-        # Adam, first step: |delta| ~= lr (weights), 2 lr (biases) wherever the gradient is not negligible
+        # ---- backward side, on the forward state of the HIP pass
+        ctx = ts.last_ctx
+        om = O.FCN32sOracle(oracle_params_from(S), S.E)
+        dpool = adopt_forward(om, ctx, S.x, masks, S.E)
+        assert dpool == 0.0                                    # max-pool of the same input: bit-identical
+        assert rel(om.saved["coarse_f"], np.ascontiguousarray(S.om.last["coarse_f"])) < 1e-3 if same_masks else True
+        f_hip = O.deconv_fwd(om.saved["coarse_f"], np.broadcast_to(O.get_upsampling_weight(1, 1, 64)[0, 0], (S.E, 64, 64)),
+                             S.H, S.H, diag=True)
+        _, odf_hip, _ = O.cosine_loss(f_hip, S.target, embed=S.emb)
+        og = om.backward(df=odf_hip)
+        errs = grad_errors(m, og, OPT_KEYS)
+        print("full-size gradient errors given the same forward state (max over the tensor / max |ref|):")
+        for k in OPT_KEYS:
+            print("  %-16s %.2e" % (k, errs[k]))
+        for k, e in errs.items():
+            assert e < (1e-3 if k.endswith(".bias") else 1e-4), (k, e)
+        if same_masks:          # for the record: against the oracle's own forward state the flips show up (not a kernel error)
+            og_ind = S.om.backward(df=odf)
+            e_ind = grad_errors(m, og_ind, OPT_KEYS)
+            print("vs an independent fp32 forward (gate / pooling flips): worst %.2e" % max(e_ind.values()))
+            assert max(e_ind.values()) < 5e-2
+        # Adam, first step from zero moments: delta = -lr * g / (|g| + eps)
         for n, b in before.items():
             p = getattr(m, n).weight
             idx = cu(probe_idx(p.numel()))
-            d = (p.detach().flatten()[idx] - b).abs()
-            g = p.grad.flatten()[idx].abs()
-            big = g > 1e-5 * float(g.max()) + 1e-12
-            if big.any():
-                assert float((d[big] - 1e-5).abs().max()) < 2e-6 + float(b.abs().max()) * 2.0 ** -22, n
+            d = (p.detach().flatten()[idx] - b).double()
+            g = p.grad.flatten()[idx].double()
+            want = -1e-5 * g / (g.abs() + 1e-8)
+            assert float((d - want).abs().max()) < 1e-7 + float(b.abs().max()) * 2.0 ** -23, n
     finally:
+        ts.last_ctx = None
         m.eval()
 
 
@@ -333,24 +359,23 @@ def test_cfg1_softmax_fcn_step_vs_oracle():
     osgd = O.SGD(1e-10, 0.99)
     for it in range(2):
         score = m(cu(x), mode="fcn")
-        of = om.forward(x, "fcn", keep=True)
+        of = om.forward(x, "fcn")
         assert rel(score, of) < 1e-3
         loss = utils.cross_entropy2d(score, cu(target), size_average=False)
-        oloss, ods, _ = O.cross_entropy2d(of, target, size_average=False)
+        oloss, _, _ = O.cross_entropy2d(of, target, size_average=False, want_grad=False)
         assert abs(loss.item() - float(oloss)) < 1e-4 * abs(float(oloss))
-        _, _, opred = O.cross_entropy2d(score.detach().cpu().numpy(), target, want_grad=False)
+        sn = score.detach().cpu().numpy()
+        _, ods, opred = O.cross_entropy2d(sn, target, size_average=False)
         assert np.array_equal(utils.channel_argmax(score).cpu().numpy(), opred)
         opt.zero_grad()
         loss.backward()
+        # backward given the HIP pass's forward state (see tests/helpers_parity.py)
+        assert adopt_forward(om, m._last_ctx, x, None, Cn) == 0.0
         og = om.backward(df=ods)
         og = {k: v for k, v in og.items() if k.split(".")[0] in O.WEIGHT_GROUP}
-        for key, ref in og.items():
-            name, kind = key.split(".")
-            gr = getattr(getattr(m, name), kind).grad
-            tol = 1e-2 if key == "conv1_1.bias" else 1e-3
-            idx = probe_idx(ref.size)
-            e1 = np.abs(gr.flatten()[cu(idx)].cpu().numpy().astype(np.float64) - ref.reshape(-1)[idx]).max() / np.abs(ref).max()
-            assert e1 < tol, (key, it, e1)
+        errs = grad_errors(m, og, list(og))
+        for k, e in errs.items():
+            assert e < (1e-3 if k.endswith(".bias") else 1e-4), (k, it, e)
         opt.step()
         osgd.step(om.p, og, lambda k: 1e-10 * (2 if k.endswith(".bias") else 1), lambda k: 0.0 if k.endswith(".bias") else 0.0005)
         for key in ("conv1_1.weight", "conv3_2.weight", "fc6.weight", "fc7.bias", "score_fr.weight", "score_fr.bias"):
@@ -361,6 +386,8 @@ def test_cfg1_softmax_fcn_step_vs_oracle():
             want = om.p[key].reshape(-1)[idx].astype(np.float64)
             ulp = np.abs(want).max() * 2.0 ** -23
             assert np.abs(got - want).max() <= 2 * ulp, (key, it)
+        # keep the oracle's weights identical to the HIP model's for the second iteration's forward comparison
+        om.p.update({k: np.ascontiguousarray(v) for k, v in oracle_params(m).items()})
 
 
 def test_cfg1_cli_end_to_end(tmp_path):

@@ -135,3 +135,13 @@ def test_seenmask_binary_target_rule():
     tr._seen_lut[torch.tensor(seen)] = 1
     got = tr.binary_target(torch.from_numpy(g["target"]))
     assert np.array_equal(got.numpy(), g["bin_target"])          # -1 -> 0 ("unseen"), not ignored
+
+
+def test_packaged_embeddings_equal_golden_capture():
+    """the K x E matrices shipped as package data are the byte-identical re-saves captured from the reference (G9)"""
+    import glob
+    pk = os.path.join(ROOT, "zeroshotsemanticsegmentation_amd", "data")
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "embeddings_*.npy")))
+    assert len(files) == 5
+    for f in files:
+        assert open(f, "rb").read() == open(os.path.join(pk, os.path.basename(f)), "rb").read()

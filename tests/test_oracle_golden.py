@@ -265,3 +265,26 @@ def test_fused_head_restatement_matches_unfused_oracle(case):
     # pred-only form
     _, _, p2, _ = O.fused_head(coarse, emb, None, H, W)
     assert np.array_equal(p2, pred)
+
+
+def test_torch_cpu_restatement_matches_golden_g7():
+    """oracle/torch_ref.py (bench.py's torch-CPU baseline) reproduces the reference's captured train step: loss,
+    class assignment and gradient probes of g7 (depthwise upscore == the reference's dense diagonal upscore)"""
+    import torch
+    from oracle import torch_ref as T
+    g = gold("g7_train_step_adam")
+    m = T.FCN32sTorch(20).load_numpy(synth.make_params(20))
+    x, t, e = torch.from_numpy(g["x"]), torch.from_numpy(g["target"]), torch.from_numpy(g["embed"])
+    f = m(x, "fcn")
+    assert rel(f.detach().numpy(), g["score0"]) < 1e-4
+    loss = T.cosine_loss(f, t, e)
+    assert abs(float(loss) - float(g["loss0"])) < 1e-5
+    pred = T.infer_lbl(f.detach(), e).numpy()
+    safe = g["margin0"][None] > 1e-5
+    assert np.array_equal(pred[safe], g["pred0"][safe])
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k in ["conv1_2.weight", "conv3_2.weight", "fc6.weight", "fc7.bias", "score_fr.weight", "score_fr.bias"]:
+        gr = named[k].grad.flatten().numpy()
+        idx = (np.arange(64, dtype=np.int64) * 2654435761 % gr.size).astype(np.int64)
+        assert rel(gr[idx], g["grad_probe/" + k]) < 1e-3, k

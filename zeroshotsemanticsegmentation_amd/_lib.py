@@ -39,7 +39,6 @@ SIGNATURES = {
     "szn_last_kernel": (C.c_char_p, []),
     "szn_prev_kernel": (C.c_char_p, []),
     "szn_version": (_I, []),
-    "szn_debug_spin": (_I, [_I, C.c_longlong, _P, _P]),
     "szn_device_info": (_I, [_I, C.POINTER(DeviceInfo)]),
     "szn_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "szn_pack_weight_dgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/szn.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -60,3 +61,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 static inline int szn_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Ablation switches (SZN_*_ABLATE) make kernels skip work and return WRONG results; they exist for the cycle-accounting
+// experiments of profiles/r01_ablations.txt and are compiled in only by `make ABLATE=1` (-DSZN_ABLATE_BUILD).
+static inline int szn_ablate_env(const char* name) {
+#ifdef SZN_ABLATE_BUILD
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}

@@ -438,7 +438,7 @@ int launch_v2(const Conv2Args& a, hipStream_t st) {
         attr_done = true;
     }
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("SZN_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) { abl = szn_ablate_env("SZN_ABLATE"); }
     if (abl && sizeof(T) == 2) {                      // debug ablations of the bf16 kernels (wrong results)
         if (abl == 1) launch_abl<T, WNF, 1>(a, lds, st);
         else if (abl == 2) launch_abl<T, WNF, 2>(a, lds, st);

@@ -312,7 +312,7 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
     if (blocks >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad: grid too large");
     a.plain_store = (a.nsplit == 1 && !accumulate) ? 1 : 0;      // fc6: 411 MB written once instead of memset + atomics
     static int wg_abl = -1;
-    if (wg_abl < 0) { const char* e = getenv("SZN_WG_ABLATE"); wg_abl = e ? atoi(e) : 0; }
+    if (wg_abl < 0) { wg_abl = szn_ablate_env("SZN_WG_ABLATE"); }
     a.ablate = wg_abl;
     if (!accumulate && !a.plain_store) {
         hipError_t e = hipMemsetAsync(dw, 0, nw * sizeof(float), st);

@@ -278,7 +278,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->ldi * 2);
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.pad = d->pad;
     a.ldi = d->ldi; a.ldd = d->ldo; a.accumulate = accumulate;
-    { static int abl = -1; if (abl < 0) { const char* e = getenv("SZN_WGT_ABLATE"); abl = e ? atoi(e) : 0; } a.ablate = abl; }
+    { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGT_ABLATE"); } a.ablate = abl; }
     hipStream_t st = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {

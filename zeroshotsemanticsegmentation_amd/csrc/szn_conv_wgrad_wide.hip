@@ -213,7 +213,7 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldd = d->ldo;
     a.M = d->B * d->Ho * d->Wo;
     a.accumulate = accumulate;
-    { static int abl = -1; if (abl < 0) { const char* e = getenv("SZN_WGW_ABLATE"); abl = e ? atoi(e) : 0; } a.ablate = abl; }
+    { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGW_ABLATE"); } a.ablate = abl; }
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_wide, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW);

@@ -304,7 +304,7 @@ int launch_wide(const WideArgs& a, hipStream_t st) {
         attr_done = true;
     }
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("SZN_WIDE_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) { abl = szn_ablate_env("SZN_WIDE_ABLATE"); }
     if (abl && sizeof(T) == 2 && WNF == 8) {          // debug ablations of the bf16 256 x 256 kernel (wrong results)
         if (abl == 1) {
             (void)hipFuncSetAttribute((const void*)conv_igemm_wide<T, WNF, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -24,34 +24,6 @@ static thread_local const char* g_prev_kernel = "";
 void szn_note_kernel(const char* name) { g_prev_kernel = g_last_kernel; g_last_kernel = name; }
 extern "C" const char* szn_last_kernel(void) { return g_last_kernel; }
 extern "C" const char* szn_prev_kernel(void) { return g_prev_kernel; }
-// Debug aid: `blocks` workgroups of 256 threads that spin for `cycles` shader clocks -- a stand-in for another queue's
-// kernel (an RCCL all-reduce) holding CUs while the training step runs (tools/contention.py).
-// HEAVY: keeps ~100 VGPRs live per lane like a collective kernel does, so that its waves cannot share a SIMD with the two
-// 244-VGPR waves of the persistent conv kernels (a light spinner co-resides with them and costs next to nothing)
-template <bool HEAVY>
-__global__ __launch_bounds__(256) void spin_kernel(long long cycles, int* sink) {
-    const long long t0 = clock64();
-    float r[HEAVY ? 96 : 1];
-#pragma unroll
-    for (int i = 0; i < (HEAVY ? 96 : 1); ++i) r[i] = (float)(threadIdx.x + i);
-    while (clock64() - t0 < cycles) {
-#pragma unroll
-        for (int i = 0; i < (HEAVY ? 96 : 1); ++i) r[i] = fmaf(r[i], 1.0001f, 0.5f);
-    }
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < (HEAVY ? 96 : 1); ++i) acc += r[i];
-    if (acc == -1.f) *sink = 1;
-}
-extern "C" int szn_debug_spin(int blocks, long long cycles, void* sink, szn_stream_t stream) {
-    if (blocks == 0 || cycles <= 0 || !sink) SZN_FAIL(SZN_ERR_ARG, "debug_spin: bad argument");
-    if (blocks < 0)       // negative block count: the register-heavy variant
-        hipLaunchKernelGGL(spin_kernel<true>, dim3(-blocks), dim3(256), 0, (hipStream_t)stream, cycles, (int*)sink);
-    else
-    hipLaunchKernelGGL(spin_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cycles, (int*)sink);
-    SZN_CHECK_LAUNCH("spin_kernel");
-    return SZN_OK;
-}
 
 extern "C" int szn_version(void) { return 100; /* 0.1.0 */ }
 extern "C" int szn_device_info(int device, szn_device_info_t* out) {

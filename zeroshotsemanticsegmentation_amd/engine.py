@@ -9,6 +9,8 @@ module's Parameters are channels_last views into them), the head runs fused from
 (szn_fused_head) and the per-layer gradient buckets are all-reduced on RCCL's stream while the rest of the
 backward pass is still running.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -25,9 +27,13 @@ class GradBuckets(object):
     tail of `flat` becomes final first.  A bucket is closed once it holds >= bucket_elems elements (or at the first
     layer) and its sum all-reduce is issued asynchronously (RCCL's own stream; gloo in the CPU tests) as soon as the
     bucket's earliest layer reports `layer_done`; `finish` waits for everything.  The 1/world scaling is applied by the
-    optimizer kernel (grad_scale), not here."""
+    optimizer kernel (grad_scale), not here.
 
-    def __init__(self, flat, layers, bucket_elems, extra=(), group=None):
+    comm_dtype=torch.bfloat16 halves the bytes on the xGMI links (271 MB instead of 542 MB per step at E = 300): the
+    bucket is rounded to bf16 into a staging buffer, summed there by the all-reduce and widened back into `flat` by
+    `finish` (gradient noise of 2^-9 relative per rank; the fp32 default is exact)."""
+
+    def __init__(self, flat, layers, bucket_elems, extra=(), group=None, comm_dtype=torch.float32):
         self.flat, self.extra, self.group = flat, list(extra), group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.buckets = []            # (start, end, name of the layer whose completion closes the bucket)
@@ -40,25 +46,56 @@ class GradBuckets(object):
                 end = None
         self.ready_after = {name: (o, e) for o, e, name in self.buckets}
         self.works = []
+        self.comm_dtype = comm_dtype
+        self.stage = None
+        if self.world > 1 and comm_dtype != torch.float32:
+            self.stage = torch.empty(flat.numel(), dtype=comm_dtype, device=flat.device)
 
     def layer_done(self, name):
         if self.world > 1 and name in self.ready_after:
             o, e = self.ready_after[name]
-            self.works.append(dist.all_reduce(self.flat[o:e], group=self.group, async_op=True))
+            if self.stage is None:
+                self.works.append((dist.all_reduce(self.flat[o:e], group=self.group, async_op=True), None))
+            else:
+                self.stage[o:e].copy_(self.flat[o:e])
+                self.works.append((dist.all_reduce(self.stage[o:e], group=self.group, async_op=True), (o, e)))
 
     def finish(self):
         if self.world > 1:
             for t in self.extra:
-                self.works.append(dist.all_reduce(t, group=self.group, async_op=True))
-            for wk in self.works:
+                self.works.append((dist.all_reduce(t, group=self.group, async_op=True), None))
+            for wk, span in self.works:
                 wk.wait()
+                if span is not None:
+                    self.flat[span[0]:span[1]].copy_(self.stage[span[0]:span[1]])
         self.works = []
+
+
+def allreduce_param_grads(params, group=None):
+    """mean of the per-rank gradients of an explicit parameter list (the autograd trainer paths: softmax / mse losses,
+    seen-mask phase): one flat all-reduce.  No-op in a single process."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, group=group)
+    flat /= world
+    off = 0
+    for p in ps:
+        p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+        off += p.numel()
 
 
 class TrainStep(object):
     def __init__(self, model, embeddings, optimizer="adam", lr=1e-5, momentum=0.99, weight_decay=0.0005,
                  precision=torch.bfloat16, fused_head=True, loss="cos", process_group=None, bucket_mb=25,
-                 train_metrics=True):
+                 train_metrics=True, betas=(0.9, 0.999), eps=1e-8, bias_lr=None, bias_weight_decay=0.0,
+                 adam_weight_decay=0.0, grad_comm_dtype=None):
         if loss not in ("cos", "mse") or (fused_head and loss != "cos"):
             raise L.SznError("TrainStep: fused head supports the cosine loss; use fused_head=False for mse")
         self.model = model
@@ -72,6 +109,14 @@ class TrainStep(object):
         if self.E != model.n_class:
             raise L.SznError("embedding dimension %d != model n_class %d" % (self.E, model.n_class))
         self.opt, self.lr, self.momentum, self.wd = optimizer, lr, momentum, weight_decay
+        # the reference wiring (train.py:126-133): biases at 2 x lr without weight decay; Adam has no weight decay at all
+        self.betas, self.eps = betas, eps
+        self.adam_wd = adam_weight_decay
+        self.bias_lr = 2 * lr if bias_lr is None else bias_lr
+        self.bias_wd = bias_weight_decay
+        if grad_comm_dtype is None:
+            grad_comm_dtype = torch.bfloat16 if os.environ.get("SZN_GRAD_COMM", "fp32") == "bf16" else torch.float32
+        self.grad_comm_dtype = grad_comm_dtype
         self.fused_head, self.loss_kind = fused_head, loss
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -83,6 +128,8 @@ class TrainStep(object):
         self.loss = torch.zeros(1, device=self.dev)
         self.stats = None
         self._ws = None
+        self.keep_ctx = False        # tests: keep the forward state of the last step (activations stay alive one step longer)
+        self.last_ctx = None
 
     # ---- flat parameter / gradient / moment storage ----------------------------------------------------
     def _flatten(self):
@@ -158,7 +205,8 @@ class TrainStep(object):
 
     def _buckets(self, bucket_mb):
         layers = [(n,) + self.woff[n] for n in _OPT_LAYERS]
-        self.buckets = GradBuckets(self.flat_gw, layers, bucket_mb * (1 << 20) // 4, extra=[self.flat_gb], group=self.pg)
+        self.buckets = GradBuckets(self.flat_gw, layers, bucket_mb * (1 << 20) // 4, extra=[self.flat_gb], group=self.pg,
+                                   comm_dtype=self.grad_comm_dtype)
 
     # ---- one training step -----------------------------------------------------------------------------
     def step(self, x, target):
@@ -168,6 +216,7 @@ class TrainStep(object):
         B, _, H, W = x.shape
         st = L.stream_ptr()
         ctx = eng.forward(x, train=m.training)
+        self.last_ctx = ctx if self.keep_ctx else None
         CP, E, K = m.head_width, self.E, self.K
         code = L.dtype_code(eng.dtype)
         pred = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
@@ -219,12 +268,13 @@ class TrainStep(object):
         st = L.stream_ptr()
         gs = 1.0 / self.world
         for key, flat, grad, lr, wd in (("w", self.flat_w, self.flat_gw, self.lr, self.wd),
-                                        ("b", self.flat_b, self.flat_gb, 2 * self.lr, 0.0)):
+                                        ("b", self.flat_b, self.flat_gb, self.bias_lr, self.bias_wd)):
             lp = L.ptr(self.flat_w_lp) if (key == "w" and self.flat_w_lp is not None) else None
             if self.opt == "adam":       # train.py:130-133 (Adam has no weight decay in the reference wiring)
                 m1, m2 = self.state[key]
-                L.call("szn_adam_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr), 0.9, 0.999,
-                       1e-8, 0.0, self.nstep, gs, lp, st)
+                L.call("szn_adam_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr),
+                       float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.bias_wd if key == "b" else self.adam_wd),
+                       self.nstep, gs, lp, st)
             else:                        # train.py:126-129
                 (buf,) = self.state[key]
                 L.call("szn_sgd_momentum_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(buf), float(lr),

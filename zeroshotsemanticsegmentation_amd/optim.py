@@ -17,6 +17,17 @@ def _dense_same_layout(p, g):
     return out
 
 
+def _state_like(p, t):
+    """optimizer state with exactly p's memory layout.  Optimizer.load_state_dict keeps the strides of the checkpoint's
+    tensors: a reference torch.optim checkpoint carries NCHW-contiguous moments while the parameters here are
+    channels_last, and the kernels walk raw storage -- re-materialise such a tensor (logical copy) before use."""
+    if t.stride() == p.stride() and t.dtype == torch.float32 and t.device == p.device:
+        return t
+    out = torch.empty_like(p)
+    out.copy_(t)
+    return out
+
+
 def _check_dense(p):
     if not p.is_cuda:
         raise L.SznError("fused optimizers need GPU parameters (no CPU fallback)")
@@ -47,6 +58,8 @@ class FusedAdam(torch.optim.Optimizer):
                     state['step'] = torch.tensor(0.0)
                     state['exp_avg'] = torch.zeros_like(p)
                     state['exp_avg_sq'] = torch.zeros_like(p)
+                for k in ('exp_avg', 'exp_avg_sq'):
+                    state[k] = _state_like(p, state[k])
                 step = int(state['step']) + 1
                 state['step'] = torch.tensor(float(step))
                 g = _dense_same_layout(p, p.grad)
@@ -76,6 +89,8 @@ class FusedSGD(torch.optim.Optimizer):
                 first = 'momentum_buffer' not in state or state['momentum_buffer'] is None
                 if first:
                     state['momentum_buffer'] = torch.zeros_like(p)
+                else:
+                    state['momentum_buffer'] = _state_like(p, state['momentum_buffer'])
                 g = _dense_same_layout(p, p.grad)
                 L.call("szn_sgd_momentum_step", p.numel(), L.ptr(p), L.ptr(g), L.ptr(state['momentum_buffer']),
                        float(group['lr']), float(group['momentum']), float(group['weight_decay']), int(first),

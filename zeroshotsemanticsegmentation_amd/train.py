@@ -177,14 +177,19 @@ def main(argv=None):
         raise RuntimeError("no GPU visible: this implementation has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     torch.manual_seed(1337)
     torch.cuda.manual_seed(1337)
 
-    log_dir = get_log_dir(args.name, args.config, cfg, args.data_dir)
+    # one log directory for the whole job: rank 0 stamps it (wall clock), the others receive the name
+    log_dir = get_log_dir(args.name, args.config, cfg, args.data_dir) if rank == 0 else None
+    if world > 1:
+        box = [log_dir]
+        dist.broadcast_object_list(box, src=0)
+        log_dir = box[0]
     tb_writer = None
     if args.tb_dir and rank == 0:
         try:
@@ -203,14 +208,22 @@ def main(argv=None):
     n_class = 21 if cfg['dataset'] == 'pascal' else 33
     all_unseen = cfg['train_unseen'] + cfg['val_unseen']
     mk = lambda split, unseen, n: SyntheticSegmentation(split=split, n_images=n, size=(H, W), n_class=n_class,
-                                                         embed_dim=cfg['embed_dim'], unseen=unseen, seed=1337 + 7919 * rank)
-    train_dataset = mk('train', [], n_img)
+                                                         embed_dim=cfg['embed_dim'], unseen=unseen, seed=1337)
+    # splits as in the reference (pascal_dataset.py:62-74, context_dataset.py:75-94): 'train' drops every image that
+    # contains a val_unseen class, 'train_seen' additionally drops the train_unseen classes, 'val' keeps everything
+    train_dataset = mk('train', cfg['val_unseen'], n_img)
     train_seen_dataset = mk('train_seen', all_unseen, n_img)
     val_dataset = mk('val', [], max(n_img // 4, 1))
     kwargs = {'num_workers': 2, 'pin_memory': True}
-    train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True, **kwargs)
-    train_seen_loader = torch.utils.data.DataLoader(train_seen_dataset, batch_size=args.batch_size, shuffle=True, **kwargs)
-    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=1, shuffle=False, **kwargs)
+
+    def loader(ds, bs, shuffle):
+        if world > 1 and shuffle:       # every rank holds the same dataset; the sampler deals disjoint shards per epoch
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=1337)
+            return torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler, **kwargs)
+        return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=shuffle, **kwargs)
+    train_loader = loader(train_dataset, args.batch_size, True)
+    train_seen_loader = loader(train_seen_dataset, args.batch_size, True)
+    val_loader = loader(val_dataset, 1, False)            # validation shards by batch index inside Trainer.validate
     label_names = train_dataset.class_names
     if rank == 0 and not osp.exists(osp.join(log_dir, 'counts.csv')):
         with open(osp.join(log_dir, 'counts.csv'), 'w') as f:
@@ -233,6 +246,7 @@ def main(argv=None):
     model = model.to(device)
     precision = torch.bfloat16 if args.precision == 'bf16' else torch.float32
     model.set_precision(precision)
+    model._engine.dropout_seed = 1337 + 7919 * rank       # data-parallel ranks draw different Dropout2d masks
 
     # 3. fcn optimizer and trainer
     optim = make_fcn_optimizer(model, cfg)
@@ -252,6 +266,8 @@ def main(argv=None):
         if cfg['seenmask_epochs'] > 0:
             freeze_for_seenmask(model)
             sm_optim = FusedAdam([{'params': list(get_parameters(model, seenmask=True))}], lr=cfg['seenmask_lr'])
+            if world > 1:
+                dist.barrier()               # rank 0 has finished writing <log_dir>/best before anyone reads it
             if not checkpoint:
                 # the reference reloads <log_dir>/best (train.py:177-179); fall back to the last checkpoint when no
                 # validation improved on best_mean_iu = 0 (tiny synthetic runs)
@@ -271,7 +287,6 @@ def main(argv=None):
     elif cfg['mode'] == 'test_all':
         fcn_trainer.validate(both_fcn_and_seenmask=True)
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

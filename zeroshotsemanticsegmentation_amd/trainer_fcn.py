@@ -18,16 +18,16 @@ import torch
 from . import engine as _engine
 from . import utils
 
-_GOLDEN = osp.join(osp.dirname(osp.dirname(osp.abspath(__file__))), "tests", "golden")
+_DATA = osp.join(osp.dirname(osp.abspath(__file__)), "data")      # package data: .npy re-saves of the reference's pickles
 
 
 def load_embeddings(dataset, dim):
     """K x E class-embedding matrix: `datasets/<ds>/embeddings/norm_embed_arr_<E>.pkl` relative to the CWD exactly
-    like the reference (trainer_fcn.py:49), else the .npy re-saves shipped with this repo's fixtures."""
+    like the reference (trainer_fcn.py:49), else the .npy re-saves shipped inside this package (data/)."""
     pkl = 'datasets/%s/embeddings/norm_embed_arr_%s' % (dataset, str(dim))
     if osp.exists(pkl + '.pkl'):
         return np.asarray(utils.load_obj(pkl), dtype=np.float32)
-    npy = osp.join(_GOLDEN, "embeddings_%s_%s.npy" % (dataset, str(dim)))
+    npy = osp.join(_DATA, "embeddings_%s_%s.npy" % (dataset, str(dim)))
     if osp.exists(npy):
         return np.load(npy)
     raise IOError("no embedding matrix for dataset=%s dim=%s (looked for %s.pkl and %s)" % (dataset, dim, pkl, npy))
@@ -77,6 +77,7 @@ class Trainer(object):
         self.precision = precision
         self._step = None
         self._fused_step = fused_step
+        self.verbose_val = os.environ.get("SZN_VERBOSE_VAL", "0") == "1"   # per-image prints cost a host sync each
 
         if self.pixel_embeddings:
             arr = np.asarray(embed_arr, dtype=np.float32) if embed_arr is not None else \
@@ -156,20 +157,36 @@ class Trainer(object):
 
     # ---- training --------------------------------------------------------------------------------------------
     def _fast_step(self):
-        """engine.TrainStep when the configuration allows it (embedding cosine loss, Adam/SGD wiring of train.py)"""
-        if self._step is None and self._fused_step and self.pixel_embeddings and self.loss_func == "cos":
-            from .optim import FusedAdam, FusedSGD
-            if isinstance(self.optim, (FusedAdam, torch.optim.Adam)):
-                kind, extra = "adam", {}
-            elif isinstance(self.optim, (FusedSGD, torch.optim.SGD)):
-                kind = "sgd"
-                extra = dict(momentum=self.optim.param_groups[0].get('momentum', 0.99),
-                             weight_decay=self.optim.param_groups[0].get('weight_decay', 0.0005))
-            else:
+        """engine.TrainStep when the configuration allows it: embedding cosine loss, no forced_unseen train metrics, and an
+        optimizer with exactly the reference's two parameter groups (train.py:126-133: all Conv2d weights | all Conv2d
+        biases).  Hyper-parameters are read per group from the optimizer object; any other wiring keeps the autograd path."""
+        if self._step is not None or not (self._fused_step and self.pixel_embeddings and self.loss_func == "cos"):
+            return self._step
+        if self.forced_unseen:
+            return None
+        from .optim import FusedAdam, FusedSGD
+        from .models import _OPT_LAYERS
+        groups = self.optim.param_groups
+        ws = [getattr(self.model, n).weight for n in _OPT_LAYERS]
+        bs = [getattr(self.model, n).bias for n in _OPT_LAYERS]
+        same = lambda a, b: len(a) == len(b) and {id(t) for t in a} == {id(t) for t in b}
+        if len(groups) != 2 or not same(groups[0]['params'], ws) or not same(groups[1]['params'], bs):
+            return None
+        gw, gb = groups
+        if isinstance(self.optim, (FusedAdam, torch.optim.Adam)):
+            if gw.get('amsgrad') or gw['betas'] != gb['betas'] or gw['eps'] != gb['eps']:
                 return None
-            self._step = _engine.TrainStep(self.model, self.embeddings, optimizer=kind, lr=self.optim.param_groups[0]['lr'],
-                                           precision=self.precision, fused_head=True, **extra)
-            self._step.import_optimizer_state(self.optim)       # resumed runs (train.py:135-136)
+            kw = dict(optimizer="adam", betas=tuple(gw['betas']), eps=gw['eps'], adam_weight_decay=gw.get('weight_decay', 0.0))
+        elif isinstance(self.optim, (FusedSGD, torch.optim.SGD)):
+            if gw.get('nesterov') or gw.get('dampening', 0) or gw.get('momentum', 0) != gb.get('momentum', 0):
+                return None
+            kw = dict(optimizer="sgd", momentum=gw.get('momentum', 0), weight_decay=gw.get('weight_decay', 0.0))
+        else:
+            return None
+        self._step = _engine.TrainStep(self.model, self.embeddings, lr=gw['lr'], bias_lr=gb['lr'],
+                                       bias_weight_decay=gb.get('weight_decay', 0.0), precision=self.precision,
+                                       fused_head=True, **kw)
+        self._step.import_optimizer_state(self.optim)       # resumed runs (train.py:135-136)
         return self._step
 
     def train_epoch(self):
@@ -178,17 +195,23 @@ class Trainer(object):
         for batch_idx, (data, target) in enumerate(self.train_loader):
             if step is not None:
                 data, target, _ = self._unpack(data, target)
+                step.hist.zero_()
                 loss, pred = step.step(data, target)
-                lossv = float(loss.item())
+                # one D2H per iteration: the loss and the K x K histogram the step already accumulated on the device
+                # (the reference logs per-iteration metrics, trainer_fcn.py:164-174)
+                packed = torch.cat([loss.reshape(1).double(), step.hist[0].reshape(-1).double()]).cpu().numpy()
+                lossv = float(packed[0])
                 if np.isnan(lossv):
                     raise ValueError('loss is nan while training')
-                metrics = utils.label_accuracy_score([target], [pred], self.n_class)
-                gsum = float(self.model.score_fr.weight.grad.sum().item())
+                metrics = utils._hist_to_metrics(packed[1:].reshape(self.n_class, self.n_class))
+                gsum = float('nan')                  # not read back on this path (a host sync per iteration for a debug print)
                 ssum = float('nan')                  # the (B,E,H,W) score is never materialised on this path
             else:
                 score, loss, lbl_pred, lbl_true = self.forward(data, target)
                 self.optim.zero_grad()
                 loss.backward()
+                # data parallel: mean of the rank gradients before the update (the fused path does this inside TrainStep)
+                _engine.allreduce_param_grads([p for g in self.optim.param_groups for p in g['params']])
                 self.optim.step()
                 lossv = float(loss.item())
                 metrics = utils.label_accuracy_score(lbl_true.numpy(), lbl_pred, self.n_class)
@@ -205,28 +228,60 @@ class Trainer(object):
                     self.tb_writer.add_scalar('fcn/train/' + name, v, self.iteration)
             self.iteration += 1
 
+    def _predict_device(self, data, target, szn):
+        """forward + loss + class assignment with everything left on the GPU -> (score, loss 0-dim, pred (n,h,w), target)"""
+        data, target, target_embed = self._unpack(data, target)
+        if szn:
+            score, seen_mask_score = self.model(data, mode='both')
+        else:
+            score = self.model(data, mode='fcn')
+        loss = self._loss(score, target, target_embed)
+        if not self.pixel_embeddings:
+            pred = utils.channel_argmax(score)
+        elif szn:
+            full = self.seen_embeddings + self.unseen_embeddings
+            pred = utils.infer_lbl_device(score, full, mode=1, unseen=self.unseen, seenmask=seen_mask_score)
+        elif self.forced_unseen:
+            full = self.seen_embeddings + self.unseen_embeddings
+            pred = utils.infer_lbl_device(score, full, mode=1, unseen=self.unseen, target=target)
+        else:
+            pred = utils.infer_lbl_device(score, self.embeddings)
+        return score, loss, pred, target
+
     def validate(self, both_fcn_and_seenmask=False):
+        """reference :182-292.  The {all, seen, unseen} K x K histograms and the loss sum are accumulated on the GPU
+        (szn_confusion_hist on the device prediction) and read back ONCE per epoch; under data parallelism the validation
+        images are split across the ranks and the histograms / loss sums are all-reduced before the metrics."""
+        import torch.distributed as dist
         self.model.eval()
-        val_loss = 0
-        lbl_trues, lbl_preds = [], []
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        hist = torch.zeros(3, self.n_class, self.n_class, dtype=torch.int64, device=self.device)
+        acc = torch.zeros(2, dtype=torch.float64, device=self.device)          # loss sum, image-batch count
         with torch.no_grad():
             for batch_idx, (data, target) in enumerate(self.val_loader):
-                fwd = self.forward_szn if both_fcn_and_seenmask else self.forward
-                score, loss, lbl_pred, lbl_true = fwd(data, target)
-                val_loss += float(loss.item())
-                if self.rank == 0:
+                if world > 1 and batch_idx % world != self.rank:
+                    continue
+                score, loss, pred, tgt = self._predict_device(data, target, both_fcn_and_seenmask)
+                acc[0] += loss.double()
+                acc[1] += 1
+                utils.confusion_hist_device(tgt, pred, self.n_class, self.val_unseen if self.unseen else None, hist)
+                if self.verbose_val and self.rank == 0:
                     print("Test Epoch {:<5} | Iteration {:<5} | Loss {:5.5f} | Score Sum {:10.5f}".format(
                         int(self.epoch), int(batch_idx), float(loss.item()), float(score.sum().item())))
-                for i in range(lbl_pred.shape[0]):
-                    lbl_trues.append(lbl_true[i].numpy())
-                    lbl_preds.append(lbl_pred[i])
+        if world > 1:
+            dist.all_reduce(hist)
+            dist.all_reduce(acc)
+        h = hist.cpu().numpy()
+        accn = acc.cpu().numpy()
+        if np.isnan(accn[0]):
+            raise ValueError('loss is nan while validating')
+        val_loss = float(accn[0])
+        n_batches = max(int(accn[1]), 1)
+        metrics = utils._hist_to_metrics(h[0])
         seen_metrics = unseen_metrics = None
         if self.unseen:
-            metrics, seen_metrics, unseen_metrics = utils.label_accuracy_score(lbl_trues, lbl_preds, self.n_class,
-                                                                               unseen=self.val_unseen)
-        else:
-            metrics = utils.label_accuracy_score(lbl_trues, lbl_preds, self.n_class)
-        val_loss /= max(len(self.val_loader), 1)        # averaged over images like the reference (:246)
+            seen_metrics, unseen_metrics = utils._hist_to_metrics(h[1]), utils._hist_to_metrics(h[2])
+        val_loss /= n_batches                           # averaged over images like the reference (:246)
         names = ['pxl_acc', 'class_acc', 'mean_iu', 'fwavacc']
         if self.rank == 0:
             with open(osp.join(self.log_dir, 'val_log.csv'), 'a') as f:
@@ -264,6 +319,8 @@ class Trainer(object):
     def train(self):
         for epoch in range(self.max_epoch):
             self.epoch = epoch
+            if hasattr(getattr(self.train_loader, 'sampler', None), 'set_epoch'):
+                self.train_loader.sampler.set_epoch(epoch)       # DistributedSampler: a new shuffle per epoch
             self.train_epoch()
             self.validate()
             # early stop once as many images were seen as in 50 epochs without zero-shot (reference :300-306)

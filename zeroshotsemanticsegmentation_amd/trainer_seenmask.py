@@ -69,45 +69,42 @@ class Trainer(object):
         idx = torch.where((t >= 0) & (t < self.n_class), t, torch.full_like(t, self.n_class))
         return self._seen_lut[idx]
 
-    def forward(self, data, target):
+    def _forward_device(self, data, target):
+        """-> (score, loss, pred (n,h,w) int64 device tensor, binary target device tensor)"""
         if isinstance(target, (tuple, list)):
             target = target[0]
         target = self.binary_target(target)
         data = data.to(self.device, non_blocking=True)
         score = self.model(data, mode='seenmask')
         loss = utils.cross_entropy2d(score, target, size_average=True)
-        lbl_pred = utils.channel_argmax(score).cpu().numpy()
-        return score, loss, lbl_pred, target.detach().cpu()
+        return score, loss, utils.channel_argmax(score), target
 
-    def _allreduce_grads(self):
-        """data parallel phase 2: one small RCCL all-reduce of the 24,578 trainable gradient elements"""
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        ps = [p for g in self.optim.param_groups for p in g['params'] if p.grad is not None]
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
-        dist.all_reduce(flat)
-        flat /= dist.get_world_size()
-        off = 0
-        for p in ps:
-            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
-            off += p.numel()
+    def forward(self, data, target):
+        """-> (score, loss, lbl_pred numpy int64 (n,h,w), lbl_true cpu tensor)   [reference :50-70]"""
+        score, loss, pred, target = self._forward_device(data, target)
+        return score, loss, pred.cpu().numpy(), target.detach().cpu()
+
+    def _metrics_device(self, loss, target, pred):
+        """loss + the K x K histogram of one batch in ONE device-to-host copy -> (loss value, metrics)"""
+        hist = utils.confusion_hist_device(target, pred, self.n_class)
+        packed = torch.cat([loss.detach().reshape(1).double(), hist[0].reshape(-1).double()]).cpu().numpy()
+        return float(packed[0]), utils._hist_to_metrics(packed[1:].reshape(self.n_class, self.n_class))
 
     def train_epoch(self):
+        from .engine import allreduce_param_grads
         self.model.train()
         for batch_idx, (data, target) in enumerate(self.train_loader):
-            score, loss, lbl_pred, lbl_true = self.forward(data, target)
+            score, loss, pred, tgt = self._forward_device(data, target)
             self.optim.zero_grad()
             loss.backward()
-            self._allreduce_grads()
+            # data parallel phase 2: one small RCCL all-reduce of the 24,578 trainable gradient elements
+            allreduce_param_grads([p for g in self.optim.param_groups for p in g['params']])
             self.optim.step()
-            lossv = float(loss.item())
-            metrics = utils.label_accuracy_score(lbl_true.numpy(), lbl_pred, self.n_class)
+            lossv, metrics = self._metrics_device(loss, tgt, pred)
+            if np.isnan(lossv):
+                raise ValueError('loss is nan while training')
             if self.rank == 0:
-                print("Seenmask Train Epoch {:<5} | Iteration {:<5} | Loss {:5.5f} | seenmask_score grad sum {:7.8f} | "
-                      "seenmask_upscore grad sum {:7.8f} | score sum {:10.5f}".format(
-                          int(self.epoch), int(batch_idx), lossv, float(self.model.seenmask_score.weight.grad.sum().item()),
-                          float(self.model.seenmask_upscore.weight.grad.sum().item()), float(score.sum().item())))
+                print("Seenmask Train Epoch {:<5} | Iteration {:<5} | Loss {:5.5f}".format(int(self.epoch), int(batch_idx), lossv))
                 with open(osp.join(self.log_dir, 'seenmask_train_log.csv'), 'a') as f:
                     elapsed = (_now() - self.timestamp_start).total_seconds()
                     f.write(','.join(map(str, [self.epoch, self.iteration, lossv] + list(metrics) + [elapsed])) + '\n')
@@ -116,21 +113,27 @@ class Trainer(object):
             self.iteration += 1
 
     def validate(self):
+        """reference :104-166; histogram and loss sum accumulated on the GPU, one read-back per epoch; validation images are
+        split across the data-parallel ranks and the sums all-reduced"""
+        import torch.distributed as dist
         self.model.eval()
-        val_loss = 0
-        lbl_trues, lbl_preds = [], []
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        hist = torch.zeros(3, self.n_class, self.n_class, dtype=torch.int64, device=self.device)
+        acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         with torch.no_grad():
             for batch_idx, (data, target) in enumerate(self.val_loader):
-                score, loss, lbl_pred, lbl_true = self.forward(data, target)
-                val_loss += float(loss.item())
-                if self.rank == 0:
-                    print("Seenmask Test Epoch {:<5} | Iteration {:<5} | Loss {:5.5f} | Score Sum {:10.5f}".format(
-                        int(self.epoch), int(batch_idx), float(loss.item()), float(score.sum().item())))
-                for i in range(lbl_pred.shape[0]):
-                    lbl_trues.append(lbl_true[i].numpy())
-                    lbl_preds.append(lbl_pred[i])
-        metrics = utils.label_accuracy_score(lbl_trues, lbl_preds, self.n_class)
-        val_loss /= max(len(self.val_loader), 1)
+                if world > 1 and batch_idx % world != self.rank:
+                    continue
+                score, loss, pred, tgt = self._forward_device(data, target)
+                acc[0] += loss.double()
+                acc[1] += 1
+                utils.confusion_hist_device(tgt, pred, self.n_class, None, hist)
+        if world > 1:
+            dist.all_reduce(hist)
+            dist.all_reduce(acc)
+        accn = acc.cpu().numpy()
+        metrics = utils._hist_to_metrics(hist[0].cpu().numpy())
+        val_loss = float(accn[0]) / max(int(accn[1]), 1)
         if self.rank == 0:
             with open(osp.join(self.log_dir, 'seenmask_val_log.csv'), 'a') as f:
                 row = [self.epoch, self.iteration, val_loss] + list(metrics) + [_now() - self.timestamp_start]
@@ -150,5 +153,7 @@ class Trainer(object):
     def train(self):
         for epoch in range(self.max_epoch):
             self.epoch = epoch
+            if hasattr(getattr(self.train_loader, 'sampler', None), 'set_epoch'):
+                self.train_loader.sampler.set_epoch(epoch)       # DistributedSampler: a new shuffle per epoch
             self.train_epoch()
             self.validate()
