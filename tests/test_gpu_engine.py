@@ -151,7 +151,8 @@ def test_fused_optimizer_resumes_from_nchw_contiguous_state(kind):
     pr = torch.nn.Parameter(w0.clone())                                   # the reference: plain torch on the CPU
     ref = torch.optim.Adam([pr], lr=1e-3) if kind == "adam" else torch.optim.SGD([pr], lr=1e-2, momentum=0.9, weight_decay=5e-4)
     pr.grad = grads[0].clone(); ref.step()
-    sd = ref.state_dict()                                                 # contiguous (NCHW) state tensors
+    import copy
+    sd = copy.deepcopy(ref.state_dict())                                  # contiguous (NCHW) state tensors, as torch.load gives
     assert all(v.is_contiguous() for st in sd["state"].values() for v in st.values() if torch.is_tensor(v) and v.dim() == 4)
     p = torch.nn.Parameter(pr.detach().clone().cuda().contiguous(memory_format=torch.channels_last))
     opt = optim.FusedAdam([p], lr=1e-3) if kind == "adam" else optim.FusedSGD([p], lr=1e-2, momentum=0.9, weight_decay=5e-4)
