@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--layers", default=",".join(SHAPES))
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands (no data-dependent switching power)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     code = L.dtype_code(dt)
@@ -36,6 +37,8 @@ def main():
         Hi, Ci, Co, K, pad = SHAPES[name]
         Ho = Hi + 2 * pad - K + 1
         x = torch.randn(B, Hi, Hi, Ci, device="cuda").to(dt)
+        if a.zeros:
+            x.zero_()
         w = (torch.randn(Co, K, K, Ci, device="cuda") / (Ci * K * K) ** 0.5).to(dt)
         wT = torch.empty(Ci, K, K, Co, device="cuda", dtype=dt)
         L.call("szn_pack_weight_dgrad", code, Co, K, K, Ci, L.ptr(w), L.ptr(wT), st)
@@ -44,6 +47,8 @@ def main():
         bias = torch.randn(Co, device="cuda")
         out = torch.empty(B, Ho, Ho, Co, device="cuda", dtype=dt)
         dout = torch.randn(B, Ho, Ho, Co, device="cuda").to(dt)
+        if a.zeros:
+            dout.zero_(); w.zero_()
         din = torch.empty_like(x)
         dw = torch.zeros(Co, K, K, Ci, device="cuda")
         d = L.ConvDesc(code, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, pad, Ci, Co, Ci, 1, 0)

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libszn_hip.so")
+LIB_PATH = os.environ.get("SZN_LIB_PATH") or os.path.join(_HERE, "lib", "libszn_hip.so")   # (override: A/B builds in tools/)
 
 SZN_F32, SZN_BF16 = 0, 1
 
