@@ -36,7 +36,7 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// ---- epilogue staged through LDS in four 64-pixel passes: shared by conv_igemm_wide and conv_igemm_pp ----
+// ---- epilogue staged through LDS in four 64-pixel passes ----
 template <typename T, int WNF>
 __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[WNF][4], char* smem, int tid, int wm, int wn,
                                               int g, int r16, int m0, int n0, int split) {
@@ -303,199 +303,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// conv_igemm_pp: the bf16 256 x 256 tile with an explicit two-group ("ping-pong") schedule.
-//
-// Why: in conv_igemm_wide every wave issues its 12 ds_read_b128 of a K half right behind the barrier and then waits for
-// all of them (lgkmcnt(0)) before its first MFMA -- and so does its SIMD partner, at the same moment: the matrix pipe of
-// each SIMD idles for an LDS round trip twice per chunk, and the 8 LDS-DMA pieces per wave are issued in one burst.
-// Here the two waves of a SIMD (w and w + 4) never do the same thing at the same time: the chunk is cut into four
-// phases (one pair of 16-cout fragments x 64 pixels x the whole K = 64: 16 MFMA), each phase = a READ slot (fragment
-// reads + two LDS-DMA pieces + addressing, ending in lgkmcnt(0) and s_barrier) followed by a MATH slot (16 MFMA at
-// s_setprio 1, s_barrier).  Group 1 (waves 4-7) runs one barrier behind group 0, so on every SIMD a MATH slot of one
-// wave always sits beside a READ slot of the other.
-//
-// LDS ring: two 64 KiB stages, but slots are recycled piecewise as soon as their last reader is done, so every piece is
-// in flight for >= 3 phases (~1.5 K-tiles for the pixel operand) without a third stage:
-//   R1(T): stage weight pieces c3, c4 of tile T+1          (their slots were last read in R3 / R4 of tile T-1)
-//   R2(T): stage pixel rows, first half, of tile T+2       (pixel fragments of tile T are all in registers after R1(T))
-//   R3(T): second half of the pixel rows of tile T+2
-//   R4(T): s_waitcnt vmcnt(4) -> everything tile T+1 needs has landed (issued >= 3 phases ago; the 4 younger loads are the
-//          pixel rows of T+2); then stage weight pieces c1, c2 of tile T+2  (read in R1 / R2 of tile T)
-// Ordering rules kept (MI355X_MICROARCH.md, LDS-DMA): a staged piece is read only after BOTH groups executed their counted
-// vmcnt AND a barrier after the later of the two (group 0 waits in slot 6 of tile T, group 1 in slot 7, the first read is
-// in slot 8); a slot is restaged only after the reads of both groups have RETIRED (lgkmcnt(0) sits before the barrier that
-// ends each READ slot).  Tiles past the end of K are staged from out-of-range offsets (zero fill, no memory traffic) so
-// that the vmcnt arithmetic is the same in every iteration.
-template <int ABL = 0, bool DMA_IN_MATH = false>
-__global__ __launch_bounds__(512, 2) void conv_igemm_pp(WideArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef bf16_raw T;
-    constexpr int ES = 2, BKE = 64, BM = 256, BN = 256, WNF = 8;
-    constexpr int STAGE = (BM + BN) * 128;        // 64 KiB
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][pixels 256 x 128 B | weights 256 x 128 B]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
-    const int grp = w >> 2;                       // waves w and w + 4 share a SIMD: opposite groups
-    const int g = lane >> 4, r16 = lane & 15;
-
-    const int nwg = a.mtiles * a.ntiles;
-    const int lid = xcd_remap_w(blockIdx.x, nwg);
-    const int nt = lid % a.ntiles, mt = lid / a.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
-
-    const int chunkA = (lane & 7) ^ (lane >> 3);
-    unsigned baseA[4], voffA[4], voffB[4];
-    int ohw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 32 * w + 8 * i + (lane >> 3);
-        if (m < a.M) {
-            const int b = m / a.HoWo, r = m - b * a.HoWo;
-            const int oh = r / a.Wo, ow = r - oh * a.Wo;
-            const int ih0 = oh - a.pad, iw0 = ow - a.pad;
-            ohw[i] = (ih0 << 16) | (iw0 & 0xffff);
-            const long px = ((long)(b * a.Hi + ih0) * a.Wi + iw0);
-            baseA[i] = (unsigned)((px * a.ldi + chunkA * (16 / ES)) * ES);
-        } else {
-            ohw[i] = 0x7fff7fff;
-            baseA[i] = 0;
-        }
-    }
-    // weight piece c_j (j = 0..3) = the two 16-cout fragments 2j, 2j+1 of both cout halves: LDS rows 32 j + [0, 32) and
-    // 128 + 32 j + [0, 32); wave w stages 8 of those 64 rows with one instruction
-    const int rowB0 = (w < 4 ? 0 : 128) + 8 * (w & 3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + rowB0 + 32 * j + (lane >> 3);
-        voffB[j] = (n < a.Co) ? (unsigned)(((long)n * a.KH * a.KW * a.Ci + chunkA * (16 / ES)) * ES) : kOOBx;
-    }
-    const int cpt = a.Ci / BKE;
-    const int split = blockIdx.y;
-    const int kbeg = split * a.chunks_per_split;
-    const int nK = min(a.KH * a.KW * cpt, kbeg + a.chunks_per_split);          // end of this split's chunk range
-
-    // ---- the pixel-operand stream (one tile ahead of the weight stream's bookkeeping): tap / cin-chunk of the next tile
-    int tileA = kbeg, itap = kbeg / cpt, ic = kbeg - itap * cpt;
-    int soffA = 0;
-    auto setA = [&]() {                       // offsets of tile `tileA`, then advance
-        const bool live = tileA < nK;
-        const int kh = itap / a.KW, kw = itap - kh * a.KW;
-        const unsigned tapoff = (unsigned)((kh * a.Wi + kw) * a.ldi * ES);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ih = (ohw[i] >> 16) + kh, iw = (int)(short)(ohw[i] & 0xffff) + kw;
-            const bool ok = live && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-            voffA[i] = ok ? baseA[i] + tapoff : kOOBx;
-        }
-        soffA = ic * 128;
-        ++tileA;
-        if (++ic == cpt) { ic = 0; ++itap; }
-    };
-    auto issueA = [&](int stage, int half) {  // pixel rows 32 w + 16 half + [0, 16) of the tile set up by setA
-        char* sb = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (32 * w + 8 * (2 * half + i)) * 128), 16,
-                                                     voffA[2 * half + i], soffA, 0, 0);
-    };
-    auto issueB = [&](int stage, int tile, int pair) {   // weight pieces c_{2 pair}, c_{2 pair + 1} of chunk `tile`
-        char* sb = smem + stage * STAGE + BM * 128;
-        const int soffB = tile * 128;                    // OHWI rows: chunk kc of cout n starts kc * 128 B into the row
-        const bool live = tile < nK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = 2 * pair + i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + (rowB0 + 32 * j) * 128), 16,
-                                                     live ? voffB[j] : kOOBx, live ? soffB : 0, 0, 0);
-        }
-    };
-
-    f32x4_t acc[WNF][4];
-#pragma unroll
-    for (int i = 0; i < WNF; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue: tile kbeg -> stage 0 (all of it), tile kbeg + 1 -> stage 1 (pixels, c1, c2); issue order = the steady
-    //      state's: A(0) c12(0) c34(0) A(1) c12(1) | loop: c34(T+1) A(T+2) c12(T+2)
-    setA(); issueA(0, 0); issueA(0, 1);
-    issueB(0, kbeg, 0); issueB(0, kbeg, 1);
-    setA(); issueA(1, 0); issueA(1, 1);
-    issueB(1, kbeg + 1, 0);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the 8 loads of the first tile
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one slot behind
-    __builtin_amdgcn_sched_barrier(0);
-
-    const int offs0 = ((g ^ (r16 & 7)) << 4), offs1 = (((4 + g) ^ (r16 & 7)) << 4);
-    u32x4_t pf[2][4], wf[2][2];
-    int stage = 0;
-    for (int kc = kbeg; kc < nK; ++kc) {
-        const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
-        const char* sw = smem + stage * STAGE + BM * 128 + (wn * 128 + r16) * 128;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            // ---------------- READ slot ----------------
-            if (ph == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            if constexpr (ABL != 2) {
-                if (ph == 0) {
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) pf[s][j] = *(const u32x4_t*)(sp + j * 16 * 128 + (s ? offs1 : offs0));
-                }
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) wf[s][i] = *(const u32x4_t*)(sw + (2 * ph + i) * 16 * 128 + (s ? offs1 : offs0));
-            }
-            auto stage_pieces = [&]() {
-                if (ph == 0) issueB(stage ^ 1, kc + 1, 1);
-                else if (ph == 1) issueA(stage, 0);
-                else if (ph == 2) issueA(stage, 1);
-                else issueB(stage, kc + 2, 0);
-            };
-            if (ph == 1) setA();
-            if constexpr (ABL != 1 && !DMA_IN_MATH) stage_pieces();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- MATH slot ----------------
-            if constexpr (ABL != 2) {
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    // the two LDS-DMA pieces of this phase ride in the gaps of the MFMA stream (an issue costs the wave ~60
-                    // cycles there, 100-185 next to ds_reads), which keeps the READ slot shorter than the partner's MATH slot
-                    if constexpr (ABL != 1 && DMA_IN_MATH) { if (s == 1) stage_pieces(); }
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[2 * ph + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8_t, wf[s][i]), __builtin_bit_cast(bf16x8_t, pf[s][j]), acc[2 * ph + i][j], 0, 0, 0);
-                }
-                __builtin_amdgcn_s_setprio(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stage ^= 1;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();            // matches group 1's extra barrier in front of the loop
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-fill loads of the two tiles past the end
-    wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, split);
-#endif
-}
-
 template <typename T, int WNF>
 int launch_wide(const WideArgs& a, hipStream_t st) {
     const size_t lds = 2 * (256 + 32 * WNF) * 128;
@@ -506,31 +313,6 @@ int launch_wide(const WideArgs& a, hipStream_t st) {
     }
     static int abl = -1;
     if (abl < 0) { abl = szn_ablate_env("SZN_WIDE_ABLATE"); }
-    if constexpr (sizeof(T) == 2 && WNF == 8) {
-        // the two-group schedule (conv_igemm_pp); SZN_PP=0 keeps the single-group loop for A/B runs
-        static int pp = -1;
-        if (pp < 0) { const char* e = getenv("SZN_PP"); pp = e ? atoi(e) : 1; }
-        if (pp && a.nmajor == 0) {
-            static bool pp_attr = false;
-            if (!pp_attr) {
-                (void)hipFuncSetAttribute((const void*)conv_igemm_pp<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                pp_attr = true;
-            }
-            if (abl == 1) {
-                (void)hipFuncSetAttribute((const void*)conv_igemm_pp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((conv_igemm_pp<1>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
-            } else if (abl == 2) {
-                (void)hipFuncSetAttribute((const void*)conv_igemm_pp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((conv_igemm_pp<2>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
-            } else if (pp == 2) {
-                (void)hipFuncSetAttribute((const void*)conv_igemm_pp<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((conv_igemm_pp<0, true>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
-            } else
-            hipLaunchKernelGGL((conv_igemm_pp<0>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
-            SZN_CHECK_LAUNCH("conv_igemm_wide");      // same role, same name for the dispatch assertions of the tests
-            return SZN_OK;
-        }
-    }
     if (abl && sizeof(T) == 2 && WNF == 8) {          // debug ablations of the bf16 256 x 256 kernel (wrong results)
         if (abl == 1) {
             (void)hipFuncSetAttribute((const void*)conv_igemm_wide<T, WNF, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
