@@ -245,6 +245,11 @@ int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, s
 /* Dropout2d factors: scale[i] = (u_i >= p) ? 1/(1-p) : 0 with a counter-based generator (seed, i)   */
 int szn_dropout2d_mask(long n, float p, uint64_t seed, uint64_t offset, float* scale,
                        szn_stream_t stream);
+/* Dataset transform on the device (context_dataset.py:143-150, pascal_dataset.py:138-145): RGB uint8 HWC image(s)
+ * [B][H][W][3] -> BGR, minus mean_bgr (three doubles, BGR order), as the (B,3,H,W) f32 NCHW network input.  The
+ * subtraction is done in float64 and rounded once to float32, like the reference (bit-identical).              */
+int szn_image_u8_to_bgr_f32(int B, int H, int W, const uint8_t* rgb_hwc, const double* mean_bgr, float* out_nchw,
+                            szn_stream_t stream);
 
 #ifdef __cplusplus
 }

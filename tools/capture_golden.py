@@ -352,6 +352,77 @@ def g0_configs():
     print("wrote configs.json")
 
 
+# ---------------------------------------------------------------------------------------- G10
+def make_tiny_dataset(root, ids, imgs, ctx_lbls, voc_lbls):
+    """lay a tiny synthetic dataset out on disk in the reference's directory layout (used by the capture here and by
+    tests/test_datasets.py on the fixture's arrays).  Images are written as PNG bytes under the .jpg names (PIL opens by
+    content), so the decode is lossless."""
+    import PIL.Image
+    import scipy.io
+    d = os.path.join
+    for sub in ("pascal/VOCdevkit/VOC2012/JPEGImages", "pascal/VOCdevkit/VOC2012/SegmentationClass",
+                "pascal/benchmark_RELEASE/dataset/img", "pascal/benchmark_RELEASE/dataset/cls", "context/33_context_labels"):
+        os.makedirs(d(root, "data", sub), exist_ok=True)
+    for sub in ("datasets/context", "datasets/pascal"):
+        os.makedirs(d(root, sub), exist_ok=True)
+    for i, did in enumerate(ids):
+        for sub in ("pascal/VOCdevkit/VOC2012/JPEGImages", "pascal/benchmark_RELEASE/dataset/img"):
+            PIL.Image.fromarray(imgs[i]).save(d(root, "data", sub, did + ".jpg"), format="PNG")
+        PIL.Image.fromarray(ctx_lbls[i].astype(np.uint8)).save(d(root, "data/context/33_context_labels", did + ".png"))
+        PIL.Image.fromarray(voc_lbls[i].astype(np.uint8)).save(d(root, "data/pascal/VOCdevkit/VOC2012/SegmentationClass", did + ".png"))
+        seg = np.empty((1,), dtype=[("Segmentation", object)])
+        seg[0]["Segmentation"] = voc_lbls[i].astype(np.uint8)
+        scipy.io.savemat(d(root, "data/pascal/benchmark_RELEASE/dataset/cls", did + ".mat"), {"GTcls": seg})
+    for ds in ("context", "pascal"):
+        for split in ("train", "val"):
+            with open(d(root, "datasets", ds, split + ".txt"), "w") as f:
+                f.write("\n".join(ids) + "\n")
+
+
+def g10_datasets():
+    """the dataset -> trainer contract (context_dataset.py:53-150, pascal_dataset.py:43-145): which images each split keeps
+    under the zero-shot filters, and the exact (img, (lbl, lbl_vec)) tuple of __getitem__, on a tiny on-disk dataset"""
+    import tempfile
+    H, W, n = 10, 12, 8
+    ids = ["2008_%06d" % i for i in range(n)]
+    rng = np.random.RandomState(1337)
+    imgs = rng.randint(0, 256, size=(n, H, W, 3)).astype(np.uint8)
+    # context labels are 1-based PNG values (0 = unlabelled); class sets chosen so that every filter rule fires
+    ctx_sets = [[1, 5], [1, 13], [17, 19], [3, 4, 0], [2, 6], [13, 17], [8], [21, 33]]
+    voc_sets = [[0, 3], [1, 15], [17, 19], [255, 2], [13, 5], [6, 0], [0], [20, 255]]
+    ctx = np.stack([np.array(s)[rng.randint(0, len(s), size=(H, W))] for s in ctx_sets]).astype(np.int32)
+    voc = np.stack([np.array(s)[rng.randint(0, len(s), size=(H, W))] for s in voc_sets]).astype(np.int32)
+    out = {"ids": np.array(ids), "imgs": imgs, "ctx_png": ctx, "voc_png": voc}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as root:
+        make_tiny_dataset(root, ids, imgs, ctx, voc)
+        for ds in ("context", "pascal"):
+            os.symlink(os.path.join(REF, "datasets", ds, "embeddings"), os.path.join(root, "datasets", ds, "embeddings"))
+        os.chdir(root)
+        try:
+            import context_dataset as ref_ctx  # reference
+            import pascal_dataset as ref_voc  # reference
+            for tag, cls, tu, vu in (("ctx", ref_ctx.PascalContext, [0, 12], [16, 18]), ("voc", ref_voc.PascalVOC, [1, 13], [17, 19])):
+                for split in ("train", "train_seen", "val"):
+                    dset = cls(split=split, transform=True, embed_dim=20, data_dir="data", train_unseen=tu, val_unseen=vu)
+                    kept = [os.path.basename(f["img"])[:-4] for f in dset.files]
+                    out["%s_%s_kept" % (tag, split)] = np.array(kept)
+                    if kept:
+                        img, (lbl, vec) = dset[0]
+                        out["%s_%s_img0" % (tag, split)] = img.numpy()
+                        out["%s_%s_lbl0" % (tag, split)] = lbl.numpy()
+                        out["%s_%s_vec0" % (tag, split)] = vec.numpy()
+                # no embeddings, no transform: raw arrays
+                dset = cls(split="val", transform=False, embed_dim=None, data_dir="data")
+                img, lbl = dset[len(dset) - 1]
+                out["%s_raw_img" % tag] = np.asarray(img)
+                out["%s_raw_lbl" % tag] = np.asarray(lbl)
+                out["%s_raw_id" % tag] = np.array(os.path.basename(dset.files[-1]["img"])[:-4])
+        finally:
+            os.chdir(cwd)
+    save("g10_datasets", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
@@ -367,6 +438,7 @@ def main():
         g2_g3_forward(m)
     if run("g7"): g7_train_step()
     if run("g8"): g8_seenmask_step()
+    if run("g10"): g10_datasets()
 
 
 if __name__ == "__main__":

@@ -75,6 +75,7 @@ SIGNATURES = {
     "szn_sgd_momentum_step": (_I, [_L, _P, _P, _P, _F, _F, _F, _I, _F, _P, _P]),
     "szn_cast": (_I, [_I, _I, _L, _P, _P, _P]),
     "szn_dropout2d_mask": (_I, [_L, _F, _U64, _U64, _P, _P]),
+    "szn_image_u8_to_bgr_f32": (_I, [_I, _I, _I, _P, C.POINTER(C.c_double), _P, _P]),
 }
 
 _lib = None

@@ -479,6 +479,31 @@ extern "C" int szn_dropout2d_mask(long n, float p, uint64_t seed, uint64_t offse
     return SZN_OK;
 }
 
+namespace {
+// one thread per pixel: 3 byte loads (one 3-byte RGB triple), three coalesced f32 plane stores
+__global__ __launch_bounds__(256) void image_u8_to_bgr_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ out, long npx,
+                                                              long hw, double m0, double m1, double m2) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    const long b = i / hw, r = i - b * hw;
+    const uint8_t* p = rgb + i * 3;
+    float* o = out + b * 3 * hw + r;
+    o[0] = (float)((double)p[2] - m0);          // B
+    o[hw] = (float)((double)p[1] - m1);         // G
+    o[2 * hw] = (float)((double)p[0] - m2);     // R
+}
+}  // namespace
+
+extern "C" int szn_image_u8_to_bgr_f32(int B, int H, int W, const uint8_t* rgb_hwc, const double* mean_bgr, float* out_nchw,
+                                       szn_stream_t stream) {
+    if (!rgb_hwc || !mean_bgr || !out_nchw || B <= 0 || H <= 0 || W <= 0) SZN_FAIL(SZN_ERR_ARG, "image_u8_to_bgr_f32: bad argument");
+    const long hw = (long)H * W, npx = (long)B * hw;
+    hipLaunchKernelGGL(image_u8_to_bgr_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rgb_hwc,
+                       out_nchw, npx, hw, mean_bgr[0], mean_bgr[1], mean_bgr[2]);
+    SZN_CHECK_LAUNCH("image_u8_to_bgr_kernel");
+    return SZN_OK;
+}
+
 extern "C" int szn_adam_step(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                              void* w_lp, szn_stream_t stream) {

@@ -6,7 +6,8 @@ configuration merge / validation (:202-251), same optimizer wiring (two paramete
 two-phase orchestration (FCN phase, then seen-mask phase with the backbone frozen, :161-194).
 
 Added for this implementation (none change the reference flags):
-  --synthetic N H W    deterministic synthetic dataset (no PASCAL data / network here; real-data loaders are row F1)
+  --synthetic N H W    deterministic synthetic dataset (no PASCAL data / network here); without it the PASCAL-VOC /
+                       PASCAL-Context readers of datasets.py load <data_dir> in the reference's layout
   --batch-size B       images per GPU per step (reference: 1)
   --precision fp32|bf16
   --init synthetic|vgg path handling: without the caffe VGG16 file the backbone starts from synth weights
@@ -201,19 +202,28 @@ def main(argv=None):
         output_cfg(cfg, log_dir, tb_writer)
 
     # 1. dataset
-    if not args.synthetic:
-        raise SystemExit("real PASCAL / PASCAL-Context loading is not part of this round (SURVEY.md 8-f F1): "
-                         "pass --synthetic N H W")
-    n_img, H, W = args.synthetic
-    n_class = 21 if cfg['dataset'] == 'pascal' else 33
     all_unseen = cfg['train_unseen'] + cfg['val_unseen']
-    mk = lambda split, unseen, n: SyntheticSegmentation(split=split, n_images=n, size=(H, W), n_class=n_class,
-                                                         embed_dim=cfg['embed_dim'], unseen=unseen, seed=1337)
-    # splits as in the reference (pascal_dataset.py:62-74, context_dataset.py:75-94): 'train' drops every image that
-    # contains a val_unseen class, 'train_seen' additionally drops the train_unseen classes, 'val' keeps everything
-    train_dataset = mk('train', cfg['val_unseen'], n_img)
-    train_seen_dataset = mk('train_seen', all_unseen, n_img)
-    val_dataset = mk('val', [], max(n_img // 4, 1))
+    if args.synthetic:
+        n_img, H, W = args.synthetic
+        n_class = 21 if cfg['dataset'] == 'pascal' else 33
+        mk = lambda split, unseen, n: SyntheticSegmentation(split=split, n_images=n, size=(H, W), n_class=n_class,
+                                                             embed_dim=cfg['embed_dim'], unseen=unseen, seed=1337)
+        # splits as in the reference (pascal_dataset.py:62-74, context_dataset.py:75-94): 'train' drops every image that
+        # contains a val_unseen class, 'train_seen' additionally drops the train_unseen classes, 'val' keeps everything
+        train_dataset = mk('train', cfg['val_unseen'], n_img)
+        train_seen_dataset = mk('train_seen', all_unseen, n_img)
+        val_dataset = mk('val', [], max(n_img // 4, 1))
+    else:
+        # real data under <data_dir> (reference layout, train.py:64-80); samples travel raw (uint8 image + label), the BGR /
+        # mean transform and the target-embedding gather run on the GPU; images differ in size, so batch size stays 1
+        from .datasets import PascalContext, PascalVOC
+        if args.batch_size != 1:
+            raise SystemExit("real PASCAL images differ in size: --batch-size must be 1 (like the reference)")
+        cls = PascalVOC if cfg['dataset'] == 'pascal' else PascalContext
+        mkr = lambda split: cls(split=split, embed_dim=cfg['embed_dim'], one_hot_embed=cfg['one_hot_embed'],
+                                data_dir=args.data_dir, train_unseen=cfg['train_unseen'], val_unseen=cfg['val_unseen'],
+                                native=True)
+        train_dataset, train_seen_dataset, val_dataset = mkr('train'), mkr('train_seen'), mkr('val')
     kwargs = {'num_workers': 2, 'pin_memory': True}
 
     def loader(ds, bs, shuffle):

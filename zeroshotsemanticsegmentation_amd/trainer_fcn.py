@@ -111,7 +111,10 @@ class Trainer(object):
         target_embed = None
         if self.pixel_embeddings and isinstance(target, (tuple, list)):
             target, target_embed = target
-        data = data.to(self.device, non_blocking=True)
+        if data.dtype == torch.uint8:              # native dataset samples: raw RGB (n,h,w,3); BGR - mean on the GPU
+            data = utils.image_to_device(data, self.device)
+        else:
+            data = data.to(self.device, non_blocking=True)
         target = target.to(self.device, non_blocking=True)
         if target_embed is not None:
             if target_embed.dim() == 4 and target_embed.is_floating_point():

@@ -74,7 +74,10 @@ class Trainer(object):
         if isinstance(target, (tuple, list)):
             target = target[0]
         target = self.binary_target(target)
-        data = data.to(self.device, non_blocking=True)
+        if data.dtype == torch.uint8:              # native dataset samples: raw RGB (n,h,w,3); BGR - mean on the GPU
+            data = utils.image_to_device(data, self.device)
+        else:
+            data = data.to(self.device, non_blocking=True)
         score = self.model(data, mode='seenmask')
         loss = utils.cross_entropy2d(score, target, size_average=True)
         return score, loss, utils.channel_argmax(score), target

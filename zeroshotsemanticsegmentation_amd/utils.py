@@ -13,6 +13,7 @@ There is no CPU fallback: tensors must live on the GPU.
 Batched semantics (the reference raises for n > 1 in cosine_loss / infer_lbl): per-image loss, mean over
 images; inference is applied per image and returns (B,H,W).
 """
+import ctypes as C
 import pickle
 
 import numpy as np
@@ -30,6 +31,27 @@ def load_obj(name):
 def save_obj(obj, name):
     with open(name + '.pkl', 'wb') as f:
         pickle.dump(obj, f, pickle.HIGHEST_PROTOCOL)
+
+
+MEAN_BGR = (104.00698793, 116.66876762, 122.67891434)          # context_dataset.py:51, pascal_dataset.py:41
+
+
+def image_to_device(img_u8, device=None, mean_bgr=MEAN_BGR):
+    """dataset transform on the GPU (context_dataset.py:143-150): uint8 RGB image(s) (H,W,3) or (B,H,W,3) -- host or device --
+    -> (B,3,H,W) f32 BGR minus mean_bgr.  The host sends 3 bytes per pixel instead of 12; results are bit-identical to the
+    reference's float64 subtraction + .float()."""
+    t = img_u8 if isinstance(img_u8, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img_u8))
+    if t.dtype != torch.uint8 or t.shape[-1] != 3 or t.dim() not in (3, 4):
+        raise L.SznError("image_to_device expects uint8 (H,W,3) or (B,H,W,3), got %s %s" % (t.dtype, tuple(t.shape)))
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    dev = torch.device(device) if device is not None else (t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+    t = t.to(dev, non_blocking=True).contiguous()
+    B, H, W, _ = t.shape
+    out = torch.empty(B, 3, H, W, device=dev, dtype=torch.float32)
+    mean = (C.c_double * 3)(*[float(m) for m in mean_bgr])
+    L.call("szn_image_u8_to_bgr_f32", B, H, W, L.ptr(t), mean, L.ptr(out), L.stream_ptr())
+    return out
 
 
 def _need_cuda(t, what):
