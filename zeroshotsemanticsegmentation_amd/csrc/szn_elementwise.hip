@@ -301,34 +301,81 @@ __global__ void dropout_mask_kernel(float* __restrict__ scale, long n, float p, 
     scale[i] = (u >= p) ? 1.0f / (1.0f - p) : 0.f;
 }
 
+// Optimizer steps over the flat fp32 parameter / gradient / moment buffers: pure streaming (28-30 B per element), so each
+// lane moves 16 B per access (four elements) and keeps two such groups in flight; the per-element arithmetic is the
+// scalar chain of torch.optim (no contraction: -ffp-contract=off), identical for the vector body and the scalar tail.
+__device__ __forceinline__ float adam_elem(float& pi, float gi, float& mi, float& vi, float b1, float b2, float eps, float wd,
+                                           float step_size, float inv_bc2_sqrt, float gscale) {
+    gi = gi * gscale;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    return pi;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                    float b1, float b2, float eps, float wd, float step_size,
-                                                   float inv_bc2_sqrt, float gscale, uint16_t* __restrict__ wlp) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float pi = p[i];
-        float gi = g[i] * gscale;
-        if (wd != 0.f) gi = fmaf(wd, pi, gi);
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
-        pi -= step_size * (mi / denom);
+                                                   float inv_bc2_sqrt, float gscale, uint16_t* __restrict__ wlp, int vec) {
+    const long n4 = vec ? (n >> 2) : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4_t pq = ((const f32x4_t*)p)[i], gq = ((const f32x4_t*)g)[i], mq = ((const f32x4_t*)m)[i], vq = ((const f32x4_t*)v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = pq[e], me = mq[e], ve = vq[e];
+            adam_elem(pe, gq[e], me, ve, b1, b2, eps, wd, step_size, inv_bc2_sqrt, gscale);
+            pq[e] = pe; mq[e] = me; vq[e] = ve;
+        }
+        ((f32x4_t*)m)[i] = mq; ((f32x4_t*)v)[i] = vq; ((f32x4_t*)p)[i] = pq;
+        if (wlp) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16_bits(pq[0]) | ((uint32_t)f32_to_bf16_bits(pq[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16_bits(pq[2]) | ((uint32_t)f32_to_bf16_bits(pq[3]) << 16);
+            ((uint2*)wlp)[i] = pk;
+        }
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_elem(pi, g[i], mi, vi, b1, b2, eps, wd, step_size, inv_bc2_sqrt, gscale);
         m[i] = mi; v[i] = vi; p[i] = pi;
         if (wlp) wlp[i] = f32_to_bf16_bits(pi);
     }
 }
 
+__device__ __forceinline__ void sgd_elem(float& pi, float gi, float& bi, float lr, float mom, float wd, int first, float gscale) {
+    gi = gi * gscale;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    bi = first ? gi : mom * bi + gi;
+    pi -= lr * bi;
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ buf, long n, float lr, float mom, float wd,
-                                                  int first, float gscale, uint16_t* __restrict__ wlp) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float pi = p[i];
-        float gi = g[i] * gscale;
-        if (wd != 0.f) gi = fmaf(wd, pi, gi);
-        const float bi = first ? gi : mom * buf[i] + gi;
-        buf[i] = bi;
-        pi -= lr * bi;
-        p[i] = pi;
+                                                  int first, float gscale, uint16_t* __restrict__ wlp, int vec) {
+    const long n4 = vec ? (n >> 2) : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4_t pq = ((const f32x4_t*)p)[i], gq = ((const f32x4_t*)g)[i];
+        f32x4_t bq = first ? f32x4_t{0.f, 0.f, 0.f, 0.f} : ((const f32x4_t*)buf)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = pq[e], be = bq[e];
+            sgd_elem(pe, gq[e], be, lr, mom, wd, first, gscale);
+            pq[e] = pe; bq[e] = be;
+        }
+        ((f32x4_t*)buf)[i] = bq; ((f32x4_t*)p)[i] = pq;
+        if (wlp) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16_bits(pq[0]) | ((uint32_t)f32_to_bf16_bits(pq[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16_bits(pq[2]) | ((uint32_t)f32_to_bf16_bits(pq[3]) << 16);
+            ((uint2*)wlp)[i] = pk;
+        }
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float pi = p[i], bi = first ? 0.f : buf[i];
+        sgd_elem(pi, g[i], bi, lr, mom, wd, first, gscale);
+        buf[i] = bi; p[i] = pi;
         if (wlp) wlp[i] = f32_to_bf16_bits(pi);
     }
 }
@@ -511,9 +558,11 @@ extern "C" int szn_adam_step(long n, float* param, const float* grad, float* exp
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale,
-                       (uint16_t*)w_lp);
+    const int vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
+                     (((uintptr_t)w_lp) & 7) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale,
+                       (uint16_t*)w_lp, vec);
     SZN_CHECK_LAUNCH("adam_kernel");
     return SZN_OK;
 }
@@ -522,8 +571,9 @@ extern "C" int szn_sgd_momentum_step(long n, float* param, const float* grad, fl
                                      float momentum, float weight_decay, int first_step, float grad_scale, void* w_lp,
                                      szn_stream_t stream) {
     if (!param || !grad || !momentum_buf || n <= 0) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step: bad argument");
-    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale, (uint16_t*)w_lp);
+    const int vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) == 0 && (((uintptr_t)w_lp) & 7) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec);
     SZN_CHECK_LAUNCH("sgd_kernel");
     return SZN_OK;
 }

@@ -143,8 +143,12 @@ class TrainStep(object):
         # bias vector (seenmask_score + zero padding), so the engine can use one contiguous view of it
         self._flat_b_store = torch.zeros(nb + CP - E, device=self.dev)
         self.flat_b = self._flat_b_store[:nb]
-        self.flat_gw = torch.zeros(nw, device=self.dev)
-        self.flat_gb = torch.zeros(nb, device=self.dev)
+        # gradients: the fused head's wgrad (CP rows: score_fr | seenmask_score | padding) writes straight into score_fr's
+        # slot at the END of the flat buffers; the (CP - E) rows behind it land in a tail that nothing reads
+        self._flat_gw_store = torch.zeros(nw + (CP - E) * F, device=self.dev)
+        self._flat_gb_store = torch.zeros(nb + CP - E, device=self.dev)
+        self.flat_gw = self._flat_gw_store[:nw]
+        self.flat_gb = self._flat_gb_store[:nb]
         self.woff, self.boff = {}, {}
         off = 0
         for n, p in zip(_OPT_LAYERS, ws):
@@ -197,11 +201,13 @@ class TrainStep(object):
             o, cnt = self.woff[n]
             bo, bc = self.boff[n]
             self.grads[n] = (self.flat_gw[o:o + cnt].view(co, kh, kw, ci), self.flat_gb[bo:bo + bc])
-        CP, F = m.head_width, m.fc7.out_channels
-        self.head_gw = torch.empty(CP, 1, 1, F, device=self.dev)
-        self.head_gb = torch.empty(CP, device=self.dev)
+        o, cnt = self.woff["score_fr"]
+        bo, bc = self.boff["score_fr"]
+        assert o + cnt == nw and bo + bc == nb       # score_fr is the last layer of both flat layouts
+        self.head_gw = self._flat_gw_store[o:o + CP * F].view(CP, 1, 1, F)
+        self.head_gb = self._flat_gb_store[bo:bo + CP]
         self.grads["head"] = (self.head_gw, self.head_gb)
-        self.grads["_flat_bias"] = self.flat_gb      # lets the engine zero all bias gradients with one fill
+        self.grads["_flat_bias"] = self._flat_gb_store      # lets the engine zero all bias gradients with one fill
 
     def _buckets(self, bucket_mb):
         layers = [(n,) + self.woff[n] for n in _OPT_LAYERS]
@@ -253,15 +259,9 @@ class TrainStep(object):
         eng.backward(ctx, dcoarse, self.grads, backbone=True, layer_done=layer_done, head_first=self._head_copy(layer_done))
 
     def _head_copy(self, layer_done):
-        def fn():
-            # rows [0,E) of the fused head gradient are score_fr's (seenmask_score is frozen in phase 1)
-            E, F = self.E, self.model.fc7.out_channels
-            o, cnt = self.woff["score_fr"]
-            self.flat_gw[o:o + cnt].view(E, F).copy_(self.head_gw.view(-1, F)[:E])
-            bo, bc = self.boff["score_fr"]
-            self.flat_gb[bo:bo + bc].copy_(self.head_gb[:E])
-            layer_done("score_fr")
-        return fn
+        # rows [0,E) of the fused head gradient ARE score_fr's slot of the flat gradient (seenmask_score is frozen in
+        # phase 1): nothing to copy, the first bucket can go as soon as the head wgrad has been queued
+        return lambda: layer_done("score_fr")
 
     def _optimizer_step(self):
         self.nstep += 1
