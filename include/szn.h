@@ -27,7 +27,7 @@ extern "C" {
 typedef void* szn_stream_t; /* hipStream_t */
 
 enum { SZN_OK = 0, SZN_ERR_ARG = -1, SZN_ERR_LAUNCH = -2, SZN_ERR_UNSUPPORTED = -3 };
-enum { SZN_F32 = 0, SZN_BF16 = 1 };
+enum { SZN_F32 = 0, SZN_BF16 = 1, SZN_F16 = 2 };   /* SZN_F16: IEEE half activations / weight images (BASELINE configs[4]) */
 
 /* ---- library -------------------------------------------------------------------------------- */
 const char* szn_last_error(void);
@@ -245,6 +245,14 @@ int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, s
 /* Dropout2d factors: scale[i] = (u_i >= p) ? 1/(1-p) : 0 with a counter-based generator (seed, i)   */
 int szn_dropout2d_mask(long n, float p, uint64_t seed, uint64_t offset, float* scale,
                        szn_stream_t stream);
+/* fp8 pixel projection (BASELINE configs[4]: "fp8 MFMA projection GEMM"; score_fr || seenmask_score forward, models.py:
+ * 93,97,145,149).  x [M][K] (x_dtype) and w [N][K] (w_dtype) are quantised to OCP e4m3 with per-tensor scales
+ * amax/448 (round to nearest even), multiplied on the fp8 matrix cores with fp32 accumulation and rescaled:
+ * out[m][n] = (sum_k xq wq) * sx * sw + bias[n], fp32, row stride ldo.  K must be a multiple of 128.  workspace:
+ * szn_proj_fp8_workspace_bytes(M, K, N) bytes, 16-B aligned.  Forward only (the backward pass keeps 16-bit operands). */
+size_t szn_proj_fp8_workspace_bytes(long M, int K, int N);
+int szn_proj_fp8_fwd(int x_dtype, int w_dtype, long M, int K, int N, int ldo, const void* x, const void* w,
+                     const float* bias, float* out_f32, void* workspace, szn_stream_t stream);
 /* Dataset transform on the device (context_dataset.py:143-150, pascal_dataset.py:138-145): RGB uint8 HWC image(s)
  * [B][H][W][3] -> BGR, minus mean_bgr (three doubles, BGR order), as the (B,3,H,W) f32 NCHW network input.  The
  * subtraction is done in float64 and rounded once to float32, like the reference (bit-identical).              */

@@ -357,6 +357,34 @@ def fused_head(coarse, embed, target, H, W, n_class=None, c0=0, crop=19, want_gr
     return np.float32(loss), stats, pred, dc
 
 
+def e4m3_round(x):
+    """round float32 values to the nearest OCP e4m3 (fn) value, ties to even, saturating at +-448 (what gfx950's
+    v_cvt_pk_fp8_f32 produces for |x| <= 448): 3 mantissa bits, normal exponents 2^-6 .. 2^8, subnormal step 2^-9"""
+    x = np.asarray(x, dtype=np.float64)
+    a = np.abs(x)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    e = np.maximum(e, -6.0)
+    step = np.exp2(e - 3.0)
+    q = np.minimum(np.rint(a / step) * step, 448.0)
+    return (np.sign(x) * q).astype(np.float32)
+
+
+def proj_fp8(x, w, bias=None):
+    """csrc/szn_proj_fp8.hip restated: per-tensor scales amax/448, e4m3 operands, exact products, rescale + bias.
+    x (M,K), w (N,K): the values the kernel reads (already rounded to their storage dtype) -> (M,N) float32."""
+    x, w = np.asarray(x, np.float32), np.asarray(w, np.float32)
+    ax, aw = np.float32(np.abs(x).max()), np.float32(np.abs(w).max())
+    ix = np.float32(448.0) / ax if ax > 0 else np.float32(1.0)
+    iw = np.float32(448.0) / aw if aw > 0 else np.float32(1.0)
+    xq, wq = e4m3_round(x * ix), e4m3_round(w * iw)
+    s = (ax / np.float32(448.0) if ax > 0 else np.float32(1.0)) * (aw / np.float32(448.0) if aw > 0 else np.float32(1.0))
+    out = (xq.astype(np.float64) @ wq.astype(np.float64).T) * np.float64(s)
+    if bias is not None:
+        out = out + np.asarray(bias, np.float64)[None, :]
+    return out.astype(np.float32)
+
+
 def confusion_hist(label_trues, label_preds, n_class, unseen=None):
     lt = _c(np.asarray(label_trues).reshape(-1), np.int64)
     lp = _c(np.asarray(label_preds).reshape(-1), np.int64)

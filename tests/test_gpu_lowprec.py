@@ -1,0 +1,78 @@
+"""GPU: the low-precision variants of BASELINE configs[4] -- fp8 (OCP e4m3) projection GEMM and fp16 activations --
+validated against the fp32 path with stated tolerances and the class-assignment agreement rate.
+There is no reference code for these variants (parity unpinned by the reference); the referee is the oracle's restatement
+of the quantisation (oracle.e4m3_round, itself checked against torch's float8_e4m3fn cast) and the fp32 HIP path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import szn_oracle as O  # noqa: E402
+from zeroshotsemanticsegmentation_amd import _lib as L  # noqa: E402
+from zeroshotsemanticsegmentation_amd import engine, models, synth, utils  # noqa: E402
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16, torch.float16])
+def test_proj_fp8_kernel_matches_oracle_restatement(xdt):
+    M, K, N, ldo = 2 * 25 * 25 + 3, 4096, 302, 320
+    g = torch.Generator().manual_seed(9)
+    x = torch.relu(torch.randn(M, K, generator=g)) * 3.0                   # post-ReLU / dropout-scaled features
+    x[5] = 0
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    xd, wd = x.to(xdt).cuda(), w.to(xdt).cuda()
+    out = torch.full((M, ldo), 7.0, device="cuda")
+    ws = torch.empty(L.load().szn_proj_fp8_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
+    L.call("szn_proj_fp8_fwd", L.dtype_code(xdt), L.dtype_code(xdt), M, K, N, ldo, L.ptr(xd), L.ptr(wd), L.ptr(bias.cuda()),
+           L.ptr(out), L.ptr(ws), L.stream_ptr())
+    torch.cuda.synchronize()
+    want = O.proj_fp8(xd.float().cpu().numpy(), wd.float().cpu().numpy(), bias.numpy())
+    got = out.cpu().numpy()
+    assert np.abs(got[:, :N] - want).max() < 2e-5 * np.abs(want).max()     # same quantised operands, fp32 accumulation order only
+    assert (got[:, N:] == 7.0).all()                                       # columns behind N untouched
+    # and how far the fp8 product is from the fp32 one (3 mantissa bits per operand, K = 4096 terms)
+    ref = xd.float().cpu().numpy().astype(np.float64) @ wd.float().cpu().numpy().astype(np.float64).T + bias.numpy()
+    err = np.abs(got[:, :N] - ref).max() / np.abs(ref).max()
+    print("fp8 projection vs fp32 product (%s operands): max error %.3e of the output scale" % (xdt, err))
+    assert err < 6e-2                                    # per-tensor e4m3 on half-normal data whose amax sits at ~4.5 sigma
+
+
+def test_fp8_head_forward_agreement_768():
+    """BASELINE configs[4] geometry: 768x768, E = 300, K = 59: class assignment with the fp8 head vs the same bf16 network
+    with its native head, and vs the fp32 path"""
+    E, K, H = 300, 59, 768
+    emb = cu(synth.make_embeddings(K, E))
+    m = models.FCN32s(E)
+    m.load_synthetic(1337, device=torch.device("cuda"))
+    m.eval()
+    x = cu(synth.make_images(1, H, H, seed=91))
+    with torch.no_grad():
+        f32 = m(x, mode="fcn")
+        p32 = utils.infer_lbl_device(f32, emb)
+        m.set_precision(torch.bfloat16)
+        f16 = m(x, mode="fcn")
+        p16 = utils.infer_lbl_device(f16, emb)
+        m.set_head_precision("fp8")
+        f8 = m(x, mode="fcn")
+        p8 = utils.infer_lbl_device(f8, emb)
+        m.set_head_precision("native")
+    scale = float(f32.abs().max())
+    e16 = float((f16 - f32).abs().max()) / scale
+    e8 = float((f8 - f32).abs().max()) / scale
+    a16 = float((p16 == p32).float().mean())
+    a8 = float((p8 == p32).float().mean())
+    a8_16 = float((p8 == p16).float().mean())
+    print("768x768 score error vs fp32: bf16 %.3e, bf16 + fp8 head %.3e; argmax agreement vs fp32: bf16 %.4f, fp8 head %.4f; "
+          "fp8 head vs bf16 head %.4f" % (e16, e8, a16, a8, a8_16))
+    assert e16 < 5e-2 and e8 < 8e-2                    # stated tolerance: fp8 head within 8 % of the output scale after 16 layers
+    assert a8 > 0.99 and a8_16 > 0.99                  # class-assignment agreement rate (measured 1.0000 on this input)

@@ -288,3 +288,20 @@ def test_torch_cpu_restatement_matches_golden_g7():
         gr = named[k].grad.flatten().numpy()
         idx = (np.arange(64, dtype=np.int64) * 2654435761 % gr.size).astype(np.int64)
         assert rel(gr[idx], g["grad_probe/" + k]) < 1e-3, k
+
+
+def test_e4m3_restatement_matches_torch_float8_cast():
+    """oracle.e4m3_round (referee of the fp8 projection kernel) against torch's own float8_e4m3fn conversion: normal,
+    subnormal, tie and saturation cases"""
+    import torch
+    rs = np.random.RandomState(0)
+    x = (rs.randn(200000) * np.exp(rs.uniform(-12, 6, 200000))).astype(np.float32)
+    x = np.clip(x, -448, 448)
+    x[:8] = [0.0, 448.0, -448.0, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10, 17.0, 0.4375]       # ties go to even
+    t = torch.from_numpy(x).to(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(O.e4m3_round(x), t)
+    # proj_fp8 is exact when every value is representable after scaling
+    xs = np.array([[448.0, -224.0, 0.0, 1.75] * 32], np.float32)
+    ws = np.array([[1.0, 0.5, -0.25, 2.0] * 32, [0.0] * 128], np.float32)
+    want = (xs.astype(np.float64) @ ws.astype(np.float64).T + np.array([0.5, -1.0])).astype(np.float32)
+    assert np.allclose(O.proj_fp8(xs, ws, np.array([0.5, -1.0], np.float32)), want, rtol=1e-6)

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SZN_LIB_PATH") or os.path.join(_HERE, "lib", "libszn_hip.so")   # (override: A/B builds in tools/)
 
-SZN_F32, SZN_BF16 = 0, 1
+SZN_F32, SZN_BF16, SZN_F16 = 0, 1, 2
 
 
 class SznError(RuntimeError):
@@ -75,6 +75,8 @@ SIGNATURES = {
     "szn_sgd_momentum_step": (_I, [_L, _P, _P, _P, _F, _F, _F, _I, _F, _P, _P]),
     "szn_cast": (_I, [_I, _I, _L, _P, _P, _P]),
     "szn_dropout2d_mask": (_I, [_L, _F, _U64, _U64, _P, _P]),
+    "szn_proj_fp8_workspace_bytes": (_SZ, [_L, _I, _I]),
+    "szn_proj_fp8_fwd": (_I, [_I, _I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "szn_image_u8_to_bgr_f32": (_I, [_I, _I, _I, _P, C.POINTER(C.c_double), _P, _P]),
 }
 
@@ -128,6 +130,8 @@ def dtype_code(t):
         return SZN_F32
     if t == torch.bfloat16:
         return SZN_BF16
+    if t == torch.float16:
+        return SZN_F16
     raise SznError("unsupported dtype %s" % t)
 
 

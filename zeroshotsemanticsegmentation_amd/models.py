@@ -67,6 +67,8 @@ class _Engine(object):
         self._gemm_ws = None          # fp32 Y of the GEMM + col2im dgrad (fc6)
         self._wg_ws = None            # slab workspace of the wgrad kernels (they run on their own stream)
         self._wg_stream = None        # torch.cuda.Stream, or False when disabled (SZN_WGRAD_STREAM=0)
+        self.head_fp8 = False         # forward of the projection head on the fp8 matrix cores (set_head_precision)
+        self._fp8_ws = None
         self.lp_views = {}          # layer -> compute-dtype OHWI weight image maintained by the optimizer kernel (TrainStep)
         self._seen_versions = None    # versions of seenmask_score mirrored into the TrainStep-owned head image
 
@@ -231,9 +233,23 @@ class _Engine(object):
         ctx.relu6 = self._conv(a, "fc6", 0, scale=s6)            # relu -> dropout factor, fused epilogue
         ctx.relu7 = self._conv(ctx.relu6, "fc7", 0, scale=s7)
         ctx.acts, ctx.pools = acts, pools
-        ctx.coarse = self._conv(ctx.relu7, "head", 0, relu=False, out_f32=True)
+        ctx.coarse = self._head_fp8(ctx.relu7) if self.head_fp8 else self._conv(ctx.relu7, "head", 0, relu=False, out_f32=True)
         ctx.h, ctx.w = ctx.coarse.shape[1:3]
         return ctx
+
+    def _head_fp8(self, feat):
+        """score_fr || seenmask_score as ONE fp8 (e4m3) GEMM with per-tensor scales (szn_proj_fp8_fwd; BASELINE configs[4]).
+        Forward only: the backward pass differentiates the 16-bit / fp32 head (straight-through)."""
+        B, h, w, F = feat.shape
+        CP = self.model.head_width
+        wimg, bimg = self._images["head.w"], self._images["head.b"]
+        nb = L.load().szn_proj_fp8_workspace_bytes(B * h * w, F, CP)
+        if self._fp8_ws is None or self._fp8_ws.numel() < nb or self._fp8_ws.device != feat.device:
+            self._fp8_ws = torch.empty(nb, dtype=torch.uint8, device=feat.device)
+        out = torch.empty(B, h, w, CP, device=feat.device, dtype=torch.float32)
+        L.call("szn_proj_fp8_fwd", L.dtype_code(feat.dtype), L.dtype_code(wimg.dtype), B * h * w, F, CP, CP, L.ptr(feat),
+               L.ptr(wimg), L.ptr(bimg), L.ptr(out), L.ptr(self._fp8_ws), L.stream_ptr())
+        return out
 
     def upscore(self, ctx):
         """coarse -> f (B,E,H,W) f32 NCHW: fixed bilinear ConvTranspose2d + crop (models.py:146-147)"""
@@ -553,6 +569,13 @@ class FCN32s(nn.Module):
     def set_precision(self, dtype):
         """compute dtype of the HIP path: torch.float32 (parity) or torch.bfloat16 (throughput)"""
         self._engine.set_precision(dtype)
+        return self
+
+    def set_head_precision(self, kind):
+        """'native' (the compute dtype) or 'fp8': projection head forward on the fp8 matrix cores (BASELINE configs[4])"""
+        if kind not in ("native", "fp8"):
+            raise L.SznError("head precision must be 'native' or 'fp8'")
+        self._engine.head_fp8 = (kind == "fp8")
         return self
 
     def load_synthetic(self, seed=1337, device=None):
