@@ -13,7 +13,7 @@
  *     to the hipStream_t passed as `stream` (pass torch.cuda.current_stream().cuda_stream).
  *   - activations are NHWC [B][H][W][C] ("pixel-major"), conv weights OHWI [Cout][KH][KW][Cin]
  *     (== torch channels_last storage of an (O,I,KH,KW) tensor), element type given by `dtype`
- *     (SZN_F32 parity path / SZN_BF16 throughput path); accumulation is always fp32.
+ *     (SZN_F32 parity path / SZN_BF16 throughput path / SZN_F16 IEEE-half variant); accumulation is always fp32.
  *   - the network-boundary tensors keep the reference's layout: input image (B,3,H,W) NCHW f32,
  *     score (B,E,H,W) NCHW f32, labels (B,H,W) int64 with -1 = ignore.
  */
@@ -232,13 +232,14 @@ int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, in
 
 /* ---- optimizers (train.py:126-133,174-175; torch.optim.Adam / SGD semantics) ----------------------
  * One launch per flat fp32 parameter buffer.  grad_scale multiplies the gradient first (1/world
- * after a sum all-reduce).  If w_lp != NULL the updated weight is also written as bf16.             */
+ * after a sum all-reduce; 1/(world * loss_scale) on the fp16 path).  If w_lp != NULL the updated weight is
+ * also written as a 16-bit image of type w_lp_dtype (SZN_BF16 | SZN_F16) for the next forward pass.    */
 int szn_adam_step(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                  float grad_scale, void* w_lp, szn_stream_t stream);
+                  float grad_scale, void* w_lp, int w_lp_dtype, szn_stream_t stream);
 int szn_sgd_momentum_step(long n, float* param, const float* grad, float* momentum_buf, float lr,
                           float momentum, float weight_decay, int first_step, float grad_scale,
-                          void* w_lp, szn_stream_t stream);
+                          void* w_lp, int w_lp_dtype, szn_stream_t stream);
 
 /* ---- small utilities -------------------------------------------------------------------------------- */
 int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, szn_stream_t stream);

@@ -76,3 +76,38 @@ def test_fp8_head_forward_agreement_768():
           "fp8 head vs bf16 head %.4f" % (e16, e8, a16, a8, a8_16))
     assert e16 < 5e-2 and e8 < 8e-2                    # stated tolerance: fp8 head within 8 % of the output scale after 16 layers
     assert a8 > 0.99 and a8_16 > 0.99                  # class-assignment agreement rate (measured 1.0000 on this input)
+
+
+def test_fp16_forward_and_train_step():
+    """SZN_F16 end to end: IEEE-half activations / weight images through every kernel of the step, static loss scaling
+    (TrainStep.loss_scale, default 4096) so that the 1e-7-sized activation gradients survive the 16-bit backward pass"""
+    E, K, H = 20, 33, 96
+    emb = synth.make_embeddings(K, E)
+    x = cu(synth.make_images(2, H, H, seed=71))
+    t = cu(synth.make_labels(2, H, H, K, seed=72, block=16))
+    sd = None
+    grads, losses = {}, {}
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        m = models.FCN32s(E)
+        m.load_synthetic(1337, device=torch.device("cuda"))
+        if sd is None:
+            sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        m.eval()
+        ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=dt, fused_head=True)
+        assert ts.loss_scale == (4096.0 if dt == torch.float16 else 1.0)
+        loss, pred = ts.step(x, t)
+        torch.cuda.synchronize()
+        losses[dt] = float(loss)
+        grads[dt] = {n: (getattr(m, n).weight.grad.detach().float() / ts.loss_scale).cpu() for n in ("conv1_2", "conv3_2", "fc6", "score_fr")}
+        assert all(torch.isfinite(g).all() for g in grads[dt].values())
+        if dt == torch.float16:
+            l2 = [float(ts.step(x, t)[0]) for _ in range(3)]
+            assert all(np.isfinite(l2)) and l2[-1] < losses[dt]
+    assert abs(losses[torch.float16] - losses[torch.float32]) < 5e-3       # 10 mantissa bits: closer to fp32 than bf16 is
+    assert abs(losses[torch.bfloat16] - losses[torch.float32]) < 2e-2
+    for n in grads[torch.float32]:
+        ref = grads[torch.float32][n]
+        e16 = float((grads[torch.float16][n] - ref).norm() / ref.norm())
+        eb = float((grads[torch.bfloat16][n] - ref).norm() / ref.norm())
+        print("%s gradient, relative l2 error vs fp32: fp16 %.3e, bf16 %.3e" % (n, e16, eb))
+        assert e16 < 2e-2 and e16 < eb                                      # unscaled fp16 gradients track fp32 better than bf16

@@ -14,7 +14,7 @@ p, g, m, v = (torch.randn(n, device="cuda") for _ in range(4))
 v.abs_()
 lp = torch.empty(n, device="cuda", dtype=torch.bfloat16)
 st = L.stream_ptr()
-fn = lambda: L.call("szn_adam_step", n, L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), 1e-5, 0.9, 0.999, 1e-8, 0.0, 3, 1.0, L.ptr(lp), st)
+fn = lambda: L.call("szn_adam_step", n, L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), 1e-5, 0.9, 0.999, 1e-8, 0.0, 3, 1.0, L.ptr(lp), L.SZN_BF16, st)
 fn(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

@@ -36,6 +36,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// IEEE half as a 16-bit storage type (SZN_F16: BASELINE configs[4] "fp16 activations"); converted by the hardware's
+// round-to-nearest-even v_cvt_f16_f32 / v_cvt_f32_f16
+struct f16_raw { uint16_t v; };
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+
 template <typename T> struct elem;
 template <> struct elem<float> {
     static constexpr int kPer16B = 4;
@@ -47,6 +53,34 @@ template <> struct elem<bf16_raw> {
     __device__ static __forceinline__ float ld(const bf16_raw* p) { return bf16_bits_to_f32(p->v); }
     __device__ static __forceinline__ void st(bf16_raw* p, float v) { p->v = f32_to_bf16_bits(v); }
 };
+
+template <> struct elem<f16_raw> {
+    static constexpr int kPer16B = 8;
+    __device__ static __forceinline__ float ld(const f16_raw* p) { return f16_bits_to_f32(p->v); }
+    __device__ static __forceinline__ void st(f16_raw* p, float v) { p->v = f32_to_f16_bits(v); }
+};
+
+// 16-bit kernels are templated on the storage type (bf16_raw | f16_raw): conversions and the MFMA opcode are the only
+// differences, the LDS-DMA / fragment plumbing moves raw 16-bit patterns
+// (primary templates = bf16, so that code shared with the float instantiation still compiles; f16_raw is specialised)
+template <typename T> __device__ __forceinline__ uint16_t to_bits16(float f) { return f32_to_bf16_bits(f); }
+template <> __device__ __forceinline__ uint16_t to_bits16<f16_raw>(float f) { return f32_to_f16_bits(f); }
+template <typename T> __device__ __forceinline__ float from_bits16(uint16_t b) { return bf16_bits_to_f32(b); }
+template <> __device__ __forceinline__ float from_bits16<f16_raw>(uint16_t b) { return f16_bits_to_f32(b); }
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)to_bits16<T>(lo) | ((uint32_t)to_bits16<T>(hi) << 16);
+}
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t szn_u32x4_t;
+// D += A(16 x 32) * B(32 x 16) with 8 consecutive k per lane in one 128-bit register group
+template <typename T> __device__ __forceinline__ f32x4_t mfma16(szn_u32x4_t a, szn_u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mfma16<f16_raw>(szn_u32x4_t a, szn_u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+static inline bool szn_is16(int dtype) { return dtype == SZN_BF16 || dtype == SZN_F16; }
+static inline size_t szn_esize(int dtype) { return dtype == SZN_F32 ? 4 : 2; }
 
 // ---- wave helpers (wave = 64 lanes) ---------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -38,6 +38,9 @@ template <> struct Mma<bf16_raw> {
                                                       __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     }
 };
+template <> struct Mma<f16_raw> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) { acc = mfma16<f16_raw>(a, b, acc); }
+};
 template <> struct Mma<float> {
     // four 16x16x4 steps; step e uses element e of every lane's 16-B chunk (k = 4*g + e)
     static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
@@ -201,12 +204,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(ConvArgs a) {
                 uint16_t* o = (uint16_t*)a.out + (long)m * a.ldo + nb;
                 if (vec_ok && nb + 3 < a.Co) {
                     u32x2_t pk;
-                    pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+                    pk.x = pack2<T>(v[0], v[1]);
+                    pk.y = pack2<T>(v[2], v[3]);
                     *(u32x2_t*)o = pk;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (nb + e < a.Co) o[e] = f32_to_bf16_bits(v[e]);
+                    for (int e = 0; e < 4; ++e) if (nb + e < a.Co) o[e] = to_bits16<T>(v[e]);
                 }
             }
         }
@@ -274,6 +277,7 @@ struct WgradArgs {
 
 template <typename T> struct WgTraits;
 template <> struct WgTraits<bf16_raw> { static constexpr int KP = 32; static constexpr int TRS = 256 + 32; };
+template <> struct WgTraits<f16_raw> { static constexpr int KP = 32; static constexpr int TRS = 256 + 32; };
 template <> struct WgTraits<float>    { static constexpr int KP = 16; static constexpr int TRS = 512 + 64; };
 
 template <typename T>
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad(WgradArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Mma<bf16_raw>::run(acc[i][j], df[i], xf[j]);
+                for (int j = 0; j < 4; ++j) Mma<T>::run(acc[i][j], df[i], xf[j]);
         } else {
             // f32: one element per lane per 16x16x4 step: lane (r16, g) reads [k = 4*s + g][ch r16]
 #pragma unroll
@@ -476,7 +480,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 int check_desc(const szn_conv_desc_t* d) {
     if (!d) SZN_FAIL(SZN_ERR_ARG, "conv: null descriptor");
-    if (d->dtype != SZN_F32 && d->dtype != SZN_BF16) SZN_FAIL(SZN_ERR_ARG, "conv: bad dtype %d", d->dtype);
+    if (d->dtype != SZN_F32 && !szn_is16(d->dtype)) SZN_FAIL(SZN_ERR_ARG, "conv: bad dtype %d", d->dtype);
     if (d->B <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ci <= 0 || d->Co <= 0 || d->KH <= 0 || d->KW <= 0 || d->pad < 0)
         SZN_FAIL(SZN_ERR_ARG, "conv: non-positive dimension");
     if (d->Ho != d->Hi + 2 * d->pad - d->KH + 1 || d->Wo != d->Wi + 2 * d->pad - d->KW + 1 || d->Ho <= 0 || d->Wo <= 0)
@@ -494,7 +498,7 @@ int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, c
                       const float* chan_scale, void* out, szn_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
-    const int bke = d->dtype == SZN_BF16 ? 64 : 32;
+    const int bke = szn_is16(d->dtype) ? 64 : 32;
     if (d->Ci % bke) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_fwd: Ci=%d must be a multiple of %d", d->Ci, bke);
     if (d->ldi < d->Ci || d->ldo < d->Co || (d->ldi % (bke / 8)))
         SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: bad pixel strides ldi=%d ldo=%d", d->ldi, d->ldo);
@@ -508,9 +512,10 @@ int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.relu = d->relu; a.out_f32 = d->out_f32;
     a.M = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo;
     a.mtiles = szn_div_up(a.M, TILE); a.ntiles = szn_div_up(a.Co, TILE);
-    rc = d->dtype == SZN_BF16 ? launch_conv<bf16_raw>(a, (hipStream_t)stream) : launch_conv<float>(a, (hipStream_t)stream);
+    rc = d->dtype == SZN_BF16 ? launch_conv<bf16_raw>(a, (hipStream_t)stream)
+       : d->dtype == SZN_F16 ? launch_conv<f16_raw>(a, (hipStream_t)stream) : launch_conv<float>(a, (hipStream_t)stream);
     if (rc || !d->colsum) return rc;
-    if (d->out_f32 && d->dtype == SZN_BF16) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_fwd(v1): colsum with out_f32 is unsupported");
+    if (d->out_f32 && szn_is16(d->dtype)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_fwd(v1): colsum with out_f32 is unsupported");
     return szn_bias_grad(d->dtype, a.M, d->Co, d->ldo, out, d->colsum, 1, stream);   // fallback path: separate pass
 }
 
@@ -518,13 +523,13 @@ extern "C" int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, 
                                      szn_stream_t stream) {
     if (!w || !wT || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) SZN_FAIL(SZN_ERR_ARG, "pack_weight_dgrad: bad argument");
     dim3 grid(szn_div_up(Ci, 32), szn_div_up(Co, 32), KH * KW);
-    if (dtype == SZN_BF16 && (Co & 63) == 0 && (Ci & 63) == 0 && !(((uintptr_t)w | (uintptr_t)wT) & 15)) {
+    if (szn_is16(dtype) && (Co & 63) == 0 && (Ci & 63) == 0 && !(((uintptr_t)w | (uintptr_t)wT) & 15)) {
         hipLaunchKernelGGL(pack_dgrad16_kernel, dim3(Ci / 64, Co / 64, KH * KW), dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t*)w, (uint16_t*)wT, Co, KH, KW, Ci);
         SZN_CHECK_LAUNCH("pack_dgrad16_kernel");
         return SZN_OK;
     }
-    if (dtype == SZN_BF16)
+    if (szn_is16(dtype))
         hipLaunchKernelGGL(pack_dgrad_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w,
                            (uint16_t*)wT, Co, KH, KW, Ci);
     else if (dtype == SZN_F32)
@@ -617,6 +622,10 @@ extern "C" int szn_conv2d_dgrad_gemm(const szn_conv_desc_t* d, const void* dout,
         hipLaunchKernelGGL(col2im_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float*)d->workspace, (bf16_raw*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
                            d->pad, d->ldi);
+    else if (d->dtype == SZN_F16)
+        hipLaunchKernelGGL(col2im_kernel<f16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)d->workspace, (f16_raw*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
+                           d->pad, d->ldi);
     else
         hipLaunchKernelGGL(col2im_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float*)d->workspace, (float*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
@@ -631,7 +640,7 @@ int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* do
     int rc = check_desc(d);
     if (rc) return rc;
     if (!in || !dout || !dw) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad: null pointer");
-    const int ch = d->dtype == SZN_BF16 ? 8 : 4;
+    const int ch = szn_is16(d->dtype) ? 8 : 4;
     if ((d->Ci % ch) || (d->ldi % ch) || (d->ldo % ch))
         SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad: Ci/ldi/ldo must be multiples of %d", ch);
     hipStream_t st = (hipStream_t)stream;
@@ -659,6 +668,8 @@ int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* do
     if (blocks >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad: grid too large");
     if (d->dtype == SZN_BF16)
         hipLaunchKernelGGL(conv_wgrad<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (d->dtype == SZN_F16)
+        hipLaunchKernelGGL(conv_wgrad<f16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(conv_wgrad<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     SZN_CHECK_LAUNCH("conv_wgrad");
@@ -668,8 +679,8 @@ int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* do
 extern "C" int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
                              szn_stream_t stream) {
     if (!dout || !db || M <= 0 || Co <= 0 || ldd < Co) SZN_FAIL(SZN_ERR_ARG, "bias_grad: bad argument");
-    if (ldd % (dtype == SZN_BF16 ? 8 : 4) || ((uintptr_t)dout & 15))
-        SZN_FAIL(SZN_ERR_UNSUPPORTED, "bias_grad: rows must be 16-B aligned (ldd multiple of %d)", dtype == SZN_BF16 ? 8 : 4);
+    if (ldd % (szn_is16(dtype) ? 8 : 4) || ((uintptr_t)dout & 15))
+        SZN_FAIL(SZN_ERR_UNSUPPORTED, "bias_grad: rows must be 16-B aligned (ldd multiple of %d)", szn_is16(dtype) ? 8 : 4);
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(db, 0, (size_t)Co * sizeof(float), st);
@@ -680,6 +691,9 @@ extern "C" int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dou
     const int blocks = szn_div_up(M, rpb);
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(bias_grad_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)dout, db, M, Co, ldd,
+                           (int)rpb);
+    else if (dtype == SZN_F16)
+        hipLaunchKernelGGL(bias_grad_kernel<f16_raw>, dim3(blocks), dim3(256), 0, st, (const f16_raw*)dout, db, M, Co, ldd,
                            (int)rpb);
     else if (dtype == SZN_F32)
         hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, db, M, Co, ldd,

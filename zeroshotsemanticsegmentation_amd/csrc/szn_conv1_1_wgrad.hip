@@ -33,6 +33,7 @@ struct C11Args {
 constexpr unsigned kOOB1 = 0x80000000u;
 constexpr int RING1 = 3;
 
+template <typename T>      // bf16_raw | f16_raw: rounding of the gathered image taps + the MFMA opcode
 __global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(C11Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
@@ -122,10 +123,10 @@ __global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(C11Args a) {
         u32x4_t xf[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            xf[f].x = (uint32_t)f32_to_bf16_bits(xn[f][0]) | ((uint32_t)f32_to_bf16_bits(xn[f][1]) << 16);
-            xf[f].y = (uint32_t)f32_to_bf16_bits(xn[f][2]) | ((uint32_t)f32_to_bf16_bits(xn[f][3]) << 16);
-            xf[f].z = (uint32_t)f32_to_bf16_bits(xn[f][4]) | ((uint32_t)f32_to_bf16_bits(xn[f][5]) << 16);
-            xf[f].w = (uint32_t)f32_to_bf16_bits(xn[f][6]) | ((uint32_t)f32_to_bf16_bits(xn[f][7]) << 16);
+            xf[f].x = pack2<T>(xn[f][0], xn[f][1]);
+            xf[f].y = pack2<T>(xn[f][2], xn[f][3]);
+            xf[f].z = pack2<T>(xn[f][4], xn[f][5]);
+            xf[f].w = pack2<T>(xn[f][6], xn[f][7]);
         }
         const bool more1 = s + nwaves < a.nseg, more2 = s + 2 * nwaves < a.nseg;
         // gather first, DMA second: the compiler's wait for the gathered values at the top of the next iteration then
@@ -149,8 +150,7 @@ __global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(C11Args a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
-                acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, df[i]),
-                                                                    __builtin_bit_cast(bf16x8_t, xf[f]), acc[i][f], 0, 0, 0);
+                acc[i][f] = mfma16<T>(df[i], xf[f], acc[i][f]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // stage drained before it is refilled
         stage = stage == 2 ? 0 : stage + 1;
     }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void conv1_1_wgrad_reduce(const float* __restr
 }  // namespace
 
 // bf16 path of szn_conv1_1_wgrad (szn_elementwise.hip).  workspace: >= nblocks * 8 KiB.  Returns 1 if not applicable.
-int szn_conv1_1_wgrad_fused_try(int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
+int szn_conv1_1_wgrad_fused_try(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
                                 void* workspace, size_t workspace_bytes, szn_stream_t stream) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     const size_t dout_bytes = (size_t)B * Ho * Wo * 128, x_bytes = (size_t)B * 3 * H * W * 4;
@@ -212,7 +212,8 @@ int szn_conv1_1_wgrad_fused_try(int B, int H, int W, int pad, const float* x, co
     if (blocks < 1) blocks = 1;
     if (workspace_bytes < (size_t)blocks * 2048 * sizeof(float)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv1_1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (dtype == SZN_F16) hipLaunchKernelGGL(conv1_1_wgrad_kernel<f16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(conv1_1_wgrad_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     SZN_CHECK_LAUNCH("conv1_1_wgrad_kernel");
     hipLaunchKernelGGL(conv1_1_wgrad_reduce, dim3(64 * 27 / 8), dim3(256), 0, st, (const float*)workspace, dw,
                        (int)blocks, accumulate);

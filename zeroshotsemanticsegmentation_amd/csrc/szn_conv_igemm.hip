@@ -42,6 +42,9 @@ template <> struct Mma2<bf16_raw> {
                                                       0, 0, 0);
     }
 };
+template <> struct Mma2<f16_raw> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) { acc = mfma16<f16_raw>(a, b, acc); }
+};
 template <> struct Mma2<float> {
     static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
@@ -374,14 +377,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
                     uint16_t* o = (uint16_t*)a.out + (long)m * a.ldo + n;
                     if (full && fast_o) {
                         u32x4_t pk;
-                        pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-                        pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-                        pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-                        pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+                        pk.x = pack2<T>(v[0], v[1]);
+                        pk.y = pack2<T>(v[2], v[3]);
+                        pk.z = pack2<T>(v[4], v[5]);
+                        pk.w = pack2<T>(v[6], v[7]);
                         *(u32x4_t*)o = pk;
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) if (n + e < a.Co) o[e] = f32_to_bf16_bits(v[e]);
+                        for (int e = 0; e < 8; ++e) if (n + e < a.Co) o[e] = to_bits16<T>(v[e]);
                     }
                 }
             }
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__
         if (gate) x = (elem<T>::ld(gate + m * a.ldg + n) > 0.f) ? x : 0.f;
         if (a.cscale) x *= a.cscale[(m / a.HoWo) * a.Co + n];
         if (a.out_f32 || sizeof(T) == 4) ((float*)a.out)[m * a.ldo + n] = x;
-        else ((uint16_t*)a.out)[m * a.ldo + n] = f32_to_bf16_bits(x);
+        else ((uint16_t*)a.out)[m * a.ldo + n] = to_bits16<T>(x);
     }
 }
 
@@ -469,17 +472,17 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     const int rc = conv2d_fwd_dispatch(d, in, w, bias, gate, chan_scale, out, stream, &pooled);
     if (rc || !d->pool_out || pooled) return rc;
     // the kernel that ran has no fused pooling: pool the tensor it wrote
-    return szn_maxpool2x2_ceil_fwd((d->out_f32 || d->dtype == SZN_F32) ? SZN_F32 : SZN_BF16, d->B, d->Ho, d->Wo, d->Co, out,
+    return szn_maxpool2x2_ceil_fwd((d->out_f32 || d->dtype == SZN_F32) ? SZN_F32 : d->dtype, d->B, d->Ho, d->Wo, d->Co, out,
                                    d->pool_out, stream);
 }
 
 static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                                const float* chan_scale, void* out, szn_stream_t stream, int* pooled) {
-    const size_t es = d->dtype == SZN_BF16 ? 2 : 4;
+    const size_t es = szn_esize(d->dtype);
     const size_t in_bytes = (size_t)d->B * d->Hi * d->Wi * d->ldi * es;
     const size_t w_bytes = (size_t)d->Co * d->KH * d->KW * d->Ci * es;
     const int bke = (int)(128 / es);
-    const bool v2_ok = (d->dtype == SZN_BF16 || d->dtype == SZN_F32) && d->Ci > 0 && (d->Ci % bke) == 0 &&
+    const bool v2_ok = (szn_is16(d->dtype) || d->dtype == SZN_F32) && d->Ci > 0 && (d->Ci % bke) == 0 &&
                        in_bytes < 0x7fff0000ul && w_bytes < 0x7fff0000ul && d->Hi < 32000 && d->Wi < 32000 && d->pad < 16000 &&
                        ((size_t)d->ldi * es) % 16 == 0;
     if (!v2_ok) return szn_conv2d_fwd_v1(d, in, w, bias, gate, chan_scale, out, stream);
@@ -567,6 +570,7 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     }
     if (rc != 0) {                                    // (rc == 0: the wide kernel wrote the slabs)
         if (d->dtype == SZN_BF16) rc = narrow ? launch_v2<bf16_raw, 2>(a, st) : launch_v2<bf16_raw, 4>(a, st);
+        else if (d->dtype == SZN_F16) rc = narrow ? launch_v2<f16_raw, 2>(a, st) : launch_v2<f16_raw, 4>(a, st);
         else rc = narrow ? launch_v2<float, 2>(a, st) : launch_v2<float, 4>(a, st);
         if (rc) return rc;
     }
@@ -575,6 +579,8 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
         if (blocks > 8192) blocks = 8192;
         if (d->dtype == SZN_BF16)
             hipLaunchKernelGGL(splitk_epilogue<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a.ws, a);
+        else if (d->dtype == SZN_F16)
+            hipLaunchKernelGGL(splitk_epilogue<f16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a.ws, a);
         else
             hipLaunchKernelGGL(splitk_epilogue<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a.ws, a);
         SZN_CHECK_LAUNCH("splitk_epilogue");

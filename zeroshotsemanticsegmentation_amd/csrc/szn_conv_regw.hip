@@ -71,7 +71,7 @@ struct RwGeom {
     static_assert(COG * CIG * PG == 8 && LDS <= 160 * 1024, "wave decomposition / LDS budget");
 };
 
-template <int COG, int CIG, bool GATED, bool COLSUM>
+template <typename T, int COG, int CIG, bool GATED, bool COLSUM>      // T = bf16_raw | f16_raw (conversions + MFMA opcode only)
 __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef RwGeom<COG, CIG> G_;
@@ -211,8 +211,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                     if (j < 0 || j > 3) continue;
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, W[kh * 3 + kw][s][i]),
-                                                                            __builtin_bit_cast(bf16x8_t, P[step & 1][s]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<T>(W[kh * 3 + kw][s][i], P[step & 1][s], acc[i][j]);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -283,10 +282,10 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                 if constexpr (COLSUM) cs[e] += ok ? x : 0.f;
             }
             u32x4_t pk;
-            pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-            pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-            pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+            pk.x = pack2<T>(v[0], v[1]);
+            pk.y = pack2<T>(v[2], v[3]);
+            pk.z = pack2<T>(v[4], v[5]);
+            pk.w = pack2<T>(v[6], v[7]);
             if (ok) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
             if constexpr (!GATED) {
                 // fused MaxPool2d(2,2,ceil): rows (j, j + 1) pair up in this lane (oh0 is even), columns (ow, ow ^ 1) in
@@ -306,10 +305,10 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                         const int poh = (oh0 + j) >> 1, pw = ow >> 1;
                         if ((r16 & 1) == 0 && okw && poh < a.Hp) {
                             u32x4_t pq;
-                            pq.x = (uint32_t)f32_to_bf16_bits(mx[0]) | ((uint32_t)f32_to_bf16_bits(mx[1]) << 16);
-                            pq.y = (uint32_t)f32_to_bf16_bits(mx[2]) | ((uint32_t)f32_to_bf16_bits(mx[3]) << 16);
-                            pq.z = (uint32_t)f32_to_bf16_bits(mx[4]) | ((uint32_t)f32_to_bf16_bits(mx[5]) << 16);
-                            pq.w = (uint32_t)f32_to_bf16_bits(mx[6]) | ((uint32_t)f32_to_bf16_bits(mx[7]) << 16);
+                            pq.x = pack2<T>(mx[0], mx[1]);
+                            pq.y = pack2<T>(mx[2], mx[3]);
+                            pq.z = pack2<T>(mx[4], mx[5]);
+                            pq.w = pack2<T>(mx[6], mx[7]);
                             *(u32x4_t*)(a.pool + ((size_t)((b * a.Hp + poh) * a.Wp + pw) * (32 * COG) + cstart) * 2) = pq;
                         }
                     }
@@ -338,23 +337,23 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
 #endif
 }
 
-template <int COG, int CIG, bool GATED, bool COLSUM>
+template <typename T, int COG, int CIG, bool GATED, bool COLSUM>
 int launch_regw(const RwArgs& a, int grid, hipStream_t st) {
     constexpr int lds = RwGeom<COG, CIG>::LDS;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_regw<COG, CIG, GATED, COLSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_regw<T, COG, CIG, GATED, COLSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_regw<COG, CIG, GATED, COLSUM>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_regw<T, COG, CIG, GATED, COLSUM>), dim3((unsigned)grid), dim3(512), lds, st, a);
     SZN_CHECK_LAUNCH("conv3x3_regw");
     return SZN_OK;
 }
 
-template <int COG, int CIG>
+template <typename T, int COG, int CIG>
 int launch_regw_flags(const RwArgs& a, int grid, hipStream_t st) {
-    if (a.gate) return a.colsum ? launch_regw<COG, CIG, true, true>(a, grid, st) : launch_regw<COG, CIG, true, false>(a, grid, st);
-    return a.colsum ? launch_regw<COG, CIG, false, true>(a, grid, st) : launch_regw<COG, CIG, false, false>(a, grid, st);
+    if (a.gate) return a.colsum ? launch_regw<T, COG, CIG, true, true>(a, grid, st) : launch_regw<T, COG, CIG, true, false>(a, grid, st);
+    return a.colsum ? launch_regw<T, COG, CIG, false, true>(a, grid, st) : launch_regw<T, COG, CIG, false, false>(a, grid, st);
 }
 
 }  // namespace
@@ -362,7 +361,7 @@ int launch_regw_flags(const RwArgs& a, int grid, hipStream_t st) {
 // Called by szn_conv2d_fwd after it has validated the descriptor. Returns 1 if the layer is not this kernel's shape.
 int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, int min_tiles, szn_stream_t stream) {
-    if (d->dtype != SZN_BF16 || d->KH != 3 || d->KW != 3 || d->pad > 2 || d->out_f32 || chan_scale) return 1;
+    if (!szn_is16(d->dtype) || d->KH != 3 || d->KW != 3 || d->pad > 2 || d->out_f32 || chan_scale) return 1;
     if ((d->Ci != 64 && d->Ci != 128) || (d->Co != 64 && d->Co != 128)) return 1;
     if ((d->ldo & 7) || (d->ldi & 7) || (gate && (d->ldg & 7))) return 1;
     if (d->pool_out && (gate || (size_t)d->B * ((d->Ho + 1) / 2) * ((d->Wo + 1) / 2) * d->Co * 2 >= 0xffff0000ul)) return 1;
@@ -392,8 +391,14 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
         if (ncu < 8) ncu = 8;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (cog == 2 && cig == 1) return launch_regw_flags<2, 1>(a, ncu, st);
-    if (cog == 4 && cig == 1) return launch_regw_flags<4, 1>(a, ncu, st);
-    if (cog == 2 && cig == 2) return launch_regw_flags<2, 2>(a, ncu, st);
-    return launch_regw_flags<4, 2>(a, ncu, st);
+    if (d->dtype == SZN_F16) {
+        if (cog == 2 && cig == 1) return launch_regw_flags<f16_raw, 2, 1>(a, ncu, st);
+        if (cog == 4 && cig == 1) return launch_regw_flags<f16_raw, 4, 1>(a, ncu, st);
+        if (cog == 2 && cig == 2) return launch_regw_flags<f16_raw, 2, 2>(a, ncu, st);
+        return launch_regw_flags<f16_raw, 4, 2>(a, ncu, st);
+    }
+    if (cog == 2 && cig == 1) return launch_regw_flags<bf16_raw, 2, 1>(a, ncu, st);
+    if (cog == 4 && cig == 1) return launch_regw_flags<bf16_raw, 4, 1>(a, ncu, st);
+    if (cog == 2 && cig == 2) return launch_regw_flags<bf16_raw, 2, 2>(a, ncu, st);
+    return launch_regw_flags<bf16_raw, 4, 2>(a, ncu, st);
 }

@@ -188,8 +188,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_v2(Wg2Args a) {
             for (int i = 0; i < FA; ++i)
 #pragma unroll
                 for (int j = 0; j < FB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, df[i]),
-                                                                        __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<T>(df[i], xf[j], acc[i][j]);
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {       // rows 4s + g; the swizzle depends on (row & 1) == (g & 1) only
@@ -260,11 +259,11 @@ void launch_wg2(const Wg2Args& a, long blocks, hipStream_t st) {
 extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                                 szn_stream_t stream) {
     if (!d) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad: null descriptor");
-    const size_t es = d->dtype == SZN_BF16 ? 2 : 4;
+    const size_t es = szn_esize(d->dtype);
     const int ch = (int)(16 / es);
     const size_t in_bytes = (size_t)d->B * d->Hi * d->Wi * d->ldi * es;
     const size_t dout_bytes = (size_t)d->B * d->Ho * d->Wo * d->ldo * es;
-    const bool ok = (d->dtype == SZN_BF16 || d->dtype == SZN_F32) && in && dout && dw && d->B > 0 && d->Hi > 0 && d->Wi > 0 &&
+    const bool ok = (szn_is16(d->dtype) || d->dtype == SZN_F32) && in && dout && dw && d->B > 0 && d->Hi > 0 && d->Wi > 0 &&
                     d->Ci > 0 && d->Co > 0 && d->KH > 0 && d->KW > 0 && d->pad >= 0 &&
                     d->Ho == d->Hi + 2 * d->pad - d->KH + 1 && d->Wo == d->Wi + 2 * d->pad - d->KW + 1 && d->Ho > 0 && d->Wo > 0 &&
                     (d->Ci % ch) == 0 && (d->ldi % ch) == 0 && (d->ldo % ch) == 0 && in_bytes < 0x7fff0000ul &&
@@ -323,6 +322,11 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
         else if (FA == 4) launch_wg2<bf16_raw, 4, 2>(a, blocks, st);
         else if (FB == 4) launch_wg2<bf16_raw, 2, 4>(a, blocks, st);
         else launch_wg2<bf16_raw, 2, 2>(a, blocks, st);
+    } else if (d->dtype == SZN_F16) {
+        if (FA == 4 && FB == 4) launch_wg2<f16_raw, 4, 4>(a, blocks, st);
+        else if (FA == 4) launch_wg2<f16_raw, 4, 2>(a, blocks, st);
+        else if (FB == 4) launch_wg2<f16_raw, 2, 4>(a, blocks, st);
+        else launch_wg2<f16_raw, 2, 2>(a, blocks, st);
     } else {
         if (FA == 4 && FB == 4) launch_wg2<float, 4, 4>(a, blocks, st);
         else if (FA == 4) launch_wg2<float, 4, 2>(a, blocks, st);

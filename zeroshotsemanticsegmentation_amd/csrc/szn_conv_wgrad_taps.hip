@@ -44,6 +44,7 @@ constexpr int OFF_DUMPt = 2 * STAGEt;
 constexpr int LDS_WT = OFF_DUMPt + 1024;
 constexpr int SLAB = 64 * 9 * 64;                   // floats per block partial
 
+template <typename T>      // bf16_raw | f16_raw: only the MFMA opcode differs (operands move as raw 16-bit patterns)
 __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
@@ -177,8 +178,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
                     const u32x4_t xf = u32x4_t{Br[kh][kw].x, Br[kh][kw].y, Br[kh + 1][kw].x, Br[kh + 1][kw].y};
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        acc[i][kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Af[i]),
-                                                                                      __builtin_bit_cast(bf16x8_t, xf), acc[i][kh * 3 + kw], 0, 0, 0);
+                        acc[i][kh * 3 + kw] = mfma16<T>(Af[i], xf, acc[i][kh * 3 + kw]);
                 }
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) { Br[0][kw] = Br[2][kw]; Br[1][kw] = Br[3][kw]; }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_reduce(WtArgs a) {
 // Called by szn_conv2d_wgrad after validation.  Returns 1 if the layer / workspace does not fit this kernel.
 int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                             int min_tiles_per_block, szn_stream_t stream) {
-    if (d->dtype != SZN_BF16 || d->KH != 3 || d->KW != 3 || (d->Ci & 63) || (d->Co & 63) || d->pad > 2 || !d->workspace)
+    if (!szn_is16(d->dtype) || d->KH != 3 || d->KW != 3 || (d->Ci & 63) || (d->Co & 63) || d->pad > 2 || !d->workspace)
         return 1;
     if ((d->ldi & 7) || (d->ldo & 7) || ((uintptr_t)dw & 15) || ((uintptr_t)d->workspace & 15)) return 1;
     WtArgs a;
@@ -282,10 +282,12 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     hipStream_t st = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_taps, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WT);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_taps<bf16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WT);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_taps<f16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WT);
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_taps, dim3((unsigned)(ns * ncombo)), dim3(512), LDS_WT, st, a);
+    if (d->dtype == SZN_F16) hipLaunchKernelGGL(conv_wgrad_taps<f16_raw>, dim3((unsigned)(ns * ncombo)), dim3(512), LDS_WT, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_taps<bf16_raw>, dim3((unsigned)(ns * ncombo)), dim3(512), LDS_WT, st, a);
     SZN_CHECK_LAUNCH("conv_wgrad_taps");
     const long total4 = (long)ncombo * (SLAB / 4);
     hipLaunchKernelGGL(wgrad_taps_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a);

@@ -40,6 +40,7 @@ constexpr int STAGEg = KPg * 1024;                   // A rows 512 B + B rows 51
 constexpr int NSTg = 4;
 constexpr int LDS_WGW = NSTg * STAGEg;               // 128 KiB
 
+template <typename T>      // bf16_raw | f16_raw: only the MFMA opcode differs
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
@@ -151,8 +152,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, df[i]),
-                                                                        __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<T>(df[i], xf[j], acc[i][j]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stage = (stage + 1) & 3;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
 // Called by szn_conv2d_wgrad after validation.  Returns 1 if the layer does not fit this kernel.
 int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                             int min_tiles, szn_stream_t stream) {
-    if (d->dtype != SZN_BF16 || d->Co < 256 || d->Ci < 256 || (d->ldi & 7) || (d->ldo & 7) || (d->Ci & 7)) return 1;
+    if (!szn_is16(d->dtype) || d->Co < 256 || d->Ci < 256 || (d->ldi & 7) || (d->ldo & 7) || (d->Ci & 7)) return 1;
     WgwArgs a;
     a.cotiles = szn_div_up(d->Co, 256); a.citiles = szn_div_up(d->Ci, 256);
     const long tiles = (long)a.cotiles * a.citiles * d->KH * d->KW;
@@ -216,10 +216,12 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGW_ABLATE"); } a.ablate = abl; }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<bf16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<f16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW);
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_wide, dim3((unsigned)tiles), dim3(512), LDS_WGW, (hipStream_t)stream, a);
+    if (d->dtype == SZN_F16) hipLaunchKernelGGL(conv_wgrad_wide<f16_raw>, dim3((unsigned)tiles), dim3(512), LDS_WGW, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_wide<bf16_raw>, dim3((unsigned)tiles), dim3(512), LDS_WGW, (hipStream_t)stream, a);
     SZN_CHECK_LAUNCH("conv_wgrad_wide");
     return SZN_OK;
 }

@@ -141,14 +141,14 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
                         uint16_t* o = (uint16_t*)a.out + (long)m * a.ldo + n;
                         if (full && fast_o) {
                             u32x4_t pk;
-                            pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-                            pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-                            pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-                            pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+                            pk.x = pack2<T>(v[0], v[1]);
+                            pk.y = pack2<T>(v[2], v[3]);
+                            pk.z = pack2<T>(v[4], v[5]);
+                            pk.w = pack2<T>(v[6], v[7]);
                             *(u32x4_t*)o = pk;
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) if (n + e < a.Co) o[e] = f32_to_bf16_bits(v[e]);
+                            for (int e = 0; e < 8; ++e) if (n + e < a.Co) o[e] = to_bits16<T>(v[e]);
                         }
                     }
                 }
@@ -285,8 +285,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if constexpr (ES == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i]),
-                                                                            __builtin_bit_cast(bf16x8_t, pf[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<T>(wf[i], pf[j], acc[i][j]);
                     } else {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].x), __uint_as_float(pf[j].x), acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i].y), __uint_as_float(pf[j].y), acc[i][j], 0, 0, 0);
@@ -343,7 +342,7 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.M = d->B * d->Ho * d->Wo;
     // cout tile 256, or 320 (bf16) when that wastes fewer columns: the 300-d projection is one 320-wide tile
     const int waste256 = szn_div_up(d->Co, 256) * 256 - d->Co, waste320 = szn_div_up(d->Co, 320) * 320 - d->Co;
-    const int bn = (d->dtype == SZN_BF16 && waste320 < waste256) ? 320 : 256;
+    const int bn = (szn_is16(d->dtype) && waste320 < waste256) ? 320 : 256;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(d->Co, bn);
     a.nmajor = 0;
     if ((long)a.mtiles * a.ntiles * a.nsplit < min_tiles) return 1; // too few blocks to fill the chip: keep 256 x 128
@@ -354,6 +353,8 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
     a.relu = d->relu; a.out_f32 = d->out_f32; a.HoWo = d->Ho * d->Wo;
-    if (bn == 320) return launch_wide<bf16_raw, 10>(a, (hipStream_t)stream);
+    if (bn == 320)
+        return d->dtype == SZN_F16 ? launch_wide<f16_raw, 10>(a, (hipStream_t)stream) : launch_wide<bf16_raw, 10>(a, (hipStream_t)stream);
+    if (d->dtype == SZN_F16) return launch_wide<f16_raw, 8>(a, (hipStream_t)stream);
     return d->dtype == SZN_BF16 ? launch_wide<bf16_raw, 8>(a, (hipStream_t)stream) : launch_wide<float, 8>(a, (hipStream_t)stream);
 }

@@ -315,6 +315,7 @@ __device__ __forceinline__ float adam_elem(float& pi, float gi, float& mi, float
     return pi;
 }
 
+template <typename LP>      // element type of the optional 16-bit weight image (bf16_raw | f16_raw)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                    float b1, float b2, float eps, float wd, float step_size,
@@ -331,8 +332,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         ((f32x4_t*)m)[i] = mq; ((f32x4_t*)v)[i] = vq; ((f32x4_t*)p)[i] = pq;
         if (wlp) {
             uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16_bits(pq[0]) | ((uint32_t)f32_to_bf16_bits(pq[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16_bits(pq[2]) | ((uint32_t)f32_to_bf16_bits(pq[3]) << 16);
+            pk.x = pack2<LP>(pq[0], pq[1]);
+            pk.y = pack2<LP>(pq[2], pq[3]);
             ((uint2*)wlp)[i] = pk;
         }
     }
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         float pi = p[i], mi = m[i], vi = v[i];
         adam_elem(pi, g[i], mi, vi, b1, b2, eps, wd, step_size, inv_bc2_sqrt, gscale);
         m[i] = mi; v[i] = vi; p[i] = pi;
-        if (wlp) wlp[i] = f32_to_bf16_bits(pi);
+        if (wlp) wlp[i] = to_bits16<LP>(pi);
     }
 }
 
@@ -351,6 +352,7 @@ __device__ __forceinline__ void sgd_elem(float& pi, float gi, float& bi, float l
     pi -= lr * bi;
 }
 
+template <typename LP>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ buf, long n, float lr, float mom, float wd,
                                                   int first, float gscale, uint16_t* __restrict__ wlp, int vec) {
@@ -367,8 +369,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
         ((f32x4_t*)buf)[i] = bq; ((f32x4_t*)p)[i] = pq;
         if (wlp) {
             uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16_bits(pq[0]) | ((uint32_t)f32_to_bf16_bits(pq[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16_bits(pq[2]) | ((uint32_t)f32_to_bf16_bits(pq[3]) << 16);
+            pk.x = pack2<LP>(pq[0], pq[1]);
+            pk.y = pack2<LP>(pq[2], pq[3]);
             ((uint2*)wlp)[i] = pk;
         }
     }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
         float pi = p[i], bi = first ? 0.f : buf[i];
         sgd_elem(pi, g[i], bi, lr, mom, wd, first, gscale);
         buf[i] = bi; p[i] = pi;
-        if (wlp) wlp[i] = f32_to_bf16_bits(pi);
+        if (wlp) wlp[i] = to_bits16<LP>(pi);
     }
 }
 
@@ -401,6 +403,9 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(conv1_1_fwd_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                            (bf16_raw*)out, B, H, W, pad, Ho, Wo);
+    else if (dtype == SZN_F16)
+        hipLaunchKernelGGL(conv1_1_fwd_kernel<f16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (f16_raw*)out, B, H, W, pad, Ho, Wo);
     else if (dtype == SZN_F32)
         hipLaunchKernelGGL(conv1_1_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                            (float*)out, B, H, W, pad, Ho, Wo);
@@ -410,13 +415,13 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
     return SZN_OK;
 }
 
-int szn_conv1_1_wgrad_fused_try(int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
+int szn_conv1_1_wgrad_fused_try(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
                                 void* workspace, size_t workspace_bytes, szn_stream_t stream);
 
 extern "C" size_t szn_conv1_1_wgrad_workspace_bytes(int dtype, int B, int H, int W, int pad) {
     if (B <= 0 || H <= 0 || W <= 0 || pad < 0) return 0;
     const size_t Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
-    return (size_t)B * Ho * Wo * 32 * (dtype == SZN_BF16 ? 2 : 4) + 64 * 32 * sizeof(float);
+    return (size_t)B * Ho * Wo * 32 * szn_esize(dtype) + 64 * 32 * sizeof(float);
 }
 
 extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw,
@@ -428,9 +433,9 @@ extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const 
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     const long M = (long)B * Ho * Wo;
     if (M >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_wgrad: more than 2^31 pixels");
-    const size_t es = dtype == SZN_BF16 ? 2 : 4;
-    if (dtype == SZN_BF16) {        // fused kernel: no im2col image, padding-only pixels skipped (szn_conv1_1_wgrad.hip)
-        const int rc = szn_conv1_1_wgrad_fused_try(B, H, W, pad, x, dout, dw, accumulate, workspace,
+    const size_t es = szn_esize(dtype);
+    if (szn_is16(dtype)) {          // fused kernel: no im2col image, padding-only pixels skipped (szn_conv1_1_wgrad.hip)
+        const int rc = szn_conv1_1_wgrad_fused_try(dtype, B, H, W, pad, x, dout, dw, accumulate, workspace,
                                                    szn_conv1_1_wgrad_workspace_bytes(dtype, B, H, W, pad), stream);
         if (rc < 0) return rc;
         if (rc == 0) return db ? szn_bias_grad(dtype, M, 64, 64, dout, db, accumulate, stream) : SZN_OK;
@@ -442,6 +447,9 @@ extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const 
     if (blocks > 65536) blocks = 65536;
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(im2col_c3_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, x, (bf16_raw*)xcol, B, H, W,
+                           pad, Ho, Wo);
+    else if (dtype == SZN_F16)
+        hipLaunchKernelGGL(im2col_c3_kernel<f16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, x, (f16_raw*)xcol, B, H, W,
                            pad, Ho, Wo);
     else if (dtype == SZN_F32)
         hipLaunchKernelGGL(im2col_c3_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, x, (float*)xcol, B, H, W, pad, Ho,
@@ -462,13 +470,16 @@ extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const 
 extern "C" int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out,
                                        szn_stream_t stream) {
     if (!in || !out || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_fwd: bad argument");
-    const int ch = dtype == SZN_BF16 ? 8 : 4;
+    const int ch = szn_is16(dtype) ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_fwd: C must be a multiple of %d", ch);
     const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
     const long total = (long)B * Ho * Wo * (C / ch);
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_raw>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_raw*)in, (bf16_raw*)out, B, Hi, Wi, C, Ho, Wo);
+    else if (dtype == SZN_F16)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<f16_raw>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                           (const f16_raw*)in, (f16_raw*)out, B, Hi, Wi, C, Ho, Wo);
     else if (dtype == SZN_F32)
         hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)in, (float*)out, B, Hi, Wi, C, Ho, Wo);
@@ -482,7 +493,7 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
                                        const void* dout, void* din, float* colsum, szn_stream_t stream) {
     if (!in || !out || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0)
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad argument");
-    const int ch = dtype == SZN_BF16 ? 8 : 4;
+    const int ch = szn_is16(dtype) ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd: C must be a multiple of %d", ch);
     const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
     const long total = (long)B * Ho * Wo * (C / ch);
@@ -491,6 +502,10 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_raw*)in, (const bf16_raw*)out, (const bf16_raw*)dout, (bf16_raw*)din, B, Hi, Wi, C,
+                           Ho, Wo, colsum);
+    else if (dtype == SZN_F16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<f16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const f16_raw*)in, (const f16_raw*)out, (const f16_raw*)dout, (f16_raw*)din, B, Hi, Wi, C,
                            Ho, Wo, colsum);
     else if (dtype == SZN_F32)
         hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
@@ -510,6 +525,10 @@ extern "C" int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, v
         hipLaunchKernelGGL((cast_kernel<float, bf16_raw>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16_raw*)dst, n);
     else if (src_dtype == SZN_BF16 && dst_dtype == SZN_F32)
         hipLaunchKernelGGL((cast_kernel<bf16_raw, float>), dim3(grid), dim3(256), 0, st, (const bf16_raw*)src, (float*)dst, n);
+    else if (src_dtype == SZN_F32 && dst_dtype == SZN_F16)
+        hipLaunchKernelGGL((cast_kernel<float, f16_raw>), dim3(grid), dim3(256), 0, st, (const float*)src, (f16_raw*)dst, n);
+    else if (src_dtype == SZN_F16 && dst_dtype == SZN_F32)
+        hipLaunchKernelGGL((cast_kernel<f16_raw, float>), dim3(grid), dim3(256), 0, st, (const f16_raw*)src, (float*)dst, n);
     else if (src_dtype == SZN_F32 && dst_dtype == SZN_F32)
         hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
     else
@@ -553,28 +572,39 @@ extern "C" int szn_image_u8_to_bgr_f32(int B, int H, int W, const uint8_t* rgb_h
 
 extern "C" int szn_adam_step(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                             void* w_lp, szn_stream_t stream) {
+                             void* w_lp, int w_lp_dtype, szn_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) SZN_FAIL(SZN_ERR_ARG, "adam_step: bad argument");
+    if (w_lp && !szn_is16(w_lp_dtype)) SZN_FAIL(SZN_ERR_ARG, "adam_step: the weight image must be SZN_BF16 or SZN_F16");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     const int vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
                      (((uintptr_t)w_lp) & 7) == 0) ? 1 : 0;
     // one 16-B group per thread, no grid-stride loop: measured 6.1 TB/s on the 135 M-element buffer vs 5.6 with 16 Ki blocks
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 1 << 24)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale,
-                       (uint16_t*)w_lp, vec);
+    const dim3 grid(grid_for(vec ? (n + 3) / 4 : n, 256, 1 << 24));
+    if (w_lp && w_lp_dtype == SZN_F16)
+        hipLaunchKernelGGL(adam_kernel<f16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                           beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale, (uint16_t*)w_lp, vec);
+    else
+        hipLaunchKernelGGL(adam_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                           beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale, (uint16_t*)w_lp, vec);
     SZN_CHECK_LAUNCH("adam_kernel");
     return SZN_OK;
 }
 
 extern "C" int szn_sgd_momentum_step(long n, float* param, const float* grad, float* momentum_buf, float lr,
                                      float momentum, float weight_decay, int first_step, float grad_scale, void* w_lp,
-                                     szn_stream_t stream) {
+                                     int w_lp_dtype, szn_stream_t stream) {
     if (!param || !grad || !momentum_buf || n <= 0) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step: bad argument");
+    if (w_lp && !szn_is16(w_lp_dtype)) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step: the weight image must be SZN_BF16 or SZN_F16");
     const int vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) == 0 && (((uintptr_t)w_lp) & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 1 << 24)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec);
+    const dim3 grid(grid_for(vec ? (n + 3) / 4 : n, 256, 1 << 24));
+    if (w_lp && w_lp_dtype == SZN_F16)
+        hipLaunchKernelGGL(sgd_kernel<f16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, n, lr, momentum,
+                           weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec);
+    else
+        hipLaunchKernelGGL(sgd_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, n, lr, momentum,
+                           weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec);
     SZN_CHECK_LAUNCH("sgd_kernel");
     return SZN_OK;
 }

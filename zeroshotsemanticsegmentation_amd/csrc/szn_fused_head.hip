@@ -318,6 +318,9 @@ extern "C" int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H
         else if (dcoarse_dtype == SZN_BF16)
             hipLaunchKernelGGL(fh_gather_kernel<bf16_raw>, dim3(B * h * w), dim3(256), 0, st, coarse, embed,
                                (const float*)ws_f, (const float*)stats, (bf16_raw*)dcoarse, B, h, w, E, ldc, c0, K, KP);
+        else if (dcoarse_dtype == SZN_F16)
+            hipLaunchKernelGGL(fh_gather_kernel<f16_raw>, dim3(B * h * w), dim3(256), 0, st, coarse, embed,
+                               (const float*)ws_f, (const float*)stats, (f16_raw*)dcoarse, B, h, w, E, ldc, c0, K, KP);
         else
             SZN_FAIL(SZN_ERR_ARG, "fused_head: bad dcoarse_dtype %d", dcoarse_dtype);
         SZN_CHECK_LAUNCH("fh_gather_kernel");

@@ -95,7 +95,7 @@ class TrainStep(object):
     def __init__(self, model, embeddings, optimizer="adam", lr=1e-5, momentum=0.99, weight_decay=0.0005,
                  precision=torch.bfloat16, fused_head=True, loss="cos", process_group=None, bucket_mb=25,
                  train_metrics=True, betas=(0.9, 0.999), eps=1e-8, bias_lr=None, bias_weight_decay=0.0,
-                 adam_weight_decay=0.0, grad_comm_dtype=None):
+                 adam_weight_decay=0.0, grad_comm_dtype=None, loss_scale=None):
         if loss not in ("cos", "mse") or (fused_head and loss != "cos"):
             raise L.SznError("TrainStep: fused head supports the cosine loss; use fused_head=False for mse")
         self.model = model
@@ -118,6 +118,10 @@ class TrainStep(object):
             grad_comm_dtype = torch.bfloat16 if os.environ.get("SZN_GRAD_COMM", "fp32") == "bf16" else torch.float32
         self.grad_comm_dtype = grad_comm_dtype
         self.fused_head, self.loss_kind = fused_head, loss
+        # static loss scaling for the fp16 path: gradients below 6e-8 vanish in IEEE half, so d(loss)/d(coarse) is multiplied
+        # by loss_scale in fp32 before it enters the 16-bit backward pass and the optimizer kernel divides it out again
+        # (grad_scale).  The .grad views then hold loss_scale x gradient.  bf16 / fp32 need none.
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if precision == torch.float16 else 1.0)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.train_metrics = train_metrics
@@ -176,9 +180,9 @@ class TrainStep(object):
         # low-precision weight image written by the optimizer kernel itself (no separate cast pass per step)
         self.flat_w_lp = None
         self.eng.lp_views = {}
-        if self.eng.dtype == torch.bfloat16:
+        if self.eng.dtype in (torch.bfloat16, torch.float16):
             # (CP - E) x F extra elements behind score_fr's slot: the fused head's weight image [CP][F] is then a view
-            store = torch.zeros(nw + (CP - E) * F, device=self.dev, dtype=torch.bfloat16)
+            store = torch.zeros(nw + (CP - E) * F, device=self.dev, dtype=self.eng.dtype)
             store[:nw].copy_(self.flat_w)
             self._flat_w_lp_store = store
             self.flat_w_lp = store[:nw]
@@ -227,7 +231,9 @@ class TrainStep(object):
         code = L.dtype_code(eng.dtype)
         pred = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
         stats = torch.empty(B, 2, device=self.dev)
-        dcoarse = torch.zeros(B, ctx.h, ctx.w, CP, device=self.dev, dtype=eng.dtype)
+        scaled = self.loss_scale != 1.0
+        dcoarse = torch.zeros(B, ctx.h, ctx.w, CP, device=self.dev, dtype=torch.float32 if scaled else eng.dtype)
+        code = L.dtype_code(dcoarse.dtype)
         if self.fused_head:
             nbytes = L.load().szn_fused_head_workspace_bytes(B, ctx.h, ctx.w, E, K)
             if self._ws is None or self._ws.numel() < nbytes:
@@ -246,6 +252,8 @@ class TrainStep(object):
             L.call(bwd, B, E, H, W, K, L.ptr(f), L.ptr(target), L.ptr(self.emb), None, L.ptr(stats), None, L.ptr(df), st)
             dc32, _ = eng.head_backward(ctx, df=df)
             dcoarse = dc32
+        if scaled:
+            dcoarse = (dcoarse.float() * self.loss_scale).to(eng.dtype)
         self.stats = stats
         self._backward(ctx, dcoarse, self.buckets.layer_done)
         self.buckets.finish()
@@ -266,7 +274,8 @@ class TrainStep(object):
     def _optimizer_step(self):
         self.nstep += 1
         st = L.stream_ptr()
-        gs = 1.0 / self.world
+        gs = 1.0 / (self.world * self.loss_scale)
+        lp_code = L.dtype_code(self.flat_w_lp.dtype) if self.flat_w_lp is not None else 0
         for key, flat, grad, lr, wd in (("w", self.flat_w, self.flat_gw, self.lr, self.wd),
                                         ("b", self.flat_b, self.flat_gb, self.bias_lr, self.bias_wd)):
             lp = L.ptr(self.flat_w_lp) if (key == "w" and self.flat_w_lp is not None) else None
@@ -274,11 +283,11 @@ class TrainStep(object):
                 m1, m2 = self.state[key]
                 L.call("szn_adam_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr),
                        float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.bias_wd if key == "b" else self.adam_wd),
-                       self.nstep, gs, lp, st)
+                       self.nstep, gs, lp, lp_code, st)
             else:                        # train.py:126-129
                 (buf,) = self.state[key]
                 L.call("szn_sgd_momentum_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(buf), float(lr),
-                       float(self.momentum), float(wd), int(self.nstep == 1), gs, lp, st)
+                       float(self.momentum), float(wd), int(self.nstep == 1), gs, lp, lp_code, st)
         self.eng.mark_dirty()
 
     # ---- checkpoint compatibility (reference dict keys: trainer_fcn.py:281-288) ------------------------------

@@ -83,8 +83,8 @@ class _Engine(object):
 
     # ---- weights ---------------------------------------------------------------------------------
     def set_precision(self, dtype):
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise L.SznError("compute dtype must be float32 or bfloat16")
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise L.SznError("compute dtype must be float32, bfloat16 or float16")
         if dtype != self.dtype:
             self.dtype = dtype
             self._versions = None
@@ -567,7 +567,8 @@ class FCN32s(nn.Module):
 
     # ---- precision / synthetic init ----------------------------------------------------------------
     def set_precision(self, dtype):
-        """compute dtype of the HIP path: torch.float32 (parity) or torch.bfloat16 (throughput)"""
+        """compute dtype of the HIP path: torch.float32 (parity), torch.bfloat16 (throughput) or torch.float16 (IEEE half
+        activations / weight images, BASELINE configs[4]; training needs TrainStep's loss scaling)"""
         self._engine.set_precision(dtype)
         return self
 

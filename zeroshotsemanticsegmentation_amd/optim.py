@@ -65,7 +65,7 @@ class FusedAdam(torch.optim.Optimizer):
                 g = _dense_same_layout(p, p.grad)
                 L.call("szn_adam_step", p.numel(), L.ptr(p), L.ptr(g), L.ptr(state['exp_avg']), L.ptr(state['exp_avg_sq']),
                        float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']), step,
-                       float(grad_scale), None, st)
+                       float(grad_scale), None, 0, st)
                 torch.autograd.graph.increment_version(p)      # weight images are refreshed lazily from this
         return loss
 
@@ -94,6 +94,6 @@ class FusedSGD(torch.optim.Optimizer):
                 g = _dense_same_layout(p, p.grad)
                 L.call("szn_sgd_momentum_step", p.numel(), L.ptr(p), L.ptr(g), L.ptr(state['momentum_buffer']),
                        float(group['lr']), float(group['momentum']), float(group['weight_decay']), int(first),
-                       float(grad_scale), None, st)
+                       float(grad_scale), None, 0, st)
                 torch.autograd.graph.increment_version(p)
         return loss
