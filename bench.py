@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--embed-dim", type=int, default=300)
     ap.add_argument("--classes", type=int, default=59, help="59 = PASCAL-Context (synthetic matrix), 21 = PASCAL-VOC matrix")
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp16", "fp32"], default="bf16",
+                    help="fp16 = IEEE-half activations / weight images with static loss scaling (BASELINE configs[4])")
+    ap.add_argument("--head-fp8", action="store_true", help="projection head forward on the fp8 (e4m3) matrix cores (configs[4])")
     ap.add_argument("--unfused-head", action="store_true", help="materialise the (B,E,H,W) score like the reference")
     ap.add_argument("--phase", choices=["fcn", "seenmask"], default="fcn",
                     help="fcn = phase 1 (headline; phase 2 is reported as a sub-record); seenmask = phase 2 as the headline")
@@ -218,13 +220,15 @@ def main():
         emb_np = synth.make_embeddings(K, E)
         n_unseen = 10 if K == 59 else max(K // 6, 1)
         seen, unseen = list(range(K - n_unseen)), list(range(K - n_unseen, K))     # K = 59: seen 0..48, unseen 49..58
-    dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
-    peak = PEAK_BF16 if dtype == torch.bfloat16 else PEAK_F32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.precision]
+    peak = PEAK_F32 if dtype == torch.float32 else PEAK_BF16          # fp16 and bf16 MFMA share the dense peak
 
     torch.manual_seed(1337)                                   # identical initial weights on every rank
     model = models.FCN32s(n_class=E)
     model.load_synthetic(1337, device=dev)
     model.train()
+    if args.head_fp8:
+        model.set_head_precision("fp8")
     model._engine.dropout_seed = 1337 + 7919 * rank           # ranks draw different Dropout2d masks
     x = torch.from_numpy(synth.make_images(B, H, H, seed=1337 + rank)).to(dev)
     # phase-1 batches contain seen classes only (the reference's train_seen split, context_dataset.py:75-94)
@@ -324,7 +328,8 @@ def main():
             "metric": "train_Mpixels_per_sec", "value": round(mpx, 3), "unit": "Mpixels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16 (+ fp8 e4m3 projection head)" if args.head_fp8 else "f16", "fp32": "f32"}[args.precision]
+            if not (args.head_fp8 and args.precision == "bf16") else "bf16 (+ fp8 e4m3 projection head)", "data": "synthetic",
             "config": {"workload": ("%s: FCN32s (the reference has no FCN8s) + %d-d pixel projection, %dx%d, K=%d (%d seen / %d "
                                     "unseen), Adam lr 1e-5, train step fwd+cosine loss+infer_lbl+bwd+optimizer"
                                     % (workload, E, H, H, K, len(seen), len(unseen))) if args.phase == "fcn" else
@@ -402,7 +407,7 @@ def main():
         events = []
 
     if rank == 0 and world == 1 and not args.no_extras:
-        if dtype == torch.bfloat16:
+        if dtype != torch.float32:
             try:
                 out["projection"] = projection_report(L, torch, out.get("roofline", {}).get("step_mfma_frac"))
             except Exception as ex:
