@@ -1,44 +1,58 @@
 #!/usr/bin/env python
-"""HBM bytes per launch of the dominant kernel class from rocprofv3 PMC passes (tools/pmc_bench.sh).
+"""HBM bytes per launch of every kernel of the bench step from two rocprofv3 PMC passes (tools/pmc_bench.sh).
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE under-counts wide (16 B/lane) streaming reads by exactly 2x
-(MI355X_MICROARCH.md, section HBM), so it is doubled.  WRITE_SIZE is uncalibrated there and used as is.
-usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [batch] [precision]"""
+(MI355X_MICROARCH.md, section HBM), so it is doubled; WRITE_SIZE is uncalibrated there and used as is.  Infinity-cache hits
+are counted too (memory-side of L2), so "traffic" is an upper bound of true HBM bytes.
+usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [batch] [precision] [size] [classes]"""
 import csv
 import json
+import re
 import sys
 
 csv.field_size_limit(1 << 30)
-MATCH = ("conv_igemm", "conv3x3_regw")     # one kernel launch per szn_conv2d_fwd / szn_conv2d_dgrad call
-EXTRA = ("splitk_epilogue", "col2im_kernel")   # second kernel of a split-K / GEMM-dgrad call: bytes count, launch does not
+
+
+def short(n):
+    n = n.replace('void ', '').replace('(anonymous namespace)::', '')
+    m = re.match(r'([A-Za-z0-9_:]+)', n)
+    return m.group(1) if m else n
 
 
 def collect(d, counter):
-    tot, n = 0.0, 0
+    tot, cnt = {}, {}
     with open(d.rstrip('/') + '/pmc_counter_collection.csv') as f:
         for row in csv.DictReader(f):
             if row['Counter_Name'] != counter:
                 continue
-            if any(m in row['Kernel_Name'] for m in MATCH):
-                tot += float(row['Counter_Value'])
-                n += 1
-            elif any(m in row['Kernel_Name'] for m in EXTRA):
-                tot += float(row['Counter_Value'])
-    return tot, n
+            k = short(row['Kernel_Name'])
+            tot[k] = tot.get(k, 0.0) + float(row['Counter_Value'])
+            cnt[k] = cnt.get(k, 0) + 1
+    return tot, cnt
 
 
 def main():
     fd, wd, out = sys.argv[1:4]
     batch = int(sys.argv[4]) if len(sys.argv) > 4 else 8
     prec = sys.argv[5] if len(sys.argv) > 5 else "bf16"
+    size = int(sys.argv[6]) if len(sys.argv) > 6 else 512
+    classes = int(sys.argv[7]) if len(sys.argv) > 7 else 59
     f, nf = collect(fd, "FETCH_SIZE")
     w, nw = collect(wd, "WRITE_SIZE")
-    per = (2.0 * f * 1024.0 / nf) + (w * 1024.0 / nw)
-    json.dump({"kernel": "conv fwd + dgrad launches (conv_igemm_v2 / conv_igemm_wide / conv3x3_regw)", "per_gpu_batch": batch, "precision": prec,
-               "launches_sampled": nf, "fetch_kb_per_launch": f / nf, "write_kb_per_launch": w / nw,
-               "hbm_bytes_per_launch": per,
-               "note": "FETCH_SIZE x2 (gfx950 wide-read under-count) + WRITE_SIZE, KB -> bytes; separate --pmc passes"},
-              open(out, "w"), indent=1)
-    print(open(out).read())
+    kernels = {}
+    for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0.0))):
+        if k.startswith("at::") or k.startswith("__amd"):
+            continue
+        fetch = 2.0 * f[k] * 1024.0 / nf[k]
+        write = w.get(k, 0.0) * 1024.0 / max(nw.get(k, 1), 1)
+        kernels[k] = {"launches_sampled": nf[k], "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
+                      "hbm_bytes_per_launch": round(fetch + write)}
+    json.dump({"command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-events", "per_gpu_batch": batch,
+               "precision": prec, "size": size, "classes": classes,
+               "note": "FETCH_SIZE x2 (gfx950 wide-read under-count) + WRITE_SIZE, KB -> bytes; separate --pmc passes; memory-side "
+                       "of L2 (infinity-cache hits included)",
+               "kernels": kernels}, open(out, "w"), indent=1)
+    for k, v in list(kernels.items())[:12]:
+        print("%-28s %5d launches  %8.1f MB/launch" % (k, v["launches_sampled"], v["hbm_bytes_per_launch"] / 1e6))
 
 
 if __name__ == "__main__":
