@@ -205,13 +205,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook: SZN_TEST_ONE_GPU=1 runs every rank on device 0 over gloo, so that the N > 1 code path can be exercised on a
+    # 1-GPU box (tests/test_gpu_bench_contract.py); the measured line of a real run always uses RCCL, one GPU per rank
+    one_gpu = os.environ.get("SZN_TEST_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torchrun with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # backend "nccl" is RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
     L.load()
 
     E, H, B, K = args.embed_dim, args.size, args.batch, args.classes

@@ -44,3 +44,41 @@ def test_bench_line_phase1_with_cpu_baseline():
 def test_bench_line_phase2():
     d = run("--phase", "seenmask", "--no-cpu-baseline")
     assert KEYS <= set(d) and d["value"] > 0 and "configs[2]" in d["config"]["workload"]
+
+
+def test_bench_two_ranks_code_path_on_one_gpu():
+    """the N > 1 branch of bench.py exactly as the driver launches it (python -m torch.distributed.run ... bench.py --gpus 2),
+    both ranks on device 0 over gloo (SZN_TEST_ONE_GPU=1): barrier + max-over-ranks timing, rank-0-only JSON line, whole-job
+    value = 2 x the per-rank pixels"""
+    env = dict(os.environ, SZN_TEST_ONE_GPU="1")
+    port = 29900 + os.getpid() % 1000
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--batch", "1", "--size", "96"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 96 * 96 * 1e-6 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    assert "cpu_baseline" not in d and "roofline" in d
+
+
+def test_train_cli_two_ranks_on_one_gpu(tmp_path):
+    """train.py under torchrun, 2 ranks (device 0, gloo): shared log directory, DistributedSampler shards, sharded validation with
+    all-reduced histograms, barrier between the phases -- cfg 18 end to end"""
+    import glob
+    env = dict(os.environ, SZN_TEST_ONE_GPU="1")
+    port = 30900 + os.getpid() % 1000
+    d = str(tmp_path)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "train.py"), "-c", "18", "-ve", "1", "-dir", d,
+                          "-n", "ddp", "--synthetic", "4", "64", "64"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    logs = glob.glob(os.path.join(d, "logs", "ddp_CFG_18_*"))
+    assert len(logs) == 1                                       # ONE log directory for the job
+    rows = open(os.path.join(logs[0], "train_log.csv")).read().strip().split("\n")
+    assert len(rows) == 1 + 2                                   # 4 images / 2 ranks = 2 iterations per rank, rank 0 logs
+    assert len(open(os.path.join(logs[0], "val_log.csv")).read().strip().split("\n")) == 2
+    assert os.path.exists(os.path.join(logs[0], "best"))

@@ -174,6 +174,9 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
+    one_gpu = os.environ.get("SZN_TEST_ONE_GPU") == "1"       # test hook: every rank on device 0 over gloo (1-GPU boxes)
+    if one_gpu:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise RuntimeError("no GPU visible: this implementation has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -181,7 +184,10 @@ def main(argv=None):
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     torch.manual_seed(1337)
     torch.cuda.manual_seed(1337)
 
