@@ -65,20 +65,21 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert "cpu_baseline" not in d and "roofline" in d
 
 
-def test_train_cli_two_ranks_on_one_gpu(tmp_path):
+def test_train_cli_two_ranks_on_one_gpu(fast_tmp):
     """train.py under torchrun, 2 ranks (device 0, gloo): shared log directory, DistributedSampler shards, sharded validation with
-    all-reduced histograms, barrier between the phases -- cfg 18 end to end"""
+    all-reduced histograms -- cfg 4 (20-d pascal embeddings, phase 1 only; the phase-2 reduction is engine.allreduce_param_grads,
+    covered in tests/test_ddp_gloo.py)"""
     import glob
     env = dict(os.environ, SZN_TEST_ONE_GPU="1")
     port = 30900 + os.getpid() % 1000
-    d = str(tmp_path)
+    d = fast_tmp
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "train.py"), "-c", "18", "-ve", "1", "-dir", d,
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "train.py"), "-c", "4", "-ve", "1", "-dir", d,
                           "-n", "ddp", "--synthetic", "4", "64", "64"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
-    logs = glob.glob(os.path.join(d, "logs", "ddp_CFG_18_*"))
+    logs = glob.glob(os.path.join(d, "logs", "ddp_CFG_4_*"))
     assert len(logs) == 1                                       # ONE log directory for the job
     rows = open(os.path.join(logs[0], "train_log.csv")).read().strip().split("\n")
     assert len(rows) == 1 + 2                                   # 4 images / 2 ranks = 2 iterations per rank, rank 0 logs
     assert len(open(os.path.join(logs[0], "val_log.csv")).read().strip().split("\n")) == 2
-    assert os.path.exists(os.path.join(logs[0], "best"))
+    assert os.path.exists(os.path.join(logs[0], "checkpoint"))

@@ -21,10 +21,11 @@ G = np.load(os.path.join(ROOT, "tests", "golden", "g10_datasets.npz"))
 
 
 @pytest.fixture()
-def tiny(tmp_path, monkeypatch):
-    make_tiny_dataset(str(tmp_path), [str(s) for s in G["ids"]], G["imgs"], G["ctx_png"], G["voc_png"])
-    monkeypatch.chdir(tmp_path)
-    return tmp_path
+def tiny(fast_tmp, monkeypatch):
+    import pathlib
+    make_tiny_dataset(fast_tmp, [str(s) for s in G["ids"]], G["imgs"], G["ctx_png"], G["voc_png"])
+    monkeypatch.chdir(fast_tmp)
+    return pathlib.Path(fast_tmp)
 
 
 def test_image_to_device_bit_identical_to_reference_transform():

@@ -390,11 +390,11 @@ def test_cfg1_softmax_fcn_step_vs_oracle():
         om.p.update({k: np.ascontiguousarray(v) for k, v in oracle_params(m).items()})
 
 
-def test_cfg1_cli_end_to_end(tmp_path):
+def test_cfg1_cli_end_to_end(fast_tmp):
     """`train.py -c 1` on the synthetic dataset at 256x256: the softmax / SGD plumbing of configs[0] end to end"""
     import glob
     from zeroshotsemanticsegmentation_amd import train
-    d = str(tmp_path)
+    d = fast_tmp
     train.main(['-c', '1', '-ve', '1', '-dir', d, '-n', 'cfg1', '--synthetic', '2', '256', '256'])
     log = glob.glob(os.path.join(d, 'logs', 'cfg1_CFG_1_*'))[0]
     rows = open(os.path.join(log, 'train_log.csv')).read().strip().split('\n')
