@@ -145,3 +145,31 @@ def test_packaged_embeddings_equal_golden_capture():
     assert len(files) == 5
     for f in files:
         assert open(f, "rb").read() == open(os.path.join(pk, os.path.basename(f)), "rb").read()
+
+
+def test_vgg16_pretrained_file_round_trip(tmp_path):
+    from zeroshotsemanticsegmentation_amd import models
+    """A6: `VGG16(pretrained=True, data_dir)` reads `<data_dir>/models/vgg16_from_caffe.pth` (the file the reference downloads,
+    models.py:195-210).  The real caffe weights are not available here; a state dict in that file's layout (torchvision VGG16
+    keys: features.N.weight/bias, classifier.{0,3,6}.weight/bias with the (4096, 512*7*7) Linear of fc6) must load and land
+    in the FCN32s layers exactly as the reference's copy loop places it (models.py:183-193)."""
+    g = torch.Generator().manual_seed(5)
+    src = models.VGG16(pretrained=False)
+    sd = {k: torch.randn(v.shape, generator=g) * 0.01 for k, v in src.state_dict().items()}
+    assert sd["classifier.0.weight"].shape == (4096, 512 * 7 * 7) and "features.28.bias" in sd
+    (tmp_path / "models").mkdir()
+    torch.save(sd, str(tmp_path / "models" / "vgg16_from_caffe.pth"))
+    vgg = models.VGG16(pretrained=True, data_dir=str(tmp_path))
+    m = models.FCN32s(n_class=20)
+    m.copy_params_from_vgg16(vgg)
+    conv_keys = [k for k in sd if k.startswith("features.") and k.endswith(".weight")]
+    ours = [n for n, _, _, _ in synth.CONV_LAYERS[:13]]
+    assert len(conv_keys) == 13
+    for k, n in zip(conv_keys, ours):
+        assert torch.equal(getattr(m, n).weight, sd[k]) and torch.equal(getattr(m, n).bias, sd[k[:-6] + "bias"]), n
+    # fc6 = the first Linear viewed as (4096, 512, 7, 7): channel-major flattening of the 7x7 window
+    assert torch.equal(m.fc6.weight, sd["classifier.0.weight"].view(4096, 512, 7, 7))
+    assert torch.equal(m.fc7.weight, sd["classifier.3.weight"].view(4096, 4096, 1, 1))
+    assert torch.equal(m.fc6.bias, sd["classifier.0.bias"]) and torch.equal(m.fc7.bias, sd["classifier.3.bias"])
+    # the kernels read the weights in OHWI order: the copy must keep channels_last storage
+    assert m.fc6.weight.is_contiguous(memory_format=torch.channels_last)
