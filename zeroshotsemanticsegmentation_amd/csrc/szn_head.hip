@@ -325,48 +325,17 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
     }
 }
 
-// ---- nearest-class-embedding argmax: thread = pixel, KP accumulators in registers --------------------
+// ---- nearest-class-embedding argmax ---------------------------------------------------------------------------------
+// thread = TWO pixels (p, p + 256 of a 512-pixel tile), 2 x KP accumulators in registers; the class matrix sits transposed in LDS
+// ([E][KP], 76.8 KB at E = 300, KP = 64) and every 16-B broadcast read of it feeds 8 FMAs (it fed 4 with one pixel per thread:
+// the kernel was LDS-issue- and latency-bound at 2 waves per SIMD, 0.7 TB/s).  A block walks several tiles so that the table is
+// staged once per block, not once per 256 pixels.  Arithmetic per (pixel, class) is unchanged: one fmaf chain over ascending
+// channels, sqrtf, IEEE division -- bit-identical to szo_embed_argmax.  At K = 59 the work is 2*E*K = 35.4 kFLOP per 1.2 KB pixel
+// (29.5 FLOP/B): above the fp32-vector ridge of the chip (157 TF / 8 TB/s = 19.6), i.e. VALU-bound; at K = 21 it is HBM-bound.
 template <int KP>
-__global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restrict__ score, const float* __restrict__ embed,
-                                                           const float* __restrict__ seenmask,
-                                                           const int64_t* __restrict__ target, int64_t* __restrict__ pred,
-                                                           int E, int HW, int K, int mode, uint64_t unseen_bits) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // embT [E][KP] | en [KP]
-    float* embT = sm;
-    float* en = sm + (long)E * KP;
-    for (int i = threadIdx.x; i < E * KP; i += 256) {
-        const int k = i % KP, c = i / KP;
-        embT[i] = (k < K) ? embed[(long)k * E + c] : 0.f;
-    }
-    __syncthreads();
-    if (threadIdx.x < KP) {
-        float s = 0.f;
-        for (int c = 0; c < E; ++c) { const float v = embT[c * KP + threadIdx.x]; s = fmaf(v, v, s); }
-        const float n = sqrtf(s);
-        en[threadIdx.x] = (n == 0.f) ? 1.f : n;     // utils.py:175
-    }
-    __syncthreads();
-    const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    const float* sp = score + (long)b * E * HW + p;
-    float acc[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) acc[k] = 0.f;
-    float ss = 0.f;
-    for (int c = 0; c < E; ++c) {
-        const float s = sp[(long)c * HW];
-        ss = fmaf(s, s, ss);
-        const float4* er = (const float4*)(embT + c * KP);
-#pragma unroll
-        for (int k4 = 0; k4 < KP / 4; ++k4) {
-            const float4 e = er[k4];
-            acc[4 * k4 + 0] = fmaf(s, e.x, acc[4 * k4 + 0]);
-            acc[4 * k4 + 1] = fmaf(s, e.y, acc[4 * k4 + 1]);
-            acc[4 * k4 + 2] = fmaf(s, e.z, acc[4 * k4 + 2]);
-            acc[4 * k4 + 3] = fmaf(s, e.w, acc[4 * k4 + 3]);
-        }
-    }
+__device__ __forceinline__ int argmax_finish(const float (&acc)[KP], float ss, const float* __restrict__ en, int K, int mode,
+                                             uint64_t unseen_bits, const float* __restrict__ seenmask,
+                                             const int64_t* __restrict__ target, int b, long p, int HW) {
     const float sn = sqrtf(ss);
     int best = 0;
     if (mode == 0) {
@@ -378,33 +347,86 @@ __global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restri
                 if (k == 0 || sim > bv) { bv = sim; best = k; }
             }
         }
-    } else {
-        // one pass over all K similarities gives both the seen-only and the unseen-only prediction:
-        // a zeroed row scores (0 / (sn * 1)) and still competes, exactly like utils.py:173-179
-        const float zero_sim = 0.f / (sn * 1.f);
-        float bs = 0.f, bu = 0.f;
-        int is = 0, iu = 0;
+        return best;
+    }
+    // one pass over all K similarities gives both the seen-only and the unseen-only prediction:
+    // a zeroed row scores (0 / (sn * 1)) and still competes, exactly like utils.py:173-179
+    const float zero_sim = 0.f / (sn * 1.f);
+    float bs = 0.f, bu = 0.f;
+    int is = 0, iu = 0;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            if (k < K) {
-                const float sim = acc[k] / (sn * en[k]);
-                const bool un = (unseen_bits >> k) & 1ull;
-                const float vs = un ? zero_sim : sim, vu = un ? sim : zero_sim;
-                if (k == 0 || vs > bs) { bs = vs; is = k; }
-                if (k == 0 || vu > bu) { bu = vu; iu = k; }
+    for (int k = 0; k < KP; ++k) {
+        if (k < K) {
+            const float sim = acc[k] / (sn * en[k]);
+            const bool un = (unseen_bits >> k) & 1ull;
+            const float vs = un ? zero_sim : sim, vu = un ? sim : zero_sim;
+            if (k == 0 || vs > bs) { bs = vs; is = k; }
+            if (k == 0 || vu > bu) { bu = vu; iu = k; }
+        }
+    }
+    bool take_unseen;
+    if (seenmask) {
+        const float s0 = seenmask[((long)b * 2 + 0) * HW + p], s1 = seenmask[((long)b * 2 + 1) * HW + p];
+        take_unseen = !(s1 > s0);          // argmax over 2 channels == 0  (utils.py:197-198)
+    } else {
+        const long t = target[(long)b * HW + p];
+        take_unseen = (t >= 0 && t < 64) && ((unseen_bits >> t) & 1ull);   // np.in1d(target, unseen)
+    }
+    return take_unseen ? iu : is;
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restrict__ score, const float* __restrict__ embed,
+                                                           const float* __restrict__ seenmask,
+                                                           const int64_t* __restrict__ target, int64_t* __restrict__ pred,
+                                                           int E, int HW, int K, int mode, uint64_t unseen_bits) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // embT [E][KP] | en [KP]
+    float* embT = sm;
+    float* en = sm + (long)E * KP;
+    for (int i = threadIdx.x; i < E * KP; i += 256) {
+        const int k = i % KP, c = i / KP;                        // conflict-free LDS writes; the 70 KB matrix is L2-resident
+        embT[i] = (k < K) ? embed[(long)k * E + c] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < KP) {
+        float s = 0.f;
+        for (int c = 0; c < E; ++c) { const float v = embT[c * KP + threadIdx.x]; s = fmaf(v, v, s); }
+        const float n = sqrtf(s);
+        en[threadIdx.x] = (n == 0.f) ? 1.f : n;     // utils.py:175
+    }
+    __syncthreads();
+    const int b = blockIdx.y;
+    const float* sb = score + (long)b * E * HW;
+    for (long p0 = (long)blockIdx.x * 512 + threadIdx.x; p0 < HW; p0 += (long)gridDim.x * 512) {
+        const long p1 = p0 + 256;
+        const bool ok1 = p1 < HW;
+        const float* sp0 = sb + p0;
+        const float* sp1 = sb + (ok1 ? p1 : p0);
+        float acc0[KP], acc1[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
+        float ss0 = 0.f, ss1 = 0.f;
+        for (int c = 0; c < E; ++c) {
+            const float s0 = sp0[(long)c * HW], s1 = sp1[(long)c * HW];
+            ss0 = fmaf(s0, s0, ss0);
+            ss1 = fmaf(s1, s1, ss1);
+            const float4* er = (const float4*)(embT + c * KP);
+#pragma unroll
+            for (int k4 = 0; k4 < KP / 4; ++k4) {
+                const float4 e = er[k4];
+                acc0[4 * k4 + 0] = fmaf(s0, e.x, acc0[4 * k4 + 0]);
+                acc0[4 * k4 + 1] = fmaf(s0, e.y, acc0[4 * k4 + 1]);
+                acc0[4 * k4 + 2] = fmaf(s0, e.z, acc0[4 * k4 + 2]);
+                acc0[4 * k4 + 3] = fmaf(s0, e.w, acc0[4 * k4 + 3]);
+                acc1[4 * k4 + 0] = fmaf(s1, e.x, acc1[4 * k4 + 0]);
+                acc1[4 * k4 + 1] = fmaf(s1, e.y, acc1[4 * k4 + 1]);
+                acc1[4 * k4 + 2] = fmaf(s1, e.z, acc1[4 * k4 + 2]);
+                acc1[4 * k4 + 3] = fmaf(s1, e.w, acc1[4 * k4 + 3]);
             }
         }
-        bool take_unseen;
-        if (seenmask) {
-            const float s0 = seenmask[((long)b * 2 + 0) * HW + p], s1 = seenmask[((long)b * 2 + 1) * HW + p];
-            take_unseen = !(s1 > s0);          // argmax over 2 channels == 0  (utils.py:197-198)
-        } else {
-            const long t = target[(long)b * HW + p];
-            take_unseen = (t >= 0 && t < 64) && ((unseen_bits >> t) & 1ull);   // np.in1d(target, unseen)
-        }
-        best = take_unseen ? iu : is;
+        pred[(long)b * HW + p0] = argmax_finish<KP>(acc0, ss0, en, K, mode, unseen_bits, seenmask, target, b, p0, HW);
+        if (ok1) pred[(long)b * HW + p1] = argmax_finish<KP>(acc1, ss1, en, K, mode, unseen_bits, seenmask, target, b, p1, HW);
     }
-    pred[(long)b * HW + p] = best;
 }
 
 // ---- confusion histogram -------------------------------------------------------------------------------
@@ -602,7 +624,11 @@ extern "C" int szn_embed_argmax(int B, int E, int H, int W, int K, const float* 
     if (K > 64) SZN_FAIL(SZN_ERR_UNSUPPORTED, "embed_argmax: K=%d > 64", K);
     if (mode != 0 && mode != 1) SZN_FAIL(SZN_ERR_ARG, "embed_argmax: bad mode %d", mode);
     if (mode == 1 && !seenmask && !target) SZN_FAIL(SZN_ERR_ARG, "embed_argmax: mode 1 needs seenmask or target");
-    const int HW = H * W, nblk = (HW + 255) / 256;
+    const int HW = H * W;
+    // 512-pixel tiles, ~2 blocks per CU in total (the LDS table allows two resident blocks): a block stages the table once
+    int nblk = (HW + 511) / 512;
+    const int cap = (512 + B - 1) / B;
+    if (nblk > cap) nblk = cap;
     const int KP = K <= 24 ? 24 : (K <= 40 ? 40 : 64);
     const size_t lds = ((size_t)E * KP + KP) * sizeof(float);
     if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "embed_argmax: E*KP*4 = %zu B exceeds the LDS budget", lds);
