@@ -16,60 +16,105 @@ namespace {
 // 1-D bilinear tap of get_upsampling_weight(k=64): factor 32, center 31.5 (models.py:13-20), in double
 __device__ __forceinline__ double bil1d(int t) { return 1.0 - fabs((double)t - 31.5) / 32.0; }
 
-// ---- upscore forward: thread = one output element of the NCHW score ---------------------------
+// ---- upscore forward ---------------------------------------------------------------------------------------------------
+// block = (8 cells of 32 columns, one cell row I, image b); thread = one column X of the uncropped 32(h+1) x 32(w+1) deconv output
+// (x = X - crop), so a half-wave is exactly one cell.  The 2 x 10 coarse vectors the segment blends are staged in LDS once and
+// reused for the cell row's 32 output rows; the four bilinear weights of a pixel are formed once per row (double product rounded
+// to float, models.py:13-24) and reused for all E channels.  Per element: 4 LDS reads + 4 fmaf (tap order (i-1,j-1), (i-1,j),
+// (i,j-1), (i,j) as before: bit-identical) + one coalesced store -- the kernel is bound by its B*E*H*W*4 B of stores.
+constexpr int UP_NJ = 10;       // coarse columns a 256-wide segment touches: cells 8 seg - 1 .. 8 seg + 8
 __global__ __launch_bounds__(256) void up32_fwd_kernel(const float* __restrict__ coarse, float* __restrict__ out, int B,
                                                        int h, int w, int E, int ldc, int c0, int H, int W, int crop) {
-    const long total = (long)B * E * H * W;
-    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
-        const int x = (int)(gid % W);
-        long t = gid / W;
-        const int y = (int)(t % H); t /= H;
-        const int c = (int)(t % E);
-        const int b = (int)(t / E);
-        const int Y = y + crop, X = x + crop;
-        const int i1 = Y >> 5, j1 = X >> 5, ty = Y & 31, tx = X & 31;
-        const double fy1 = bil1d(ty), fy0 = bil1d(ty + 32), fx1 = bil1d(tx), fx0 = bil1d(tx + 32);
-        const float* base = coarse + (long)b * h * w * ldc + c0 + c;
-        float acc = 0.f;
-        if (i1 - 1 >= 0 && i1 - 1 < h) {
-            if (j1 - 1 >= 0 && j1 - 1 < w) acc = fmaf(base[((long)(i1 - 1) * w + (j1 - 1)) * ldc], (float)(fy0 * fx0), acc);
-            if (j1 < w) acc = fmaf(base[((long)(i1 - 1) * w + j1) * ldc], (float)(fy0 * fx1), acc);
+    extern __shared__ __attribute__((aligned(16))) float taps[];      // [2][UP_NJ][E]
+    const int seg = blockIdx.x, I = blockIdx.y, b = blockIdx.z;
+    const int jbase = 8 * seg - 1;
+    for (int idx = threadIdx.x; idx < 2 * UP_NJ * E; idx += 256) {
+        const int r = idx / (UP_NJ * E), rem = idx - r * UP_NJ * E;
+        const int jj = rem / E, c = rem - jj * E;
+        const int i = I - 1 + r, j = jbase + jj;
+        taps[idx] = (i >= 0 && i < h && j >= 0 && j < w) ? coarse[(((long)b * h + i) * w + j) * ldc + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    const int X = 256 * seg + threadIdx.x, x = X - crop;
+    if (x < 0 || x >= W) return;
+    const int jl = threadIdx.x >> 5, tx = threadIdx.x & 31;          // cell inside the segment (J = 8 seg + jl), column inside it
+    const double fx1 = bil1d(tx), fx0 = bil1d(tx + 32);
+    const float* t00 = taps + (0 * UP_NJ + jl) * E;                   // (I-1, J-1)
+    const float* t01 = t00 + E;                                       // (I-1, J)
+    const float* t10 = taps + (1 * UP_NJ + jl) * E;                   // (I,   J-1)
+    const float* t11 = t10 + E;                                       // (I,   J)
+    for (int ty = 0; ty < 32; ++ty) {
+        const int y = 32 * I + ty - crop;
+        if (y < 0 || y >= H) continue;
+        const double fy1 = bil1d(ty), fy0 = bil1d(ty + 32);
+        const float w00 = (float)(fy0 * fx0), w01 = (float)(fy0 * fx1), w10 = (float)(fy1 * fx0), w11 = (float)(fy1 * fx1);
+        float* op = out + ((long)b * E * H + y) * W + x;
+        for (int c = 0; c < E; ++c) {
+            float acc = fmaf(t00[c], w00, 0.f);
+            acc = fmaf(t01[c], w01, acc);
+            acc = fmaf(t10[c], w10, acc);
+            acc = fmaf(t11[c], w11, acc);
+            op[(long)c * H * W] = acc;
         }
-        if (i1 < h) {
-            if (j1 - 1 >= 0 && j1 - 1 < w) acc = fmaf(base[((long)i1 * w + (j1 - 1)) * ldc], (float)(fy1 * fx0), acc);
-            if (j1 < w) acc = fmaf(base[((long)i1 * w + j1) * ldc], (float)(fy1 * fx1), acc);
-        }
-        out[gid] = acc;
     }
 }
 
-// ---- upscore backward: one wave per (b, c, i, j); lane = x offset in the 64-wide window --------
+// ---- upscore backward ----------------------------------------------------------------------------------------------------
+// dcoarse[b][i][j][c] = sum over the 64 x 64 window of (i, j).  block = (coarse row i, image b, channel slice); thread = column X
+// of the uncropped output.  Per channel a thread forms ONE weighted column sum over the window's 64 rows (ky = Y - 32 i), then
+// its column contributes bil1d(tx) * col to output J (left half of J's window) and bil1d(32 + tx) * col to output J - 1 (right
+// half): two half-wave reductions per cell, combined through LDS, plain stores -- deterministic, every dscore element is read by
+// 2 blocks (the row overlap) instead of 4 waves.
 __global__ __launch_bounds__(256) void up32_bwd_kernel(const float* __restrict__ dscore, float* __restrict__ dcoarse,
                                                        int B, int h, int w, int E, int ldc, int c0, int H, int W,
-                                                       int crop) {
-    const int lane = threadIdx.x & 63;
-    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long total = (long)B * h * w * E;
-    if (wid >= total) return;
-    // channel fastest so that the 4 waves of a block write neighbouring dcoarse elements
-    const int c = (int)(wid % E);
-    long t = wid / E;
-    const int j = (int)(t % w); t /= w;
-    const int i = (int)(t % h);
-    const int b = (int)(t / h);
-    const int x = 32 * j - crop + lane;
-    const double fx = bil1d(lane);
-    float acc = 0.f;
-    if (x >= 0 && x < W) {
-        const float* plane = dscore + ((long)b * E + c) * H * W;
-        for (int ty = 0; ty < 64; ++ty) {
-            const int y = 32 * i - crop + ty;
-            if (y < 0 || y >= H) continue;
-            acc = fmaf(plane[(long)y * W + x], (float)(bil1d(ty) * fx), acc);
+                                                       int crop, int cper) {
+    extern __shared__ __attribute__((aligned(16))) float red[];       // [2][cper][ncell]: R (own cell) | L (for the cell to the left)
+    const int i = blockIdx.x, b = blockIdx.y, cbeg = blockIdx.z * cper;
+    const int cend = min(E, cbeg + cper);
+    const int ncell = w + 1;
+    const int lane32 = threadIdx.x & 31;
+    const float fL = (float)bil1d(lane32), fR = (float)bil1d(lane32 + 32);
+    __shared__ float wy[64];
+    if (threadIdx.x < 64) wy[threadIdx.x] = (float)bil1d(threadIdx.x);
+    __syncthreads();
+    for (int seg = 0; seg * 8 < ncell; ++seg) {
+        const int X = 256 * seg + threadIdx.x, x = X - crop;
+        const int J = X >> 5;
+        const bool okx = x >= 0 && x < W && J < ncell;
+        // four channels at a time: four independent accumulation chains, 16 loads in flight per lane
+        const int ky_lo = max(0, crop - 32 * i), ky_hi = min(64, H + crop - 32 * i);
+        for (int c = cbeg; c < cend; c += 4) {
+            float col[4] = {0.f, 0.f, 0.f, 0.f};
+            if (okx) {
+                const float* plane = dscore + ((long)b * E + c) * H * W + x;
+                const long cs = (long)H * W;
+                const int nc = min(4, cend - c);
+                for (int ky = ky_lo; ky < ky_hi; ++ky) {
+                    const float wv = wy[ky];
+                    const float* rp = plane + (long)(32 * i + ky - crop) * W;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < nc) col[u] = fmaf(rp[u * cs], wv, col[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float pl = col[u] * fL, pr = col[u] * fR;      // this column inside the window of output J / of output J - 1
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { pl += __shfl_xor(pl, o, 64); pr += __shfl_xor(pr, o, 64); }
+                if (lane32 == 0 && J < ncell && c + u < cend) {
+                    red[(c + u - cbeg) * ncell + J] = pl;
+                    red[(cper + c + u - cbeg) * ncell + J] = pr;
+                }
+            }
         }
     }
-    acc = wave_sum(acc);
-    if (lane == 0) dcoarse[(((long)b * h + i) * w + j) * ldc + c0 + c] = acc;
+    __syncthreads();
+    // output j = (columns of cell j, left half of the window) + (columns of cell j + 1, right half)
+    for (int idx = threadIdx.x; idx < (cend - cbeg) * w; idx += 256) {
+        const int j = idx / (cend - cbeg), cc = idx - j * (cend - cbeg);
+        dcoarse[(((long)b * h + i) * w + j) * ldc + c0 + cbeg + cc] = red[cc * ncell + j] + red[(cper + cc) * ncell + j + 1];
+    }
 }
 
 // ---- seenmask_upscore (dense learned ConvTranspose2d, C <= 4) -----------------------------------
@@ -473,8 +518,12 @@ extern "C" int szn_bilinear_up32_crop_fwd(int B, int h, int w, int E, int ldc, i
                                           const float* coarse, float* score, szn_stream_t stream) {
     int rc = check_up(B, h, w, E, ldc, c0, H, W, crop, coarse, score);
     if (rc) return rc;
-    hipLaunchKernelGGL(up32_fwd_kernel, dim3(grid_for((long)B * E * H * W, 1 << 20)), dim3(256), 0, (hipStream_t)stream,
-                       coarse, score, B, h, w, E, ldc, c0, H, W, crop);
+    const size_t lds = (size_t)2 * UP_NJ * E * sizeof(float);
+    if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "up32_fwd: E = %d too large for the LDS tap table", E);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)up32_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // uncropped columns crop .. crop + W - 1 in 256-wide segments, cell rows (crop >> 5) .. ((H - 1 + crop) >> 5)
+    const dim3 grid((unsigned)((W + crop + 255) / 256), (unsigned)(((H - 1 + crop) >> 5) + 1), (unsigned)B);
+    hipLaunchKernelGGL(up32_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, coarse, score, B, h, w, E, ldc, c0, H, W, crop);
     SZN_CHECK_LAUNCH("up32_fwd_kernel");
     return SZN_OK;
 }
@@ -483,9 +532,17 @@ extern "C" int szn_bilinear_up32_crop_bwd(int B, int h, int w, int E, int ldc, i
                                           const float* dscore, float* dcoarse, szn_stream_t stream) {
     int rc = check_up(B, h, w, E, ldc, c0, H, W, crop, dscore, dcoarse);
     if (rc) return rc;
-    const long waves = (long)B * h * w * E;
-    hipLaunchKernelGGL(up32_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dscore, dcoarse,
-                       B, h, w, E, ldc, c0, H, W, crop);
+    // channel slices so that ~2 blocks per CU exist; LDS = 2 x slice x (w + 1) floats
+    int csplit = (1536 + B * h - 1) / (B * h);
+    if (csplit < 1) csplit = 1;
+    if (csplit > E) csplit = E;
+    const int cper = (E + csplit - 1) / csplit;
+    csplit = (E + cper - 1) / cper;
+    const size_t lds = (size_t)2 * cper * (w + 1) * sizeof(float);
+    if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "up32_bwd: coarse row too wide for LDS (w = %d)", w);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)up32_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(up32_bwd_kernel, dim3((unsigned)h, (unsigned)B, (unsigned)csplit), dim3(256), lds, (hipStream_t)stream, dscore,
+                       dcoarse, B, h, w, E, ldc, c0, H, W, crop, cper);
     SZN_CHECK_LAUNCH("up32_bwd_kernel");
     return SZN_OK;
 }
