@@ -182,27 +182,36 @@ __global__ __launch_bounds__(256) void deconv_dgrad_kernel(const float* __restri
 }
 
 // dwt[ci][co][ky][kx] (+)= sum_{b,i,j} coarse[b][i][j][ci] * dout[b][co][32i+ky-crop][32j+kx-crop]
+// block = one filter row (ci, co, ky): 64 kx lanes x 4 parts; part q sums the coarse rows i = q, q + 4, ... (four independent
+// chains per output instead of one 2,312-term chain on 64 blocks), the parts are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void deconv_wgrad_kernel(const float* __restrict__ coarse, const float* __restrict__ dout,
                                                            float* __restrict__ dwt, int B, int h, int w, int C, int ldc,
                                                            int c0, int H, int W, int crop, int accumulate) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= C * C * 4096) return;
-    const int kx = gid & 63, ky = (gid >> 6) & 63;
-    const int co = (gid >> 12) % C, ci = (gid >> 12) / C;
+    __shared__ float part[4][64];
+    const int kx = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int ky = blockIdx.x & 63, co = (blockIdx.x >> 6) % C, ci = (blockIdx.x >> 6) / C;
     float acc = 0.f;
     for (int b = 0; b < B; ++b) {
         const float* plane = dout + ((long)b * C + co) * H * W;
-        for (int i = 0; i < h; ++i) {
+        for (int i = q; i < h; i += 4) {
             const int y = 32 * i - crop + ky;
             if (y < 0 || y >= H) continue;
+            const float* cr = coarse + (((long)b * h + i) * w) * ldc + c0 + ci;
+            const float* row = plane + (long)y * W - crop + kx;
             for (int j = 0; j < w; ++j) {
                 const int x = 32 * j - crop + kx;
                 if (x < 0 || x >= W) continue;
-                acc = fmaf(coarse[(((long)b * h + i) * w + j) * ldc + c0 + ci], plane[(long)y * W + x], acc);
+                acc = fmaf(cr[(long)j * ldc], row[32 * j], acc);
             }
         }
     }
-    dwt[gid] = accumulate ? dwt[gid] + acc : acc;
+    part[q][kx] = acc;
+    __syncthreads();
+    if (q == 0) {
+        const float v = (part[0][kx] + part[1][kx]) + (part[2][kx] + part[3][kx]);
+        const int gid = ((ci * C + co) * 64 + ky) * 64 + kx;
+        dwt[gid] = accumulate ? dwt[gid] + v : v;
+    }
 }
 
 // ---- block reduction of (sum, count) into a per-(image, block) partial --------------------------
@@ -576,7 +585,7 @@ extern "C" int szn_deconv64s32_wgrad(int B, int h, int w, int C, int ldc, int c0
     int rc = check_up(B, h, w, C, ldc, c0, H, W, crop, coarse, dout);
     if (rc) return rc;
     if (!dweight || C > 4) SZN_FAIL(SZN_ERR_ARG, "deconv64s32_wgrad: dweight missing or C > 4");
-    hipLaunchKernelGGL(deconv_wgrad_kernel, dim3(C * C * 16), dim3(256), 0, (hipStream_t)stream, coarse, dout, dweight, B, h,
+    hipLaunchKernelGGL(deconv_wgrad_kernel, dim3(C * C * 64), dim3(256), 0, (hipStream_t)stream, coarse, dout, dweight, B, h,
                        w, C, ldc, c0, H, W, crop, accumulate);
     SZN_CHECK_LAUNCH("deconv_wgrad_kernel");
     return SZN_OK;
