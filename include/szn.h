@@ -69,7 +69,6 @@ typedef struct {
                          (models.py:47,54,63,72,81 follow a ReLU'd conv): [B][ceil(Ho/2)][ceil(Wo/2)][Co], same element
                          type as out, dense (needs ldo == Co, relu != 0).  Fused into the conv epilogue where the
                          kernel supports it (the 710^2 / 355^2 layers), else szn_maxpool2x2_ceil_fwd runs behind it */
-    uint8_t* pool_idx; /* optional with pool_out: winner index of every pooled element (szn_maxpool2x2_ceil_fwd_idx) */
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
@@ -142,13 +141,6 @@ int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void*
 int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void* in,
                             const void* out, const void* dout, void* din, float* colsum /* [C] += sum of din, or NULL */,
                             szn_stream_t stream);
-/* The same pair with a 1-byte winner index per pooled element [B][ceil(Hi/2)][ceil(Wi/2)][C]: 0..3 = position of the
- * first maximum in scan order (0,0),(0,1),(1,0),(1,1), 4 = the maximum is not positive (ReLU gate closed).  The backward
- * pass then reads dout + idx only (2.75 instead of 4.5 bytes per input element at 16 bits); results are identical.   */
-int szn_maxpool2x2_ceil_fwd_idx(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out, uint8_t* idx,
-                                szn_stream_t stream);
-int szn_maxpool2x2_ceil_bwd_idx(int dtype, int B, int Hi, int Wi, int C, const uint8_t* idx, const void* dout, void* din,
-                                float* colsum, szn_stream_t stream);
 
 /* ---- upscore: ConvTranspose2d(E,E,64,stride 32,bias=False) with the fixed bilinear kernel of
  * get_upsampling_weight (models.py:11-24,94,146) fused with the crop [19:19+H] (models.py:147).

@@ -105,24 +105,17 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     if d.ldo == Co:
         pooled = torch.full((B, (Ho + 1) // 2, (Wo + 1) // 2, Co), float("nan"), device=dev, dtype=dtype)
         out2 = torch.full_like(out, float("nan"))
-        pidx = torch.full(pooled.shape, 99, device=dev, dtype=torch.uint8)
-        d.pool_out, d.pool_idx = pooled.data_ptr(), pidx.data_ptr()
+        d.pool_out = pooled.data_ptr()
         L.call("szn_conv2d_fwd", C.byref(d), L.ptr(xd), L.ptr(wd), L.ptr(bd), None, None, L.ptr(out2), L.stream_ptr())
         if expect[0] == "conv3x3_regw":
             assert L.last_kernel() == "conv3x3_regw", L.last_kernel()      # pooled inside the conv epilogue
         else:
             assert L.last_kernel() == "maxpool_fwd_kernel", L.last_kernel()
-        d.pool_out = d.pool_idx = None
+        d.pool_out = None
         torch.cuda.synchronize()
         assert torch.equal(out2, out)
         pref = F.max_pool2d(out.float().permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
         assert torch.equal(pooled.float(), pref)
-        # winner index: the same as a stand-alone index pool over the stored tensor (first maximum, 4 = not positive)
-        p2, i2 = torch.empty_like(pooled), torch.empty_like(pidx)
-        L.call("szn_maxpool2x2_ceil_fwd_idx", L.dtype_code(dtype), B, Ho, Wo, Co, L.ptr(out), L.ptr(p2), L.ptr(i2), L.stream_ptr())
-        torch.cuda.synchronize()
-        assert torch.equal(p2, pooled) and torch.equal(i2, pidx)
-        assert int(pidx.max()) <= 4 and bool(((pidx == 4) == (pooled.float() <= 0)).all())
 
     # ---- backward: dout random, gate = x > 0 is applied by the dgrad epilogue
     dout = torch.randn(B, Co, Ho, Wo, generator=g)
@@ -303,14 +296,6 @@ def test_maxpool(dtype, hw):
     torch.cuda.synchronize()
     assert torch.equal(din.float().cpu().permute(0, 3, 1, 2), dref)
     assert relerr(cs.cpu(), dref.sum((0, 2, 3))) < 1e-5          # fused bias gradient = column sums of din
-    # the index form (what the training step uses): forward writes a 1-byte winner per window, backward reads only that
-    out2, idx = torch.empty_like(out), torch.empty(B, Ho, Wo, Cc, device="cuda", dtype=torch.uint8)
-    L.call("szn_maxpool2x2_ceil_fwd_idx", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out2), L.ptr(idx), L.stream_ptr())
-    din2, cs2 = torch.full_like(din, float("nan")), torch.zeros(Cc, device="cuda")
-    L.call("szn_maxpool2x2_ceil_bwd_idx", dt, B, Hi, Wi, Cc, L.ptr(idx), L.ptr(doutd), L.ptr(din2), L.ptr(cs2), L.stream_ptr())
-    torch.cuda.synchronize()
-    assert torch.equal(out2, out) and torch.equal(din2, din)
-    assert relerr(cs2.cpu(), cs.cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

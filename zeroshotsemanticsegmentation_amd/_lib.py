@@ -21,7 +21,7 @@ class SznError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")] + [
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p), ("pool_idx", C.c_void_p)]
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p)]
 
 
 class DeviceInfo(C.Structure):
@@ -55,8 +55,6 @@ SIGNATURES = {
     "szn_conv1_1_wgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "szn_maxpool2x2_ceil_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
     "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "szn_maxpool2x2_ceil_fwd_idx": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "szn_maxpool2x2_ceil_bwd_idx": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "szn_bilinear_up32_crop_fwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_bilinear_up32_crop_bwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_deconv64s32_fwd": (_I, [_I] * 9 + [_P, _P, _P, _P]),

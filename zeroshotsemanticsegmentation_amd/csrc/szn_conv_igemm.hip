@@ -459,8 +459,7 @@ int launch_v2(const Conv2Args& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int szn_maxpool2x2_ceil_fwd_idx(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out, uint8_t* idx,
-                                           szn_stream_t stream);
+extern "C" int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out, szn_stream_t stream);
 static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                                const float* chan_scale, void* out, szn_stream_t stream, int* pooled);
 
@@ -473,8 +472,8 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     const int rc = conv2d_fwd_dispatch(d, in, w, bias, gate, chan_scale, out, stream, &pooled);
     if (rc || !d->pool_out || pooled) return rc;
     // the kernel that ran has no fused pooling: pool the tensor it wrote
-    return szn_maxpool2x2_ceil_fwd_idx((d->out_f32 || d->dtype == SZN_F32) ? SZN_F32 : d->dtype, d->B, d->Ho, d->Wo, d->Co, out,
-                                       d->pool_out, d->pool_idx, stream);
+    return szn_maxpool2x2_ceil_fwd((d->out_f32 || d->dtype == SZN_F32) ? SZN_F32 : d->dtype, d->B, d->Ho, d->Wo, d->Co, out,
+                                   d->pool_out, stream);
 }
 
 static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,

@@ -30,7 +30,6 @@ namespace {
 struct RwArgs {
     const char* in; const char* w; const float* bias; const char* gate; char* out; float* colsum;
     char* pool;                        // optional: MaxPool2d(2,2,ceil) of the (ReLU'd) output, [B][Hp][Wp][Co] dense
-    uint8_t* pool_idx;                 // optional with pool: winner index per pooled element (0..3 scan order, 4 = not positive)
     unsigned in_bytes, gate_bytes;
     int Hp, Wp;
     int B, Hi, Wi, Ho, Wo, pad;
@@ -296,28 +295,12 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) pm[e] = ok ? v[e] : 0.f;
                     } else {
-                        // window members in scan order: a = (row j-1, even col), b = (row j-1, odd col), c = (row j, even), d = (row j,
-                        // odd); this lane holds its own column of both rows, quad_perm [1,0,3,2] fetches the other column's
                         float mx[8];
-                        uint8_t wn[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float lo = ok ? v[e] : 0.f;
-                            const float m2 = fmaxf(pm[e], lo);
+                            const float m2 = fmaxf(pm[e], ok ? v[e] : 0.f);
                             const float nb = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(m2), 0xB1, 0xF, 0xF, true));
                             mx[e] = fmaxf(m2, nb);                         // quad_perm [1,0,3,2]: the lane of column ow ^ 1
-                            if (a.pool_idx) {
-                                // the winner is decided on the STORED (16-bit rounded) values, like a pool pass over the tensor would
-                                const float sa = from_bits16<T>(to_bits16<T>(pm[e])), sc = from_bits16<T>(to_bits16<T>(lo));
-                                const float sb = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(sa), 0xB1, 0xF, 0xF, true));
-                                const float sd = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(sc), 0xB1, 0xF, 0xF, true));
-                                float m = sa;
-                                int wi = 0;
-                                if (sb > m) { m = sb; wi = 1; }
-                                if (sc > m) { m = sc; wi = 2; }
-                                if (sd > m) { m = sd; wi = 3; }
-                                wn[e] = (uint8_t)((m > 0.f) ? wi : 4);
-                            }
                         }
                         const int poh = (oh0 + j) >> 1, pw = ow >> 1;
                         if ((r16 & 1) == 0 && okw && poh < a.Hp) {
@@ -326,9 +309,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                             pq.y = pack2<T>(mx[2], mx[3]);
                             pq.z = pack2<T>(mx[4], mx[5]);
                             pq.w = pack2<T>(mx[6], mx[7]);
-                            const size_t po = (size_t)((b * a.Hp + poh) * a.Wp + pw) * (32 * COG) + cstart;
-                            *(u32x4_t*)(a.pool + po * 2) = pq;
-                            if (a.pool_idx) *(uint2*)(a.pool_idx + po) = *(const uint2*)wn;
+                            *(u32x4_t*)(a.pool + ((size_t)((b * a.Hp + poh) * a.Wp + pw) * (32 * COG) + cstart) * 2) = pq;
                         }
                     }
                 }
@@ -394,7 +375,6 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.out = (char*)out;
     a.colsum = d->colsum;
     a.pool = (char*)d->pool_out; a.Hp = (d->Ho + 1) / 2; a.Wp = (d->Wo + 1) / 2;
-    a.pool_idx = d->pool_out ? d->pool_idx : nullptr;
     a.in_bytes = (unsigned)in_bytes; a.gate_bytes = (unsigned)gate_bytes;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.pad = d->pad;
     a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg; a.relu = d->relu;

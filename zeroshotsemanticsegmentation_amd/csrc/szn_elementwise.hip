@@ -170,12 +170,9 @@ __global__ void unpack_dw32_kernel(const float* __restrict__ dw32, float* __rest
 }
 
 // ---- MaxPool2d(2,2,ceil_mode=True) on NHWC: thread = (output pixel, 16-B channel chunk) -----------
-// idx (optional, uint8 per pooled element): position 0..3 of the FIRST maximum of the window in scan order (0,0),(0,1),
-// (1,0),(1,1) -- torch's rule -- or 4 when that maximum is not positive (the ReLU gate of the layer in front of the pool is
-// closed).  szn_maxpool2x2_ceil_bwd_idx then needs neither the pool input nor its output.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Hi,
-                                                          int Wi, int C, int Ho, int Wo, uint8_t* __restrict__ idx) {
+                                                          int Wi, int C, int Ho, int Wo) {
     constexpr int CH = elem<T>::kPer16B;
     const int cpp = C / CH;
     const long total = (long)B * Ho * Wo * cpp;
@@ -186,9 +183,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         const long t = p / Wo;
         const int oh = (int)(t % Ho), b = (int)(t / Ho);
         float best[CH];
-        uint8_t win[CH];
 #pragma unroll
-        for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; win[e] = 0; }
+        for (int e = 0; e < CH; ++e) best[e] = -INFINITY;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             const int ih = 2 * oh + dy;
@@ -200,10 +196,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 const u32x4_t v = *(const u32x4_t*)(in + (((long)b * Hi + ih) * Wi + iw) * C + cc * CH);
                 const T* ve = (const T*)&v;
 #pragma unroll
-                for (int e = 0; e < CH; ++e) {
-                    const float x = elem<T>::ld(ve + e);
-                    if (x > best[e]) { best[e] = x; win[e] = (uint8_t)(dy * 2 + dx); }      // strict >: the first maximum wins
-                }
+                for (int e = 0; e < CH; ++e) best[e] = fmaxf(best[e], elem<T>::ld(ve + e));
             }
         }
         u32x4_t o;
@@ -211,13 +204,6 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int e = 0; e < CH; ++e) elem<T>::st(oe + e, best[e]);
         *(u32x4_t*)(out + p * C + cc * CH) = o;
-        if (idx) {
-#pragma unroll
-            for (int e = 0; e < CH; ++e) if (!(best[e] > 0.f)) win[e] = 4;
-            uint8_t* ip = idx + p * C + cc * CH;
-            if constexpr (CH == 8) *(uint2*)ip = *(const uint2*)win;
-            else *(uint32_t*)ip = *(const uint32_t*)win;
-        }
     }
 }
 
@@ -282,60 +268,6 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     if (colsum) {
         // bias gradient of the conv in front of this pool: column sums of din.  The launcher makes the grid stride a
         // multiple of cpp, so a thread keeps one channel chunk (cc = threadIdx.x % cpp) for all its pixels.
-#pragma unroll
-        for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = cs[e];
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) {
-            const int cc = c / CH, e = c - cc * CH;
-            float t = 0.f;
-            for (int r = cc; r < 256; r += cpp) t += red[r * CH + e];
-            if (t != 0.f) atomicAdd(colsum + c, t);
-        }
-    }
-}
-
-// pool + ReLU backward from the winner index written by the forward pool: 16 B of dout + CH index bytes in, four 16-B stores
-// out per thread (2.75 B per input element at 16 bits instead of 4.5 when the pool input has to be re-read and compared)
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dout,
-                                                              T* __restrict__ din, int B, int Hi, int Wi, int C, int Ho, int Wo,
-                                                              float* __restrict__ colsum) {
-    constexpr int CH = elem<T>::kPer16B;
-    __shared__ float red[256 * CH];
-    const int cpp = C / CH;
-    const long total = (long)B * Ho * Wo * cpp;
-    float cs[CH];
-#pragma unroll
-    for (int e = 0; e < CH; ++e) cs[e] = 0.f;
-    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
-        const int cc = (int)(gid % cpp);
-        const long po = gid / cpp;
-        const int ow = (int)(po % Wo);
-        const long t = po / Wo;
-        const int oh = (int)(t % Ho), b = (int)(t / Ho);
-        const int ih = 2 * oh, iw = 2 * ow;
-        const bool okw = iw + 1 < Wi, okh = ih + 1 < Hi;
-        const long p00 = ((long)b * Hi + ih) * Wi + iw;
-        const u32x4_t vd = *(const u32x4_t*)(dout + po * C + cc * CH);
-        const T* de = (const T*)&vd;
-        uint8_t wn[CH];
-        if constexpr (CH == 8) *(uint2*)wn = *(const uint2*)(idx + po * C + cc * CH);
-        else *(uint32_t*)wn = *(const uint32_t*)(idx + po * C + cc * CH);
-        u32x4_t o[4];
-#pragma unroll
-        for (int e = 0; e < CH; ++e) {
-            const float dv = elem<T>::ld(de + e);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) elem<T>::st((T*)&o[k] + e, wn[e] == k ? dv : 0.f);
-            cs[e] += (wn[e] < 4) ? elem<T>::ld(de + e) : 0.f;          // the one stored term (already in storage precision)
-        }
-        T* op = din + p00 * C + cc * CH;
-        *(u32x4_t*)op = o[0];
-        if (okw) *(u32x4_t*)(op + C) = o[1];
-        if (okh) *(u32x4_t*)(op + (long)Wi * C) = o[2];
-        if (okh && okw) *(u32x4_t*)(op + (long)Wi * C + C) = o[3];
-    }
-    if (colsum) {
 #pragma unroll
         for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = cs[e];
         __syncthreads();
@@ -537,11 +469,6 @@ extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const 
 
 extern "C" int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out,
                                        szn_stream_t stream) {
-    return szn_maxpool2x2_ceil_fwd_idx(dtype, B, Hi, Wi, C, in, out, nullptr, stream);
-}
-
-extern "C" int szn_maxpool2x2_ceil_fwd_idx(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out, uint8_t* idx,
-                                           szn_stream_t stream) {
     if (!in || !out || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_fwd: bad argument");
     const int ch = szn_is16(dtype) ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_fwd: C must be a multiple of %d", ch);
@@ -549,13 +476,13 @@ extern "C" int szn_maxpool2x2_ceil_fwd_idx(int dtype, int B, int Hi, int Wi, int
     const long total = (long)B * Ho * Wo * (C / ch);
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_raw>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_raw*)in, (bf16_raw*)out, B, Hi, Wi, C, Ho, Wo, idx);
+                           (const bf16_raw*)in, (bf16_raw*)out, B, Hi, Wi, C, Ho, Wo);
     else if (dtype == SZN_F16)
         hipLaunchKernelGGL(maxpool_fwd_kernel<f16_raw>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
-                           (const f16_raw*)in, (f16_raw*)out, B, Hi, Wi, C, Ho, Wo, idx);
+                           (const f16_raw*)in, (f16_raw*)out, B, Hi, Wi, C, Ho, Wo);
     else if (dtype == SZN_F32)
         hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)in, (float*)out, B, Hi, Wi, C, Ho, Wo, idx);
+                           (const float*)in, (float*)out, B, Hi, Wi, C, Ho, Wo);
     else
         SZN_FAIL(SZN_ERR_ARG, "maxpool_fwd: bad dtype %d", dtype);
     SZN_CHECK_LAUNCH("maxpool_fwd_kernel");
@@ -586,31 +513,6 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
     else
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad dtype %d", dtype);
     SZN_CHECK_LAUNCH("maxpool_bwd_kernel");
-    return SZN_OK;
-}
-
-extern "C" int szn_maxpool2x2_ceil_bwd_idx(int dtype, int B, int Hi, int Wi, int C, const uint8_t* idx, const void* dout,
-                                           void* din, float* colsum, szn_stream_t stream) {
-    if (!idx || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_idx: bad argument");
-    const int ch = szn_is16(dtype) ? 8 : 4;
-    if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_idx: C must be a multiple of %d", ch);
-    const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
-    const long total = (long)B * Ho * Wo * (C / ch);
-    if (colsum && (256 % (C / ch)) != 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_idx: colsum needs C/%d to divide 256", ch);
-    const int grid = grid_for(total, 256, colsum ? 4096 : 65536);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == SZN_BF16)
-        hipLaunchKernelGGL(maxpool_bwd_idx_kernel<bf16_raw>, dim3(grid), dim3(256), 0, st, idx, (const bf16_raw*)dout, (bf16_raw*)din,
-                           B, Hi, Wi, C, Ho, Wo, colsum);
-    else if (dtype == SZN_F16)
-        hipLaunchKernelGGL(maxpool_bwd_idx_kernel<f16_raw>, dim3(grid), dim3(256), 0, st, idx, (const f16_raw*)dout, (f16_raw*)din,
-                           B, Hi, Wi, C, Ho, Wo, colsum);
-    else if (dtype == SZN_F32)
-        hipLaunchKernelGGL(maxpool_bwd_idx_kernel<float>, dim3(grid), dim3(256), 0, st, idx, (const float*)dout, (float*)din,
-                           B, Hi, Wi, C, Ho, Wo, colsum);
-    else
-        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_idx: bad dtype %d", dtype);
-    SZN_CHECK_LAUNCH("maxpool_bwd_idx_kernel");
     return SZN_OK;
 }
 

@@ -177,13 +177,12 @@ class _Engine(object):
         out = torch.empty(B, Ho, Wo, co, device=x.device, dtype=torch.float32 if out_f32 else self.dtype)
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, co, k, k, pad, Ci, co, 0, int(relu), int(out_f32))
         self._workspace(d, B * Ho * Wo * co * 4, x.device)
-        pooled = pidx = None
+        pooled = None
         if pool:
             pooled = torch.empty(B, (Ho + 1) // 2, (Wo + 1) // 2, co, device=x.device, dtype=out.dtype)
-            pidx = torch.empty(pooled.shape, device=x.device, dtype=torch.uint8)     # winner of every window (1 B): the pool
-            d.pool_out, d.pool_idx = pooled.data_ptr(), pidx.data_ptr()               # backward reads this, not the activations
+            d.pool_out = pooled.data_ptr()
         L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), None, L.ptr(scale), L.ptr(out), L.stream_ptr())
-        return (out, pooled, pidx) if pool else out
+        return (out, pooled) if pool else out
 
     def make_masks(self, B, F, device):
         """Dropout2d factors (B,F) in {0, 2} for drop6 / drop7 (models.py:86,91; p = 0.5)"""
@@ -220,9 +219,9 @@ class _Engine(object):
                 continue                                  # pooled by the conv in front of it (pool_out)
             name, pad = item
             if i + 1 < len(items) and items[i + 1] == "P":
-                pin, a, pidx = self._conv(a, name, pad, pool=True)
+                pin, a = self._conv(a, name, pad, pool=True)
                 acts[name] = pin
-                pools.append((pin, a, pidx))
+                pools.append((pin, a))
             else:
                 a = self._conv(a, name, pad)
                 acts[name] = a
@@ -402,12 +401,12 @@ class _Engine(object):
         for idx in range(len(items) - 1, -1, -1):
             item = items[idx]
             if item == "P":
-                pin, pout, pidx = ctx.pools[pi]
+                pin, pout = ctx.pools[pi]
                 pi -= 1
                 B, Hi, Wi, Cc = pin.shape
                 dn = torch.empty_like(pin)
                 producer = items[idx - 1][0]                   # the conv whose (ReLU'd) output this pool reads
-                L.call("szn_maxpool2x2_ceil_bwd_idx", code, B, Hi, Wi, Cc, L.ptr(pidx), L.ptr(d), L.ptr(dn),
+                L.call("szn_maxpool2x2_ceil_bwd", code, B, Hi, Wi, Cc, L.ptr(pin), L.ptr(pout), L.ptr(d), L.ptr(dn),
                        L.ptr(grads[producer][1]), st)
                 d = dn
                 continue
