@@ -75,7 +75,7 @@ def test_train_cli_two_ranks_on_one_gpu(fast_tmp):
     d = fast_tmp
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "train.py"), "-c", "4", "-ve", "1", "-dir", d,
-                          "-n", "ddp", "--synthetic", "4", "64", "64"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+                          "-n", "ddp", "--synthetic", "4", "64", "64", "--workers", "0"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     logs = glob.glob(os.path.join(d, "logs", "ddp_CFG_4_*"))
     assert len(logs) == 1                                       # ONE log directory for the job

@@ -69,7 +69,7 @@ def test_trainer_accepts_dense_reference_tuple_and_native_samples(tiny):
 
 
 def test_train_cli_on_real_layout_dataset(tiny, capsys):
-    train.main(['-c', '18', '-ve', '1', '-dir', 'data', '-n', 'real'])
+    train.main(['-c', '18', '-ve', '1', '-dir', 'data', '-n', 'real', '--workers', '0'])
     log = glob.glob(os.path.join('data', 'logs', 'real_CFG_18_*'))[0]
     rows = open(os.path.join(log, 'train_log.csv')).read().strip().split('\n')
     assert len(rows) == 1 + len(G["ctx_train_seen_kept"])                   # one epoch over the train_seen split

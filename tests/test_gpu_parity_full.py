@@ -395,7 +395,7 @@ def test_cfg1_cli_end_to_end(fast_tmp):
     import glob
     from zeroshotsemanticsegmentation_amd import train
     d = fast_tmp
-    train.main(['-c', '1', '-ve', '1', '-dir', d, '-n', 'cfg1', '--synthetic', '2', '256', '256'])
+    train.main(['-c', '1', '-ve', '1', '-dir', d, '-n', 'cfg1', '--synthetic', '2', '256', '256', '--workers', '0'])
     log = glob.glob(os.path.join(d, 'logs', 'cfg1_CFG_1_*'))[0]
     rows = open(os.path.join(log, 'train_log.csv')).read().strip().split('\n')
     assert len(rows) == 3

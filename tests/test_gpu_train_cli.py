@@ -18,7 +18,7 @@ from zeroshotsemanticsegmentation_amd import train  # noqa: E402
 def test_train_cfg18_then_test_all(fast_tmp, capsys):
     d = fast_tmp
     # cfg 18: context, 20-d embeddings, cosine loss, Adam, seen-mask phase (10 epochs, -se is ignored like the reference)
-    train.main(['-c', '18', '-ve', '1', '-dir', d, '-n', 'smoke', '--synthetic', '2', '64', '64'])
+    train.main(['-c', '18', '-ve', '1', '-dir', d, '-n', 'smoke', '--synthetic', '2', '64', '64', '--workers', '0'])
     logs = glob.glob(os.path.join(d, 'logs', 'smoke_CFG_18_*'))
     assert len(logs) == 1
     log = logs[0]
@@ -42,6 +42,6 @@ def test_train_cfg18_then_test_all(fast_tmp, capsys):
     assert all(l == l for l in sl) and sl[0] != sl[-1]
     # test_all on the checkpoint (cfg 19 = test mode of cfg 18): full SZN inference path
     run = os.path.basename(log)
-    train.main(['-c', '19', '-r', run, '-dir', d, '-n', 'smoke_test', '--synthetic', '2', '64', '64'])
+    train.main(['-c', '19', '-r', run, '-dir', d, '-n', 'smoke_test', '--synthetic', '2', '64', '64', '--workers', '0'])
     out = capsys.readouterr().out
     assert 'unseen mean_iu' in out and 'overall mean_iu' in out

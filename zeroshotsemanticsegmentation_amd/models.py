@@ -61,6 +61,7 @@ class _Engine(object):
         self.dtype = torch.float32
         self._versions = None
         self._images = {}
+        self._layer_versions = {}     # layer -> parameter versions its images were built from
         self.dropout_seed = 1337
         self.dropout_calls = 0
         self._splitk_ws = None
@@ -88,9 +89,13 @@ class _Engine(object):
         if dtype != self.dtype:
             self.dtype = dtype
             self._versions = None
+            self._layer_versions = {}
 
     def mark_dirty(self):
+        """parameters were rewritten behind torch's back (the optimizer kernel of TrainStep works on the flat buffers): every
+        image is rebuilt by the next sync_weights"""
         self._versions = None
+        self._layer_versions = {}
 
     def _param_versions(self):
         return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
@@ -112,10 +117,20 @@ class _Engine(object):
         if dev.type != "cuda":
             raise L.SznError("FCN32s parameters live on %s: the HIP path needs them on the GPU (model.cuda())" % dev)
         dt, code = self.dtype, L.dtype_code(self.dtype)
-        img = {}
+        # per-layer refresh: only the layers whose parameters changed since the images were built are repacked (phase 2 and
+        # fine-tuning touch the heads only; a full TrainStep touches everything)
+        img = dict(self._images) if (self._images and self._layer_versions.get("_dtype") == (dt, dev)) else {}
+        if not img:
+            self._layer_versions = {"_dtype": (dt, dev)}
+        lv = self._layer_versions
         st = L.stream_ptr()
         for name, co, ci, k in synth.CONV_LAYERS:
             layer = getattr(m, name)
+            ver = (layer.weight.data_ptr(), layer.weight._version, layer.bias.data_ptr(), layer.bias._version,
+                   id(self.lp_views.get(name)))
+            if lv.get(name) == ver and (name + ".w") in img:
+                continue
+            lv[name] = ver
             w32 = self._ohwi(layer.weight)
             img[name + ".b"] = layer.bias.detach().float().contiguous()
             if name == "conv1_1":
@@ -138,6 +153,17 @@ class _Engine(object):
             img[name + ".wT"] = wt
         # fused projection head: rows [0,E) = score_fr, [E,E+2) = seenmask_score, zero rows up to CP
         E, CP, F = m.n_class, m.head_width, m.fc7.out_channels
+        hver = tuple((p.data_ptr(), p._version) for p in (m.score_fr.weight, m.score_fr.bias, m.seenmask_score.weight,
+                                                          m.seenmask_score.bias)) + (id(self.lp_views.get("head")),)
+        uver = (m.seenmask_upscore.weight.data_ptr(), m.seenmask_upscore.weight._version)
+        if lv.get("up") != uver or "up.w" not in img:
+            img["up.w"] = m.seenmask_upscore.weight.detach().float().contiguous()
+            lv["up"] = uver
+        if lv.get("head") == hver and "head.w" in img:
+            self._images = img
+            self._versions = v
+            return
+        lv["head"] = hver
         hv = self.lp_views.get("head")
         if hv is not None and hv[0].dtype == dt:
             # TrainStep keeps the image itself: score_fr's rows are written by the optimizer kernel, the rows behind them
@@ -159,7 +185,6 @@ class _Engine(object):
         wht = torch.empty(F, CP, device=dev, dtype=dt)
         L.call("szn_pack_weight_dgrad", code, CP, 1, 1, F, L.ptr(whc), L.ptr(wht), st)
         img["head.w"], img["head.b"], img["head.wT"] = whc.view(CP, 1, 1, F), bh, wht.view(F, 1, 1, CP)
-        img["up.w"] = m.seenmask_upscore.weight.detach().float().contiguous()
         self._images = img
         self._versions = v
 

@@ -55,7 +55,8 @@ def build_parser():
     # additions
     p.add_argument('--synthetic', type=int, nargs=3, metavar=('N', 'H', 'W'), help='synthetic dataset: N images of HxW')
     p.add_argument('--batch-size', type=int, default=1)
-    p.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32')
+    p.add_argument('--precision', choices=['fp32', 'bf16', 'fp16'], default='fp32')
+    p.add_argument('--workers', type=int, default=2, help='DataLoader worker processes per loader (0 = load in the main process)')
     return p
 
 
@@ -230,7 +231,7 @@ def main(argv=None):
                                 data_dir=args.data_dir, train_unseen=cfg['train_unseen'], val_unseen=cfg['val_unseen'],
                                 native=True)
         train_dataset, train_seen_dataset, val_dataset = mkr('train'), mkr('train_seen'), mkr('val')
-    kwargs = {'num_workers': 2, 'pin_memory': True}
+    kwargs = {'num_workers': args.workers, 'pin_memory': True}
 
     def loader(ds, bs, shuffle):
         if world > 1 and shuffle:       # every rank holds the same dataset; the sampler deals disjoint shards per epoch
@@ -260,7 +261,7 @@ def main(argv=None):
             print("%s -> deterministic synthetic initialisation" % e)
             model.load_synthetic(1337)
     model = model.to(device)
-    precision = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+    precision = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.precision]
     model.set_precision(precision)
     model._engine.dropout_seed = 1337 + 7919 * rank       # data-parallel ranks draw different Dropout2d masks
 
