@@ -68,8 +68,8 @@ def test_validate_device_metrics_equal_host_metrics(tmp_path):
     lts, lps, losses = [], [], []
     with torch.no_grad():
         for data, target in loader:
-            _, loss, pred, lt = t.forward(data, target)
-            lts.append(lt[0].numpy()); lps.append(pred[0]); losses.append(float(loss))
+            _, loss, pred, lt = t._predict_device(data, target, False)       # the path validate() runs (fused head)
+            lts.append(lt[0].cpu().numpy()); lps.append(pred[0].cpu().numpy()); losses.append(float(loss))
     want, seen_m, unseen_m = utils.label_accuracy_score(lts, lps, K, unseen=VAL_UNSEEN)
     np.testing.assert_allclose(np.array(metrics), np.array(want), rtol=1e-12, equal_nan=True)
     got_row = np.array([float(v) for v in row[2:15]])
@@ -96,3 +96,22 @@ def test_seenmask_trainer_forward_contract(tmp_path):
     oloss, _, opred = O.cross_entropy2d(score.cpu().numpy(), want_t, size_average=True, want_grad=False)
     assert abs(float(loss) - float(oloss)) < 1e-5 * max(1.0, abs(float(oloss)))
     assert np.array_equal(pred, opred) and pred.dtype == np.int64
+
+
+def test_embed_predict_equals_unfused_head(tmp_path):
+    """FCN32s.embed_predict (what Trainer.validate uses for plain embedding inference) against forward + utils on the
+    materialised score: same loss to rounding, same class assignment except near-ties"""
+    m, loader, t = make(tmp_path)
+    m.eval()
+    data, target = next(iter(loader))
+    lbl = target[0]
+    with torch.no_grad():
+        score = m(data.cuda(), mode="fcn")
+        loss_u = utils.cosine_loss(score, lbl.cuda(), t.embeddings)
+        pred_u = utils.infer_lbl_device(score, t.embeddings)
+    loss, pred = m.embed_predict(data.cuda(), t.embeddings, lbl)
+    assert abs(float(loss) - float(loss_u)) < 2e-6 and pred.dtype == torch.int64 and tuple(pred.shape) == (1, H, W)
+    bad = pred != pred_u
+    assert float(bad.float().mean()) < 2e-3
+    l2, p2 = m.embed_predict(data.cuda(), t.embeddings)
+    assert l2 is None and torch.equal(p2, pred)

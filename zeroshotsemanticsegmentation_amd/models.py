@@ -642,6 +642,31 @@ class FCN32s(nn.Module):
             return s
         return f, s
 
+    def embed_predict(self, x, embeddings, target=None):
+        """forward pass + nearest-class-embedding prediction (+ cosine loss when `target` is given) WITHOUT materialising the
+        (B,E,H,W) score: the fused-from-coarse head (szn_fused_head) evaluates upscore + crop (models.py:146-147), cosine_loss
+        (utils.py:75-102) and infer_lbl (utils.py:159-185) per 32x32 cell of the 1/32 map.  -> (loss 0-dim tensor or None,
+        pred (B,H,W) int64 device tensor).  Same numbers as `forward` + utils up to rounding order (class assignment differs only
+        on pixels whose top-2 cosine margin is < 1e-5).  Used by Trainer.validate."""
+        eng = self._engine
+        with torch.no_grad():
+            ctx = eng.forward(x.detach() if isinstance(x, torch.Tensor) else x, train=False)
+            emb = torch.as_tensor(embeddings).to(ctx.coarse.device, torch.float32).contiguous()
+            K, E = emb.shape
+            if E != self.n_class:
+                raise L.SznError("embedding dimension %d != model n_class %d" % (E, self.n_class))
+            B, H, W = ctx.B, ctx.H, ctx.W
+            dev = ctx.coarse.device
+            pred = torch.empty(B, H, W, dtype=torch.int64, device=dev)
+            ws = torch.empty(L.load().szn_fused_head_workspace_bytes(B, ctx.h, ctx.w, E, K), dtype=torch.uint8, device=dev)
+            loss = stats = tgt = None
+            if target is not None:
+                tgt = target.to(device=dev, dtype=torch.int64).contiguous()
+                loss, stats = torch.empty(1, device=dev), torch.empty(B, 2, device=dev)
+            L.call("szn_fused_head", B, ctx.h, ctx.w, E, self.head_width, 0, H, W, CROP, K, L.ptr(ctx.coarse), L.ptr(emb),
+                   L.ptr(tgt), L.ptr(loss), L.ptr(stats), L.ptr(pred), L.SZN_F32, None, L.ptr(ws), L.stream_ptr())
+        return (loss.reshape(()) if loss is not None else None), pred
+
     def copy_params_from_vgg16(self, vgg16):
         """reference models.py:162-193: zip vgg16.features with our conv list; fc6/fc7 from classifier[0], [3]"""
         features = []

@@ -234,6 +234,11 @@ class Trainer(object):
     def _predict_device(self, data, target, szn):
         """forward + loss + class assignment with everything left on the GPU -> (score, loss 0-dim, pred (n,h,w), target)"""
         data, target, target_embed = self._unpack(data, target)
+        if (self.pixel_embeddings and self.loss_func == "cos" and not szn and not self.forced_unseen and target_embed is None
+                and not self.verbose_val and self.embeddings.shape[0] <= 64):
+            # plain embedding inference: loss + class assignment straight from the 1/32 map (no (n,E,h,w) score in HBM)
+            loss, pred = self.model.embed_predict(data, self.embeddings, target)
+            return None, loss, pred, target
         if szn:
             score, seen_mask_score = self.model(data, mode='both')
         else:
