@@ -151,6 +151,18 @@ int szn_bilinear_up32_crop_fwd(int B, int h, int w, int E, int ldc, int c0, int 
 int szn_bilinear_up32_crop_bwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
                                const float* dscore_nchw, float* dcoarse, szn_stream_t stream);
 
+/* ---- the same fixed bilinear ConvTranspose2d(E,E,2*stride,stride) + crop for stride 32 (== the two entries above) and
+ * stride 8: the last stage of the FCN8s skip head (BASELINE north_star / SURVEY N1: public pytorch-fcn FCN8s, `upscore8`
+ * ConvTranspose2d(E,E,16,stride 8) + crop 31; NOT in /root/reference -- parity unpinned).                              */
+int szn_bilinear_up_crop_fwd(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                             const float* coarse, float* score_nchw, szn_stream_t stream);
+int szn_bilinear_up_crop_bwd(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                             const float* dscore_nchw, float* dcoarse, szn_stream_t stream);
+/* FCN8s `upscore2` / `upscore_pool4`: fixed bilinear ConvTranspose2d(C,C,4,stride 2) between NHWC f32 maps with pixel stride ld:
+ * in [B][h][w][ld] -> out [B][2h+2][2w+2][ld], channels [0,C); bwd is its transpose (dout -> din).                         */
+int szn_bilinear_up2_nhwc_fwd(int B, int h, int w, int C, int ld, const float* in, float* out, szn_stream_t stream);
+int szn_bilinear_up2_nhwc_bwd(int B, int h, int w, int C, int ld, const float* dout, float* din, szn_stream_t stream);
+
 /* ---- seenmask_upscore: ConvTranspose2d(C,C,64,stride 32,bias=False) with a LEARNED dense kernel
  * (models.py:98,150-151; trained in phase 2, train.py:170-175).  weight is torch layout
  * (Cin,Cout,64,64) f32; C <= 4.                                                                   */

@@ -75,6 +75,51 @@ class FCN32sTorch(nn.Module):
         return out[0] if len(out) == 1 else tuple(out)
 
 
+class FCN8sTorch(FCN32sTorch):
+    """FCN8s skip head on the same trunk -- the PUBLIC pytorch-fcn FCN8s definition (score_pool3 / score_pool4 1x1 convs,
+    upscore2 / upscore_pool4 ConvTranspose2d(E,E,4,s2), upscore8 ConvTranspose2d(E,E,16,s8), crops 5 / 9 / 31), with the
+    transposed convolutions fixed to their bilinear initialisation (models.py:11-24,109-112) and run depthwise.
+    PARITY UNPINNED: /root/reference has no FCN8s (its models.py:27 is FCN32s only), so there is no reference output to
+    capture; this class is the checker for zeroshotsemanticsegmentation_amd.models.FCN8s and nothing more."""
+
+    def __init__(self, n_class):
+        super().__init__(n_class)
+        self.score_pool3 = nn.Conv2d(256, n_class, 1)
+        self.score_pool4 = nn.Conv2d(512, n_class, 1)
+        for name, k in (("up2_filt", 4), ("up8_filt", 16)):
+            f = _bilinear_1d(k)
+            filt = torch.from_numpy((f[:, None] * f[None, :]).astype(np.float32))
+            self.register_buffer(name, filt.expand(n_class, 1, k, k).contiguous())
+
+    def forward(self, x, mode="fcn", masks=None):
+        H, W = x.shape[2:]
+        h = x
+        pools = []
+        for item in _CFG:
+            if item == "P":
+                h = F.max_pool2d(h, 2, 2, ceil_mode=True)
+                pools.append(h)
+            else:
+                h = F.relu(getattr(self, item[0])(h))
+        h = F.relu(self.fc6(h))
+        h = h * masks[0][:, :, None, None] if masks is not None else h
+        h = F.relu(self.fc7(h))
+        h = h * masks[1][:, :, None, None] if masks is not None else h
+        out = []
+        if mode in ("fcn", "both"):
+            E = self.n_class
+            up2 = F.conv_transpose2d(self.score_fr(h), self.up2_filt, stride=2, groups=E)
+            sp4 = self.score_pool4(pools[3])[:, :, 5:5 + up2.shape[2], 5:5 + up2.shape[3]]
+            up4 = F.conv_transpose2d(up2 + sp4, self.up2_filt, stride=2, groups=E)
+            sp3 = self.score_pool3(pools[2])[:, :, 9:9 + up4.shape[2], 9:9 + up4.shape[3]]
+            f = F.conv_transpose2d(up4 + sp3, self.up8_filt, stride=8, groups=E)
+            out.append(f[:, :, 31:31 + H, 31:31 + W].contiguous())
+        if mode in ("seenmask", "both"):
+            s = F.conv_transpose2d(self.seenmask_score(h), self.seenmask_upscore, stride=32)
+            out.append(s[:, :, 19:19 + H, 19:19 + W].contiguous())
+        return out[0] if len(out) == 1 else tuple(out)
+
+
 def cosine_loss(score, target, embed):
     """utils.py:75-102 with the target embedding gathered by label; per-image loss, mean over images"""
     B, E = score.shape[:2]

@@ -57,6 +57,10 @@ SIGNATURES = {
     "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "szn_bilinear_up32_crop_fwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_bilinear_up32_crop_bwd": (_I, [_I] * 9 + [_P, _P, _P]),
+    "szn_bilinear_up_crop_fwd": (_I, [_I] * 10 + [_P, _P, _P]),
+    "szn_bilinear_up_crop_bwd": (_I, [_I] * 10 + [_P, _P, _P]),
+    "szn_bilinear_up2_nhwc_fwd": (_I, [_I] * 5 + [_P, _P, _P]),
+    "szn_bilinear_up2_nhwc_bwd": (_I, [_I] * 5 + [_P, _P, _P]),
     "szn_deconv64s32_fwd": (_I, [_I] * 9 + [_P, _P, _P, _P]),
     "szn_deconv64s32_dgrad": (_I, [_I] * 9 + [_P, _P, _P, _P]),
     "szn_deconv64s32_wgrad": (_I, [_I] * 9 + [_P, _P, _P, _I, _P]),

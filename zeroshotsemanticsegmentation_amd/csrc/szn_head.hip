@@ -13,23 +13,26 @@
 
 namespace {
 
-// 1-D bilinear tap of get_upsampling_weight(k=64): factor 32, center 31.5 (models.py:13-20), in double
-__device__ __forceinline__ double bil1d(int t) { return 1.0 - fabs((double)t - 31.5) / 32.0; }
+// 1-D bilinear tap of get_upsampling_weight(k = 2 S): factor S, center S - 0.5 (models.py:13-20), in double
+template <int S>
+__device__ __forceinline__ double bil1d(int t) { return 1.0 - fabs((double)t - ((double)S - 0.5)) / (double)S; }
 
 // ---- upscore forward ---------------------------------------------------------------------------------------------------
-// block = (8 cells of 32 columns, one cell row I, image b); thread = one column X of the uncropped 32(h+1) x 32(w+1) deconv output
-// (x = X - crop), so a half-wave is exactly one cell.  The 2 x 10 coarse vectors the segment blends are staged in LDS once and
-// reused for the cell row's 32 output rows; the four bilinear weights of a pixel are formed once per row (double product rounded
+// Fixed bilinear ConvTranspose2d(E, E, 2 S, stride S) + crop; S = 32 is FCN32s' upscore (models.py:94,146-147), S = 8 the last
+// stage of the FCN8s head.  block = (256 / S cells of S columns, one cell row I, image b); thread = one column X of the uncropped
+// S(h+1) x S(w+1) deconv output (x = X - crop).  The 2 x (256/S + 2) coarse vectors the segment blends are staged in LDS once and
+// reused for the cell row's S output rows; the four bilinear weights of a pixel are formed once per row (double product rounded
 // to float, models.py:13-24) and reused for all E channels.  Per element: 4 LDS reads + 4 fmaf (tap order (i-1,j-1), (i-1,j),
-// (i,j-1), (i,j) as before: bit-identical) + one coalesced store -- the kernel is bound by its B*E*H*W*4 B of stores.
-constexpr int UP_NJ = 10;       // coarse columns a 256-wide segment touches: cells 8 seg - 1 .. 8 seg + 8
-__global__ __launch_bounds__(256) void up32_fwd_kernel(const float* __restrict__ coarse, float* __restrict__ out, int B,
-                                                       int h, int w, int E, int ldc, int c0, int H, int W, int crop) {
-    extern __shared__ __attribute__((aligned(16))) float taps[];      // [2][UP_NJ][E]
+// (i,j-1), (i,j): bit-identical to the gather form) + one coalesced store -- the kernel is bound by its B*E*H*W*4 B of stores.
+template <int S>
+__global__ __launch_bounds__(256) void up_fwd_kernel(const float* __restrict__ coarse, float* __restrict__ out, int B,
+                                                     int h, int w, int E, int ldc, int c0, int H, int W, int crop) {
+    constexpr int NC = 256 / S, NJ = NC + 2;     // cells per segment; coarse columns it touches: NC seg - 1 .. NC seg + NC
+    extern __shared__ __attribute__((aligned(16))) float taps[];      // [2][NJ][E]
     const int seg = blockIdx.x, I = blockIdx.y, b = blockIdx.z;
-    const int jbase = 8 * seg - 1;
-    for (int idx = threadIdx.x; idx < 2 * UP_NJ * E; idx += 256) {
-        const int r = idx / (UP_NJ * E), rem = idx - r * UP_NJ * E;
+    const int jbase = NC * seg - 1;
+    for (int idx = threadIdx.x; idx < 2 * NJ * E; idx += 256) {
+        const int r = idx / (NJ * E), rem = idx - r * NJ * E;
         const int jj = rem / E, c = rem - jj * E;
         const int i = I - 1 + r, j = jbase + jj;
         taps[idx] = (i >= 0 && i < h && j >= 0 && j < w) ? coarse[(((long)b * h + i) * w + j) * ldc + c0 + c] : 0.f;
@@ -37,16 +40,16 @@ __global__ __launch_bounds__(256) void up32_fwd_kernel(const float* __restrict__
     __syncthreads();
     const int X = 256 * seg + threadIdx.x, x = X - crop;
     if (x < 0 || x >= W) return;
-    const int jl = threadIdx.x >> 5, tx = threadIdx.x & 31;          // cell inside the segment (J = 8 seg + jl), column inside it
-    const double fx1 = bil1d(tx), fx0 = bil1d(tx + 32);
-    const float* t00 = taps + (0 * UP_NJ + jl) * E;                   // (I-1, J-1)
+    const int jl = threadIdx.x / S, tx = threadIdx.x % S;            // cell inside the segment (J = NC seg + jl), column inside it
+    const double fx1 = bil1d<S>(tx), fx0 = bil1d<S>(tx + S);
+    const float* t00 = taps + (0 * NJ + jl) * E;                      // (I-1, J-1)
     const float* t01 = t00 + E;                                       // (I-1, J)
-    const float* t10 = taps + (1 * UP_NJ + jl) * E;                   // (I,   J-1)
+    const float* t10 = taps + (1 * NJ + jl) * E;                      // (I,   J-1)
     const float* t11 = t10 + E;                                       // (I,   J)
-    for (int ty = 0; ty < 32; ++ty) {
-        const int y = 32 * I + ty - crop;
+    for (int ty = 0; ty < S; ++ty) {
+        const int y = S * I + ty - crop;
         if (y < 0 || y >= H) continue;
-        const double fy1 = bil1d(ty), fy0 = bil1d(ty + 32);
+        const double fy1 = bil1d<S>(ty), fy0 = bil1d<S>(ty + S);
         const float w00 = (float)(fy0 * fx0), w01 = (float)(fy0 * fx1), w10 = (float)(fy1 * fx0), w11 = (float)(fy1 * fx1);
         float* op = out + ((long)b * E * H + y) * W + x;
         for (int c = 0; c < E; ++c) {
@@ -60,29 +63,31 @@ __global__ __launch_bounds__(256) void up32_fwd_kernel(const float* __restrict__
 }
 
 // ---- upscore backward ----------------------------------------------------------------------------------------------------
-// dcoarse[b][i][j][c] = sum over the 64 x 64 window of (i, j).  block = (coarse row i, image b, channel slice); thread = column X
-// of the uncropped output.  Per channel a thread forms ONE weighted column sum over the window's 64 rows (ky = Y - 32 i), then
-// its column contributes bil1d(tx) * col to output J (left half of J's window) and bil1d(32 + tx) * col to output J - 1 (right
-// half): two half-wave reductions per cell, combined through LDS, plain stores -- deterministic, every dscore element is read by
+// dcoarse[b][i][j][c] = sum over the 2S x 2S window of (i, j).  block = (coarse row i, image b, channel slice); thread = column X
+// of the uncropped output.  Per channel a thread forms ONE weighted column sum over the window's 2S rows (ky = Y - S i), then
+// its column contributes bil1d(tx) * col to output J (left half of J's window) and bil1d(S + tx) * col to output J - 1 (right
+// half): two S-lane reductions per cell, combined through LDS, plain stores -- deterministic, every dscore element is read by
 // 2 blocks (the row overlap) instead of 4 waves.
-__global__ __launch_bounds__(256) void up32_bwd_kernel(const float* __restrict__ dscore, float* __restrict__ dcoarse,
-                                                       int B, int h, int w, int E, int ldc, int c0, int H, int W,
-                                                       int crop, int cper) {
+template <int S>
+__global__ __launch_bounds__(256) void up_bwd_kernel(const float* __restrict__ dscore, float* __restrict__ dcoarse,
+                                                     int B, int h, int w, int E, int ldc, int c0, int H, int W,
+                                                     int crop, int cper) {
+    constexpr int NC = 256 / S;
     extern __shared__ __attribute__((aligned(16))) float red[];       // [2][cper][ncell]: R (own cell) | L (for the cell to the left)
     const int i = blockIdx.x, b = blockIdx.y, cbeg = blockIdx.z * cper;
     const int cend = min(E, cbeg + cper);
     const int ncell = w + 1;
-    const int lane32 = threadIdx.x & 31;
-    const float fL = (float)bil1d(lane32), fR = (float)bil1d(lane32 + 32);
-    __shared__ float wy[64];
-    if (threadIdx.x < 64) wy[threadIdx.x] = (float)bil1d(threadIdx.x);
+    const int laneS = threadIdx.x % S;
+    const float fL = (float)bil1d<S>(laneS), fR = (float)bil1d<S>(laneS + S);
+    __shared__ float wy[2 * S];
+    if (threadIdx.x < 2 * S) wy[threadIdx.x] = (float)bil1d<S>(threadIdx.x);
     __syncthreads();
-    for (int seg = 0; seg * 8 < ncell; ++seg) {
+    for (int seg = 0; seg * NC < ncell; ++seg) {
         const int X = 256 * seg + threadIdx.x, x = X - crop;
-        const int J = X >> 5;
+        const int J = X / S;
         const bool okx = x >= 0 && x < W && J < ncell;
         // four channels at a time: four independent accumulation chains, 16 loads in flight per lane
-        const int ky_lo = max(0, crop - 32 * i), ky_hi = min(64, H + crop - 32 * i);
+        const int ky_lo = max(0, crop - S * i), ky_hi = min(2 * S, H + crop - S * i);
         for (int c = cbeg; c < cend; c += 4) {
             float col[4] = {0.f, 0.f, 0.f, 0.f};
             if (okx) {
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256) void up32_bwd_kernel(const float* __restrict__
                 const int nc = min(4, cend - c);
                 for (int ky = ky_lo; ky < ky_hi; ++ky) {
                     const float wv = wy[ky];
-                    const float* rp = plane + (long)(32 * i + ky - crop) * W;
+                    const float* rp = plane + (long)(S * i + ky - crop) * W;
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (u < nc) col[u] = fmaf(rp[u * cs], wv, col[u]);
@@ -101,8 +106,8 @@ __global__ __launch_bounds__(256) void up32_bwd_kernel(const float* __restrict__
             for (int u = 0; u < 4; ++u) {
                 float pl = col[u] * fL, pr = col[u] * fR;      // this column inside the window of output J / of output J - 1
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { pl += __shfl_xor(pl, o, 64); pr += __shfl_xor(pr, o, 64); }
-                if (lane32 == 0 && J < ncell && c + u < cend) {
+                for (int o = S / 2; o > 0; o >>= 1) { pl += __shfl_xor(pl, o, 64); pr += __shfl_xor(pr, o, 64); }
+                if (laneS == 0 && J < ncell && c + u < cend) {
                     red[(c + u - cbeg) * ncell + J] = pl;
                     red[(cper + c + u - cbeg) * ncell + J] = pr;
                 }
@@ -114,6 +119,61 @@ __global__ __launch_bounds__(256) void up32_bwd_kernel(const float* __restrict__
     for (int idx = threadIdx.x; idx < (cend - cbeg) * w; idx += 256) {
         const int j = idx / (cend - cbeg), cc = idx - j * (cend - cbeg);
         dcoarse[(((long)b * h + i) * w + j) * ldc + c0 + cbeg + cc] = red[cc * ncell + j] + red[(cper + cc) * ncell + j + 1];
+    }
+}
+
+// ---- FCN8s skip fusion: x2 bilinear ConvTranspose2d(E, E, 4, stride 2) between coarse NHWC maps (a few MB) ---------------------
+// out (B, 2h+2, 2w+2, ld) [c] = sum_{i,j} in[i][j][c] f[Y - 2i] f[X - 2j], f = (0.25, 0.75, 0.75, 0.25): every output blends
+// <= 2 x 2 inputs, tap order (i-1,j-1), (i-1,j), (i,j-1), (i,j) with i = Y >> 1
+__global__ __launch_bounds__(256) void up2_nhwc_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int h,
+                                                           int w, int C, int ld) {
+    const int Ho = 2 * h + 2, Wo = 2 * w + 2;
+    const long total = (long)B * Ho * Wo * C;
+    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+        const int c = (int)(gid % C);
+        long t = gid / C;
+        const int X = (int)(t % Wo); t /= Wo;
+        const int Y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const int i1 = Y >> 1, j1 = X >> 1, ty = Y & 1, tx = X & 1;
+        float acc = 0.f;
+#pragma unroll
+        for (int di = 0; di < 2; ++di) {
+            const int i = i1 - 1 + di;
+            if (i < 0 || i >= h) continue;
+            const double fy = bil1d<2>(ty + 2 - 2 * di);
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const int j = j1 - 1 + dj;
+                if (j < 0 || j >= w) continue;
+                const float wt = (float)(fy * bil1d<2>(tx + 2 - 2 * dj));
+                acc = fmaf(in[(((long)b * h + i) * w + j) * ld + c], wt, acc);
+            }
+        }
+        out[(((long)b * Ho + Y) * Wo + X) * ld + c] = acc;
+    }
+}
+
+// din[i][j][c] = sum over the 4 x 4 window (ky, kx) of dout[2i + ky][2j + kx][c] f[ky] f[kx], ascending (ky, kx)
+__global__ __launch_bounds__(256) void up2_nhwc_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int h,
+                                                           int w, int C, int ld) {
+    const int Wo = 2 * w + 2, Ho = 2 * h + 2;
+    const long total = (long)B * h * w * C;
+    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+        const int c = (int)(gid % C);
+        long t = gid / C;
+        const int j = (int)(t % w); t /= w;
+        const int i = (int)(t % h);
+        const int b = (int)(t / h);
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const float wt = (float)(bil1d<2>(ky) * bil1d<2>(kx));
+                acc = fmaf(dout[(((long)b * Ho + 2 * i + ky) * Wo + 2 * j + kx) * ld + c], wt, acc);
+            }
+        din[(((long)b * h + i) * w + j) * ld + c] = acc;
     }
 }
 
@@ -510,37 +570,33 @@ inline int grid_for(long n, int cap) {
     return (int)b;
 }
 
-int check_up(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, const void* a, const void* b) {
-    if (!a || !b || B <= 0 || h <= 0 || w <= 0 || E <= 0 || c0 < 0 || ldc < c0 + E || H <= 0 || W <= 0 || crop < 0)
+int check_up(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, const void* a, const void* b, int S = 32) {
+    if (B <= 0 || h <= 0 || w <= 0 || E <= 0 || ldc < c0 + E || c0 < 0 || H <= 0 || W <= 0 || crop < 0 || !a || !b)
         SZN_FAIL(SZN_ERR_ARG, "upsample: bad argument");
-    if (H + crop > 32 * h + 32 || W + crop > 32 * w + 32)
-        SZN_FAIL(SZN_ERR_ARG, "upsample: crop window [%d,%d)+%d exceeds the %dx%d deconv output", H, W, crop, 32 * h + 32,
-                 32 * w + 32);
+    if (H + crop > S * h + S || W + crop > S * w + S)
+        SZN_FAIL(SZN_ERR_ARG, "upsample: crop window [%d,%d)+%d exceeds the %dx%d deconv output", H, W, crop, S * h + S,
+                 S * w + S);
     return SZN_OK;
 }
 
 constexpr size_t kMaxDynLds = 160 * 1024 - 2048;
 
-}  // namespace
-
-extern "C" int szn_bilinear_up32_crop_fwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
-                                          const float* coarse, float* score, szn_stream_t stream) {
-    int rc = check_up(B, h, w, E, ldc, c0, H, W, crop, coarse, score);
-    if (rc) return rc;
-    const size_t lds = (size_t)2 * UP_NJ * E * sizeof(float);
-    if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "up32_fwd: E = %d too large for the LDS tap table", E);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)up32_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    // uncropped columns crop .. crop + W - 1 in 256-wide segments, cell rows (crop >> 5) .. ((H - 1 + crop) >> 5)
-    const dim3 grid((unsigned)((W + crop + 255) / 256), (unsigned)(((H - 1 + crop) >> 5) + 1), (unsigned)B);
-    hipLaunchKernelGGL(up32_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, coarse, score, B, h, w, E, ldc, c0, H, W, crop);
-    SZN_CHECK_LAUNCH("up32_fwd_kernel");
+template <int S>
+int launch_up_fwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, const float* coarse, float* score,
+                  hipStream_t st) {
+    const size_t lds = (size_t)2 * (256 / S + 2) * E * sizeof(float);
+    if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "up_fwd: E = %d too large for the LDS tap table", E);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)up_fwd_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // uncropped columns crop .. crop + W - 1 in 256-wide segments, cell rows (crop / S) .. ((H - 1 + crop) / S)
+    const dim3 grid((unsigned)((W + crop + 255) / 256), (unsigned)((H - 1 + crop) / S + 1), (unsigned)B);
+    hipLaunchKernelGGL(up_fwd_kernel<S>, grid, dim3(256), lds, st, coarse, score, B, h, w, E, ldc, c0, H, W, crop);
+    SZN_CHECK_LAUNCH("up_fwd_kernel");
     return SZN_OK;
 }
 
-extern "C" int szn_bilinear_up32_crop_bwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
-                                          const float* dscore, float* dcoarse, szn_stream_t stream) {
-    int rc = check_up(B, h, w, E, ldc, c0, H, W, crop, dscore, dcoarse);
-    if (rc) return rc;
+template <int S>
+int launch_up_bwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, const float* dscore, float* dcoarse,
+                  hipStream_t st) {
     // channel slices so that ~2 blocks per CU exist; LDS = 2 x slice x (w + 1) floats
     int csplit = (1536 + B * h - 1) / (B * h);
     if (csplit < 1) csplit = 1;
@@ -548,11 +604,57 @@ extern "C" int szn_bilinear_up32_crop_bwd(int B, int h, int w, int E, int ldc, i
     const int cper = (E + csplit - 1) / csplit;
     csplit = (E + cper - 1) / cper;
     const size_t lds = (size_t)2 * cper * (w + 1) * sizeof(float);
-    if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "up32_bwd: coarse row too wide for LDS (w = %d)", w);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)up32_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(up32_bwd_kernel, dim3((unsigned)h, (unsigned)B, (unsigned)csplit), dim3(256), lds, (hipStream_t)stream, dscore,
-                       dcoarse, B, h, w, E, ldc, c0, H, W, crop, cper);
-    SZN_CHECK_LAUNCH("up32_bwd_kernel");
+    if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "up_bwd: coarse row too wide for LDS (w = %d)", w);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)up_bwd_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(up_bwd_kernel<S>, dim3((unsigned)h, (unsigned)B, (unsigned)csplit), dim3(256), lds, st, dscore, dcoarse, B, h,
+                       w, E, ldc, c0, H, W, crop, cper);
+    SZN_CHECK_LAUNCH("up_bwd_kernel");
+    return SZN_OK;
+}
+
+}  // namespace
+
+extern "C" int szn_bilinear_up_crop_fwd(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                                        const float* coarse, float* score, szn_stream_t stream) {
+    if (stride != 32 && stride != 8) SZN_FAIL(SZN_ERR_UNSUPPORTED, "bilinear_up_crop_fwd: stride %d (32 and 8 are built)", stride);
+    int rc = check_up(B, h, w, E, ldc, c0, H, W, crop, coarse, score, stride);
+    if (rc) return rc;
+    return stride == 32 ? launch_up_fwd<32>(B, h, w, E, ldc, c0, H, W, crop, coarse, score, (hipStream_t)stream)
+                        : launch_up_fwd<8>(B, h, w, E, ldc, c0, H, W, crop, coarse, score, (hipStream_t)stream);
+}
+
+extern "C" int szn_bilinear_up_crop_bwd(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                                        const float* dscore, float* dcoarse, szn_stream_t stream) {
+    if (stride != 32 && stride != 8) SZN_FAIL(SZN_ERR_UNSUPPORTED, "bilinear_up_crop_bwd: stride %d (32 and 8 are built)", stride);
+    int rc = check_up(B, h, w, E, ldc, c0, H, W, crop, dscore, dcoarse, stride);
+    if (rc) return rc;
+    return stride == 32 ? launch_up_bwd<32>(B, h, w, E, ldc, c0, H, W, crop, dscore, dcoarse, (hipStream_t)stream)
+                        : launch_up_bwd<8>(B, h, w, E, ldc, c0, H, W, crop, dscore, dcoarse, (hipStream_t)stream);
+}
+
+extern "C" int szn_bilinear_up32_crop_fwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                                          const float* coarse, float* score, szn_stream_t stream) {
+    return szn_bilinear_up_crop_fwd(32, B, h, w, E, ldc, c0, H, W, crop, coarse, score, stream);
+}
+
+extern "C" int szn_bilinear_up32_crop_bwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop,
+                                          const float* dscore, float* dcoarse, szn_stream_t stream) {
+    return szn_bilinear_up_crop_bwd(32, B, h, w, E, ldc, c0, H, W, crop, dscore, dcoarse, stream);
+}
+
+extern "C" int szn_bilinear_up2_nhwc_fwd(int B, int h, int w, int C, int ld, const float* in, float* out, szn_stream_t stream) {
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || ld < C || !in || !out) SZN_FAIL(SZN_ERR_ARG, "bilinear_up2_nhwc_fwd: bad argument");
+    hipLaunchKernelGGL(up2_nhwc_fwd_kernel, dim3(grid_for((long)B * (2 * h + 2) * (2 * w + 2) * C, 1 << 16)), dim3(256), 0,
+                       (hipStream_t)stream, in, out, B, h, w, C, ld);
+    SZN_CHECK_LAUNCH("up2_nhwc_fwd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_bilinear_up2_nhwc_bwd(int B, int h, int w, int C, int ld, const float* dout, float* din, szn_stream_t stream) {
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || ld < C || !dout || !din) SZN_FAIL(SZN_ERR_ARG, "bilinear_up2_nhwc_bwd: bad argument");
+    hipLaunchKernelGGL(up2_nhwc_bwd_kernel, dim3(grid_for((long)B * h * w * C, 1 << 16)), dim3(256), 0, (hipStream_t)stream, dout,
+                       din, B, h, w, C, ld);
+    SZN_CHECK_LAUNCH("up2_nhwc_bwd_kernel");
     return SZN_OK;
 }
 

@@ -357,13 +357,13 @@ class _Engine(object):
             if after is not None:
                 after()
 
-    def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None, colsum=None):
+    def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None, colsum=None, wT=None):
         """din = conv(dout, flipped weights) with the ReLU gate / dropout factor of the producing layer fused; colsum
         (f32 [Ci], pre-zeroed) receives the column sums of din = that layer's bias gradient"""
         B, Hi, Wi, Ci = in_shape
         Ho, Wo, Co = dout.shape[1:]
         din = torch.empty(B, Hi, Wi, Ci, device=dout.device, dtype=self.dtype)
-        wG = self._images.get(name + ".wG")
+        wG = self._images.get(name + ".wG") if wT is None else None
         if wG is not None:      # large window (fc6): GEMM + col2im, no gate / dropout factor / column sums on this edge
             if gate is not None or scale is not None or colsum is not None:
                 raise L.SznError("dgrad of %s: the GEMM form has no gate / scale / colsum epilogue" % name)
@@ -375,7 +375,7 @@ class _Engine(object):
             d.workspace, d.workspace_bytes = self._gemm_ws.data_ptr(), self._gemm_ws.numel()
             L.call("szn_conv2d_dgrad_gemm", C.byref(d), L.ptr(dout), L.ptr(wG), L.ptr(din), L.stream_ptr())
             return din
-        wT = self._images[name + ".wT"]
+        wT = self._images[name + ".wT"] if wT is None else wT
         k = wT.shape[1]
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, Ci, 0, 0)
         if colsum is not None:
@@ -385,9 +385,11 @@ class _Engine(object):
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
         return din
 
-    def backward(self, ctx, dcoarse, grads, backbone=True, layer_done=None, head_first=None):
+    def backward(self, ctx, dcoarse, grads, backbone=True, layer_done=None, head_first=None, skips=None):
         """dcoarse (B,h,w,CP) f32 or compute dtype -> fills grads[name] = (dw OHWI f32, db f32) for every layer
-        present in `grads` ('head' holds the fused score_fr||seenmask_score gradient, CP rows)."""
+        present in `grads` ('head' holds the fused score_fr||seenmask_score gradient, CP rows).  skips: {pool index: gradient
+        arriving at that pool's OUTPUT from a side branch} (the FCN8s score_pool3 / score_pool4 taps), added where the chain
+        reaches it."""
         m = self.model
         dt = self.dtype
         code = L.dtype_code(dt)
@@ -453,9 +455,46 @@ class _Engine(object):
             # next d: wrt this conv's input; gate by the ReLU of the producing conv unless a pool sits in between
             if prev == "P":
                 d = self._dgrad(d, name, xin.shape, pad)
+                side = skips.get(pi) if skips else None
+                if side is not None:
+                    d = d + side.to(d.dtype)
             else:
                 d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1])
         self._join_wgrad()
+
+
+def _backbone_backward(ctx, dcoarse, skips=None):
+    """shared by _Backbone / _Backbone8: run the dgrad / wgrad chain and hand every parameter its gradient"""
+    model, c = ctx.model, ctx.c
+    eng = model._engine
+    dev = dcoarse.device
+    need = ctx.needs_input_grad[4:]
+    names = [n for n, _ in model.named_parameters()]
+    need_of = dict(zip(names, need))
+    backbone = any(need_of.get(n + ".weight", False) for n in _TRUNK)
+    grads = {}
+    for name, co, ci, k in synth.CONV_LAYERS:
+        if backbone:
+            grads[name] = (torch.empty(co, k, k, ci, device=dev), torch.empty(co, device=dev))
+    CP, F, E = model.head_width, model.fc7.out_channels, model.n_class
+    grads["head"] = (torch.empty(CP, 1, 1, F, device=dev), torch.empty(CP, device=dev))
+    eng.backward(c, dcoarse.contiguous(), grads, backbone=backbone, skips=skips)
+    out = []
+    for n in names:
+        layer, kind = n.rsplit(".", 1)
+        if not need_of[n] or layer in ("upscore", "seenmask_upscore"):
+            out.append(None)
+        elif layer == "score_fr":
+            g = grads["head"][0][:E].reshape(E, F, 1, 1) if kind == "weight" else grads["head"][1][:E]
+            out.append(g.clone())
+        elif layer == "seenmask_score":
+            g = grads["head"][0][E:E + 2].reshape(2, F, 1, 1) if kind == "weight" else grads["head"][1][E:E + 2]
+            out.append(g.clone())
+        elif layer in grads:
+            out.append(grads[layer][0].permute(0, 3, 1, 2) if kind == "weight" else grads[layer][1])
+        else:
+            out.append(None)
+    return (None, None, None, None) + tuple(out)
 
 
 class _Backbone(torch.autograd.Function):
@@ -471,36 +510,7 @@ class _Backbone(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcoarse):
-        model, c = ctx.model, ctx.c
-        eng = model._engine
-        dev = dcoarse.device
-        need = ctx.needs_input_grad[4:]
-        names = [n for n, _ in model.named_parameters()]
-        need_of = dict(zip(names, need))
-        backbone = any(need_of.get(n + ".weight", False) for n in _TRUNK)
-        grads = {}
-        for name, co, ci, k in synth.CONV_LAYERS:
-            if backbone:
-                grads[name] = (torch.empty(co, k, k, ci, device=dev), torch.empty(co, device=dev))
-        CP, F, E = model.head_width, model.fc7.out_channels, model.n_class
-        grads["head"] = (torch.empty(CP, 1, 1, F, device=dev), torch.empty(CP, device=dev))
-        eng.backward(c, dcoarse.contiguous(), grads, backbone=backbone)
-        out = []
-        for n in names:
-            layer, kind = n.rsplit(".", 1)
-            if not need_of[n] or layer in ("upscore", "seenmask_upscore"):
-                out.append(None)
-            elif layer == "score_fr":
-                g = grads["head"][0][:E].reshape(E, F, 1, 1) if kind == "weight" else grads["head"][1][:E]
-                out.append(g.clone())
-            elif layer == "seenmask_score":
-                g = grads["head"][0][E:E + 2].reshape(2, F, 1, 1) if kind == "weight" else grads["head"][1][E:E + 2]
-                out.append(g.clone())
-            elif layer in grads:
-                out.append(grads[layer][0].permute(0, 3, 1, 2) if kind == "weight" else grads[layer][1])
-            else:
-                out.append(None)
-        return (None, None, None, None) + tuple(out)
+        return _backbone_backward(ctx, dcoarse)
 
 
 class _Upscore(torch.autograd.Function):
@@ -687,6 +697,182 @@ class FCN32s(nn.Module):
             l2.weight.data.copy_(l1.weight.data.view(l2.weight.size()))
             l2.bias.data.copy_(l1.bias.data.view(l2.bias.size()))
         self._engine.mark_dirty()
+
+
+# ---- FCN8s: the skip head BASELINE's north_star names -----------------------------------------------------------
+# NOT in /root/reference (models.py:27 is FCN32s only): this follows the public pytorch-fcn FCN8s head on top of the same
+# backbone -- score_pool3 Conv2d(256,E,1), score_pool4 Conv2d(512,E,1), upscore2 / upscore_pool4 ConvTranspose2d(E,E,4,stride 2),
+# upscore8 ConvTranspose2d(E,E,16,stride 8), all transposed convolutions bias-free with the fixed bilinear kernel
+# (models.py:11-24,109-112 initialise them that way and train.py:324-327 never updates them), crops 5 / 9 / 31.  PARITY UNPINNED:
+# the checker is oracle/torch_ref.FCN8sTorch, a torch-CPU restatement of that public definition, not reference output.
+CROP_POOL4, CROP_POOL3, CROP_UP8 = 5, 9, 31
+
+
+class _Backbone8(torch.autograd.Function):
+    """_Backbone that also exposes the pool3 / pool4 outputs (NHWC, compute dtype) and takes their gradients back"""
+
+    @staticmethod
+    def forward(ctx, model, x, train, masks, *params):
+        c = model._engine.forward(x, train=train, masks=masks)
+        ctx.model, ctx.c = model, c
+        model._last_ctx = c
+        ctx.set_materialize_grads(False)
+        return c.coarse, c.pools[2][1], c.pools[3][1]
+
+    @staticmethod
+    def backward(ctx, dcoarse, dpool3, dpool4):
+        if dcoarse is None:
+            dcoarse = torch.zeros_like(ctx.c.coarse)
+        return _backbone_backward(ctx, dcoarse, skips={2: dpool3, 3: dpool4})
+
+
+class _SkipScore(torch.autograd.Function):
+    """score_pool3 / score_pool4: 1x1 conv of a pooled NHWC map into the (padded) projection width, fp32 output"""
+
+    @staticmethod
+    def forward(ctx, model, x, weight, bias):
+        eng = model._engine
+        E, Ci = weight.shape[0], weight.shape[1]
+        CP = model.head_width
+        wimg = torch.zeros(CP, 1, 1, Ci, device=x.device, dtype=eng.dtype)
+        wimg[:E] = weight.detach().reshape(E, 1, 1, Ci).to(eng.dtype)
+        bimg = torch.zeros(CP, device=x.device, dtype=torch.float32)
+        bimg[:E] = bias.detach().float()
+        ctx.model, ctx.x, ctx.wimg, ctx.E = model, x, wimg, E
+        return eng._conv(x, None, 0, relu=False, out_f32=True, w=wimg, b=bimg)
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng, x, wimg, E = ctx.model._engine, ctx.x, ctx.wimg, ctx.E
+        CP, Ci = wimg.shape[0], wimg.shape[3]
+        dc = dout.contiguous().to(eng.dtype)
+        dw = torch.empty(CP, 1, 1, Ci, device=x.device)
+        db = torch.empty(CP, device=x.device)
+        eng._wgrad(x, dc, dw, db, Ci, CP, 1, 0)
+        eng._join_wgrad()
+        wT = torch.empty(Ci, 1, 1, CP, device=x.device, dtype=eng.dtype)
+        L.call("szn_pack_weight_dgrad", L.dtype_code(eng.dtype), CP, 1, 1, Ci, L.ptr(wimg), L.ptr(wT), L.stream_ptr())
+        dx = eng._dgrad(dc, None, x.shape, 0, wT=wT)
+        return None, dx, dw[:E].permute(0, 3, 1, 2), db[:E]
+
+
+class _Up2(torch.autograd.Function):
+    """upscore2 / upscore_pool4 (fixed bilinear x2) between NHWC fp32 maps"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, h, w, ld = x.shape
+        ctx.shape = (B, h, w, ld)
+        out = torch.empty(B, 2 * h + 2, 2 * w + 2, ld, device=x.device, dtype=torch.float32)
+        L.call("szn_bilinear_up2_nhwc_fwd", B, h, w, ld, ld, L.ptr(x), L.ptr(out), L.stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, h, w, ld = ctx.shape
+        dout = dout.contiguous().float()
+        din = torch.empty(B, h, w, ld, device=dout.device, dtype=torch.float32)
+        L.call("szn_bilinear_up2_nhwc_bwd", B, h, w, ld, ld, L.ptr(dout), L.ptr(din), L.stream_ptr())
+        return din
+
+
+class _Up8Crop(torch.autograd.Function):
+    """upscore8 + crop 31: NHWC fp32 (B,h,w,ld) at 1/8 -> the (B,E,H,W) NCHW score"""
+
+    @staticmethod
+    def forward(ctx, x, E, H, W):
+        x = x.contiguous()
+        B, h, w, ld = x.shape
+        ctx.args = (B, h, w, E, ld, H, W)
+        f = torch.empty(B, E, H, W, device=x.device, dtype=torch.float32)
+        L.call("szn_bilinear_up_crop_fwd", 8, B, h, w, E, ld, 0, H, W, CROP_UP8, L.ptr(x), L.ptr(f), L.stream_ptr())
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        B, h, w, E, ld, H, W = ctx.args
+        df = df.contiguous().float()
+        dx = torch.zeros(B, h, w, ld, device=df.device, dtype=torch.float32)
+        L.call("szn_bilinear_up_crop_bwd", 8, B, h, w, E, ld, 0, H, W, CROP_UP8, L.ptr(df), L.ptr(dx), L.stream_ptr())
+        return dx, None, None, None
+
+
+class FCN8s(FCN32s):
+    """FCN8s skip architecture on the FCN32s trunk (see the note above: public pytorch-fcn definition, parity unpinned).
+    state_dict keys follow pytorch-fcn's FCN8s: the trunk + score_fr, score_pool3, score_pool4, upscore2, upscore8,
+    upscore_pool4 (+ this repo's seenmask_score / seenmask_upscore, which keep the reference's x32 seen-mask head,
+    models.py:97-98,149-151).  Runs through the autograd bridge (Trainer's per-tensor path, optim.Adam / SGD kernels);
+    engine.TrainStep's flat fused step is specific to the FCN32s layer list."""
+
+    pretrained_model = 'data/fcn8s_from_caffe.pth'
+
+    def __init__(self, n_class=21):
+        super(FCN8s, self).__init__(n_class)
+        del self.upscore
+        self.score_pool3 = nn.Conv2d(256, n_class, 1)
+        self.score_pool4 = nn.Conv2d(512, n_class, 1)
+        self.upscore2 = nn.ConvTranspose2d(n_class, n_class, 4, stride=2, bias=False)
+        self.upscore8 = nn.ConvTranspose2d(n_class, n_class, 16, stride=8, bias=False)
+        self.upscore_pool4 = nn.ConvTranspose2d(n_class, n_class, 4, stride=2, bias=False)
+        self._initialize_weights()
+
+    def load_synthetic(self, seed=1337, device=None):
+        if device is not None:
+            return super(FCN8s, self).load_synthetic(seed, device)
+        sd = self.state_dict()
+        for k, v in synth.make_params(self.n_class, seed).items():
+            if k in sd:
+                sd[k].copy_(torch.from_numpy(v))
+        rs = np.random.RandomState(seed + 8)
+        with torch.no_grad():
+            for mod in (self.score_pool3, self.score_pool4):
+                b = math.sqrt(6.0 / mod.in_channels)
+                mod.weight.copy_(torch.from_numpy(rs.uniform(-b, b, size=tuple(mod.weight.shape)).astype(np.float32)))
+                mod.bias.copy_(torch.from_numpy(rs.uniform(-0.1, 0.1, size=tuple(mod.bias.shape)).astype(np.float32)))
+        self._engine.mark_dirty()
+        return self
+
+    def _run(self, x, mode, train, masks):
+        params = [p for _, p in self.named_parameters()]
+        coarse, pool3, pool4 = _Backbone8.apply(self, x, train, masks, *params)
+        f = s = None
+        if mode in ('fcn', 'both'):
+            H, W = x.shape[2:]
+            up2 = _Up2.apply(coarse)                                                       # upscore2
+            sp4 = _SkipScore.apply(self, pool4, self.score_pool4.weight, self.score_pool4.bias)
+            n, m_ = up2.shape[1:3]
+            if sp4.shape[1] < CROP_POOL4 + n or sp4.shape[2] < CROP_POOL4 + m_:
+                raise L.SznError("FCN8s: pool4 map %s too small for the %dx%d upscore2 output" % (tuple(sp4.shape[1:3]), n, m_))
+            fuse4 = up2 + sp4[:, CROP_POOL4:CROP_POOL4 + n, CROP_POOL4:CROP_POOL4 + m_, :]
+            up4 = _Up2.apply(fuse4)                                                        # upscore_pool4
+            sp3 = _SkipScore.apply(self, pool3, self.score_pool3.weight, self.score_pool3.bias)
+            n, m_ = up4.shape[1:3]
+            fuse3 = up4 + sp3[:, CROP_POOL3:CROP_POOL3 + n, CROP_POOL3:CROP_POOL3 + m_, :]
+            f = _Up8Crop.apply(fuse3, self.n_class, H, W)                                  # upscore8 + crop
+        if mode in ('seenmask', 'both'):
+            s = _SeenmaskUpscore.apply(self, coarse, self.seenmask_upscore.weight)
+        return f, s
+
+    def forward(self, x, mode='fcn', dropout_masks=None):
+        if mode not in ('fcn', 'seenmask', 'both'):
+            raise Exception('model given unexpected forward mode')
+        f, s = self._run(x, mode, self.training, dropout_masks)
+        return f if mode == 'fcn' else (s if mode == 'seenmask' else (f, s))
+
+    def embed_predict(self, x, embeddings, target=None):
+        """forward + cosine loss + nearest-embedding prediction through the materialised score (the fused-from-coarse head is
+        built for the x32 geometry only) -> (loss or None, pred (B,H,W) int64 on the device)"""
+        from . import utils
+        with torch.no_grad():
+            f, _ = self._run(x.detach(), 'fcn', False, None)
+            emb = torch.as_tensor(embeddings).to(f.device, torch.float32).contiguous()
+            if emb.shape[1] != self.n_class:
+                raise L.SznError("embedding dimension %d != model n_class %d" % (emb.shape[1], self.n_class))
+            loss = None
+            if target is not None:
+                loss = utils.cosine_loss(f, target.to(f.device), emb)
+            return loss, utils.infer_lbl_device(f, emb)
 
 
 def VGG16(pretrained=False, data_dir='data'):
