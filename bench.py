@@ -51,6 +51,9 @@ def parse():
                     help="fp16 = IEEE-half activations / weight images with static loss scaling (BASELINE configs[4])")
     ap.add_argument("--head-fp8", action="store_true", help="projection head forward on the fp8 (e4m3) matrix cores (configs[4])")
     ap.add_argument("--unfused-head", action="store_true", help="materialise the (B,E,H,W) score like the reference")
+    ap.add_argument("--arch", choices=["fcn32s", "fcn8s"], default="fcn32s",
+                    help="fcn8s: the public FCN8s skip head BASELINE's north_star names (not in the reference; autograd path, "
+                         "per-tensor fused Adam) -- a secondary line, the default stays the reference's FCN32s")
     ap.add_argument("--phase", choices=["fcn", "seenmask"], default="fcn",
                     help="fcn = phase 1 (headline; phase 2 is reported as a sub-record); seenmask = phase 2 as the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,6 +94,9 @@ def call_work(name, a):
     if name == "szn_fused_head":           # label in, prediction out, coarse map in, dcoarse out
         B, h, w, E, ldc, c0, H, W = a[:8]
         return "hbm", B * H * W * 16.0 + 2.0 * B * h * w * E * 4.0
+    if name == "szn_fused_head_strided":
+        B, h, w, E, ldc, c0, H, W = a[1:9]
+        return "hbm", B * H * W * 16.0 + 2.0 * B * h * w * E * 4.0
     if name == "szn_pack_weight_dgrad":
         code, co, kh, kw, ci = a[:5]
         return "hbm", 2.0 * co * kh * kw * ci * _esize(code)
@@ -108,10 +114,13 @@ def call_work(name, a):
     if name in ("szn_bilinear_up32_crop_fwd", "szn_bilinear_up32_crop_bwd"):
         B, h, w, E, ldc, c0, H, W = a[:8]
         return "hbm", B * H * W * E * 4.0
+    if name in ("szn_bilinear_up_crop_fwd", "szn_bilinear_up_crop_bwd"):
+        B, h, w, E, ldc, c0, H, W = a[1:9]
+        return "hbm", B * H * W * E * 4.0
     return None
 
 
-def cpu_baseline(E, K, H, emb):
+def cpu_baseline(E, K, H, emb, arch="fcn32s"):
     """the train step on ONE image on this host's cores: torch-CPU restatement (primary) and the C + OpenMP oracle"""
     from oracle import szn_oracle as O
     from oracle import torch_ref as T
@@ -121,12 +130,14 @@ def cpu_baseline(E, K, H, emb):
     tgt = synth.make_labels(1, H, H, K)
     cores = os.cpu_count()
     out = {"unit": "Mpixels/s", "cores": cores, "kind": "port"}
-    t = T.timed_train_step(E, K, H, emb, x, tgt, steps=2)            # second step timed (first pays allocation / mkldnn setup)
+    t = T.timed_train_step(E, K, H, emb, x, tgt, steps=2, arch=arch)  # second step timed (first pays allocation / mkldnn setup)
     out["value"] = round(H * H / t["total"] / 1e6, 6)
     out["threads"] = torch.get_num_threads()
-    out["sample"] = ("torch-CPU restatement of the reference step (oracle/torch_ref.py; depthwise upscore), 1 image %dx%d, "
+    out["sample"] = ("torch-CPU restatement of the %s step (oracle/torch_ref.py; depthwise upscore), 1 image %dx%d, "
                      "E=%d, K=%d, fp32, 2nd of 2 steps: fwd %.2fs loss %.2fs infer %.2fs bwd %.2fs adam %.2fs"
-                     % (H, H, E, K, t["fwd"], t["loss"], t["infer"], t["bwd"], t["adam"]))
+                     % ("reference" if arch == "fcn32s" else "FCN8s", H, H, E, K, t["fwd"], t["loss"], t["infer"], t["bwd"], t["adam"]))
+    if arch != "fcn32s":
+        return out                      # the C oracle restates the reference's FCN32s only
     try:
         rng = np.random.default_rng(1337)
         params = {}
@@ -232,7 +243,7 @@ def main():
     peak = PEAK_F32 if dtype == torch.float32 else PEAK_BF16          # fp16 and bf16 MFMA share the dense peak
 
     torch.manual_seed(1337)                                   # identical initial weights on every rank
-    model = models.FCN32s(n_class=E)
+    model = (models.FCN8s if args.arch == "fcn8s" else models.FCN32s)(n_class=E)
     model.load_synthetic(1337, device=dev)
     model.train()
     if args.head_fp8:
@@ -245,6 +256,34 @@ def main():
 
     def make_phase1():
         return engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=not args.unfused_head)
+
+    def make_phase1_fcn8s():
+        # autograd path: forward (skip head, materialised score) -> cosine loss -> infer_lbl -> backward -> two-group Adam
+        # (train.py:126-133 wiring: Conv2d weights at lr, biases at 2 lr; the bilinear ConvTranspose2d kernels stay fixed)
+        from zeroshotsemanticsegmentation_amd import optim as szn_optim, utils as szn_utils
+        model.set_precision(dtype)
+        emb = torch.from_numpy(emb_np).to(dev)
+        ws = [m_.weight for n_, m_ in model.named_modules() if isinstance(m_, torch.nn.Conv2d) and not n_.startswith("seenmask")]
+        bs = [m_.bias for n_, m_ in model.named_modules() if isinstance(m_, torch.nn.Conv2d) and not n_.startswith("seenmask")]
+        for n_, p_ in model.named_parameters():
+            p_.requires_grad = not (n_.startswith("seenmask") or n_.startswith("upscore"))
+        opt = szn_optim.FusedAdam([{"params": ws}, {"params": bs, "lr": 2e-5}], lr=1e-5)
+
+        class _Phase1(object):
+            def step(self, xx, tt):
+                if args.unfused_head:
+                    score = model(xx)
+                    loss = szn_utils.cosine_loss(score, tt, emb)
+                    pred = szn_utils.infer_lbl_device(score.detach(), emb)
+                else:
+                    loss, pred = model.embed_loss(xx, emb, tt)       # fused head over 8x8 cells of the 1/8 map
+                opt.zero_grad()
+                loss.backward()
+                if world > 1:
+                    engine.allreduce_param_grads(ws + bs)
+                opt.step()
+                return loss.detach(), pred
+        return _Phase1()
 
     def make_phase2():
         # train.py:164-175: everything frozen except seenmask_score (w, b) and seenmask_upscore (w); binary target
@@ -275,7 +314,9 @@ def main():
 
     if args.phase == "seenmask" and world > 1:
         raise SystemExit("--phase seenmask is a single-GPU line (98 KB of gradients)")
-    ts = make_phase1() if args.phase == "fcn" else make_phase2()
+    if args.arch == "fcn8s" and args.head_fp8:
+        raise SystemExit("--arch fcn8s has no fp8 head")
+    ts = (make_phase1_fcn8s() if args.arch == "fcn8s" else make_phase1()) if args.phase == "fcn" else make_phase2()
 
     # ---- HIP events on the launch stream around C-ABI calls (torch's current stream IS the stream handed to the C-ABI) ----
     CONV_ENTRIES = ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm")
@@ -296,7 +337,7 @@ def main():
                   "wgrad_taps_reduce": "+reduce", "conv1_1_wgrad_reduce": "+reduce"}.get(kern)
         if helper:
             kern = L.prev_kernel() + helper
-        elif name == "szn_fused_head":
+        elif name in ("szn_fused_head", "szn_fused_head_strided"):
             kern = "fused_head (fh_prep + fh_cell + fh_finalize + fh_gather)"
         events.append((e0, e1, name, kern, wk[0] if wk else None, wk[1] if wk else 0.0))
     if not args.no_kernel_events:
@@ -338,9 +379,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp16": "f16 (+ fp8 e4m3 projection head)" if args.head_fp8 else "f16", "fp32": "f32"}[args.precision]
             if not (args.head_fp8 and args.precision == "bf16") else "bf16 (+ fp8 e4m3 projection head)", "data": "synthetic",
-            "config": {"workload": ("%s: FCN32s (the reference has no FCN8s) + %d-d pixel projection, %dx%d, K=%d (%d seen / %d "
+            "config": {"workload": ("%s: %s + %d-d pixel projection, %dx%d, K=%d (%d seen / %d "
                                     "unseen), Adam lr 1e-5, train step fwd+cosine loss+infer_lbl+bwd+optimizer"
-                                    % (workload, E, H, H, K, len(seen), len(unseen))) if args.phase == "fcn" else
+                                    % (workload, "FCN32s (the reference has no FCN8s)" if args.arch == "fcn32s" else
+                                       "FCN8s skip head (public definition, not in the reference: parity unpinned)", E, H, H, K,
+                                       len(seen), len(unseen))) if args.phase == "fcn" else
                        ("BASELINE configs[2] (phase 2): seen-mask head on the frozen FCN32s backbone, %dx%d, K=%d, 2-class CE, "
                         "train step fwd+CE+argmax+head bwd+Adam" % (H, H, K)),
                        "per_gpu_batch": B, "global_batch": B * world,
@@ -375,7 +418,7 @@ def main():
                                                          "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / peak, 4),
                                                          "launches_per_step": len(timed_events) // args.steps,
                                                          "share_of_step": round(fam_ms / (dt * 1e3), 3)}}
-            if H in STEP_MFLOP_PER_PX and E == 300 and args.phase == "fcn":
+            if H in STEP_MFLOP_PER_PX and E == 300 and args.phase == "fcn" and args.arch == "fcn32s":
                 out["roofline"]["step_mfma_frac"] = round(STEP_MFLOP_PER_PX[H] * 1e6 * B * H * H * args.steps / dt / 1e12 / peak, 4)
 
     # ---- instrumented pass: every C-ABI call of 3 more steps (same state, not part of `value`) ----
@@ -441,7 +484,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(E, K, H, emb_np)
+                out["cpu_baseline"] = cpu_baseline(E, K, H, emb_np, args.arch)
             except Exception as ex:      # the baseline is a reported extra: never lose the measured line
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (ex,)}

@@ -241,6 +241,11 @@ int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, in
                    const float* coarse, const float* embed, const int64_t* target,
                    float* loss, float* stats, int64_t* pred, int dcoarse_dtype, void* dcoarse,
                    void* workspace, szn_stream_t stream);
+/* the same head over stride-8 cells (coarse = the 1/8 fused map of the FCN8s skip head, crop 31); stride in {32, 8};
+ * szn_fused_head == stride 32.  The workspace size is szn_fused_head_workspace_bytes of the map's own h, w.            */
+int szn_fused_head_strided(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
+                           const float* coarse, const float* embed, const int64_t* target, float* loss, float* stats,
+                           int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace, szn_stream_t stream);
 
 /* ---- optimizers (train.py:126-133,174-175; torch.optim.Adam / SGD semantics) ----------------------
  * One launch per flat fp32 parameter buffer.  grad_scale multiplies the gradient first (1/world

@@ -49,6 +49,7 @@ def lib():
         _lib.szo_mse_loss.restype = C.c_double
         _lib.szo_ce2d.restype = C.c_double
         _lib.szo_fused_head.restype = C.c_double
+        _lib.szo_fused_head_s.restype = C.c_double
     return _lib
 
 
@@ -339,7 +340,7 @@ def infer_lbl_forced_unseen(score, target, embed, unseen):
     return pred
 
 
-def fused_head(coarse, embed, target, H, W, n_class=None, c0=0, crop=19, want_grad=True, want_pred=True):
+def fused_head(coarse, embed, target, H, W, n_class=None, c0=0, crop=19, want_grad=True, want_pred=True, stride=32):
     """The fused-from-coarse head of the training step (csrc/szn_fused_head.hip) restated: coarse (B,h,w,ldc) f32
     NHWC projection map -> (loss, stats (B,2), pred (B,H,W) int64, dcoarse (B,h,w,ldc) f32 with channels [c0,c0+E) filled).
     Same math as deconv_fwd(diag) -> cosine_loss -> infer_lbl (models.py:146-147, utils.py:75-102,159-185), different
@@ -353,7 +354,8 @@ def fused_head(coarse, embed, target, H, W, n_class=None, c0=0, crop=19, want_gr
     stats = np.zeros((B, 2), np.float32)
     pred = np.empty((B, H, W), np.int64) if want_pred else None
     dc = np.zeros_like(coarse) if (want_grad and t is not None) else None
-    loss = lib().szo_fused_head(B, h, w, E, ldc, c0, H, W, crop, K, _p(coarse), _p(embed), _p(t), _p(stats), _p(pred), _p(dc))
+    loss = lib().szo_fused_head_s(stride, B, h, w, E, ldc, c0, H, W, crop, K, _p(coarse), _p(embed), _p(t), _p(stats), _p(pred),
+                                  _p(dc))
     return np.float32(loss), stats, pred, dc
 
 

@@ -227,10 +227,12 @@ static float wave_tree64(float* v) {
     return v[0];
 }
 
-static double fh_bil1d(int t) { return 1.0 - fabs((double)t - 31.5) / 32.0; }
+static double fh_bil1d(int t, int S) { return 1.0 - fabs((double)t - ((double)S - 0.5)) / (double)S; }
 
-double szo_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K, const float* coarse,
-                      const float* embed, const int64_t* target, float* stats, int64_t* pred, float* dcoarse) {
+/* S = the upsampling stride (kernel 2S): 32 = the reference's upscore (models.py:94,146-147); 8 = upscore8 of the public FCN8s
+ * head (crop 31) -- same arithmetic over S x S cells.                                                                    */
+double szo_fused_head_s(int S, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K, const float* coarse,
+                        const float* embed, const int64_t* target, float* stats, int64_t* pred, float* dcoarse) {
     float* en = (float*)malloc((size_t)K * sizeof(float));
     float* ent = (float*)malloc((size_t)K * sizeof(float));
     for (int k = 0; k < K; ++k) {
@@ -271,11 +273,11 @@ double szo_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W,
                 }
             double* dc = dC ? dC + ((size_t)b * cells + cell) * 4 * E : NULL;
             double csum = 0.0, cnt = 0.0;
-            for (int ty = 0; ty < 32; ++ty)
-                for (int tx = 0; tx < 32; ++tx) {
-                    const int y = 32 * I + ty - crop, x = 32 * J + tx - crop;
+            for (int ty = 0; ty < S; ++ty)
+                for (int tx = 0; tx < S; ++tx) {
+                    const int y = S * I + ty - crop, x = S * J + tx - crop;
                     if (y < 0 || y >= H || x < 0 || x >= W) continue;
-                    const double fy1 = fh_bil1d(ty), fy0 = fh_bil1d(ty + 32), fx1 = fh_bil1d(tx), fx0 = fh_bil1d(tx + 32);
+                    const double fy1 = fh_bil1d(ty, S), fy0 = fh_bil1d(ty + S, S), fx1 = fh_bil1d(tx, S), fx0 = fh_bil1d(tx + S, S);
                     const float wt[4] = {(float)(fy0 * fx0), (float)(fy0 * fx1), (float)(fy1 * fx0), (float)(fy1 * fx1)};
                     float ss = 0.f;
                     for (int t = 0; t < 4; ++t)
@@ -339,4 +341,9 @@ double szo_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W,
     }
     free(en); free(ent); free(cs); free(dC);
     return target ? total / B : 0.0;
+}
+
+double szo_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K, const float* coarse,
+                      const float* embed, const int64_t* target, float* stats, int64_t* pred, float* dcoarse) {
+    return szo_fused_head_s(32, B, h, w, E, ldc, c0, H, W, crop, K, coarse, embed, target, stats, pred, dcoarse);
 }

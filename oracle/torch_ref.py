@@ -150,12 +150,12 @@ def param_groups(model):
     return ws, bs
 
 
-def timed_train_step(E, K, H, emb, x, target, steps=1, threads=None):
+def timed_train_step(E, K, H, emb, x, target, steps=1, threads=None, arch="fcn32s"):
     """one (or more) full train steps on torch-CPU; returns seconds per phase of the LAST step"""
     if threads:
         torch.set_num_threads(threads)
     torch.manual_seed(1337)
-    m = FCN32sTorch(E)
+    m = FCN8sTorch(E) if arch == "fcn8s" else FCN32sTorch(E)
     ws, bs = param_groups(m)
     opt = torch.optim.Adam([{"params": ws}, {"params": bs, "lr": 2e-5}], lr=1e-5)
     xt, tt, et = torch.from_numpy(x), torch.from_numpy(target), torch.from_numpy(emb)

@@ -45,3 +45,24 @@ def test_train_cfg18_then_test_all(fast_tmp, capsys):
     train.main(['-c', '19', '-r', run, '-dir', d, '-n', 'smoke_test', '--synthetic', '2', '64', '64', '--workers', '0'])
     out = capsys.readouterr().out
     assert 'unseen mean_iu' in out and 'overall mean_iu' in out
+
+
+def test_train_cli_fcn8s_arch(fast_tmp, capsys):
+    """--arch fcn8s: the same CLI flow over the skip head (autograd path + fused per-tensor Adam: 17 Conv2d weight / bias pairs
+    incl. score_pool3 / score_pool4), seen-mask phase, checkpoint, then test_all from the checkpoint"""
+    d = fast_tmp
+    train.main(['-c', '18', '-ve', '1', '-dir', d, '-n', 'f8', '--synthetic', '2', '64', '64', '--workers', '0', '--arch', 'fcn8s',
+                '--precision', 'bf16'])
+    log = glob.glob(os.path.join(d, 'logs', 'f8_CFG_18_*'))[0]
+    rows = open(os.path.join(log, 'train_log.csv')).read().strip().split('\n')
+    assert len(rows) == 1 + 2 and all(float(r.split(',')[2]) == float(r.split(',')[2]) for r in rows[1:])
+    ck = torch.load(os.path.join(log, 'best'), map_location='cpu', weights_only=False)
+    sd = ck['model_state_dict']
+    assert ck['arch'] == 'FCN8s' and 'upscore.weight' not in sd
+    assert tuple(sd['score_pool3.weight'].shape) == (20, 256, 1, 1) and tuple(sd['upscore8.weight'].shape) == (20, 20, 16, 16)
+    assert len(ck['optim_state_dict']['state']) == 36                       # 18 Conv2d layers x (weight, bias)
+    run = os.path.basename(log)
+    train.main(['-c', '19', '-r', run, '-dir', d, '-n', 'f8_test', '--synthetic', '2', '64', '64', '--workers', '0', '--arch', 'fcn8s',
+                '--precision', 'bf16'])
+    out = capsys.readouterr().out
+    assert 'unseen mean_iu' in out and 'overall mean_iu' in out

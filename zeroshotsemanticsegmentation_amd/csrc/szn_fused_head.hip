@@ -1,9 +1,10 @@
 // szn_fused_head.hip -- the SZN head evaluated from the 1/32-resolution projection map without ever
 // materialising the (B,E,H,W) score: bilinear x32 upsample + crop (models.py:146-147), cosine loss
 // (utils.py:75-102), nearest-class-embedding argmax (utils.py:159-185) and the gradient back to the
-// coarse map, per 32x32 output cell.
+// coarse map, per 32x32 output cell.  The same kernels are instantiated for stride 8 (8x8 cells of the 1/8 map: the last
+// stage of the FCN8s skip head, upscore8 + crop 31).
 //
-// Inside one cell (Y>>5, X>>5 fixed) every pixel's score vector is a blend of the SAME four coarse
+// Inside one cell (Y / S, X / S fixed) every pixel's score vector is a blend of the SAME four coarse
 // vectors C_t with per-pixel bilinear weights w_t, so
 //     s . e_k = sum_t w_t (C_t . e_k)            -> per-cell table G[4][K]
 //     |s|^2   = sum_{t,t'} w_t w_t' (C_t . C_t') -> per-cell Gram matrix Q[4][4]
@@ -20,7 +21,8 @@
 
 namespace {
 
-__device__ __forceinline__ double bil1d(int t) { return 1.0 - fabs((double)t - 31.5) / 32.0; }
+template <int S>
+__device__ __forceinline__ double bil1d(int t) { return 1.0 - fabs((double)t - ((double)S - 0.5)) / (double)S; }
 
 struct FhArgs {
     const float* coarse; const float* embed; const int64_t* target;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void fh_prep_kernel(const float* __restrict__ 
     }
 }
 
-template <int KP>
+template <int KP, int S>
 __global__ __launch_bounds__(256) void fh_cell_kernel(FhArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Ct = sm;                       // [4][E]
@@ -107,21 +109,21 @@ __global__ __launch_bounds__(256) void fh_cell_kernel(FhArgs a) {
     }
     __syncthreads();
 
-    // ---- pixels of this cell: Y in [32I, 32I+32) x X in [32J, 32J+32), image coords y = Y - crop ----
+    // ---- pixels of this cell: Y in [S I, S I + S) x X in [S J, S J + S), image coords y = Y - crop ----
     float bm[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) bm[u] = 0.f;
     double cos_sum = 0.0, cnt = 0.0;
     float* myA = Aw + wave * 4 * KP;
-    for (int q = tid; q < 1024; q += 256) {          // q>>5 = row in cell, q&31 = col: a wave covers 2 rows
-        const int ty = q >> 5, tx = q & 31;
-        const int y = 32 * I + ty - a.crop, x = 32 * J + tx - a.crop;
+    for (int q = tid; q < S * S; q += 256) {         // S = 32: a wave covers 2 rows of the cell; S = 8: wave 0 holds the whole cell
+        const int ty = q / S, tx = q % S;
+        const int y = S * I + ty - a.crop, x = S * J + tx - a.crop;
         const bool inside = (y >= 0 && y < a.H && x >= 0 && x < a.W);
         long lbl = -1;
         float wt[4] = {0.f, 0.f, 0.f, 0.f};
         float aco = 0.f;
         if (inside) {
-            const double fy1 = bil1d(ty), fy0 = bil1d(ty + 32), fx1 = bil1d(tx), fx0 = bil1d(tx + 32);
+            const double fy1 = bil1d<S>(ty), fy0 = bil1d<S>(ty + S), fx1 = bil1d<S>(tx), fx0 = bil1d<S>(tx + S);
             wt[0] = (float)(fy0 * fx0); wt[1] = (float)(fy0 * fx1); wt[2] = (float)(fy1 * fx0); wt[3] = (float)(fy1 * fx1);
             float ss = 0.f;
 #pragma unroll
@@ -192,6 +194,171 @@ __global__ __launch_bounds__(256) void fh_cell_kernel(FhArgs a) {
     }
 }
 
+// ---- small cells (stride 8): per-POSITION tables instead of per-cell dot products -----------------------------------------------
+// With 8x8 cells a block per cell would spend its time re-deriving G and Q (each coarse vector is a tap of 4 cells).  Both only
+// depend on coarse positions:  D[pos][k] = C_pos . e_k,  N[pos][n] = C_pos . C_nbr for nbr in {self, E, S, SE, SW}; a cell's
+// G[t][k] / Q[t][u] are lookups.  Same chains as fh_cell_kernel (ascending fmaf for D; 64 strided partial chains + xor butterfly
+// for N), so the two paths -- and the CPU restatement -- agree bit for bit.
+template <int KP>
+__global__ __launch_bounds__(256) void fh_tables_kernel(FhArgs a, float* __restrict__ D, float* __restrict__ N) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];            // [4 waves][E]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long npos = (long)a.B * a.h * a.w;
+    const long pos = (long)blockIdx.x * 4 + wave;
+    const bool ok = pos < npos;
+    const long p = ok ? pos : 0;
+    const int b = (int)(p / (a.h * a.w)), r = (int)(p % (a.h * a.w));
+    const int i = r / a.w, j = r % a.w;
+    const float* cv = a.coarse + (size_t)p * a.ldc + a.c0;
+    float* Cs = sm + wave * a.E;
+    for (int c = lane; c < a.E; c += 64) Cs[c] = cv[c];
+    __syncthreads();
+    const float* embT = a.ws_f;
+    if (ok && lane < KP) {
+        float g = 0.f;
+        for (int c = 0; c < a.E; ++c) g = fmaf(Cs[c], embT[(size_t)c * KP + lane], g);
+        D[(size_t)pos * KP + lane] = g;
+    }
+    const int di[5] = {0, 0, 1, 1, 1}, dj[5] = {0, 1, 0, 1, -1};
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {
+        const int ni = i + di[n], nj = j + dj[n];
+        float q = 0.f;
+        if (ni < a.h && nj >= 0 && nj < a.w) {
+            const float* nv = a.coarse + (((size_t)b * a.h + ni) * a.w + nj) * a.ldc + a.c0;
+            for (int c = lane; c < a.E; c += 64) q = fmaf(Cs[c], nv[c], q);
+        }
+        q = wave_sum(q);
+        if (ok && lane == 0) N[(size_t)pos * 8 + n] = q;
+    }
+}
+
+// one wave per cell (S * S <= 64 pixels), four cells per block; same per-pixel arithmetic and the same outputs as fh_cell_kernel
+template <int KP, int S>
+__global__ __launch_bounds__(256) void fh_cell_tab_kernel(FhArgs a, const float* __restrict__ D, const float* __restrict__ N) {
+    static_assert(S * S <= 64, "one wave per cell");
+    __shared__ float Gs[4][4 * KP];
+    __shared__ float Qs[4][16];
+    __shared__ float As[4][4 * KP];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cells_w = a.w + 1, cells = (a.h + 1) * cells_w;
+    const long ncell = (long)a.B * cells;
+    const long cid = (long)blockIdx.x * 4 + wave;
+    const bool ok = cid < ncell;
+    const long cc = ok ? cid : 0;
+    const int b = (int)(cc / cells), cell = (int)(cc % cells);
+    const int I = cell / cells_w, J = cell % cells_w;
+    const float* en = a.ws_f + (size_t)a.E * KP;
+    const float* ent = en + KP;
+    float* G = Gs[wave];
+    float* Q = Qs[wave];
+    float* myA = As[wave];
+    long tp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ci = I - 1 + (t >> 1), cj = J - 1 + (t & 1);
+        tp[t] = (ci >= 0 && ci < a.h && cj >= 0 && cj < a.w) ? ((long)b * a.h + ci) * a.w + cj : -1;
+    }
+    if (lane < KP) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            G[t * KP + lane] = (tp[t] >= 0) ? D[(size_t)tp[t] * KP + lane] : 0.f;
+            myA[t * KP + lane] = 0.f;
+        }
+    }
+    if (lane < 16) {
+        const int t = min(lane >> 2, lane & 3), u = max(lane >> 2, lane & 3);
+        // (t, u) -> neighbour slot of the LOWER tap: self, E, S, SE | (1,2) SW, (1,3) S | (2,3) E
+        const int slot = (t == u) ? 0 : (t == 0 ? u : (t == 1 ? (u == 2 ? 4 : 2) : 1));
+        const long pt = (t == 0) ? tp[0] : (t == 1) ? tp[1] : (t == 2) ? tp[2] : tp[3];
+        const long pu = (u == 0) ? tp[0] : (u == 1) ? tp[1] : (u == 2) ? tp[2] : tp[3];
+        Q[lane] = (pt >= 0 && pu >= 0) ? N[(size_t)pt * 8 + slot] : 0.f;
+    }
+    __syncthreads();
+
+    float bm[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bm[u] = 0.f;
+    double cos_sum = 0.0, cnt = 0.0;
+    {
+        const int q = lane;
+        const int ty = q / S, tx = q % S;
+        const int y = S * I + ty - a.crop, x = S * J + tx - a.crop;
+        const bool inside = ok && q < S * S && (y >= 0 && y < a.H && x >= 0 && x < a.W);
+        long lbl = -1;
+        float wt[4] = {0.f, 0.f, 0.f, 0.f};
+        float aco = 0.f;
+        if (inside) {
+            const double fy1 = bil1d<S>(ty), fy0 = bil1d<S>(ty + S), fx1 = bil1d<S>(tx), fx0 = bil1d<S>(tx + S);
+            wt[0] = (float)(fy0 * fx0); wt[1] = (float)(fy0 * fx1); wt[2] = (float)(fy1 * fx0); wt[3] = (float)(fy1 * fx1);
+            float ss = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ss = fmaf(wt[t] * wt[u], Q[t * 4 + u], ss);
+            const float sn = sqrtf(ss);
+            const size_t pix = ((size_t)b * a.H + y) * a.W + x;
+            lbl = a.target ? a.target[pix] : -1;
+            if (a.pred) {
+                int best = 0;
+                float bv = 0.f;
+                for (int k = 0; k < a.K; ++k) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) d = fmaf(wt[t], G[t * KP + k], d);
+                    const float sim = d / (sn * en[k]);
+                    if (k == 0 || sim > bv) { bv = sim; best = k; }
+                }
+                a.pred[pix] = best;
+            }
+            if (lbl >= 0) {
+                const int kl = lbl < a.K ? (int)lbl : 0;
+                float d = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d = fmaf(wt[t], G[t * KP + kl], d);
+                const float nt = ent[kl];
+                const float cosv = d / (sn * nt);
+                cos_sum += (double)cosv;
+                cnt += 1.0;
+                aco = 1.f / (sn * nt);
+                const float bco = cosv / ss;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bm[t * 4 + u] = fmaf(wt[t] * wt[u], bco, bm[t * 4 + u]);
+            }
+        }
+        unsigned long long todo = __ballot(lbl >= 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const int kl = (int)__shfl((int)(lbl < a.K ? lbl : 0), src, 64);
+            const bool mine = (lbl >= 0) && ((int)(lbl < a.K ? lbl : 0) == kl);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float s = wave_sum(mine ? wt[t] * aco : 0.f);
+                if (lane == 0) myA[t * KP + kl] += s;
+            }
+            todo &= ~__ballot(mine);
+        }
+    }
+    float bs[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bs[u] = wave_sum(bm[u]);
+    cos_sum = wave_sum_d(cos_sum); cnt = wave_sum_d(cnt);
+    __syncthreads();
+    if (!ok) return;
+    float* wc = a.ws_f + ws_cell_off(a.E, KP) + (size_t)cid * ws_cell_stride(KP);
+    for (int i = lane; i < 4 * KP; i += 64) wc[i] = myA[i];
+    if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wc[4 * KP + u] = bs[u];
+        a.part[(size_t)cid * 2] = cos_sum;
+        a.part[(size_t)cid * 2 + 1] = cnt;
+    }
+}
+
 // loss = mean_b (N_b - S_b)/N_b ; stats[b] = {S_b, N_b}
 __global__ void fh_finalize_kernel(const double* __restrict__ part, int B, int cells, float* __restrict__ loss,
                                    float* __restrict__ stats) {
@@ -234,13 +401,15 @@ __global__ __launch_bounds__(256) void fh_gather_kernel(const float* __restrict_
         }
     }
     __syncthreads();
+    // the class term is linear in A: sum the four cells' rows first, one pass over the K embeddings instead of four
+    if (threadIdx.x < 64) Al[0][threadIdx.x] = (threadIdx.x < KP) ? (Al[0][threadIdx.x] + Al[1][threadIdx.x]) + (Al[2][threadIdx.x] + Al[3][threadIdx.x]) : 0.f;
+    __syncthreads();
     const float scale = 1.f / ((float)B * stats[2 * b + 1]);
     for (int c = threadIdx.x; c < E; c += 256) {
         float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(-Al[0][k], embed[(size_t)k * E + c], acc);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            float au = 0.f;
-            for (int k = 0; k < K; ++k) au = fmaf(Al[u][k], embed[(size_t)k * E + c], au);
             float bu = 0.f;
             const int I = i + 1 - (u >> 1), J = j + 1 - (u & 1);
 #pragma unroll
@@ -249,7 +418,7 @@ __global__ __launch_bounds__(256) void fh_gather_kernel(const float* __restrict_
                 if (ci >= 0 && ci < h && cj >= 0 && cj < w)
                     bu = fmaf(Bl[u][t2], coarse[(((size_t)b * h + ci) * w + cj) * ldc + c0 + c], bu);
             }
-            acc += bu - au;
+            acc += bu;
         }
         elem<T>::st(dcoarse + ((size_t)pos) * ldc + c0 + c, acc * scale);
     }
@@ -265,17 +434,21 @@ extern "C" size_t szn_fused_head_workspace_bytes(int B, int h, int w, int E, int
     const size_t cells = (size_t)B * (h + 1) * (w + 1);
     size_t fl = ws_cell_off(E, KP) + cells * ws_cell_stride(KP);
     fl = (fl + 1) / 2 * 2;                                   // keep the double region 8-B aligned
-    return fl * sizeof(float) + cells * 2 * sizeof(double);
+    // + the per-position tables of the small-cell path (D [pos][KP], N [pos][8])
+    return fl * sizeof(float) + cells * 2 * sizeof(double) + (size_t)B * h * w * (KP + 8) * sizeof(float);
 }
 
-extern "C" int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
-                              const float* coarse, const float* embed, const int64_t* target, float* loss, float* stats,
-                              int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace, szn_stream_t stream) {
+extern "C" int szn_fused_head_strided(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
+                                      const float* coarse, const float* embed, const int64_t* target, float* loss,
+                                      float* stats, int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace,
+                                      szn_stream_t stream) {
+    if (stride != 32 && stride != 8) SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head: stride %d (32 and 8 are built)", stride);
     if (!coarse || !embed || !workspace || B <= 0 || h <= 0 || w <= 0 || E <= 0 || c0 < 0 || ldc < c0 + E || H <= 0 ||
         W <= 0 || crop < 0 || K <= 0)
         SZN_FAIL(SZN_ERR_ARG, "fused_head: bad argument");
     if (K > 64) SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head: K=%d > 64", K);
-    if (H + crop > 32 * h + 32 || W + crop > 32 * w + 32) SZN_FAIL(SZN_ERR_ARG, "fused_head: crop window exceeds the deconv output");
+    if (H + crop > stride * h + stride || W + crop > stride * w + stride)
+        SZN_FAIL(SZN_ERR_ARG, "fused_head: crop window exceeds the deconv output");
     if ((target == nullptr) != (loss == nullptr) || (loss && !stats)) SZN_FAIL(SZN_ERR_ARG, "fused_head: target/loss/stats go together");
     if (dcoarse && !target) SZN_FAIL(SZN_ERR_ARG, "fused_head: dcoarse needs target");
     if (((uintptr_t)workspace) & 15) SZN_FAIL(SZN_ERR_ARG, "fused_head: workspace must be 16-B aligned");
@@ -286,6 +459,8 @@ extern "C" int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H
     size_t fl = ws_cell_off(E, KP) + (size_t)B * cells * ws_cell_stride(KP);
     fl = (fl + 1) / 2 * 2;
     double* part = (double*)(ws_f + fl);
+    float* tabD = (float*)(part + (size_t)B * cells * 2);
+    float* tabN = tabD + (size_t)B * h * w * KP;
     hipLaunchKernelGGL(fh_prep_kernel, dim3(szn_div_up((long)E * KP, 256)), dim3(256), 0, st, embed, ws_f, E, K, KP);
     SZN_CHECK_LAUNCH("fh_prep_kernel");
     FhArgs a;
@@ -297,10 +472,17 @@ extern "C" int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H
     if (lds > 150 * 1024) SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head: E=%d too large for LDS", E);
 #define SZN_FH_LAUNCH(KPV)                                                                                           \
     do {                                                                                                             \
-        auto kern = fh_cell_kernel<KPV>;                                                                             \
-        if (lds > 48 * 1024)                                                                                         \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(kern, dim3(B * cells), dim3(256), lds, st, a);                                            \
+        if (stride == 8) {                                                                                           \
+            hipLaunchKernelGGL(fh_tables_kernel<KPV>, dim3((unsigned)(((long)B * h * w + 3) / 4)), dim3(256),        \
+                               (size_t)4 * E * sizeof(float), st, a, tabD, tabN);                                    \
+            hipLaunchKernelGGL((fh_cell_tab_kernel<KPV, 8>), dim3((unsigned)(((long)B * cells + 3) / 4)), dim3(256), 0, st, a,  \
+                               (const float*)tabD, (const float*)tabN);                                              \
+        } else {                                                                                                     \
+            auto kern = fh_cell_kernel<KPV, 32>;                                                                     \
+            if (lds > 48 * 1024)                                                                                     \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL(kern, dim3(B * cells), dim3(256), lds, st, a);                                        \
+        }                                                                                                            \
     } while (0)
     if (KP == 24) SZN_FH_LAUNCH(24);
     else if (KP == 40) SZN_FH_LAUNCH(40);
@@ -326,4 +508,11 @@ extern "C" int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H
         SZN_CHECK_LAUNCH("fh_gather_kernel");
     }
     return SZN_OK;
+}
+
+extern "C" int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
+                              const float* coarse, const float* embed, const int64_t* target, float* loss, float* stats,
+                              int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace, szn_stream_t stream) {
+    return szn_fused_head_strided(32, B, h, w, E, ldc, c0, H, W, crop, K, coarse, embed, target, loss, stats, pred, dcoarse_dtype,
+                                  dcoarse, workspace, stream);
 }

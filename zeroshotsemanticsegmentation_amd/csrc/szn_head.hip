@@ -601,7 +601,8 @@ int launch_up_bwd(int B, int h, int w, int E, int ldc, int c0, int H, int W, int
     int csplit = (1536 + B * h - 1) / (B * h);
     if (csplit < 1) csplit = 1;
     if (csplit > E) csplit = E;
-    const int cper = (E + csplit - 1) / csplit;
+    int cper = (E + csplit - 1) / csplit;
+    if (cper > 32) cper = 32;            // bounds the LDS footprint (occupancy) when B * h alone already fills the chip (stride 8)
     csplit = (E + cper - 1) / cper;
     const size_t lds = (size_t)2 * cper * (w + 1) * sizeof(float);
     if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "up_bwd: coarse row too wide for LDS (w = %d)", w);

@@ -592,6 +592,7 @@ class FCN32s(nn.Module):
                 mod.weight.data = mod.weight.data.contiguous(memory_format=torch.channels_last)
         object.__setattr__(self, "_engine", _Engine(self))
         object.__setattr__(self, "_last_ctx", None)
+        object.__setattr__(self, "_last_pred", None)
 
     def _initialize_weights(self):
         # only the transposed convolutions are (re)initialised -- bilinear kernels (models.py:102-112)
@@ -704,7 +705,7 @@ class FCN32s(nn.Module):
 # backbone -- score_pool3 Conv2d(256,E,1), score_pool4 Conv2d(512,E,1), upscore2 / upscore_pool4 ConvTranspose2d(E,E,4,stride 2),
 # upscore8 ConvTranspose2d(E,E,16,stride 8), all transposed convolutions bias-free with the fixed bilinear kernel
 # (models.py:11-24,109-112 initialise them that way and train.py:324-327 never updates them), crops 5 / 9 / 31.  PARITY UNPINNED:
-# the checker is oracle/torch_ref.FCN8sTorch, a torch-CPU restatement of that public definition, not reference output.
+# the checker the tests use is a torch-CPU restatement of that public definition (FCN8sTorch), not reference output.
 CROP_POOL4, CROP_POOL3, CROP_UP8 = 5, 9, 31
 
 
@@ -798,6 +799,35 @@ class _Up8Crop(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _FusedHead8(torch.autograd.Function):
+    """upscore8 + crop + cosine loss + nearest-embedding prediction straight from the 1/8 fused map (szn_fused_head_strided,
+    8x8 cells): the (B,E,H,W) score and its gradient never exist in HBM.  forward -> loss (0-dim); the prediction is left in
+    model._last_pred; backward hands back d loss / d map, which the kernel produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, model, x, emb, target, H, W, want_grad):
+        x = x.contiguous()
+        B, h, w, ld = x.shape
+        K, E = emb.shape
+        dev = x.device
+        pred = torch.empty(B, H, W, dtype=torch.int64, device=dev)
+        ws = torch.empty(L.load().szn_fused_head_workspace_bytes(B, h, w, E, K), dtype=torch.uint8, device=dev)
+        loss = stats = dx = None
+        if target is not None:
+            loss, stats = torch.empty(1, device=dev), torch.empty(B, 2, device=dev)
+            if want_grad:
+                dx = torch.zeros(B, h, w, ld, device=dev, dtype=torch.float32)
+        L.call("szn_fused_head_strided", 8, B, h, w, E, ld, 0, H, W, CROP_UP8, K, L.ptr(x), L.ptr(emb), L.ptr(target), L.ptr(loss),
+               L.ptr(stats), L.ptr(pred), L.SZN_F32, L.ptr(dx), L.ptr(ws), L.stream_ptr())
+        ctx.dx = dx
+        model._last_pred = pred
+        return loss.reshape(()) if loss is not None else x.new_zeros(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, ctx.dx * g, None, None, None, None, None
+
+
 class FCN8s(FCN32s):
     """FCN8s skip architecture on the FCN32s trunk (see the note above: public pytorch-fcn definition, parity unpinned).
     state_dict keys follow pytorch-fcn's FCN8s: the trunk + score_fr, score_pool3, score_pool4, upscore2, upscore8,
@@ -833,23 +863,28 @@ class FCN8s(FCN32s):
         self._engine.mark_dirty()
         return self
 
-    def _run(self, x, mode, train, masks):
+    def _fuse(self, x, train, masks):
+        """-> (coarse (B,h,w,CP) at 1/32, fused map (B,h8,w8,CP) fp32 at 1/8: upscore_pool4(upscore2(score_fr) + score_pool4c)
+        + score_pool3c)"""
         params = [p for _, p in self.named_parameters()]
         coarse, pool3, pool4 = _Backbone8.apply(self, x, train, masks, *params)
+        up2 = _Up2.apply(coarse)                                                           # upscore2
+        sp4 = _SkipScore.apply(self, pool4, self.score_pool4.weight, self.score_pool4.bias)
+        n, m_ = up2.shape[1:3]
+        fuse4 = up2 + sp4[:, CROP_POOL4:CROP_POOL4 + n, CROP_POOL4:CROP_POOL4 + m_, :]
+        up4 = _Up2.apply(fuse4)                                                            # upscore_pool4
+        sp3 = _SkipScore.apply(self, pool3, self.score_pool3.weight, self.score_pool3.bias)
+        n, m_ = up4.shape[1:3]
+        return coarse, up4 + sp3[:, CROP_POOL3:CROP_POOL3 + n, CROP_POOL3:CROP_POOL3 + m_, :]
+
+    def _run(self, x, mode, train, masks):
         f = s = None
         if mode in ('fcn', 'both'):
-            H, W = x.shape[2:]
-            up2 = _Up2.apply(coarse)                                                       # upscore2
-            sp4 = _SkipScore.apply(self, pool4, self.score_pool4.weight, self.score_pool4.bias)
-            n, m_ = up2.shape[1:3]
-            if sp4.shape[1] < CROP_POOL4 + n or sp4.shape[2] < CROP_POOL4 + m_:
-                raise L.SznError("FCN8s: pool4 map %s too small for the %dx%d upscore2 output" % (tuple(sp4.shape[1:3]), n, m_))
-            fuse4 = up2 + sp4[:, CROP_POOL4:CROP_POOL4 + n, CROP_POOL4:CROP_POOL4 + m_, :]
-            up4 = _Up2.apply(fuse4)                                                        # upscore_pool4
-            sp3 = _SkipScore.apply(self, pool3, self.score_pool3.weight, self.score_pool3.bias)
-            n, m_ = up4.shape[1:3]
-            fuse3 = up4 + sp3[:, CROP_POOL3:CROP_POOL3 + n, CROP_POOL3:CROP_POOL3 + m_, :]
-            f = _Up8Crop.apply(fuse3, self.n_class, H, W)                                  # upscore8 + crop
+            coarse, fuse3 = self._fuse(x, train, masks)
+            f = _Up8Crop.apply(fuse3, self.n_class, x.shape[2], x.shape[3])                # upscore8 + crop
+        else:
+            params = [p for _, p in self.named_parameters()]
+            coarse, _, _ = _Backbone8.apply(self, x, train, masks, *params)
         if mode in ('seenmask', 'both'):
             s = _SeenmaskUpscore.apply(self, coarse, self.seenmask_upscore.weight)
         return f, s
@@ -860,19 +895,32 @@ class FCN8s(FCN32s):
         f, s = self._run(x, mode, self.training, dropout_masks)
         return f if mode == 'fcn' else (s if mode == 'seenmask' else (f, s))
 
+    def _emb(self, embeddings, dev):
+        emb = torch.as_tensor(embeddings).to(dev, torch.float32).contiguous()
+        if emb.shape[1] != self.n_class:
+            raise L.SznError("embedding dimension %d != model n_class %d" % (emb.shape[1], self.n_class))
+        if emb.shape[0] > 64:
+            raise L.SznError("the fused head holds at most 64 classes, got %d: use forward() + utils" % emb.shape[0])
+        return emb
+
+    def embed_loss(self, x, embeddings, target, dropout_masks=None):
+        """training-time fused head: -> (cosine loss with autograd history, pred (B,H,W) int64).  Same numbers as
+        utils.cosine_loss(self(x), target, embeddings) / utils.infer_lbl_device up to rounding order, without the
+        (B,E,H,W) score or its gradient in HBM."""
+        emb = self._emb(embeddings, x.device)
+        _, fuse3 = self._fuse(x, self.training, dropout_masks)
+        tgt = target.to(device=x.device, dtype=torch.int64).contiguous()
+        loss = _FusedHead8.apply(self, fuse3, emb, tgt, x.shape[2], x.shape[3], torch.is_grad_enabled())
+        return loss, self._last_pred
+
     def embed_predict(self, x, embeddings, target=None):
-        """forward + cosine loss + nearest-embedding prediction through the materialised score (the fused-from-coarse head is
-        built for the x32 geometry only) -> (loss or None, pred (B,H,W) int64 on the device)"""
-        from . import utils
+        """inference-time fused head -> (loss 0-dim tensor or None, pred (B,H,W) int64 device tensor); see FCN32s.embed_predict"""
         with torch.no_grad():
-            f, _ = self._run(x.detach(), 'fcn', False, None)
-            emb = torch.as_tensor(embeddings).to(f.device, torch.float32).contiguous()
-            if emb.shape[1] != self.n_class:
-                raise L.SznError("embedding dimension %d != model n_class %d" % (emb.shape[1], self.n_class))
-            loss = None
-            if target is not None:
-                loss = utils.cosine_loss(f, target.to(f.device), emb)
-            return loss, utils.infer_lbl_device(f, emb)
+            emb = self._emb(embeddings, x.device)
+            _, fuse3 = self._fuse(x.detach(), False, None)
+            tgt = None if target is None else target.to(device=x.device, dtype=torch.int64).contiguous()
+            loss = _FusedHead8.apply(self, fuse3, emb, tgt, x.shape[2], x.shape[3], False)
+            return (loss if target is not None else None), self._last_pred
 
 
 def VGG16(pretrained=False, data_dir='data'):

@@ -56,6 +56,9 @@ def build_parser():
     p.add_argument('--synthetic', type=int, nargs=3, metavar=('N', 'H', 'W'), help='synthetic dataset: N images of HxW')
     p.add_argument('--batch-size', type=int, default=1)
     p.add_argument('--precision', choices=['fp32', 'bf16', 'fp16'], default='fp32')
+    p.add_argument('--arch', choices=['fcn32s', 'fcn8s'], default='fcn32s',
+                   help="fcn32s = the reference's only backbone (train.py:103,105); fcn8s = the public FCN8s skip head "
+                        "(not in the reference: BASELINE north_star wording, parity unpinned)")
     p.add_argument('--workers', type=int, default=2, help='DataLoader worker processes per loader (0 = load in the main process)')
     return p
 
@@ -248,7 +251,7 @@ def main(argv=None):
                                                                  len(val_loader)))
 
     # 2. model
-    model = models.FCN32s(n_class=cfg['embed_dim'] if cfg['embed_dim'] else 21)
+    model = {'fcn32s': models.FCN32s, 'fcn8s': models.FCN8s}[args.arch](n_class=cfg['embed_dim'] if cfg['embed_dim'] else 21)
     start_epoch, start_iteration, checkpoint = 0, 0, None
     if cfg['load_fcn_path']:
         checkpoint = torch.load(osp.join(args.data_dir, 'logs', cfg['load_fcn_path'], 'best'), map_location='cpu', weights_only=False)

@@ -209,6 +209,22 @@ class Trainer(object):
                 metrics = utils._hist_to_metrics(packed[1:].reshape(self.n_class, self.n_class))
                 gsum = float('nan')                  # not read back on this path (a host sync per iteration for a debug print)
                 ssum = float('nan')                  # the (B,E,H,W) score is never materialised on this path
+            elif (hasattr(self.model, 'embed_loss') and self._fused_step and self.pixel_embeddings and self.loss_func == "cos"
+                  and not self.forced_unseen and self.embeddings.shape[0] <= 64):
+                # FCN8s: autograd chain with the fused-from-1/8-map head (no (n,E,h,w) score), per-tensor fused optimizer
+                data, target, _ = self._unpack(data, target)
+                loss, pred = self.model.embed_loss(data, self.embeddings, target)
+                self.optim.zero_grad()
+                loss.backward()
+                _engine.allreduce_param_grads([p for g in self.optim.param_groups for p in g['params']])
+                self.optim.step()
+                hist = utils.confusion_hist_device(target, pred, self.n_class)[0]
+                packed = torch.cat([loss.detach().reshape(1).double(), hist.reshape(-1).double()]).cpu().numpy()
+                lossv = float(packed[0])
+                if np.isnan(lossv):
+                    raise ValueError('loss is nan while training')
+                metrics = utils._hist_to_metrics(packed[1:].reshape(self.n_class, self.n_class))
+                gsum = ssum = float('nan')
             else:
                 score, loss, lbl_pred, lbl_true = self.forward(data, target)
                 self.optim.zero_grad()
