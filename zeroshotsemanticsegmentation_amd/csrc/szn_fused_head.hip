@@ -359,19 +359,30 @@ __global__ __launch_bounds__(256) void fh_cell_tab_kernel(FhArgs a, const float*
     }
 }
 
-// loss = mean_b (N_b - S_b)/N_b ; stats[b] = {S_b, N_b}
-__global__ void fh_finalize_kernel(const double* __restrict__ part, int B, int cells, float* __restrict__ loss,
-                                   float* __restrict__ stats) {
-    const int lane = threadIdx.x;
-    double acc = 0.0;
-    for (int b = 0; b < B; ++b) {
-        double s = 0.0, n = 0.0;
-        for (int k = lane; k < cells; k += 64) { s += part[((size_t)b * cells + k) * 2]; n += part[((size_t)b * cells + k) * 2 + 1]; }
-        s = wave_sum_d(s); n = wave_sum_d(n);
-        if (lane == 0) { stats[2 * b] = (float)s; stats[2 * b + 1] = (float)n; }
-        acc += (n - s) / n;
+// loss = mean_b (N_b - S_b)/N_b ; stats[b] = {S_b, N_b}.  One block per image sums its cells (fixed order: 256 strided double
+// chains, wave butterflies, then the four wave totals), a single wave combines the images.
+__global__ __launch_bounds__(256) void fh_image_sums_kernel(const double* __restrict__ part, int cells, float* __restrict__ stats,
+                                                            double* __restrict__ sums) {
+    __shared__ double red[4][2];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0, n = 0.0;
+    for (int k = threadIdx.x; k < cells; k += 256) { s += part[((size_t)b * cells + k) * 2]; n += part[((size_t)b * cells + k) * 2 + 1]; }
+    s = wave_sum_d(s); n = wave_sum_d(n);
+    if (lane == 0) { red[wave][0] = s; red[wave][1] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double st = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]), nt = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        sums[2 * b] = st; sums[2 * b + 1] = nt;
+        stats[2 * b] = (float)st; stats[2 * b + 1] = (float)nt;
     }
-    if (lane == 0) loss[0] = (float)(acc / B);
+}
+
+__global__ void fh_finalize_kernel(const double* __restrict__ sums, int B, float* __restrict__ loss) {
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int b = 0; b < B; ++b) acc += (sums[2 * b + 1] - sums[2 * b]) / sums[2 * b + 1];
+        loss[0] = (float)(acc / B);
+    }
 }
 
 template <typename T>
@@ -435,7 +446,7 @@ extern "C" size_t szn_fused_head_workspace_bytes(int B, int h, int w, int E, int
     size_t fl = ws_cell_off(E, KP) + cells * ws_cell_stride(KP);
     fl = (fl + 1) / 2 * 2;                                   // keep the double region 8-B aligned
     // + the per-position tables of the small-cell path (D [pos][KP], N [pos][8])
-    return fl * sizeof(float) + cells * 2 * sizeof(double) + (size_t)B * h * w * (KP + 8) * sizeof(float);
+    return fl * sizeof(float) + (cells + B) * 2 * sizeof(double) + (size_t)B * h * w * (KP + 8) * sizeof(float);
 }
 
 extern "C" int szn_fused_head_strided(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
@@ -459,7 +470,8 @@ extern "C" int szn_fused_head_strided(int stride, int B, int h, int w, int E, in
     size_t fl = ws_cell_off(E, KP) + (size_t)B * cells * ws_cell_stride(KP);
     fl = (fl + 1) / 2 * 2;
     double* part = (double*)(ws_f + fl);
-    float* tabD = (float*)(part + (size_t)B * cells * 2);
+    double* sums = part + (size_t)B * cells * 2;             // per-image {sum cos, count}
+    float* tabD = (float*)(sums + 2 * (size_t)B);
     float* tabN = tabD + (size_t)B * h * w * KP;
     hipLaunchKernelGGL(fh_prep_kernel, dim3(szn_div_up((long)E * KP, 256)), dim3(256), 0, st, embed, ws_f, E, K, KP);
     SZN_CHECK_LAUNCH("fh_prep_kernel");
@@ -490,7 +502,8 @@ extern "C" int szn_fused_head_strided(int stride, int B, int h, int w, int E, in
 #undef SZN_FH_LAUNCH
     SZN_CHECK_LAUNCH("fh_cell_kernel");
     if (loss) {
-        hipLaunchKernelGGL(fh_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)part, B, cells, loss, stats);
+        hipLaunchKernelGGL(fh_image_sums_kernel, dim3(B), dim3(256), 0, st, (const double*)part, cells, stats, sums);
+        hipLaunchKernelGGL(fh_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)sums, B, loss);
         SZN_CHECK_LAUNCH("fh_finalize_kernel");
     }
     if (dcoarse) {
