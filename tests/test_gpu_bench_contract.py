@@ -46,16 +46,17 @@ def test_bench_line_phase2():
     assert KEYS <= set(d) and d["value"] > 0 and "configs[2]" in d["config"]["workload"]
 
 
-def test_bench_two_ranks_code_path_on_one_gpu():
+@pytest.mark.parametrize("arch", ["fcn32s", "fcn8s"])
+def test_bench_two_ranks_code_path_on_one_gpu(arch):
     """the N > 1 branch of bench.py exactly as the driver launches it (python -m torch.distributed.run ... bench.py --gpus 2),
     both ranks on device 0 over gloo (SZN_TEST_ONE_GPU=1): barrier + max-over-ranks timing, rank-0-only JSON line, whole-job
-    value = 2 x the per-rank pixels"""
+    value = 2 x the per-rank pixels (fcn8s: the autograd path with engine.allreduce_param_grads)"""
     env = dict(os.environ, SZN_TEST_ONE_GPU="1")
-    port = 29900 + os.getpid() % 1000
+    port = 29900 + os.getpid() % 1000 + (500 if arch == "fcn8s" else 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-                          "--warmup", "1", "--batch", "1", "--size", "96"], capture_output=True, text=True, timeout=900, cwd=ROOT,
-                         env=env)
+                          "--warmup", "1", "--batch", "1", "--size", "96", "--arch", arch], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
