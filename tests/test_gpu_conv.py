@@ -43,6 +43,8 @@ CASES = [
     (1, 181, 190, 64, 128, 3, 1),        # regw <COG 4, CIG 1>: 8-row tiles
     (1, 190, 181, 128, 64, 3, 1),        # regw <2, 2>: cin halves in partner waves, exchange through LDS
     (1, 183, 187, 128, 128, 3, 1),       # regw <4, 2>: 4-row tiles
+    (3, 150, 151, 64, 256, 3, 1),        # row-resident 3x3 wide kernel (bf16): one cin chunk, tiles run across rows and images
+    (1, 260, 258, 256, 256, 3, 1),       # ... four cin chunks, forward and dgrad, ragged last tile
 ]
 
 
@@ -54,6 +56,8 @@ EXPECT_BF16 = {
     (1, 190, 181, 128, 64, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
     (1, 183, 187, 128, 128, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
     (1, 260, 260, 64, 300, 1, 0): ("conv_igemm_wide", None, None),
+    (3, 150, 151, 64, 256, 3, 1): ("conv3x3_wide_rows", None, None),
+    (1, 260, 258, 256, 256, 3, 1): ("conv3x3_wide_rows", "conv3x3_wide_rows", None),
     (1, 9, 9, 256, 512, 7, 0): (None, None, "conv_wgrad_wide"),
     (2, 7, 6, 448, 512, 5, 1): (None, None, "conv_wgrad_wide"),
     (2, 8, 8, 512, 128, 7, 0): ("splitk_epilogue", None, None),

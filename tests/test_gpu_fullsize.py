@@ -2,7 +2,7 @@
 
 The oracle finishes a full-size forward in seconds, so (a) compares the fp32 HIP forward against it directly.  The
 rest are size-independent properties that must hold bit-exactly, run on the real BASELINE layer shapes so that every
-specialised kernel (conv3x3_regw, conv_igemm_wide, conv_wgrad_taps, conv_wgrad_wide, split-K) is exercised where the
+specialised kernel (conv3x3_regw, conv_igemm_wide, conv3x3_wide_rows, conv_wgrad_taps, conv_wgrad_wide, split-K) is exercised where the
 bench exercises it:
   (b) scaling by a power of two commutes with every conv kernel (bf16 operands, fp32 accumulation, bf16 rounding:
       conv(2x) == 2 conv(x), dgrad(2 dout) == 2 dgrad(dout), wgrad(x, 2 dout) == 2 wgrad(x, dout)), and the result of a
@@ -66,8 +66,8 @@ def test_fullsize_fp32_forward_matches_oracle():
 # name: (Hi, Ci, Co, K, pad) at 512x512 input (the bench's layers), expected forward kernel in bf16
 LAYERS = {   # (shape), batch, expected forward kernel (None: a split-K epilogue kernel runs last at this batch)
     "conv1_2": ((710, 64, 64, 3, 1), 2, "conv3x3_regw"), "conv2_1": ((355, 64, 128, 3, 1), 2, "conv3x3_regw"),
-    "conv2_2": ((355, 128, 128, 3, 1), 2, "conv3x3_regw"), "conv3_2": ((178, 256, 256, 3, 1), 4, "conv_igemm_wide"),
-    "conv4_2": ((89, 512, 512, 3, 1), 8, "conv_igemm_wide"), "conv5_1": ((45, 512, 512, 3, 1), 8, "conv_igemm_v2"),
+    "conv2_2": ((355, 128, 128, 3, 1), 2, "conv3x3_regw"), "conv3_2": ((178, 256, 256, 3, 1), 4, "conv3x3_wide_rows"),
+    "conv4_2": ((89, 512, 512, 3, 1), 8, "conv3x3_wide_rows"), "conv5_1": ((45, 512, 512, 3, 1), 8, "conv_igemm_v2"),
     "fc6": ((23, 512, 4096, 7, 0), 8, None), "fc7": ((17, 4096, 4096, 1, 0), 8, "conv_igemm_v2"),
 }
 WGRAD_KERNEL = {"conv1_2": "wgrad_taps_reduce", "conv2_1": "wgrad_taps_reduce", "conv2_2": "wgrad_taps_reduce",

@@ -302,6 +302,174 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
 #endif
 }
 
+// ---- 3x3 / pad 1 / same-size layers (conv3_x .. conv5_x, forward and dgrad): row-resident pixel operand ------------------------
+// For these layers the input pixel of output m under tap (kh, kw) is the FLATTENED pixel m + (kh - 1) Wi + (kw - 1), so the three
+// kw taps of one kernel row read the same 258 consecutive input pixels shifted by one LDS row.  The pixel operand is therefore
+// staged once per (kh, cin chunk) -- 264 x 128 B -- and used for three K steps; only the weights (256 x 128 B) change per step:
+// 43 KiB of LDS-DMA per 8.4 MFLOP step instead of 64 KiB (the fill rate is what bounds conv_igemm_wide, see the header).
+// Pixels whose tap falls outside the image (borders; tiles also run across rows and images) read a real neighbour from the
+// flattened buffer: their fragment is replaced by zeros with a per-lane select (a lane of the pixel fragment holds ONE pixel).
+// K order: (kh, cin chunk, kw).  LDS: pixels 2 x 33 KiB + weights 2 x 32 KiB = 130 KiB.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv3x3_wide_rows(WideArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(T) == 2, "16-bit storage only");
+    constexpr int ES = 2, BM = 256, BN = 256, WNF = 8, NBW = 4;
+    constexpr int AROWS = 264;                              // 256 pixels + 2 halo rows, padded to whole 8-row DMA groups
+    constexpr int ABYTES = AROWS * 128, BBYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // pixels [2][264 x 128 B] | weights [2][256 x 128 B]
+    char* const sA = smem;
+    char* const sB = smem + 2 * ABYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int g = lane >> 4, r16 = lane & 15;
+
+    const int nwg = a.mtiles * a.ntiles;
+    const int lid = xcd_remap_w(blockIdx.x, nwg);
+    const int nt = lid % a.ntiles, mt = lid / a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+
+    const int chunkA = (lane & 7) ^ (lane >> 3);
+    const long npix = (long)a.B * a.Hi * a.Wi;
+    // LDS row r of the pixel buffer <-> flattened input pixel m0 - 1 + (kh - 1) Wi + r.  Wave w fills row groups 4w .. 4w+3,
+    // wave 0 also group 32 (rows 256 .. 263, of which 256 and 257 are used)
+    unsigned voffA[5], voffB[NBW];
+    auto set_kh = [&](int kh) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int row = (i < 4 ? 32 * w + 8 * i : 256) + (lane >> 3);
+            const long p = (long)m0 - 1 + (long)(kh - 1) * a.Wi + row;
+            const bool ok = p >= 0 && p < npix && row < BM + 2;
+            voffA[i] = ok ? (unsigned)((p * a.ldi + chunkA * 8) * ES) : kOOBx;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int n = n0 + (NBW * w + i) * 8 + (lane >> 3);
+        voffB[i] = (n < a.Co) ? (unsigned)(((long)n * 9 * a.Ci + chunkA * 8) * ES) : kOOBx;
+    }
+    // tap validity of the four pixels this lane supplies (pixel fragment j, row r16): bit kh * 3 + kw
+    unsigned vmask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + 16 * j + r16;
+        unsigned mk = 0;
+        if (m < a.M) {
+            const int r = m % a.HoWo;
+            const int oh = r / a.Wo, ow = r - oh * a.Wo;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if ((unsigned)(oh + kh - 1) < (unsigned)a.Hi && (unsigned)(ow + kw - 1) < (unsigned)a.Wi) mk |= 1u << (kh * 3 + kw);
+        }
+        vmask[j] = mk;
+    }
+
+    const int cpt = a.Ci / 64;
+    const int nK = 9 * cpt;
+    // the step being issued FOR (one ahead of the step being computed)
+    int ikh = 0, iic = 0, ikw = 0, igrp = 0, voff_kh = 0;
+    auto issue = [&](int step) {          // loads for `step`: its weights, and -- at kw 1 / 2 -- half of the NEXT group's pixels
+        const int soffB = ((ikh * 3 + ikw) * a.Ci) * ES + iic * 128;
+        char* sb = sB + (step & 1) * BBYTES;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + (NBW * w + i) * 1024), 16, voffB[i], soffB, 0, 0);
+        if (ikw > 0) {
+            // pixels of the group AFTER the one `step` belongs to.  issue(step) runs while step - 1 is being computed: at kw 1 / 2
+            // that is kw 0 / 1 of the same group, so the other pixel buffer (last read by the previous group) is free
+            int nkh = ikh, nic = iic + 1;
+            if (nic == cpt) { nic = 0; ++nkh; }
+            if (nkh < 3) {
+                if (nkh != voff_kh) { set_kh(nkh); voff_kh = nkh; }
+                char* sa = sA + ((igrp + 1) & 1) * ABYTES;
+                const int soffA = nic * 128;
+                if (ikw == 1) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + (32 * w + 0) * 128), 16, voffA[0], soffA, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + (32 * w + 8) * 128), 16, voffA[1], soffA, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + (32 * w + 16) * 128), 16, voffA[2], soffA, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + (32 * w + 24) * 128), 16, voffA[3], soffA, 0, 0);
+                    if (w == 0)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + 256 * 128), 16, voffA[4], soffA, 0, 0);
+                }
+            }
+        }
+        if (++ikw == 3) { ikw = 0; ++igrp; if (++iic == cpt) { iic = 0; ++ikh; } }
+    };
+
+    f32x4_t acc[WNF][4];
+#pragma unroll
+    for (int i = 0; i < WNF; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: the pixels of group 0 (kh = 0, chunk 0) and everything `issue(0)` brings
+    set_kh(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sA + (32 * w + 8 * i) * 128), 16, voffA[i], 0, 0, 0);
+    if (w == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sA + 256 * 128), 16, voffA[4], 0, 0, 0);
+    issue(0);
+
+    const int turn = a.stagger == 2 ? w : (a.stagger ? 2 * (w >> 1) : 0);
+    int ckw = 0, cgrp = 0, ctap_base = 0, cic = 0;       // the step being computed: tap = ctap_base + ckw
+    for (int kc = 0; kc < nK; ++kc) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool fill = kc + 1 < nK;
+        if (fill && turn == 0) issue(kc + 1);
+        const int rsh = (r16 + ckw) & 7;
+        const char* sp = sA + (cgrp & 1) * ABYTES + (wm * 64 + r16 + ckw) * 128;
+        const char* sw = sB + (kc & 1) * BBYTES + (wn * (BN / 2) + r16) * 128;
+        const int tap = ctap_base + ckw;
+        bool keep[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep[j] = (vmask[j] >> tap) & 1u;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int offp = (((4 * s + g) ^ rsh) << 4), offw = (((4 * s + g) ^ (r16 & 7)) << 4);
+            u32x4_t wf[WNF], pf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4_t v = *(const u32x4_t*)(sp + j * 16 * 128 + offp);
+                pf[j].x = keep[j] ? v.x : 0u; pf[j].y = keep[j] ? v.y : 0u; pf[j].z = keep[j] ? v.z : 0u; pf[j].w = keep[j] ? v.w : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + offw);
+#pragma unroll
+            for (int i = 0; i < WNF; ++i) {
+                if (s == 0 && i > 0 && fill && turn == i) issue(kc + 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(wf[i], pf[j], acc[i][j]);
+            }
+        }
+        if (++ckw == 3) { ckw = 0; ++cgrp; if (++cic == cpt) { cic = 0; ctap_base += 3; } }
+    }
+
+    wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, 0);
+#endif
+}
+
+template <typename T>
+int launch_wide_rows(const WideArgs& a, hipStream_t st) {
+    const size_t lds = 2 * 264 * 128 + 2 * 256 * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wide_rows<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_wide_rows<T>), dim3(a.mtiles * a.ntiles), dim3(512), lds, st, a);
+    SZN_CHECK_LAUNCH("conv3x3_wide_rows");
+    return SZN_OK;
+}
+
 template <typename T, int WNF>
 int launch_wide(const WideArgs& a, hipStream_t st) {
     const size_t lds = 2 * (256 + 32 * WNF) * 128;
@@ -353,6 +521,14 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
     a.relu = d->relu; a.out_f32 = d->out_f32; a.HoWo = d->Ho * d->Wo;
+    {
+        static int rows = -1;
+        if (rows < 0) { const char* e = getenv("SZN_WIDE_ROWS"); rows = e ? atoi(e) : 1; }
+        if (rows && bn == 256 && szn_is16(d->dtype) && a.nsplit == 1 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->Hi == d->Ho &&
+            d->Wi == d->Wo && (d->Ci % 64) == 0)
+            return d->dtype == SZN_F16 ? launch_wide_rows<f16_raw>(a, (hipStream_t)stream)
+                                       : launch_wide_rows<bf16_raw>(a, (hipStream_t)stream);
+    }
     if (bn == 320)
         return d->dtype == SZN_F16 ? launch_wide<f16_raw, 10>(a, (hipStream_t)stream) : launch_wide<bf16_raw, 10>(a, (hipStream_t)stream);
     if (d->dtype == SZN_F16) return launch_wide<f16_raw, 8>(a, (hipStream_t)stream);
