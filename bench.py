@@ -13,7 +13,7 @@ drawn from the seen classes), E = 300, bf16 operands / fp32 accumulate / fp32 ma
 is its FCN32s.)
 
 Prints ONE JSON line: metric train_Mpixels_per_sec (whole job) plus
-  roofline      the dominant kernel (conv_igemm_wide: conv3_x / conv4_x forward + dgrad, fc6 GEMMs): algorithmic FLOPs of
+  roofline      the dominant kernel (conv3x3_wide_rows: conv3_x / conv4_x forward + dgrad): algorithmic FLOPs of
                 its launches / their HIP-event-measured duration INSIDE the timed region, against the dense MFMA peak;
                 `traffic` = HBM bytes per launch from the committed PMC passes (source file named; null if none matches)
   kernels       per kernel family, MFMA-class and HBM-class, from 3 extra instrumented steps after the timed region
