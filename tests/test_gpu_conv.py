@@ -45,6 +45,8 @@ CASES = [
     (1, 183, 187, 128, 128, 3, 1),       # regw <4, 2>: 4-row tiles
     (3, 150, 151, 64, 256, 3, 1),        # row-resident 3x3 wide kernel (bf16): one cin chunk, tiles run across rows and images
     (1, 260, 258, 256, 256, 3, 1),       # ... four cin chunks, forward and dgrad, ragged last tile
+    (37, 43, 42, 64, 256, 3, 1),         # ... small maps: every 256-pixel tile crosses image boundaries
+    (1, 3, 25000, 64, 256, 3, 1),        # ... three very long rows: two thirds of the pixels are border pixels in the vertical direction
 ]
 
 
@@ -58,6 +60,8 @@ EXPECT_BF16 = {
     (1, 260, 260, 64, 300, 1, 0): ("conv_igemm_wide", None, None),
     (3, 150, 151, 64, 256, 3, 1): ("conv3x3_wide_rows", None, None),
     (1, 260, 258, 256, 256, 3, 1): ("conv3x3_wide_rows", "conv3x3_wide_rows", None),
+    (37, 43, 42, 64, 256, 3, 1): ("conv3x3_wide_rows", None, None),
+    (1, 3, 25000, 64, 256, 3, 1): ("conv3x3_wide_rows", None, None),
     (1, 9, 9, 256, 512, 7, 0): (None, None, "conv_wgrad_wide"),
     (2, 7, 6, 448, 512, 5, 1): (None, None, "conv_wgrad_wide"),
     (2, 8, 8, 512, 128, 7, 0): ("splitk_epilogue", None, None),
@@ -164,12 +168,15 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     L.call("szn_bias_grad", dt, B * Ho * Wo, Co, d.ldo, L.ptr(doutd), L.ptr(db), 0, L.stream_ptr())
     torch.cuda.synchronize()
     got = dw.cpu().permute(0, 3, 1, 2)
-    assert relerr(got, dw_ref) < tol, ("wgrad", relerr(got, dw_ref))
+    # a weight gradient sums B*Ho*Wo products per entry: the fp32 reduction-order noise (vs torch's own order) grows with the
+    # pixel count (1.1e-5 at 66 k pixels)
+    wtol = tol * (3.0 if (dtype == torch.float32 and B * Ho * Wo > 50000) else 1.0)
+    assert relerr(got, dw_ref) < wtol, ("wgrad", relerr(got, dw_ref))
     assert relerr(db.cpu(), db_ref) < 1e-4, ("bias", relerr(db.cpu(), db_ref))
     # accumulate = 1 adds on top
     L.call("szn_conv2d_wgrad", C.byref(dgd), L.ptr(xd), L.ptr(doutd), L.ptr(dw), 1, L.stream_ptr())
     torch.cuda.synchronize()
-    assert relerr(dw.cpu().permute(0, 3, 1, 2), 2 * dw_ref) < tol
+    assert relerr(dw.cpu().permute(0, 3, 1, 2), 2 * dw_ref) < wtol
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 512, 128, 7, 0), (2, 7, 6, 448, 512, 5, 1), (1, 9, 9, 128, 200, 7, 0),
