@@ -97,6 +97,9 @@ def call_work(name, a):
     if name == "szn_fused_head_strided":
         B, h, w, E, ldc, c0, H, W = a[1:9]
         return "hbm", B * H * W * 16.0 + 2.0 * B * h * w * E * 4.0
+    if name == "szn_pack_weight_dgrad_batch":
+        code, n, _, _, co, k, ci = a[:7]
+        return "hbm", sum(2.0 * co[i] * k[i] * k[i] * ci[i] * _esize(code) for i in range(n))
     if name == "szn_pack_weight_dgrad":
         code, co, kh, kw, ci = a[:5]
         return "hbm", 2.0 * co * kh * kw * ci * _esize(code)

@@ -81,6 +81,10 @@ int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const void* w, cons
 /* wT[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]: the weight image szn_conv2d_dgrad consumes.  */
 int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, const void* w, void* wT,
                           szn_stream_t stream);
+/* the same for n layers in ONE launch (the per-step refresh after the optimizer, train.py:126-133: most layers are a few
+ * tiles and would each pay a dispatch): 16-bit images, square K x K filters, Co and Ci multiples of 64, n <= 24.          */
+int szn_pack_weight_dgrad_batch(int dtype, int n, const void* const* w, void* const* wT, const int* Co, const int* K,
+                                const int* Ci, szn_stream_t stream);
 
 /* d (forward geometry) -> din[B][Hi][Wi][Ci] = conv(dout, wT) with pad' = KH-1-pad; epilogue as
  * above with gate = the forward INPUT activation (ReLU backward) and chan_scale = the dropout

@@ -42,6 +42,7 @@ SIGNATURES = {
     "szn_device_info": (_I, [_I, C.POINTER(DeviceInfo)]),
     "szn_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "szn_pack_weight_dgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
+    "szn_pack_weight_dgrad_batch": (_I, [_I, _I, _P, _P, _P, _P, _P, _P]),
     "szn_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "szn_conv2d_dgrad_gemm_workspace_bytes": (C.c_size_t, [_D]),
     "szn_conv2d_dgrad_gemm": (_I, [_D, _P, _P, _P, _P]),

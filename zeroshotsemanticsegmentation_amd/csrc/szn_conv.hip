@@ -265,6 +265,46 @@ __global__ __launch_bounds__(256) void pack_dgrad16_kernel(const uint16_t* __res
     }
 }
 
+// several layers in one launch (the per-step refresh of every flipped / transposed image: 15 of the 17 launches are a few blocks
+// each and cost their ~4.6 us dispatch floor): block -> (item, ci tile, co tile, tap) through the items' block prefix
+constexpr int kPackMax = 24;
+struct PackItem { const uint16_t* w; uint16_t* wT; int Co, K, Ci, block0; };
+struct PackBatch { PackItem it[kPackMax]; int n; };
+
+__global__ __launch_bounds__(256) void pack_dgrad16_batch_kernel(PackBatch pb) {
+    __shared__ uint16_t tile[64][66];
+    int i = 0;
+    while (i + 1 < pb.n && (int)blockIdx.x >= pb.it[i + 1].block0) ++i;
+    const uint16_t* __restrict__ w = pb.it[i].w;
+    uint16_t* __restrict__ wT = pb.it[i].wT;
+    const int Co = pb.it[i].Co, K = pb.it[i].K, Ci = pb.it[i].Ci;
+    int lb = blockIdx.x - pb.it[i].block0;
+    const int nci = Ci / 64, nco = Co / 64;
+    const int cit = lb % nci; lb /= nci;
+    const int cot = lb % nco;
+    const int tap = lb / nco, kh = tap / K, kw = tap - kh * K;
+    const int co0 = cot * 64, ci0 = cit * 64;
+    const int c8 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = r0 + 32 * p;
+        const uint4 v = *(const uint4*)(w + ((long)((co0 + r) * K + kh) * K + kw) * Ci + ci0 + c8 * 8);
+        uint32_t* d32 = (uint32_t*)&tile[r][c8 * 8];
+        d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
+    }
+    __syncthreads();
+    const int tapT = (K - 1 - kh) * K + (K - 1 - kw);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int ci = r0 + 32 * p;
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (uint32_t)tile[c8 * 8 + 2 * e][ci] | ((uint32_t)tile[c8 * 8 + 2 * e + 1][ci] << 16);
+        *(uint4*)(wT + ((long)(ci0 + ci) * K * K + tapT) * Co + co0 + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
     const char* dout; const char* in; float* dw;
@@ -538,6 +578,28 @@ extern "C" int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, 
     else
         SZN_FAIL(SZN_ERR_ARG, "pack_weight_dgrad: bad dtype %d", dtype);
     SZN_CHECK_LAUNCH("pack_dgrad_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_pack_weight_dgrad_batch(int dtype, int n, const void* const* w, void* const* wT, const int* Co, const int* K,
+                                           const int* Ci, szn_stream_t stream) {
+    if (n <= 0 || !w || !wT || !Co || !K || !Ci) SZN_FAIL(SZN_ERR_ARG, "pack_weight_dgrad_batch: bad argument");
+    if (!szn_is16(dtype)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "pack_weight_dgrad_batch: 16-bit images only (use szn_pack_weight_dgrad)");
+    if (n > kPackMax) SZN_FAIL(SZN_ERR_UNSUPPORTED, "pack_weight_dgrad_batch: at most %d layers per call", kPackMax);
+    PackBatch pb;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!w[i] || !wT[i] || Co[i] <= 0 || K[i] <= 0 || Ci[i] <= 0) SZN_FAIL(SZN_ERR_ARG, "pack_weight_dgrad_batch: bad item %d", i);
+        if ((Co[i] & 63) || (Ci[i] & 63) || (((uintptr_t)w[i] | (uintptr_t)wT[i]) & 15))
+            SZN_FAIL(SZN_ERR_UNSUPPORTED, "pack_weight_dgrad_batch: item %d needs Co, Ci multiples of 64 and 16-B aligned images", i);
+        pb.it[i].w = (const uint16_t*)w[i]; pb.it[i].wT = (uint16_t*)wT[i];
+        pb.it[i].Co = Co[i]; pb.it[i].K = K[i]; pb.it[i].Ci = Ci[i]; pb.it[i].block0 = (int)blocks;
+        blocks += (long)(Ci[i] / 64) * (Co[i] / 64) * K[i] * K[i];
+        if (blocks > 0x7fffffffL) SZN_FAIL(SZN_ERR_UNSUPPORTED, "pack_weight_dgrad_batch: too many tiles");
+    }
+    pb.n = n;
+    hipLaunchKernelGGL(pack_dgrad16_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pb);
+    SZN_CHECK_LAUNCH("pack_dgrad16_batch_kernel");
     return SZN_OK;
 }
 

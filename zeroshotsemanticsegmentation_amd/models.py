@@ -124,6 +124,7 @@ class _Engine(object):
             self._layer_versions = {"_dtype": (dt, dev)}
         lv = self._layer_versions
         st = L.stream_ptr()
+        jobs = []                     # (image, flipped / transposed image, Co, K, Ci) to refresh: one batched launch at the end
         for name, co, ci, k in synth.CONV_LAYERS:
             layer = getattr(m, name)
             ver = (layer.weight.data_ptr(), layer.weight._version, layer.bias.data_ptr(), layer.bias._version,
@@ -145,11 +146,11 @@ class _Engine(object):
             img[name + ".w"] = wc
             if k >= 5:      # fc6: dgrad runs as GEMM + col2im on the plain transpose [k*k*ci][co] (szn_conv2d_dgrad_gemm)
                 wg = torch.empty(k * k * ci, co, device=dev, dtype=dt)
-                L.call("szn_pack_weight_dgrad", code, co, 1, 1, k * k * ci, L.ptr(wc), L.ptr(wg), st)
+                jobs.append((wc, wg, co, 1, k * k * ci))
                 img[name + ".wG"] = wg
                 continue
             wt = torch.empty(ci, k, k, co, device=dev, dtype=dt)
-            L.call("szn_pack_weight_dgrad", code, co, k, k, ci, L.ptr(wc), L.ptr(wt), st)
+            jobs.append((wc, wt, co, k, ci))
             img[name + ".wT"] = wt
         # fused projection head: rows [0,E) = score_fr, [E,E+2) = seenmask_score, zero rows up to CP
         E, CP, F = m.n_class, m.head_width, m.fc7.out_channels
@@ -160,6 +161,7 @@ class _Engine(object):
             img["up.w"] = m.seenmask_upscore.weight.detach().float().contiguous()
             lv["up"] = uver
         if lv.get("head") == hver and "head.w" in img:
+            self._pack(jobs, code, st)
             self._images = img
             self._versions = v
             return
@@ -183,10 +185,27 @@ class _Engine(object):
             bh[E:E + 2] = m.seenmask_score.bias.detach().float()
             whc = wh if dt == torch.float32 else wh.to(dt)
         wht = torch.empty(F, CP, device=dev, dtype=dt)
-        L.call("szn_pack_weight_dgrad", code, CP, 1, 1, F, L.ptr(whc), L.ptr(wht), st)
+        jobs.append((whc, wht, CP, 1, F))
+        self._pack(jobs, code, st)
         img["head.w"], img["head.b"], img["head.wT"] = whc.view(CP, 1, 1, F), bh, wht.view(F, 1, 1, CP)
         self._images = img
         self._versions = v
+
+    @staticmethod
+    def _pack(jobs, code, st):
+        """dgrad images of `jobs`: one szn_pack_weight_dgrad_batch launch for the 16-bit images it accepts (Co, Ci multiples of
+        64), szn_pack_weight_dgrad for the rest"""
+        batch = [j for j in jobs if code != L.SZN_F32 and j[2] % 64 == 0 and j[4] % 64 == 0]
+        if len(batch) > 1:
+            n = len(batch)
+            VP, IA = C.c_void_p * n, C.c_int * n
+            L.call("szn_pack_weight_dgrad_batch", code, n, VP(*[j[0].data_ptr() for j in batch]), VP(*[j[1].data_ptr() for j in batch]),
+                   IA(*[j[2] for j in batch]), IA(*[j[3] for j in batch]), IA(*[j[4] for j in batch]), st)
+        else:
+            batch = []
+        for wc, wt, co, k, ci in jobs:
+            if not any(wt is b[1] for b in batch):
+                L.call("szn_pack_weight_dgrad", code, co, k, k, ci, L.ptr(wc), L.ptr(wt), st)
 
     # ---- kernels ---------------------------------------------------------------------------------
     def _conv(self, x, name, pad, relu=True, scale=None, out_f32=False, w=None, b=None, co=None, k=None, pool=False):
