@@ -258,7 +258,8 @@ def main():
     target_all = torch.from_numpy(synth.make_labels(B, H, H, K, seed=4337 + rank)).to(dev)
 
     def make_phase1():
-        return engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=not args.unfused_head)
+        return engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype,
+                                fused_head=not (args.unfused_head and args.arch == "fcn32s"))
 
     def make_phase1_fcn8s():
         # autograd path: forward (skip head, materialised score) -> cosine loss -> infer_lbl -> backward -> two-group Adam
@@ -274,12 +275,9 @@ def main():
 
         class _Phase1(object):
             def step(self, xx, tt):
-                if args.unfused_head:
-                    score = model(xx)
-                    loss = szn_utils.cosine_loss(score, tt, emb)
-                    pred = szn_utils.infer_lbl_device(score.detach(), emb)
-                else:
-                    loss, pred = model.embed_loss(xx, emb, tt)       # fused head over 8x8 cells of the 1/8 map
+                score = model(xx)
+                loss = szn_utils.cosine_loss(score, tt, emb)
+                pred = szn_utils.infer_lbl_device(score.detach(), emb)
                 opt.zero_grad()
                 loss.backward()
                 if world > 1:
@@ -319,7 +317,8 @@ def main():
         raise SystemExit("--phase seenmask is a single-GPU line (98 KB of gradients)")
     if args.arch == "fcn8s" and args.head_fp8:
         raise SystemExit("--arch fcn8s has no fp8 head")
-    ts = (make_phase1_fcn8s() if args.arch == "fcn8s" else make_phase1()) if args.phase == "fcn" else make_phase2()
+    # FCN8s: engine.TrainStep runs its fused stride-8 head; --unfused-head = the autograd path with the materialised score
+    ts = (make_phase1_fcn8s() if (args.arch == "fcn8s" and args.unfused_head) else make_phase1()) if args.phase == "fcn" else make_phase2()
 
     # ---- HIP events on the launch stream around C-ABI calls (torch's current stream IS the stream handed to the C-ABI) ----
     CONV_ENTRIES = ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm")

@@ -24,7 +24,7 @@ def _data():
     return synth.make_images(2, H, H, seed=61), synth.make_labels(2, H, H, K, seed=62, block=16), synth.make_embeddings(K, E)
 
 
-def _worker(rank, world, port, optname, comm, q):
+def _worker(rank, world, port, optname, comm, q, arch="FCN32s"):
     try:
         import torch.distributed as dist
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,7 +34,7 @@ def _worker(rank, world, port, optname, comm, q):
         from zeroshotsemanticsegmentation_amd import engine, models
         x, t, emb = _data()
         dev = torch.device("cuda", 0)
-        m = models.FCN32s(E)
+        m = getattr(models, arch)(E)
         m.load_synthetic(1337, device=dev)
         m.eval()
         ts = engine.TrainStep(m, emb, optimizer=optname, lr=1e-5, precision=torch.float32, fused_head=True, bucket_mb=25,
@@ -63,13 +63,14 @@ def _worker(rank, world, port, optname, comm, q):
         q.put({"rank": rank, "error": "%r\n%s" % (ex, traceback.format_exc())})
 
 
-@pytest.mark.parametrize("optname,comm", [("adam", "fp32"), ("sgd", "fp32"), ("adam", "bf16")])
-def test_two_ranks_on_one_gpu_equal_one_process_batch2(optname, comm):
+@pytest.mark.parametrize("optname,comm,arch", [("adam", "fp32", "FCN32s"), ("sgd", "fp32", "FCN32s"), ("adam", "bf16", "FCN32s"),
+                                               ("sgd", "fp32", "FCN8s")])
+def test_two_ranks_on_one_gpu_equal_one_process_batch2(optname, comm, arch):
     from zeroshotsemanticsegmentation_amd import engine, models
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, optname, comm, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, optname, comm, q, arch)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -81,10 +82,10 @@ def test_two_ranks_on_one_gpu_equal_one_process_batch2(optname, comm):
         p.join(120)
     # backward reports every optimizer-visible layer, last layer first
     assert res[0]["layers_reported"][0] == "score_fr" and res[0]["layers_reported"][-1] == "conv1_1"
-    assert set(res[0]["layers_reported"]) == set(models._OPT_LAYERS)
+    assert set(res[0]["layers_reported"]) == set(models._OPT_LAYERS8 if arch == "FCN8s" else models._OPT_LAYERS)
     # the single-process reference: both images in one batch
     x, t, emb = _data()
-    m = models.FCN32s(E)
+    m = getattr(models, arch)(E)
     m.load_synthetic(1337, device=torch.device("cuda", 0))
     m.eval()
     ts = engine.TrainStep(m, emb, optimizer=optname, lr=1e-5, precision=torch.float32, fused_head=True)

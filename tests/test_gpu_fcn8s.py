@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import szn_oracle as O  # noqa: E402
 from oracle import torch_ref as T  # noqa: E402
-from zeroshotsemanticsegmentation_amd import _lib as L, models, optim, synth, utils  # noqa: E402
+from zeroshotsemanticsegmentation_amd import _lib as L, engine, models, optim, synth, utils  # noqa: E402
 
 
 def rel(a, b):
@@ -286,3 +286,64 @@ def test_fcn8s_learns_finer_blocks_than_the_x32_head_can_resolve():
             first = float(loss) if first is None else first
     print("FCN8s: loss %.4f -> %.4f, pixel accuracy %s" % (first, float(loss), ["%.2f" % a for a in accs]))
     assert float(loss) < 0.5 * first and accs[-1] > 0.8
+
+
+@pytest.mark.parametrize("opt,precision", [("adam", torch.float32), ("sgd", torch.float32), ("adam", torch.bfloat16)])
+def test_trainstep_fcn8s_equals_the_autograd_path(opt, precision):
+    """engine.TrainStep(FCN8s) -- flat buffers, hand-written head chain, skip gradients through _Engine.backward(skips=) --
+    against the autograd path (embed_loss + per-tensor fused optimizer) from the same initial weights: loss of each step and every
+    parameter after three steps"""
+    E, K, B, H = 20, 6, 2, 96
+    emb = synth.make_embeddings(K, E, seed=3)
+    x = torch.from_numpy(synth.make_images(B, H, H, seed=9)).cuda()
+    target = torch.randint(-1, K, (B, H, H), generator=torch.Generator().manual_seed(4)).cuda()
+    lr = 1e-4 if opt == "adam" else 1e-6
+
+    def fresh():
+        m = models.FCN8s(E)
+        m.load_synthetic(1337)
+        m = m.cuda().eval()                          # no dropout: the two paths draw masks differently
+        m.set_precision(precision)
+        return m
+
+    ma = fresh()
+    names = models.opt_layers(ma)
+    assert names[-1] == "score_fr" and "score_pool3" in names and len(names) == 18
+    ws, bs = [getattr(ma, n).weight for n in names], [getattr(ma, n).bias for n in names]
+    for n_, p_ in ma.named_parameters():
+        p_.requires_grad = not (n_.startswith("seenmask") or n_.startswith("upscore"))
+    if opt == "adam":
+        oa = optim.FusedAdam([{"params": ws}, {"params": bs, "lr": 2 * lr}], lr=lr)
+    else:
+        oa = optim.FusedSGD([{"params": ws}, {"params": bs, "lr": 2 * lr, "weight_decay": 0}], lr=lr, momentum=0.99, weight_decay=0.0005)
+    mb = fresh()
+    ts = engine.TrainStep(mb, emb, optimizer=opt, lr=lr, precision=precision, fused_head=True)
+    embd = torch.from_numpy(emb).cuda()
+    tol = 1e-5 if precision == torch.float32 else 5e-3
+    for it in range(3):
+        la, pa = ma.embed_loss(x, embd, target)
+        oa.zero_grad()
+        la.backward()
+        oa.step()
+        lb, pb = ts.step(x, target)
+        assert abs(float(la.detach()) - float(lb)) < tol, (it, float(la.detach()), float(lb))
+        assert float((pa != pb).float().mean()) < (1e-4 if precision == torch.float32 else 2e-2)
+    pa_, pb_, p0_ = dict(ma.named_parameters()), dict(mb.named_parameters()), dict(fresh().named_parameters())
+    worst = {}
+    for n in names:
+        for k in ("weight", "bias"):
+            key = "%s.%s" % (n, k)
+            a, b, z = pa_[key].detach().float(), pb_[key].detach().float(), p0_[key].detach().float()
+            worst[key] = float((a - b).abs().max() / ((a - z).abs().max() + 1e-30))      # relative to the largest update made
+    if opt == "sgd":
+        # SGD is linear in the gradient: the two paths must make the same update everywhere
+        bad = {n: e for n, e in worst.items() if e > 2e-3}
+        assert not bad, bad
+    elif precision == torch.float32:
+        # Adam moves every element by ~lr * sign(g): elements whose gradient is ~0 may step the other way (reduction order),
+        # which bounds the difference by two steps out of three; the loss trajectory above is the tight check
+        assert max(worst.values()) < 0.7, worst
+    else:
+        assert max(worst.values()) < 2.0, worst
+    with pytest.raises(L.SznError):
+        engine.TrainStep(fresh(), emb, fused_head=False)

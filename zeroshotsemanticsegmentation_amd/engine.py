@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from . import synth
-from .models import _OPT_LAYERS, CROP
+from .models import CROP, CROP_POOL3, CROP_POOL4, CROP_UP8, opt_layers
 from .synth import unseen_bits
 
 
@@ -100,6 +100,12 @@ class TrainStep(object):
             raise L.SznError("TrainStep: fused head supports the cosine loss; use fused_head=False for mse")
         self.model = model
         self.eng = model._engine
+        # FCN8s (models.FCN8s: public skip head, not in the reference): two more Conv2d layers in the flat buffers and the head
+        # chain upscore2 -> +score_pool4 -> upscore_pool4 -> +score_pool3 -> fused head over 8x8 cells, run without autograd
+        self.layers = opt_layers(model)
+        self.is8 = len(self.layers) > 17
+        if self.is8 and not fused_head:
+            raise L.SznError("TrainStep(FCN8s) runs the fused stride-8 head only; the materialised score goes through autograd")
         model.set_precision(precision)
         self.dev = model.conv1_1.weight.device
         if self.dev.type != "cuda":
@@ -138,8 +144,8 @@ class TrainStep(object):
     # ---- flat parameter / gradient / moment storage ----------------------------------------------------
     def _flatten(self):
         m = self.model
-        ws = [getattr(m, n).weight for n in _OPT_LAYERS]
-        bs = [getattr(m, n).bias for n in _OPT_LAYERS]
+        ws = [getattr(m, n).weight for n in self.layers]
+        bs = [getattr(m, n).bias for n in self.layers]
         nw, nb = sum(p.numel() for p in ws), sum(p.numel() for p in bs)
         CP, E, F = m.head_width, m.n_class, m.fc7.out_channels
         self.flat_w = torch.empty(nw, device=self.dev)
@@ -155,7 +161,7 @@ class TrainStep(object):
         self.flat_gb = self._flat_gb_store[:nb]
         self.woff, self.boff = {}, {}
         off = 0
-        for n, p in zip(_OPT_LAYERS, ws):
+        for n, p in zip(self.layers, ws):
             co, ci, kh, kw = p.shape
             seg = self.flat_w[off:off + p.numel()].view(co, kh, kw, ci)
             seg.copy_(p.detach().permute(0, 2, 3, 1))
@@ -164,7 +170,7 @@ class TrainStep(object):
             self.woff[n] = (off, p.numel())
             off += p.numel()
         off = 0
-        for n, p in zip(_OPT_LAYERS, bs):
+        for n, p in zip(self.layers, bs):
             seg = self.flat_b[off:off + p.numel()]
             seg.copy_(p.detach())
             p.data = seg
@@ -186,11 +192,13 @@ class TrainStep(object):
             store[:nw].copy_(self.flat_w)
             self._flat_w_lp_store = store
             self.flat_w_lp = store[:nw]
-            for n in _OPT_LAYERS[:-1]:
+            for n in self.layers[:-1]:
                 co, ci, kh, kw = getattr(m, n).weight.shape
                 o, cnt = self.woff[n]
+                if n.startswith("score_pool"):
+                    continue                                  # padded images are assembled per step (_skip_images)
                 self.eng.lp_views[n] = self.flat_w_lp[o:o + cnt].view(co, kh, kw, ci)
-            assert _OPT_LAYERS[-1] == "score_fr"
+            assert self.layers[-1] == "score_fr"
             o, cnt = self.woff["score_fr"]
             bo, bc = self.boff["score_fr"]
             assert o + cnt == nw and bo + bc == nb
@@ -199,7 +207,16 @@ class TrainStep(object):
         self.eng.mark_dirty()
         # per-layer gradient targets handed to the engine (OHWI views of the flat gradient)
         self.grads = {}
-        for n in _OPT_LAYERS[:-1]:
+        self.skip = {}               # FCN8s: per skip layer (padded weight image, dgrad image, bias image, gradient scratch)
+        for n in self.layers[:-1]:
+            if n.startswith("score_pool"):
+                ci = getattr(m, n).in_channels
+                dt = self.eng.dtype
+                self.skip[n] = dict(w=torch.zeros(CP, 1, 1, ci, device=self.dev, dtype=dt),
+                                    wT=torch.zeros(ci, 1, 1, CP, device=self.dev, dtype=dt),
+                                    b=torch.zeros(CP, device=self.dev), gw=torch.empty(CP, 1, 1, ci, device=self.dev),
+                                    gb=torch.empty(CP, device=self.dev))
+                continue
             p = getattr(m, n).weight
             co, ci, kh, kw = p.shape
             o, cnt = self.woff[n]
@@ -214,7 +231,7 @@ class TrainStep(object):
         self.grads["_flat_bias"] = self._flat_gb_store      # lets the engine zero all bias gradients with one fill
 
     def _buckets(self, bucket_mb):
-        layers = [(n,) + self.woff[n] for n in _OPT_LAYERS]
+        layers = [(n,) + self.woff[n] for n in self.layers]
         self.buckets = GradBuckets(self.flat_gw, layers, bucket_mb * (1 << 20) // 4, extra=[self.flat_gb], group=self.pg,
                                    comm_dtype=self.grad_comm_dtype)
 
@@ -227,6 +244,8 @@ class TrainStep(object):
         st = L.stream_ptr()
         ctx = eng.forward(x, train=m.training)
         self.last_ctx = ctx if self.keep_ctx else None
+        if self.is8:
+            return self._step8(ctx, target, B, H, W)
         CP, E, K = m.head_width, self.E, self.K
         code = L.dtype_code(eng.dtype)
         pred = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
@@ -256,6 +275,94 @@ class TrainStep(object):
             dcoarse = (dcoarse.float() * self.loss_scale).to(eng.dtype)
         self.stats = stats
         self._backward(ctx, dcoarse, self.buckets.layer_done)
+        self.buckets.finish()
+        self._optimizer_step()
+        if self.train_metrics:
+            L.call("szn_confusion_hist", target.numel(), K, L.ptr(target), L.ptr(pred), 0, L.ptr(self.hist), st)
+        return self.loss.reshape(()), pred
+
+    # ---- FCN8s head chain (forward and backward by hand: no autograd objects on the step path) ----------------------------
+    def _skip_images(self):
+        """padded [CP][Ci] images of score_pool3 / score_pool4 (rows >= E stay zero) + their dgrad transposes, from the flat
+        masters the optimizer kernel just wrote"""
+        m, E = self.model, self.E
+        code = L.dtype_code(self.eng.dtype)
+        for n, s in self.skip.items():
+            o, cnt = self.woff[n]
+            ci = s["w"].shape[3]
+            src = self.flat_w_lp if (self.flat_w_lp is not None) else self.flat_w
+            s["w"][:E].copy_(src[o:o + cnt].view(E, 1, 1, ci))
+            bo, bc = self.boff[n]
+            s["b"][:E].copy_(self.flat_b[bo:bo + bc])
+            L.call("szn_pack_weight_dgrad", code, s["w"].shape[0], 1, 1, ci, L.ptr(s["w"]), L.ptr(s["wT"]), L.stream_ptr())
+
+    @staticmethod
+    def _up2(x, fwd=True, shape=None):
+        x = x.contiguous()
+        if fwd:
+            B, h, w, ld = x.shape
+            out = torch.empty(B, 2 * h + 2, 2 * w + 2, ld, device=x.device, dtype=torch.float32)
+            L.call("szn_bilinear_up2_nhwc_fwd", B, h, w, ld, ld, L.ptr(x), L.ptr(out), L.stream_ptr())
+            return out
+        B, h, w, ld = shape
+        out = torch.empty(B, h, w, ld, device=x.device, dtype=torch.float32)
+        L.call("szn_bilinear_up2_nhwc_bwd", B, h, w, ld, ld, L.ptr(x), L.ptr(out), L.stream_ptr())
+        return out
+
+    def _step8(self, ctx, target, B, H, W):
+        m, eng = self.model, self.eng
+        st = L.stream_ptr()
+        CP, E, K = m.head_width, self.E, self.K
+        dt = eng.dtype
+        self._skip_images()
+        pool3, pool4 = ctx.pools[2][1], ctx.pools[3][1]
+        s3, s4 = self.skip["score_pool3"], self.skip["score_pool4"]
+        # forward: upscore2(score_fr) + score_pool4c -> upscore_pool4 -> + score_pool3c
+        up2 = self._up2(ctx.coarse)
+        sp4 = eng._conv(pool4, None, 0, relu=False, out_f32=True, w=s4["w"], b=s4["b"])
+        n4, m4 = up2.shape[1:3]
+        fuse4 = up2 + sp4[:, CROP_POOL4:CROP_POOL4 + n4, CROP_POOL4:CROP_POOL4 + m4]
+        up4 = self._up2(fuse4)
+        sp3 = eng._conv(pool3, None, 0, relu=False, out_f32=True, w=s3["w"], b=s3["b"])
+        n3, m3 = up4.shape[1:3]
+        fuse3 = (up4 + sp3[:, CROP_POOL3:CROP_POOL3 + n3, CROP_POOL3:CROP_POOL3 + m3]).contiguous()
+        # fused head over 8x8 cells: loss, prediction, d(fuse3)
+        pred = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
+        stats = torch.empty(B, 2, device=self.dev)
+        dfuse3 = torch.zeros(B, n3, m3, CP, device=self.dev, dtype=torch.float32)
+        nbytes = L.load().szn_fused_head_workspace_bytes(B, n3, m3, E, K)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        L.call("szn_fused_head_strided", 8, B, n3, m3, E, CP, 0, H, W, CROP_UP8, K, L.ptr(fuse3), L.ptr(self.emb), L.ptr(target),
+               L.ptr(self.loss), L.ptr(stats), L.ptr(pred), L.SZN_F32, L.ptr(dfuse3), L.ptr(self._ws), st)
+        self.stats = stats
+        if self.loss_scale != 1.0:
+            dfuse3 = dfuse3 * self.loss_scale
+        # backward of the head chain; the skip gradients join the backbone chain at the pool3 / pool4 outputs
+        skips = {}
+        dmap = dfuse3
+        for (name, s, pool, crop, pi, up_shape) in (("score_pool3", s3, pool3, CROP_POOL3, 2, fuse4.shape),
+                                                    ("score_pool4", s4, pool4, CROP_POOL4, 3, ctx.coarse.shape)):
+            Bp, hp, wp, ci = pool.shape
+            nn, mm = dmap.shape[1:3]
+            dsp = torch.zeros(Bp, hp, wp, CP, device=self.dev, dtype=dt)
+            dsp[:, crop:crop + nn, crop:crop + mm] = dmap
+            eng._wgrad(pool, dsp, s["gw"], s["gb"], ci, CP, 1, 0)
+            o, cnt = self.woff[name]
+            self.flat_gw[o:o + cnt].view(E, 1, 1, ci).copy_(s["gw"][:E])
+            skips[pi] = eng._dgrad(dsp, None, pool.shape, 0, wT=s["wT"])
+            dmap = self._up2(dmap, fwd=False, shape=tuple(up_shape))
+        eng._join_wgrad()
+        dcoarse = dmap if dmap.dtype == dt else dmap.to(dt)
+        done = self.buckets.layer_done
+
+        def head_first():                 # flat order is (..., score_pool3, score_pool4, score_fr): report them last-to-first
+            done("score_fr"); done("score_pool4"); done("score_pool3")
+        # the bias gradients of the skip layers live in the flat bias buffer the engine zeroes first: re-apply them after
+        saved = [(self.boff[n], self.skip[n]["gb"]) for n in ("score_pool3", "score_pool4")]
+        eng.backward(ctx, dcoarse, self.grads, backbone=True, layer_done=done, head_first=head_first, skips=skips)
+        for (bo, bc), gb in saved:
+            self.flat_gb[bo:bo + bc].copy_(gb[:E])
         self.buckets.finish()
         self._optimizer_step()
         if self.train_metrics:
@@ -293,7 +400,7 @@ class TrainStep(object):
     # ---- checkpoint compatibility (reference dict keys: trainer_fcn.py:281-288) ------------------------------
     def _param_slots(self):
         m = self.model
-        for n in _OPT_LAYERS:
+        for n in self.layers:
             p = getattr(m, n).weight
             co, ci, kh, kw = p.shape
             o, cnt = self.woff[n]

@@ -46,6 +46,12 @@ _BACKBONE = [("conv1_1", PAD1), ("conv1_2", 1), "P", ("conv2_1", 1), ("conv2_2",
              ("conv5_1", 1), ("conv5_2", 1), ("conv5_3", 1), "P"]
 _TRUNK = [n for n, _, _, _ in synth.CONV_LAYERS]          # conv1_1 .. fc7
 _OPT_LAYERS = _TRUNK + ["score_fr"]                        # the layers train.get_parameters yields (train.py:302-331)
+_OPT_LAYERS8 = _TRUNK + ["score_pool3", "score_pool4", "score_fr"]       # ... for FCN8s (score_fr stays last: engine.TrainStep)
+
+
+def opt_layers(model):
+    """names of the Conv2d layers the phase-1 optimizer updates, in the order of TrainStep's flat buffers"""
+    return _OPT_LAYERS8 if hasattr(model, "score_pool3") else _OPT_LAYERS
 
 
 class _Ctx(object):

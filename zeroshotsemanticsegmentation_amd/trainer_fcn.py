@@ -168,7 +168,8 @@ class Trainer(object):
         if self.forced_unseen:
             return None
         from .optim import FusedAdam, FusedSGD
-        from .models import _OPT_LAYERS
+        from .models import opt_layers
+        _OPT_LAYERS = opt_layers(self.model)
         groups = self.optim.param_groups
         ws = [getattr(self.model, n).weight for n in _OPT_LAYERS]
         bs = [getattr(self.model, n).bias for n in _OPT_LAYERS]
