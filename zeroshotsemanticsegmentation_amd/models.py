@@ -857,8 +857,8 @@ class FCN8s(FCN32s):
     """FCN8s skip architecture on the FCN32s trunk (see the note above: public pytorch-fcn definition, parity unpinned).
     state_dict keys follow pytorch-fcn's FCN8s: the trunk + score_fr, score_pool3, score_pool4, upscore2, upscore8,
     upscore_pool4 (+ this repo's seenmask_score / seenmask_upscore, which keep the reference's x32 seen-mask head,
-    models.py:97-98,149-151).  Runs through the autograd bridge (Trainer's per-tensor path, optim.Adam / SGD kernels);
-    engine.TrainStep's flat fused step is specific to the FCN32s layer list."""
+    models.py:97-98,149-151).  forward() / embed_loss() run through the autograd bridge; engine.TrainStep (what the
+    trainer and bench.py use for the cosine-loss configurations) runs the same chain by hand on its flat buffers."""
 
     pretrained_model = 'data/fcn8s_from_caffe.pth'
 
