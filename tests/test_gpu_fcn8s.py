@@ -329,20 +329,25 @@ def test_trainstep_fcn8s_equals_the_autograd_path(opt, precision):
         assert abs(float(la.detach()) - float(lb)) < tol, (it, float(la.detach()), float(lb))
         assert float((pa != pb).float().mean()) < (1e-4 if precision == torch.float32 else 2e-2)
     pa_, pb_, p0_ = dict(ma.named_parameters()), dict(mb.named_parameters()), dict(fresh().named_parameters())
-    worst = {}
+    worst, frac = {}, {}
     for n in names:
         for k in ("weight", "bias"):
             key = "%s.%s" % (n, k)
             a, b, z = pa_[key].detach().float(), pb_[key].detach().float(), p0_[key].detach().float()
-            worst[key] = float((a - b).abs().max() / ((a - z).abs().max() + 1e-30))      # relative to the largest update made
+            rel = (a - b).abs() / ((a - z).abs().max() + 1e-30)                          # relative to the largest update made
+            worst[key] = float(rel.max())
+            frac[key] = (int((rel > 1e-2).sum()), rel.numel())                           # elements that moved apart
     if opt == "sgd":
         # SGD is linear in the gradient: the two paths must make the same update everywhere
         bad = {n: e for n, e in worst.items() if e > 2e-3}
         assert not bad, bad
     elif precision == torch.float32:
-        # Adam moves every element by ~lr * sign(g): elements whose gradient is ~0 may step the other way (reduction order),
-        # which bounds the difference by two steps out of three; the loss trajectory above is the tight check
-        assert max(worst.values()) < 0.7, worst
+        # Adam moves every element by ~lr * sign(g): an element whose gradient is ~0 may step the other way in each of the
+        # three steps (reduction order; the head wgrad sums with fp32 atomics), which bounds a single element's difference by
+        # twice the largest update; such elements must stay rare, and the loss trajectory above is the tight check
+        assert max(worst.values()) < 2.0, worst
+        apart, total = sum(v[0] for v in frac.values()), sum(v[1] for v in frac.values())
+        assert apart < 1e-2 * total, (apart, total, {k: v for k, v in frac.items() if v[0]})
     else:
         assert max(worst.values()) < 2.0, worst
     with pytest.raises(L.SznError):
