@@ -353,3 +353,35 @@ def test_gemm_proj_aliases_and_cast(dt):
     L.call("szn_gemm_proj_dgrad", code, M, K, NP, NP, L.ptr(dp), L.ptr(wT), L.ptr(x), None, L.ptr(dx), st)
     ref_dx = (dout[:, :N].double() @ w.double()) * (x.double() > 0)
     assert float((dx.double() - ref_dx).abs().max() / ref_dx.abs().max()) < (1e-4 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,out32,N", [(65536 + 77, False, 300), (4 * 65536, True, 300), (65536, True, 304), (65536 + 8, False, 320)])
+def test_proj_gemm_stream(dt, M, out32, N):
+    """the HBM-streaming projection kernel (proj_gemm_stream: M x 4096 x 300 with >= 256 pixel tiles -- the full-resolution
+    "H*W x 300" shape of the north star) through szn_gemm_proj_fwd, against torch matmul on the same rounded operands; a ragged
+    last tile, padded output rows, 16-bit and fp32 output, 19 and 20 cout fragments (N <= 304 / N = 320); run-to-run bit-identical"""
+    K = 4096
+    ldo = 328 if out32 else (N + 7) // 8 * 8 + 8
+    code = L.dtype_code(dt)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.relu(torch.randn(M, K, device="cuda", generator=g)).to(dt)           # fc7's output is post-ReLU
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(dt)
+    bias = torch.randn(N, device="cuda", generator=g)
+    st = L.stream_ptr()
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, ldo), 7.0, device="cuda", dtype=torch.float32 if out32 else dt)
+        d = L.ConvDesc(code, 1, 1, M, K, 1, M, N, 1, 1, 0, K, ldo, 0, 0, int(out32))
+        L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, None, L.ptr(out), st)
+        torch.cuda.synchronize()
+        assert L.last_kernel() == "proj_gemm_stream"
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert bool((outs[0][:, N:] == 7.0).all())                                   # the padding columns are not touched
+    worst = 0.0
+    for s in range(0, M, 65536):                                                 # reference in slices (fp32 matmul on the GPU)
+        ref = x[s:s + 65536].float() @ w.float().t() + bias
+        got = outs[0][s:s + 65536, :N].float()
+        worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
+    assert worst < (2e-4 if out32 else 6e-3), worst

@@ -26,6 +26,8 @@ typedef __attribute__((address_space(3))) void* ldsptr_t;
 
 int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, szn_stream_t stream);
+int szn_proj_stream_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                        const float* chan_scale, void* out, int min_tiles, szn_stream_t stream);
 int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, unsigned in_bytes, unsigned w_bytes, int min_tiles,
                       float* ws, int nsplit, int chunks_per_split, szn_stream_t stream);
@@ -485,6 +487,12 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     const bool v2_ok = (szn_is16(d->dtype) || d->dtype == SZN_F32) && d->Ci > 0 && (d->Ci % bke) == 0 &&
                        in_bytes < 0x7fff0000ul && w_bytes < 0x7fff0000ul && d->Hi < 32000 && d->Wi < 32000 && d->pad < 16000 &&
                        ((size_t)d->ldi * es) % 16 == 0;
+    {   // the pixel projection at full-resolution sizes (>= 256 pixel tiles x one 320-wide cout tile): HBM-streaming kernel
+        static int wide_min0 = -1;
+        if (wide_min0 < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min0 = e ? atoi(e) : 256; }
+        const int rc = szn_proj_stream_try(d, in, w, bias, gate, chan_scale, out, wide_min0, stream);
+        if (rc <= 0) return rc;
+    }
     if (!v2_ok) return szn_conv2d_fwd_v1(d, in, w, bias, gate, chan_scale, out, stream);
     // argument validation is shared with the v1 path (same contract)
     if (d->B <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Co <= 0 || d->KH <= 0 || d->KW <= 0 || d->pad < 0 ||

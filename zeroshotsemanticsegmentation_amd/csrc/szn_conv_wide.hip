@@ -457,6 +457,135 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_rows(WideArgs a) {
 #endif
 }
 
+// ---- pixel projection (1x1, K >> N, N <= 320): activation operand streamed from HBM ----------------------------------------------
+// score_fr is M x 4096 x 300: every activation row is used by ONE block, once (AI = 300 FLOP per activation byte -- at the HBM
+// ridge), while the 2.6 MB filter matrix is re-read by every block from its XCD's L2.  conv_igemm_wide<T, 10> keeps one 72 KiB chunk
+// of prefetch in flight per CU (8 MB on the chip): enough for operands that come from L2 / MALL, not for 2 us of loaded HBM latency
+// (measured: 1.7 TB/s of activation stream, 0.5 PF).  Here the two operands get their own rings:
+//   * activations: 3 units of 256 px x 128 B (K = 64), two units = 64 KiB per CU in flight (16 MB on the chip), whole 128-B lines per
+//     request, non-temporal (aux = nt: streamed once, must not push the filter matrix out of L2);
+//   * filters: 3 units of 320 x 64 B (K = 32), two in flight, default policy (L2 hits);
+//   * one s_barrier per K = 32 half step (40 MFMA per wave between barriers), counted s_waitcnt vmcnt: a wave's loads complete in
+//     issue order, and behind the unit a half step needs there are always exactly one filter unit and one activation unit.
+//     (Staggering the issue across waves, which pays in the conv kernels, measured nothing here: the loads per half step are few.)
+// 64-B filter rows: a 16 x 64 B fragment block spans 1 KiB, slot = chunk ^ ((row >> 2) & 3) puts the 16 rows of a ds_read_b128
+// group on 16 different 16-B bank groups.  Accumulators / epilogue as conv_igemm_wide<T, 10> (bias, 16-bit or fp32 rows).
+// Co <= 304 (the 300-d projection): the 20th 16-cout fragment is pure padding.  Its filter rows are not loaded and the waves of the
+// upper cout half run 9 fragments; waves w and w + 4 share a SIMD, so (wm, wn) = (w & 3, w >> 2) gives every SIMD 40 + 36 MFMA per half
+// step instead of 80.
+template <typename T, bool NT, bool NF19>
+__global__ __launch_bounds__(512, 2) void proj_gemm_stream(WideArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(T) == 2, "16-bit storage only");
+    constexpr int BM = 256, BN = 320, WNF = 10;
+    constexpr int AUNIT = BM * 128, WUNIT = BN * 64;           // 32 KiB, 20 KiB
+    constexpr int AUXA = NT ? 2 : 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // activations [3][256 x 128 B] | filters [3][320 x 64 B]
+    char* const sA = smem;
+    char* const sW = smem + 3 * AUNIT;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w & 3, wn = w >> 2;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int mt = xcd_remap_w(blockIdx.x, a.mtiles);
+    const int m0 = mt * BM;
+
+    // the activation resource covers this block's rows only (base = row m0): no 2 GB limit on the matrix, rows >= M fall outside
+    const int rows = min(BM, a.M - m0);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)m0 * a.ldi * 2), 0, (int)((size_t)rows * a.ldi * 2), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+
+    // activations: wave w fills pixel rows 32 w .. 32 w + 31, one instruction = 8 rows x 128 B (lane -> row lane >> 3, 16-B chunk
+    // (lane & 7) ^ row: the source-side XOR swizzle of the other kernels)
+    unsigned voffA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 32 * w + 8 * i + (lane >> 3);
+        voffA[i] = (r < rows) ? (unsigned)(((long)r * a.ldi + ((lane & 7) ^ (lane >> 3)) * 8) * 2) : kOOBx;
+    }
+    // filters: 20 instructions of 16 rows x 64 B per unit; wave w takes row blocks w, w + 8, w + 16 (the third only for w < 4)
+    constexpr int W3 = NF19 ? 3 : 4;                            // waves below W3 issue three filter loads per unit, the others two
+    const int nwi = w < W3 ? 3 : 2;
+    unsigned voffB[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int row = (w + 8 * i) * 16 + (lane >> 2);
+        const int n = row;                                      // one cout tile: n0 = 0
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        voffB[i] = (i < nwi && n < a.Co) ? (unsigned)(((long)n * a.Ci + chunk * 8) * 2) : kOOBx;
+    }
+    const int nU = a.Ci / 64, H = 2 * nU;
+    auto issueA = [&](int u) {
+        char* sa = sA + (u % 3) * AUNIT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + (32 * w + 8 * i) * 128), 16, voffA[i], u * 128, 0, AUXA);
+    };
+    auto issueW = [&](int h) {
+        char* sw = sW + (h % 3) * WUNIT;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sw + (w + 0) * 1024), 16, voffB[0], h * 64, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sw + (w + 8) * 1024), 16, voffB[1], h * 64, 0, 0);
+        if (w < W3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sw + (w + 16) * 1024), 16, voffB[2], h * 64, 0, 0);
+    };
+
+    f32x4_t acc[WNF][4];
+#pragma unroll
+    for (int i = 0; i < WNF; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // issue order A0 W0 A1 W1 | W2 A2 | W3 | W4 A3 | W5 | ...: when half step h needs (A[h/2], W[h]) the loads issued after them are
+    // always one filter unit and one activation unit -> vmcnt(4 + nwi)
+    issueA(0); issueW(0);
+    if (nU > 1) issueA(1);
+    if (H > 1) issueW(1);
+    const int offw = ((g ^ ((r16 >> 2) & 3)) << 4);
+    for (int h = 0; h < H; ++h) {
+        if (h + 4 >= H) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (w < W3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // (A[h/2], W[h]) landed for every wave; everyone left half step h - 1
+        if (h + 2 < H) issueW(h + 2);                 // into the slot of W[h - 1]
+        if (!(h & 1) && (h >> 1) + 2 < nU) issueA((h >> 1) + 2);     // into the slot of A[h/2 - 1]
+        const char* sp = sA + ((h >> 1) % 3) * AUNIT + (wm * 64 + r16) * 128 + (((4 * (h & 1) + g) ^ (r16 & 7)) << 4);
+        const char* sw = sW + (h % 3) * WUNIT + (wn * 160 + r16) * 64 + offw;
+        u32x4_t pf[4], wf[WNF];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pf[j] = *(const u32x4_t*)(sp + j * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < WNF - 1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(wf[i], pf[j], acc[i][j]);
+        if (!NF19 || wn == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[WNF - 1][j] = mfma16<T>(wf[WNF - 1], pf[j], acc[WNF - 1][j]);
+        }
+    }
+    wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, 0, 0);
+#endif
+}
+
+template <typename T, bool NT, bool NF19>
+void launch_proj_variant(const WideArgs& a, size_t lds, hipStream_t st) {
+    (void)hipFuncSetAttribute((const void*)proj_gemm_stream<T, NT, NF19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((proj_gemm_stream<T, NT, NF19>), dim3(a.mtiles), dim3(512), lds, st, a);
+}
+
+template <typename T>
+int launch_proj_stream(const WideArgs& a, hipStream_t st) {
+    const size_t lds = 3 * 256 * 128 + 3 * 320 * 64;
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("SZN_PROJ_NT"); nt = e ? atoi(e) : 1; }
+    const bool nf19 = a.Co <= 304;
+    if (nt) { if (nf19) launch_proj_variant<T, true, true>(a, lds, st); else launch_proj_variant<T, true, false>(a, lds, st); }
+    else { if (nf19) launch_proj_variant<T, false, true>(a, lds, st); else launch_proj_variant<T, false, false>(a, lds, st); }
+    SZN_CHECK_LAUNCH("proj_gemm_stream");
+    return SZN_OK;
+}
+
 template <typename T>
 int launch_wide_rows(const WideArgs& a, hipStream_t st) {
     const size_t lds = 2 * 264 * 128 + 2 * 256 * 128;
@@ -533,4 +662,32 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
         return d->dtype == SZN_F16 ? launch_wide<f16_raw, 10>(a, (hipStream_t)stream) : launch_wide<bf16_raw, 10>(a, (hipStream_t)stream);
     if (d->dtype == SZN_F16) return launch_wide<f16_raw, 8>(a, (hipStream_t)stream);
     return d->dtype == SZN_BF16 ? launch_wide<bf16_raw, 8>(a, (hipStream_t)stream) : launch_wide<float, 8>(a, (hipStream_t)stream);
+}
+
+// The streaming projection kernel (proj_gemm_stream): 1x1 / pad 0, 16-bit operands, 256 < Co <= 320 (one cout tile), Ci a multiple
+// of 64, no gate / dropout factor / column sums / split-K, at least `min_tiles` pixel tiles.  Called by szn_conv2d_fwd BEFORE the
+// 2 GB operand check of the generic kernels: the activation resource is rebased per block.  Returns 1 when the shape does not fit.
+int szn_proj_stream_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
+                        const float* chan_scale, void* out, int min_tiles, szn_stream_t stream) {
+    static int proj = -1;
+    if (proj < 0) { const char* e = getenv("SZN_PROJ_STREAM"); proj = e ? atoi(e) : 1; }
+    if (!proj || !szn_is16(d->dtype) || d->KH != 1 || d->KW != 1 || d->pad != 0 || d->Co <= 256 || d->Co > 320 || d->Ci < 256 ||
+        (d->Ci % 64) || gate || chan_scale || d->colsum || d->pool_out || d->relu)
+        return 1;
+    if (d->B <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho != d->Hi || d->Wo != d->Wi || d->ldi < d->Ci || d->ldo < d->Co || !in || !w ||
+        !out || (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) || (((size_t)d->ldi * 2) & 15) ||
+        (long)d->B * d->Ho * d->Wo >= (1L << 31) || (size_t)256 * d->ldi * 2 >= 0x7fff0000ul)
+        return 1;
+    WideArgs a;
+    a.M = d->B * d->Ho * d->Wo;
+    a.mtiles = szn_div_up(a.M, 256); a.ntiles = 1; a.nmajor = 0;
+    if (a.mtiles < min_tiles) return 1;
+    a.ws = nullptr; a.nsplit = 1; a.chunks_per_split = 1 << 30; a.stagger = 0;
+    a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = nullptr; a.cscale = nullptr;
+    a.out = (char*)out; a.colsum = nullptr;
+    a.in_bytes = 0; a.w_bytes = (unsigned)((size_t)d->Co * d->Ci * 2);
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.KH = 1; a.KW = 1; a.pad = 0; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = 0;
+    a.relu = 0; a.out_f32 = d->out_f32; a.HoWo = d->Ho * d->Wo;
+    return d->dtype == SZN_F16 ? launch_proj_stream<f16_raw>(a, (hipStream_t)stream) : launch_proj_stream<bf16_raw>(a, (hipStream_t)stream);
 }
