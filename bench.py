@@ -174,10 +174,13 @@ def projection_report(L, torch, step_frac, iters=10):
     """(1) true shape M = B*289, (2) step aggregate, (3) nominal full-resolution shape; bf16, K=4096, N=300"""
     import ctypes as C
 
-    def run(B, H, W, N=300, K=4096):
+    def run(B, H, W, N=300, K=4096, relu=True):
         dt = torch.bfloat16
         ldo = (N + 7) // 8 * 8
-        x = torch.randn(B, H, W, K, device="cuda").to(dt)
+        x = torch.randn(B, H, W, K, device="cuda")
+        if relu:                                   # score_fr reads relu7: non-negative, half of the elements zero
+            x = torch.relu(x)
+        x = x.to(dt)
         w = (torch.randn(N, 1, 1, K, device="cuda") / K ** 0.5).to(dt)
         bias = torch.randn(N, device="cuda")
         out = torch.empty(B, H, W, ldo, device="cuda", dtype=dt)
@@ -197,13 +200,16 @@ def projection_report(L, torch, step_frac, iters=10):
         ms = e0.elapsed_time(e1) / iters
         tf = 2.0 * B * H * W * K * N / (ms * 1e-3) / 1e12
         return {"M": B * H * W, "K": K, "N": N, "ms": round(ms, 4), "TF": round(tf, 1), "frac": round(tf / PEAK_BF16, 4),
-                "kernel": L.last_kernel()}
+                "kernel": L.last_kernel(), "operand": "relu(randn)" if relu else "randn",
+                "activation_stream_TBps": round(B * H * W * K * 2 / (ms * 1e-3) / 1e12, 2)}
     return {"peak_TF": PEAK_BF16,
             "true_shape": [run(B, 17, 17) for B in (1, 8, 64)],
             "step_aggregate_frac": step_frac,
             "nominal_shape": run(1, 512, 512),
+            "nominal_shape_randn": run(1, 512, 512, relu=False),
             "note": "true = what score_fr executes (17x17 map, before the x32 upsampling); nominal = a full-resolution "
-                    "H*W x 4096 x 300 projection the path never runs (AI = 300 FLOP/B: HBM-bound at N = 300)"}
+                    "H*W x 4096 x 300 projection the path never runs (proj_gemm_stream: the 2.1 GB activation operand is read "
+                    "once from HBM, AI = 300 FLOP/B; operands relu(randn) like fc7's output, randn beside it)"}
 
 
 def main():

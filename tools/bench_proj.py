@@ -23,11 +23,14 @@ from zeroshotsemanticsegmentation_amd import _lib as L
 PEAK = 2500.0   # TFLOP/s dense bf16 (MI355X_MICROARCH.md)
 
 
-def run(B, H, W, iters, N=300, K=4096):
+def run(B, H, W, iters, N=300, K=4096, relu=True):
     dt = torch.bfloat16
     code = L.dtype_code(dt)
     ldo = (N + 7) // 8 * 8
-    x = torch.randn(B, H, W, K, device="cuda").to(dt)
+    x = torch.randn(B, H, W, K, device="cuda")
+    if relu:                       # score_fr reads relu7: non-negative, half of the elements zero
+        x = torch.relu(x)
+    x = x.to(dt)
     w = (torch.randn(N, 1, 1, K, device="cuda") / K ** 0.5).to(dt)
     bias = torch.randn(N, device="cuda")
     out = torch.empty(B, H, W, ldo, device="cuda", dtype=dt)
@@ -42,21 +45,25 @@ def run(B, H, W, iters, N=300, K=4096):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * B * H * W * K * N / (ms * 1e-3) / 1e12
-    return ms, tf
+    return ms, tf, L.last_kernel()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--nominal-only", action="store_true", help="only the 262,144-row shape (the PMC passes)")
     a = ap.parse_args()
     L.load()
     res = {"peak_TF": PEAK, "true_shape": [], "nominal_shape": []}
-    for B in (1, 8, 64):
-        ms, tf = run(B, 17, 17, a.iters)
-        res["true_shape"].append({"M": B * 289, "K": 4096, "N": 300, "ms": round(ms, 4), "TF": round(tf, 1), "frac": round(tf / PEAK, 4)})
-    for B in (1, 4):
-        ms, tf = run(B, 512, 512, a.iters)
-        res["nominal_shape"].append({"M": B * 262144, "K": 4096, "N": 300, "ms": round(ms, 4), "TF": round(tf, 1), "frac": round(tf / PEAK, 4)})
+    for B in (() if a.nominal_only else (1, 8, 64)):
+        ms, tf, kern = run(B, 17, 17, a.iters)
+        res["true_shape"].append({"M": B * 289, "K": 4096, "N": 300, "ms": round(ms, 4), "TF": round(tf, 1), "frac": round(tf / PEAK, 4),
+                                  "kernel": kern})
+    for B, relu in ((1, True),) if a.nominal_only else ((1, True), (1, False), (4, True)):
+        ms, tf, kern = run(B, 512, 512, a.iters, relu=relu)
+        res["nominal_shape"].append({"M": B * 262144, "K": 4096, "N": 300, "ms": round(ms, 4), "TF": round(tf, 1), "frac": round(tf / PEAK, 4),
+                                     "kernel": kern, "operand": "relu(randn)" if relu else "randn",
+                                     "activation_stream_TBps": round(B * 262144 * 4096 * 2 / (ms * 1e-3) / 1e12, 2)})
     res["aggregate"] = "see bench.py roofline.step_mfma_frac"
     print(json.dumps(res))
 

@@ -468,8 +468,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_rows(WideArgs a) {
 //   * one s_barrier per K = 32 half step (40 MFMA per wave between barriers), counted s_waitcnt vmcnt: a wave's loads complete in
 //     issue order, and behind the unit a half step needs there are always exactly one filter unit and one activation unit.
 //     (Staggering the issue across waves, which pays in the conv kernels, measured nothing here: the loads per half step are few.)
-// 64-B filter rows: a 16 x 64 B fragment block spans 1 KiB, slot = chunk ^ ((row >> 2) & 3) puts the 16 rows of a ds_read_b128
-// group on 16 different 16-B bank groups.  Accumulators / epilogue as conv_igemm_wide<T, 10> (bias, 16-bit or fp32 rows).
+// 64-B filter rows: ds_read_b128 is served 8 lanes (128 B) at a time, so the eight rows r .. r + 7 a lane group reads (same chunk)
+// must fall on eight different 16-B slots of a 128-B window: slot = chunk ^ ((row >> 1) & 3) (with (row >> 2) the PMC pass showed
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.40).  Accumulators / epilogue as conv_igemm_wide<T, 10> (bias, 16-bit or fp32 rows).
 // Co <= 304 (the 300-d projection): the 20th 16-cout fragment is pure padding.  Its filter rows are not loaded and the waves of the
 // upper cout half run 9 fragments; waves w and w + 4 share a SIMD, so (wm, wn) = (w & 3, w >> 2) gives every SIMD 40 + 36 MFMA per half
 // step instead of 80.
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_stream(WideArgs a) {
     for (int i = 0; i < 3; ++i) {
         const int row = (w + 8 * i) * 16 + (lane >> 2);
         const int n = row;                                      // one cout tile: n0 = 0
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        const int chunk = (lane & 3) ^ ((row >> 1) & 3);
         voffB[i] = (i < nwi && n < a.Co) ? (unsigned)(((long)n * a.Ci + chunk * 8) * 2) : kOOBx;
     }
     const int nU = a.Ci / 64, H = 2 * nU;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_stream(WideArgs a) {
     issueA(0); issueW(0);
     if (nU > 1) issueA(1);
     if (H > 1) issueW(1);
-    const int offw = ((g ^ ((r16 >> 2) & 3)) << 4);
+    const int offw = ((g ^ ((r16 >> 1) & 3)) << 4);
     for (int h = 0; h < H; ++h) {
         if (h + 4 >= H) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (w < W3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
