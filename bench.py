@@ -189,7 +189,8 @@ def projection_report(L, torch, step_frac, iters=10):
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         st = L.stream_ptr()
         fn = lambda: L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, None, L.ptr(out), st)
-        fn()
+        for _ in range(3):                         # the first launches after the small shapes run on ramping clocks
+            fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
