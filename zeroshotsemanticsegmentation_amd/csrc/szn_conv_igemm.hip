@@ -489,7 +489,7 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
                        ((size_t)d->ldi * es) % 16 == 0;
     {   // the pixel projection at full-resolution sizes (>= 256 pixel tiles x one 320-wide cout tile): HBM-streaming kernel
         static int wide_min0 = -1;
-        if (wide_min0 < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min0 = e ? atoi(e) : 256; }
+        if (wide_min0 < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min0 = e ? atoi(e) : 240; }
         const int rc = szn_proj_stream_try(d, in, w, bias, gate, chan_scale, out, wide_min0, stream);
         if (rc <= 0) return rc;
     }
@@ -571,7 +571,7 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     // >= 256 couts and enough tiles to fill the chip: 256 x 256 tiles (1.5x less LDS fill per FLOP), szn_conv_wide.hip
     if (a.nsplit == 1 || use_wide) {
         static int wide_min = -1;
-        if (wide_min < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min = e ? atoi(e) : 256; }
+        if (wide_min < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min = e ? atoi(e) : 240; }
         rc = szn_conv_wide_try(d, in, w, bias, gate, chan_scale, out, a.in_bytes, a.w_bytes, use_wide ? 1 : wide_min, a.ws,
                                a.nsplit, a.chunks_per_split, stream);
         if (rc < 0 || (rc == 0 && a.nsplit == 1)) return rc;

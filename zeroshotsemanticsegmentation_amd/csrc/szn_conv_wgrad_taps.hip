@@ -263,7 +263,8 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     // must amortise), slabs must fit the workspace; too little parallelism left -> conv_wgrad_v2
     // SZN_WGT_OVERSUB = k (default 1): k blocks per CU instead of one.  One block per CU is fastest on an idle GPU but its
     // static partition has a full-kernel tail whenever another queue (an RCCL all-reduce running under the backward
-    // pass) holds CUs: the data-parallel trainer sets k = 2 so that the late blocks are half as long.
+    // pass) holds CUs; k = 2 halves the late blocks.  Measured with a 32-CU stand-in hog (profiles/r01_ablations.txt): 12.2 vs 12.3
+    // ms/step under contention, 11.7 vs 11.9 without -- no net gain, so nothing sets it by default.
     static int oversub = 0;
     if (!oversub) { const char* e = getenv("SZN_WGT_OVERSUB"); oversub = e ? atoi(e) : 1; if (oversub < 1) oversub = 1; }
     long ns = (long)ncu * oversub / ncombo;

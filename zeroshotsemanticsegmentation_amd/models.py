@@ -370,7 +370,7 @@ class _Engine(object):
         code = L.dtype_code(self.dtype)
         d = L.ConvDesc(code, B, Hi, Wi, ci, Ho, Wo, co, k, k, pad, ci, ldo, 0, 0, 0)
         if k == 3:      # slabs of the all-taps kernel (szn_conv_wgrad_taps.hip): <= 256 blocks x 64*9*64 fp32
-            nb = 2 * 256 * 64 * 9 * 64 * 4      # (two blocks per CU when the data-parallel trainer asks for it)
+            nb = 2 * 256 * 64 * 9 * 64 * 4      # (room for SZN_WGT_OVERSUB=2: two blocks per CU)
             if self._wg_ws is None or self._wg_ws.device != x.device:
                 self._wg_ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
             d.workspace, d.workspace_bytes = self._wg_ws.data_ptr(), nb
