@@ -28,13 +28,10 @@ struct bf16_raw { uint16_t v; };
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
     return __uint_as_float(((uint32_t)b) << 16);
 }
-// round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16 cast)
-__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+// round-to-nearest-even, NaN stays NaN (same rule as torch's float -> bfloat16 cast): gfx950 converts in hardware
+// (v_cvt_pk_bf16_f32: one instruction per PAIR instead of ~7 VALU operations per element -- the conversions were a third of the
+// VALU work of the 16-bit epilogues)
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
 // IEEE half as a 16-bit storage type (SZN_F16: BASELINE configs[4] "fp16 activations"); converted by the hardware's
 // round-to-nearest-even v_cvt_f16_f32 / v_cvt_f32_f16
@@ -67,8 +64,14 @@ template <typename T> __device__ __forceinline__ uint16_t to_bits16(float f) { r
 template <> __device__ __forceinline__ uint16_t to_bits16<f16_raw>(float f) { return f32_to_f16_bits(f); }
 template <typename T> __device__ __forceinline__ float from_bits16(uint16_t b) { return bf16_bits_to_f32(b); }
 template <> __device__ __forceinline__ float from_bits16<f16_raw>(uint16_t b) { return f16_bits_to_f32(b); }
-template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)to_bits16<T>(lo) | ((uint32_t)to_bits16<T>(hi) << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 szn_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 szn_f16x2_t;
+typedef __attribute__((ext_vector_type(2))) float szn_f32x2_t;
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {       // v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((szn_f32x2_t){lo, hi}, szn_bf16x2_t));
+}
+template <> __device__ __forceinline__ uint32_t pack2<f16_raw>(float lo, float hi) {        // v_cvt_pk_f16_f32 (RNE)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((szn_f32x2_t){lo, hi}, szn_f16x2_t));
 }
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t szn_u32x4_t;

@@ -35,7 +35,14 @@ struct RwArgs {
     int B, Hi, Wi, Ho, Wo, pad;
     int ldi, ldo, ldg, relu;
     int tiles_x, tiles_y, ntiles;      // ntiles = B * tiles_y * tiles_x
+    int ablate;                        // SZN_REGW_ABLATE (make ABLATE=1 only; WRONG results): 1 no MFMA phase, 2 no global stores, 4 no patch DMA
+    int shift;                         // 1: phase-shifted wave groups (CIG = 1 kernels; SZN_REGW_SHIFT=0 restores the lockstep order)
 };
+#ifdef SZN_ABLATE_BUILD
+#define RW_ABL(bit) (a.ablate & (bit))
+#else
+#define RW_ABL(bit) 0
+#endif
 
 constexpr unsigned kOOBr = 0x80000000u;
 constexpr int PWr = 18;
@@ -158,6 +165,16 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
     }
     __syncthreads();
 
+    // Phase shift (CIG = 1).  The two waves of a SIMD (w, w + 4) used to run the same phase at the same time -- MFMA phase, then
+    // epilogue (permlane / bias / ReLU / pack / stores) -- and the phases simply added up (SZN_REGW_ABLATE accounting of conv1_2
+    // forward: 0.42 ms = 0.14 epilogue + barriers, + 0.19 MFMA phase, + 0.05 stores, + 0.09 patch DMA).  Waves 4 .. 7 (group B) now take
+    // the per-tile block barrier BETWEEN their MFMA phase and their epilogue, waves 0 .. 3 (group A) behind the epilogue as before:
+    //     A:  MFMA(t) epi(t) | MFMA(t+1) epi(t+1) | ...          B:  MFMA(t) | epi(t) MFMA(t+1) | epi(t+1) MFMA(t+2) | ...
+    // so between two barriers every SIMD has one wave in each phase.  Same number of barriers per wave, same buffer hand-over rule
+    // (after barrier k everyone has finished the MFMAs of tile first + k - 1, whose patch buffer is the one refilled next, and has
+    // waited for its own pieces of patch first + k), no extra registers.  CIG = 2 keeps the lockstep order: its mid-tile partner
+    // exchange needs a block barrier that both groups reach at the same point.
+    const bool grpB = CIG == 1 && a.shift && w >= 4;
     int buf = 0;
     for (int t = first; t < last; ++t) {
         const bool more = t + NBUF - 1 < last;
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (ldsptr_t)(smem + G_::OFF_GATE + (w * NJ + jj) * 1024), 16, v, 0, 0, 0);
             }
         }
-        if (more) issue(t + NBUF - 1, (buf + NBUF - 1) % NBUF);
+        if (more && !RW_ABL(4)) issue(t + NBUF - 1, (buf + NBUF - 1) % NBUF);
 
         f32x4_t acc[2][4];
 #pragma unroll
@@ -199,6 +216,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             dst[1] = *(const u32x4_t*)(rowp + (((cig * 8 + 4 + g) ^ sw) << 4));
         };
         ldP(0, P[0]);
+        if (!RW_ABL(1))
 #pragma unroll
         for (int step = 0; step < 18; ++step) {
             const int pr = step / 3, kw = step - pr * 3;
@@ -253,6 +271,10 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
         // retire the gate pieces of t, the patch pieces of t + 1 and the stores of t - 1
         if (NBUF == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SLOTS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (grpB) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         float cs[8];
         float pm[8];                                                       // pooling: the even row of the current row pair
 #pragma unroll
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             pk.y = pack2<T>(v[2], v[3]);
             pk.z = pack2<T>(v[4], v[5]);
             pk.w = pack2<T>(v[6], v[7]);
-            if (ok) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
+            if (ok && !RW_ABL(2)) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
             if constexpr (!GATED) {
                 // fused MaxPool2d(2,2,ceil): rows (j, j + 1) pair up in this lane (oh0 is even), columns (ow, ow ^ 1) in
                 // neighbouring lanes; post-ReLU values are >= 0, so out-of-range window members count as 0
@@ -303,7 +325,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                             mx[e] = fmaxf(m2, nb);                         // quad_perm [1,0,3,2]: the lane of column ow ^ 1
                         }
                         const int poh = (oh0 + j) >> 1, pw = ow >> 1;
-                        if ((r16 & 1) == 0 && okw && poh < a.Hp) {
+                        if ((r16 & 1) == 0 && okw && poh < a.Hp && !RW_ABL(2)) {
                             u32x4_t pq;
                             pq.x = pack2<T>(mx[0], mx[1]);
                             pq.y = pack2<T>(mx[2], mx[3]);
@@ -323,14 +345,20 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                 if (r16 == 0) __hip_atomic_fetch_add(red + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f32
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!grpB) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         buf = (buf == NBUF - 1) ? 0 : buf + 1;
+    }
+    if constexpr (COLSUM && CIG == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // group B's last column sums are in LDS before the flush below
     }
 
     if constexpr (COLSUM) {
         if (tid < CO) {
-            const float s = ((const float*)(smem + G_::OFF_RED))[tid];     // complete: behind the last tile's barrier
+            const float s = ((const float*)(smem + G_::OFF_RED))[tid];     // complete: behind the last barrier
             if (s != 0.f) atomicAdd(a.colsum + tid, s);
         }
     }
@@ -382,6 +410,8 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     const long nt = (long)a.B * a.tiles_y * a.tiles_x;
     if (nt >= (1L << 30) || nt * tr * 16 < (long)min_tiles * 256) return 1;      // min_tiles counts 256-pixel tiles
     a.ntiles = (int)nt;
+    { static int abl = -1; if (abl < 0) abl = szn_ablate_env("SZN_REGW_ABLATE"); a.ablate = abl; }
+    { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_REGW_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t p;
