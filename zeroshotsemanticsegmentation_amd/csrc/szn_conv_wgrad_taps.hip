@@ -116,6 +116,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
     int offA[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) offA[i] = kk * 128 + (((h * 4 + i * 2) ^ (((kk >> 1) & 3) << 1)) << 4) + sub;
+    // patch reads: per-lane bases for (parity of s, (s >> 1) & 3), s = 18 R + kw (see the K loop)
+    int Xb[2][4];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            Xb[par][m] = kk * 128 + sub + (((c * 2) ^ (((((kk + par) >> 1) + m) & 3) << 1)) << 4);
 
     if (first < last) {
         prepare(first);
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
 #pragma unroll
         for (int p = 0; p < 6; ++p) fireB(p, 0);
     }
+    const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of the dynamic segment
     int stage = 0;
     long long tw = 0, ti = 0, tc = 0, c0 = 0, c1 = 0, c2 = 0;   // SZN_WGT_ABLATE=9: cycles in wait+barrier / issue / compute
     for (int t = first; t < last; ++t) {
@@ -133,25 +141,49 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
         if (a.ablate == 9) { c1 = clock64(); tw += c1 - c0; }
         const bool fill = t + 1 < last && a.ablate != 1;
         if (a.ablate == 9) { c2 = clock64(); ti += c2 - c1; }
-        const char* sd = smem + stage * STAGEt;
-        const char* sp = sd + DOUTB;
+        // Fragment addresses = per-lane base + compile-time offset (the ds_read offset field), and reads issued ONE K step ahead.
+        // A patch read of row R at column shift kw touches flattened patch pixel q = s + kk with s = 18 R + kw known at compile
+        // time; its row swizzle ((q >> 1) & 3) is ((kk + (s & 1)) >> 1) + (s >> 1) mod 4, so eight per-lane bases Xb[s & 1][(s >> 1) & 3]
+        // cover every (R, kw) and the address costs no VALU work (the compiler had hoisted ~60 per-site offsets into VGPRs and
+        // then had no registers left to move the reads away from their MFMAs: each MFMA group waited out the LDS latency of reads
+        // issued a few instructions earlier -- the compute phase took 6,800 cycles per tile for 4,600 cycles of MFMA).
+        const int sdo = stage * STAGEt;
+        int Xt[2][4], At[2];
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) Xt[par][m] = Xb[par][m] + sdo + DOUTB;
+        At[0] = offA[0] + sdo; At[1] = offA[1] + sdo;
+        // The transpose reads are issued as inline asm: behind a `buffer_load ... lds` the compiler puts s_waitcnt vmcnt(0) in front
+        // of the next LDS read it knows about (the DMA might alias it), so the wave that had just issued the fill of tile t + 1
+        // sat out the whole HBM latency of that fill in the middle of its MFMAs -- once per tile, every wave.  The fill goes to the
+        // OTHER stage; the waits are explicit: lgkmcnt(0) behind the 18 MFMAs of a K step for the reads issued in front of them
+        // (tied to their destination registers), vmcnt(0) + barrier at the top of a tile.
+        auto rd_tr = [&](int addr, int off) -> u32x2_t {
+            u32x2_t v;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+            return v;
+        };
         auto rdA = [&](int p, int i) -> u32x4_t {
-            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sd + p * 4096 + offA[i]));
-            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sd + p * 4096 + 2048 + offA[i]));
-            const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+            const u32x2_t l2 = rd_tr(smem_lds + At[i], p * 4096), h2 = rd_tr(smem_lds + At[i], p * 4096 + 2048);
             return u32x4_t{l2.x, l2.y, h2.x, h2.y};
         };
         auto rdB = [&](int R, int kw) -> u32x2_t {          // patch row R (0..17), column shift kw, 16 pixels
-            const int q = R * PWt + kw + kk;
-            const bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sp + q * 128 + (((c * 2) ^ (((q >> 1) & 3) << 1)) << 4) + sub));
-            return __builtin_bit_cast(u32x2_t, v);
+            const int sq = R * PWt + kw;
+            return rd_tr(smem_lds + Xt[sq & 1][(sq >> 1) & 3], sq * 128);
         };
-        u32x2_t Br[4][3];
-        u32x4_t Af[2];
+        u32x2_t Br[6][3];
+        u32x4_t Af[2][2];
 #pragma unroll
-        for (int R = 0; R < 2; ++R)
+        for (int R = 0; R < 4; ++R)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) Br[R][kw] = rdB(R, kw);
+        Af[0][0] = rdA(0, 0); Af[0][1] = rdA(0, 1);
+        // the waits name the registers the reads are landing in ("+v"): nothing -- not even a register copy -- may touch them earlier
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(Br[0][0]), "+v"(Br[0][1]), "+v"(Br[0][2]), "+v"(Br[1][0]), "+v"(Br[1][1]), "+v"(Br[1][2]),
+                       "+v"(Br[2][0]), "+v"(Br[2][1]), "+v"(Br[2][2]), "+v"(Br[3][0]), "+v"(Br[3][1]), "+v"(Br[3][2]),
+                       "+v"(Af[0][0]), "+v"(Af[0][1]));
         if (a.ablate != 2)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -165,12 +197,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) fireB(q, stage ^ 1);
             }
-            // rows 2p, 2p + 1 are in Br[0], Br[1]; fetch 2p + 2, 2p + 3 and the dout fragments of this step
+            // fetch rows 2p + 4, 2p + 5 and the dout fragments of the NEXT step while this step's 18 MFMAs run
+            if (p < 7) {
 #pragma unroll
-            for (int R = 2; R < 4; ++R)
+                for (int R = 4; R < 6; ++R)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) Br[R][kw] = rdB(2 * p + R, kw);
-            Af[0] = rdA(p, 0); Af[1] = rdA(p, 1);
+                    for (int kw = 0; kw < 3; ++kw) Br[R][kw] = rdB(2 * p + R, kw);
+                Af[(p + 1) & 1][0] = rdA(p + 1, 0); Af[(p + 1) & 1][1] = rdA(p + 1, 1);
+            }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -178,10 +212,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
                     const u32x4_t xf = u32x4_t{Br[kh][kw].x, Br[kh][kw].y, Br[kh + 1][kw].x, Br[kh + 1][kw].y};
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        acc[i][kh * 3 + kw] = mfma16<T>(Af[i], xf, acc[i][kh * 3 + kw]);
+                        acc[i][kh * 3 + kw] = mfma16<T>(Af[p & 1][i], xf, acc[i][kh * 3 + kw]);
                 }
+            if (p < 7) {
+                // behind this step's MFMAs (acc[1][8] is the last one's result): the reads issued in front of them have landed
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(Br[4][0]), "+v"(Br[4][1]), "+v"(Br[4][2]), "+v"(Br[5][0]), "+v"(Br[5][1]), "+v"(Br[5][2]),
+                               "+v"(Af[(p + 1) & 1][0]), "+v"(Af[(p + 1) & 1][1]), "+v"(acc[1][8]));
+            }
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) { Br[0][kw] = Br[2][kw]; Br[1][kw] = Br[3][kw]; }
+            for (int R = 0; R < 4; ++R)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) Br[R][kw] = Br[R + 2][kw];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (a.ablate == 9) tc += clock64() - c2;
