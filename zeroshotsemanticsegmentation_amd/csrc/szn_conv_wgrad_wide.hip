@@ -32,6 +32,7 @@ struct WgwArgs {
     int cotiles, citiles;
     int accumulate;
     int ablate;                // debug (env SZN_WGW_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no reads / MFMA
+    int use_tab;               // 1: pixel -> input-offset table of this block's tap in LDS behind the ring (M <= kTabMax)
 };
 
 constexpr unsigned kOOBg = 0x80000000u;
@@ -39,6 +40,7 @@ constexpr int KPg = 32;                              // pixels per stage
 constexpr int STAGEg = KPg * 1024;                   // A rows 512 B + B rows 512 B
 constexpr int NSTg = 4;
 constexpr int LDS_WGW = NSTg * STAGEg;               // 128 KiB
+constexpr int kTabMax = 8000;                        // pixels whose 4-B table entries fit behind the ring (160 KiB LDS)
 
 template <typename T>      // bf16_raw | f16_raw: only the MFMA opcode differs
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
@@ -72,23 +74,55 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
         q += ((q + 1) * d <= m) ? 1 : 0;
         return q;
     };
-    unsigned vA[2], vB[2];
+    const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of the dynamic segment
+    // Pixel -> byte offset of the input pixel under THIS block's tap (or out of range), built once: the per-step address work
+    // (two float reciprocal divisions, bounds tests and multiplies per slot, ~100 VALU operations per wave per 32 MFMAs) sat in
+    // the issue slots of the MFMA phase.  With the table a slot costs one ds_read_b32, issued in front of the fragment reads and
+    // covered by their wait.
+    auto tap_offset = [&](int m) -> unsigned {
+        const int b = divq(m, HW, invHW), r = m - b * HW;
+        const int oh = divq(r, a.Wo, invW), ow = r - oh * a.Wo;
+        const int ih = oh + kh - a.pad, iw = ow + kw - a.pad;
+        const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+        return ok ? (unsigned)((b * a.Hi + ih) * a.Wi + iw) * (unsigned)(a.ldi * 2) : kOOBg;
+    };
+    if (a.use_tab) {
+        unsigned* tab = (unsigned*)(smem + LDS_WGW);
+        for (int m = tid; m < a.M; m += 512) tab[m] = tap_offset(m);
+        __syncthreads();
+    }
+    unsigned vA[2], vB[2], tb[2];
     int mnext = 4 * w + hrow;                                       // pixel of slot 0 in the step being prepared
-    auto prepare = [&]() {
+    int mcur[2];
+    auto prepare_issue = [&]() {                                    // vA; table reads for vB (asm: see the K loop)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = mnext + 2 * i;
+            mcur[i] = m;
             const int chunk = slot ^ (((4 * (w & 1) + 2 * i + hrow) & 7) << 1);     // row & 7
-            const int co = co0 + chunk * 8, ci = ci0 + chunk * 8;
-            const bool inm = m < a.M;
-            vA[i] = (inm && co < a.Co && co + 8 <= a.ldd) ? (unsigned)m * (unsigned)(a.ldd * 2) + (unsigned)(co * 2) : kOOBg;
-            const int b = divq(m, HW, invHW), r = m - b * HW;
-            const int oh = divq(r, a.Wo, invW), ow = r - oh * a.Wo;
-            const int ih = oh + kh - a.pad, iw = ow + kw - a.pad;
-            const bool ok = inm && ci < a.Ci && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-            vB[i] = ok ? (unsigned)((b * a.Hi + ih) * a.Wi + iw) * (unsigned)(a.ldi * 2) + (unsigned)(ci * 2) : kOOBg;
+            const int co = co0 + chunk * 8;
+            vA[i] = (m < a.M && co < a.Co && co + 8 <= a.ldd) ? (unsigned)m * (unsigned)(a.ldd * 2) + (unsigned)(co * 2) : kOOBg;
+            if (a.use_tab) {
+                const int addr = smem_lds + LDS_WGW + 4 * min(m, a.M - 1);
+                asm volatile("ds_read_b32 %0, %1" : "=v"(tb[i]) : "v"(addr));
+            }
         }
         mnext += KPg;
+    };
+    auto prepare_finish = [&]() {                                   // (behind a wait that covers the table reads)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mcur[i];
+            const int chunk = slot ^ (((4 * (w & 1) + 2 * i + hrow) & 7) << 1);
+            const int ci = ci0 + chunk * 8;
+            const unsigned t = a.use_tab ? tb[i] : tap_offset(min(m, a.M - 1));
+            vB[i] = (m < a.M && ci < a.Ci && t != kOOBg) ? t + (unsigned)(ci * 2) : kOOBg;
+        }
+    };
+    auto prepare = [&]() {
+        prepare_issue();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]));
+        prepare_finish();
     };
     auto fire = [&](int stage) {
         char* sb = smem + stage * STAGEg;
@@ -129,32 +163,50 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kc + 3 < nK && a.ablate != 1) fire((stage + 3) & 3);       // the stage drained in step kc - 1
-        prepare();                                    // offsets of step kc + 4: VALU work under this step's MFMAs
-        const char* sb = smem + stage * STAGEg;
+        prepare_issue();                              // offsets of step kc + 4 (table reads go out in front of the fragment reads)
+        // Transpose reads as inline asm with explicit waits: behind the `buffer_load ... lds` of fire() the compiler puts
+        // s_waitcnt vmcnt(0) in front of the next LDS read it knows about (the DMA might alias it) -- every K step then waited for
+        // the stage it had JUST issued, i.e. the ring never had anything in flight (0.32 of peak).  The fill goes to another stage;
+        // the counted vmcnt above is the only wait on it.
+        const int sbo = smem_lds + stage * STAGEg;
         if (a.ablate != 2) {
-            constexpr int h = 0;
-            u32x4_t df[8], xf[4];
+            auto rd_tr = [&](int addr, int off) -> u32x2_t {
+                u32x2_t v;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+                return v;
+            };
+            u32x2_t dl[8], dh[8], xl[4], xh[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + h * 32 * 512 + offA[i]));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + h * 32 * 512 + 16 * 512 + offA[i]));
-                const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-                df[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+            for (int j = 0; j < 4; ++j) { xl[j] = rd_tr(sbo + offB[j], 0); xh[j] = rd_tr(sbo + offB[j], 16 * 512); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dl[i] = rd_tr(sbo + offA[i], 0); dh[i] = rd_tr(sbo + offA[i], 16 * 512); }
+#pragma unroll
+            for (int i = 4; i < 8; ++i) { dl[i] = rd_tr(sbo + offA[i], 0); dh[i] = rd_tr(sbo + offA[i], 16 * 512); }
+            // first half: the pixel fragments and dout fragments 0 .. 3 have landed (8 reads may still be in flight)
+            asm volatile("s_waitcnt lgkmcnt(8)"
+                         : "+v"(tb[0]), "+v"(tb[1]), "+v"(xl[0]), "+v"(xh[0]), "+v"(xl[1]), "+v"(xh[1]), "+v"(xl[2]), "+v"(xh[2]), "+v"(xl[3]), "+v"(xh[3]),
+                           "+v"(dl[0]), "+v"(dh[0]), "+v"(dl[1]), "+v"(dh[1]), "+v"(dl[2]), "+v"(dh[2]), "+v"(dl[3]), "+v"(dh[3]));
+            u32x4_t xf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[j] = u32x4_t{xl[j].x, xl[j].y, xh[j].x, xh[j].y};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4_t df = u32x4_t{dl[i].x, dl[i].y, dh[i].x, dh[i].y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(df, xf[j], acc[i][j]);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(dl[4]), "+v"(dh[4]), "+v"(dl[5]), "+v"(dh[5]), "+v"(dl[6]), "+v"(dh[6]), "+v"(dl[7]), "+v"(dh[7]),
+                           "+v"(acc[3][3]));            // (behind the 16 MFMAs of the first half)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + h * 32 * 512 + offB[j]));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + h * 32 * 512 + 16 * 512 + offB[j]));
-                const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-                xf[j] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+            for (int i = 4; i < 8; ++i) {
+                const u32x4_t df = u32x4_t{dl[i].x, dl[i].y, dh[i].x, dh[i].y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(df, xf[j], acc[i][j]);
             }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = mfma16<T>(df[i], xf[j], acc[i][j]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]) : : "memory");
+        prepare_finish();
         stage = (stage + 1) & 3;
     }
 
@@ -214,14 +266,16 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     a.M = d->B * d->Ho * d->Wo;
     a.accumulate = accumulate;
     { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGW_ABLATE"); } a.ablate = abl; }
+    { static int tab = -1; if (tab < 0) { const char* e = getenv("SZN_WGW_TAB"); tab = e ? atoi(e) : 1; } a.use_tab = (tab && a.M <= kTabMax) ? 1 : 0; }
+    const int lds = LDS_WGW + (a.use_tab ? kTabMax * 4 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<bf16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<f16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<bf16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW + kTabMax * 4);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<f16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW + kTabMax * 4);
         attr_done = true;
     }
-    if (d->dtype == SZN_F16) hipLaunchKernelGGL(conv_wgrad_wide<f16_raw>, dim3((unsigned)tiles), dim3(512), LDS_WGW, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv_wgrad_wide<bf16_raw>, dim3((unsigned)tiles), dim3(512), LDS_WGW, (hipStream_t)stream, a);
+    if (d->dtype == SZN_F16) hipLaunchKernelGGL(conv_wgrad_wide<f16_raw>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_wide<bf16_raw>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a);
     SZN_CHECK_LAUNCH("conv_wgrad_wide");
     return SZN_OK;
 }
