@@ -5,9 +5,11 @@
 // layers.  Here: 512 threads = 8 waves (2 x 4), wave = 128 couts x 64 cins (8 x 4 accumulator fragments = 128 VGPRs),
 // K step = 32 pixels per barrier, 128 B of LDS fill per MFMA.  dout / input slices are used by few blocks, so most of
 // the fill misses L2 and sees HBM / MALL latency (~3 us measured): the fill rate is (bytes in flight) / latency, hence a
-// 4-stage ring of 32-KiB stages with THREE stages in flight (96 KiB) rather than two 64-KiB stages with one in flight.
+// 4-stage ring of 32-KiB stages rather than two 64-KiB stages with one in flight (two stages = 64 KiB stay in flight since the
+// wave groups are phase-shifted: see the K loop).
 //   * per filter tap a GEMM D[co][ci] = A^T B, A = dout [pixel][256 co], B = shifted input [pixel][256 ci]; both
-//     staged pixel-major ([32 px][512 B]) by LDS-DMA into a 4-stage ring (counted vmcnt), fragments by ds_read_b64_tr_b16;
+//     staged pixel-major ([32 px][512 B]) by LDS-DMA into a 4-stage ring (counted vmcnt), fragments by ds_read_b64_tr_b16 (inline asm:
+//     behind an LDS-DMA load the compiler would put s_waitcnt vmcnt(0) in front of an LDS read it knows about);
 //   * 16-B chunk index XOR-swizzled by (row & 7) << 1 on the DMA source side (8 consecutive 512-B rows of a transpose
 //     read land in 8 distinct 32-B bank groups);
 //   * out-of-image taps / tile edges / the pixel tail are out-of-range buffer offsets (zeros); pixel coordinates advance
@@ -33,6 +35,7 @@ struct WgwArgs {
     int accumulate;
     int ablate;                // debug (env SZN_WGW_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no reads / MFMA
     int use_tab;               // 1: pixel -> input-offset table of this block's tap in LDS behind the ring (M <= kTabMax)
+    int shift;                 // 1: phase-shifted wave groups (SZN_WGW_SHIFT=0: lockstep)
 };
 
 constexpr unsigned kOOBg = 0x80000000u;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
         for (int m = tid; m < a.M; m += 512) tab[m] = tap_offset(m);
         __syncthreads();
     }
-    unsigned vA[2], vB[2], tb[2];
+    unsigned vA[2], vB[2], vAn[2], tb[2];          // vAn: dout offsets of the step being prepared (vA / vB are live until fire())
     int mnext = 4 * w + hrow;                                       // pixel of slot 0 in the step being prepared
     int mcur[2];
     auto prepare_issue = [&]() {                                    // vA; table reads for vB (asm: see the K loop)
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
             mcur[i] = m;
             const int chunk = slot ^ (((4 * (w & 1) + 2 * i + hrow) & 7) << 1);     // row & 7
             const int co = co0 + chunk * 8;
-            vA[i] = (m < a.M && co < a.Co && co + 8 <= a.ldd) ? (unsigned)m * (unsigned)(a.ldd * 2) + (unsigned)(co * 2) : kOOBg;
+            vAn[i] = (m < a.M && co < a.Co && co + 8 <= a.ldd) ? (unsigned)m * (unsigned)(a.ldd * 2) + (unsigned)(co * 2) : kOOBg;
             if (a.use_tab) {
                 const int addr = smem_lds + LDS_WGW + 4 * min(m, a.M - 1);
                 asm volatile("ds_read_b32 %0, %1" : "=v"(tb[i]) : "v"(addr));
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
             const int ci = ci0 + chunk * 8;
             const unsigned t = a.use_tab ? tb[i] : tap_offset(min(m, a.M - 1));
             vB[i] = (m < a.M && ci < a.Ci && t != kOOBg) ? t + (unsigned)(ci * 2) : kOOBg;
+            vA[i] = vAn[i];
         }
     };
     auto prepare = [&]() {
@@ -155,14 +159,24 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
     prepare(); if (nK > 1) fire(1);
     prepare(); if (nK > 2) fire(2);
     prepare();                                        // offsets of step 3
+    // Phase shift: the two waves of a SIMD (w, w + 4) used to run the same phase at the same time (24 transpose reads -- 96 KiB per
+    // CU per step through the LDS port -- then 32 MFMAs).  Waves 4 .. 7 (group B) take the per-step barrier between their reads and
+    // their MFMAs, waves 0 .. 3 (group A) in front of their reads as before:
+    //     A:  W | fire reads(k) MFMA(k)  W | fire reads(k+1) MFMA(k+1) ...      B:  W reads(k) | MFMA(k) fire  W reads(k+1) | MFMA(k+1) fire ...
+    // so between two barriers every SIMD has one wave reading and one multiplying.  Rules of the ring under this order:
+    //   * W at the top of step k waits for the wave's own pieces of stage k + 1 (B reads stage k + 1 behind barrier k), so two
+    //     stages stay in flight instead of three; a prologue barrier covers stage 0;
+    //   * a wave fires stage k + 3 (the buffer of step k - 1) only behind barrier k, when everybody has finished reading step k - 1.
+    const bool grpB = a.shift && w >= 4;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // stage 0 (the prologue fired up to three stages of four loads)
+    __builtin_amdgcn_s_barrier();
     int stage = 0;
     for (int kc = 0; kc < nK; ++kc) {
-        // four LDS-DMA instructions per wave per stage; stages kc + 1, kc + 2 may stay in flight
-        if (kc + 2 < nK) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // four LDS-DMA instructions per wave per stage: only stage kc + 2 may stay in flight here
+        if (kc + 2 < nK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kc + 3 < nK && a.ablate != 1) fire((stage + 3) & 3);       // the stage drained in step kc - 1
+        if (!grpB) __builtin_amdgcn_s_barrier();
+        if (!grpB && kc + 3 < nK && a.ablate != 1) fire((stage + 3) & 3);       // the stage drained in step kc - 1
         prepare_issue();                              // offsets of step kc + 4 (table reads go out in front of the fragment reads)
         // Transpose reads as inline asm with explicit waits: behind the `buffer_load ... lds` of fire() the compiler puts
         // s_waitcnt vmcnt(0) in front of the next LDS read it knows about (the DMA might alias it) -- every K step then waited for
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
             asm volatile("s_waitcnt lgkmcnt(8)"
                          : "+v"(tb[0]), "+v"(tb[1]), "+v"(xl[0]), "+v"(xh[0]), "+v"(xl[1]), "+v"(xh[1]), "+v"(xl[2]), "+v"(xh[2]), "+v"(xl[3]), "+v"(xh[3]),
                            "+v"(dl[0]), "+v"(dh[0]), "+v"(dl[1]), "+v"(dh[1]), "+v"(dl[2]), "+v"(dh[2]), "+v"(dl[3]), "+v"(dh[3]));
+            if (grpB) __builtin_amdgcn_s_barrier();
             u32x4_t xf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) xf[j] = u32x4_t{xl[j].x, xl[j].y, xh[j].x, xh[j].y};
@@ -206,6 +221,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]) : : "memory");
+        if (grpB && a.ablate == 2) __builtin_amdgcn_s_barrier();
+        if (grpB && kc + 3 < nK && a.ablate != 1) fire((stage + 3) & 3);        // (behind B's barrier)
         prepare_finish();
         stage = (stage + 1) & 3;
     }
@@ -267,6 +284,7 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     a.accumulate = accumulate;
     { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGW_ABLATE"); } a.ablate = abl; }
     { static int tab = -1; if (tab < 0) { const char* e = getenv("SZN_WGW_TAB"); tab = e ? atoi(e) : 1; } a.use_tab = (tab && a.M <= kTabMax) ? 1 : 0; }
+    { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_WGW_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
     const int lds = LDS_WGW + (a.use_tab ? kTabMax * 4 : 0);
     static bool attr_done = false;
     if (!attr_done) {
