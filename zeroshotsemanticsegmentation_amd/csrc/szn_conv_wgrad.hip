@@ -168,22 +168,31 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_v2(Wg2Args a) {
         if (kc + 2 < nK) issue(stage >= 1 ? stage - 1 : 2);
         const char* sb = smem + stage * STAGE;
         if constexpr (ES == 2) {
-            typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+            // transpose reads as inline asm with an explicit wait: behind the `buffer_load ... lds` of issue() the compiler puts
+            // s_waitcnt vmcnt(0) in front of a builtin LDS read (the DMA might alias it) -- the step then waited for the stage it
+            // had just issued (profiles/r02_ablations.txt section 12)
+            auto rd_tr = [&](int addr, int off) -> u32x2_t {
+                u32x2_t v;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+                return v;
+            };
+            const int sbo = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem + stage * STAGE;
+            u32x2_t dl[FA], dh[FA], xl[FB], xh[FB];
+#pragma unroll
+            for (int i = 0; i < FA; ++i) { dl[i] = rd_tr(sbo + offA[i], 0); dh[i] = rd_tr(sbo + offA[i], 16 * RBA); }
+#pragma unroll
+            for (int j = 0; j < FB; ++j) { xl[j] = rd_tr(sbo + offB[j], 0); xh[j] = rd_tr(sbo + offB[j], 16 * RBB); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (volatile asm statements keep their order: every fragment register is redefined BEHIND the wait, so no use can move above it)
+#pragma unroll
+            for (int i = 0; i < FA; ++i) asm volatile("" : "+v"(dl[i]), "+v"(dh[i]));
+#pragma unroll
+            for (int j = 0; j < FB; ++j) asm volatile("" : "+v"(xl[j]), "+v"(xh[j]));
             u32x4_t df[FA], xf[FB];
 #pragma unroll
-            for (int i = 0; i < FA; ++i) {
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offA[i]));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offA[i] + 16 * RBA));
-                const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-                df[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
-            }
+            for (int i = 0; i < FA; ++i) df[i] = u32x4_t{dl[i].x, dl[i].y, dh[i].x, dh[i].y};
 #pragma unroll
-            for (int j = 0; j < FB; ++j) {
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offB[j]));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offB[j] + 16 * RBB));
-                const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-                xf[j] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
-            }
+            for (int j = 0; j < FB; ++j) xf[j] = u32x4_t{xl[j].x, xl[j].y, xh[j].x, xh[j].y};
 #pragma unroll
             for (int i = 0; i < FA; ++i)
 #pragma unroll

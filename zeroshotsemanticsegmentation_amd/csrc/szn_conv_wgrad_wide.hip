@@ -168,7 +168,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
     //     stages stay in flight instead of three; a prologue barrier covers stage 0;
     //   * a wave fires stage k + 3 (the buffer of step k - 1) only behind barrier k, when everybody has finished reading step k - 1.
     const bool grpB = a.shift && w >= 4;
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // stage 0 (the prologue fired up to three stages of four loads)
+    // stage 0 has landed for every wave before group B reads it (the prologue fired min(nK, 3) stages of four loads each)
+    if (nK > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nK > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int stage = 0;
     for (int kc = 0; kc < nK; ++kc) {
