@@ -498,7 +498,11 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
     const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
     const long total = (long)B * Ho * Wo * (C / ch);
     if (colsum && (256 % (C / ch)) != 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd: colsum needs C/%d to divide 256", ch);
-    const int grid = grid_for(total, 256, colsum ? 4096 : 65536);
+    // with column sums every block ends in C atomicAdds on the same C addresses: 4096 blocks spent more time there than streaming
+    // (pool3 .. pool5); two blocks per CU stream at 5.3 TB/s (tools/bench sweep in profiles/r02_ablations.txt section 13)
+    static int capx = -1;
+    if (capx < 0) { const char* e = getenv("SZN_POOLBWD_BLOCKS"); capx = e ? atoi(e) : 512; if (capx < 1) capx = 1; }
+    const int grid = grid_for(total, 256, colsum ? capx : 65536);
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_raw*)in, (const bf16_raw*)out, (const bf16_raw*)dout, (bf16_raw*)din, B, Hi, Wi, C,
