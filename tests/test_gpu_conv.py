@@ -47,6 +47,8 @@ CASES = [
     (1, 260, 258, 256, 256, 3, 1),       # ... four cin chunks, forward and dgrad, ragged last tile
     (37, 43, 42, 64, 256, 3, 1),         # ... small maps: every 256-pixel tile crosses image boundaries
     (1, 3, 25000, 64, 256, 3, 1),        # ... three very long rows: two thirds of the pixels are border pixels in the vertical direction
+    (5, 32, 32, 64, 2000, 1, 0),         # 256 x 192 tiles (bf16): 20 x 11 = 220 tiles in one round where 256 x 128 needs 320; ragged last tile
+    (8, 17, 17, 4096, 4096, 1, 0),       # ... fc7 at the bench shape, forward and dgrad (gate, column sums)
 ]
 
 
@@ -58,6 +60,8 @@ EXPECT_BF16 = {
     (1, 190, 181, 128, 64, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
     (1, 183, 187, 128, 128, 3, 1): ("conv3x3_regw", "conv3x3_regw", "wgrad_taps_reduce"),
     (1, 260, 260, 64, 300, 1, 0): ("conv_igemm_wide", None, None),
+    (5, 32, 32, 64, 2000, 1, 0): ("conv_igemm_wide", None, None),
+    (8, 17, 17, 4096, 4096, 1, 0): ("conv_igemm_wide", "conv_igemm_wide", "conv_wgrad_wide"),
     (3, 150, 151, 64, 256, 3, 1): ("conv3x3_wide_rows", None, None),
     (1, 260, 258, 256, 256, 3, 1): ("conv3x3_wide_rows", "conv3x3_wide_rows", None),
     (37, 43, 42, 64, 256, 3, 1): ("conv3x3_wide_rows", None, None),

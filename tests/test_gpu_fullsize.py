@@ -68,7 +68,7 @@ LAYERS = {   # (shape), batch, expected forward kernel (None: a split-K epilogue
     "conv1_2": ((710, 64, 64, 3, 1), 2, "conv3x3_regw"), "conv2_1": ((355, 64, 128, 3, 1), 2, "conv3x3_regw"),
     "conv2_2": ((355, 128, 128, 3, 1), 2, "conv3x3_regw"), "conv3_2": ((178, 256, 256, 3, 1), 4, "conv3x3_wide_rows"),
     "conv4_2": ((89, 512, 512, 3, 1), 8, "conv3x3_wide_rows"), "conv5_1": ((45, 512, 512, 3, 1), 8, "conv_igemm_v2"),
-    "fc6": ((23, 512, 4096, 7, 0), 8, None), "fc7": ((17, 4096, 4096, 1, 0), 8, "conv_igemm_v2"),
+    "fc6": ((23, 512, 4096, 7, 0), 8, None), "fc7": ((17, 4096, 4096, 1, 0), 8, "conv_igemm_wide"),      # 256 x 192 tiles: one round of 220
 }
 WGRAD_KERNEL = {"conv1_2": "wgrad_taps_reduce", "conv2_1": "wgrad_taps_reduce", "conv2_2": "wgrad_taps_reduce",
                 "conv3_2": "wgrad_taps_reduce", "conv4_2": "wgrad_taps_reduce", "conv5_1": "wgrad_taps_reduce",

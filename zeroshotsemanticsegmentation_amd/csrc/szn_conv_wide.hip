@@ -172,13 +172,13 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
 }
 
 // ABL (debug, SZN_WIDE_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no fragment reads / MFMA
-template <typename T, int WNF, int ABL = 0>       // WNF = 16-cout fragments per wave: 8 -> BN = 256, 10 -> BN = 320
+template <typename T, int WNF, int ABL = 0>       // WNF = 16-cout fragments per wave: 6 -> BN = 192, 8 -> 256, 10 -> 320
 __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ES = sizeof(T);
     constexpr int BKE = 128 / ES;
     constexpr int BM = 256, BN = 32 * WNF;
-    constexpr int NBW = BN / 64;                  // weight LDS-DMA instructions per wave per chunk (4 / 5)
+    constexpr int NBW = BN / 64;                  // weight LDS-DMA instructions per wave per chunk (3 / 4 / 5)
     constexpr int STAGE = (BM + BN) * 128;        // 64 / 72 KiB
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][pixels 256 x 128 B | weights 256 x 128 B]
 
@@ -266,7 +266,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
         const bool fill = ABL != 1 && kc + 1 < nK;
         // turn = the weight-fragment index (of the first K half) behind which this wave issues: stagger 1 -> pairs at
         // 0, 2, 4, 6; stagger 2 -> every wave its own slot
-        const int turn = a.stagger == 2 ? w : (a.stagger ? 2 * (w >> 1) : 0);
+        // (WNF < 8, the 192-wide tile: pairs at 0, 1, 2, 3 -- every slot has to be below WNF)
+        const int turn = WNF < 8 ? (a.stagger ? (w >> 1) : 0) : a.stagger == 2 ? w : (a.stagger ? 2 * (w >> 1) : 0);
         if (fill && turn == 0) issue(stage ^ 1);
         const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
         const char* sw = smem + stage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
@@ -640,11 +641,24 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.M = d->B * d->Ho * d->Wo;
     // cout tile 256, or 320 (bf16) when that wastes fewer columns: the 300-d projection is one 320-wide tile
     const int waste256 = szn_div_up(d->Co, 256) * 256 - d->Co, waste320 = szn_div_up(d->Co, 320) * 320 - d->Co;
-    const int bn = (szn_is16(d->dtype) && waste320 < waste256) ? 320 : 256;
+    int bn = (szn_is16(d->dtype) && waste320 < waste256) ? 320 : 256;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(d->Co, bn);
     a.nmajor = 0;
-    if ((long)a.mtiles * a.ntiles * a.nsplit < min_tiles) return 1; // too few blocks to fill the chip: keep 256 x 128
-    if ((long)a.ntiles * bn - d->Co > 64) return 1;                 // would waste > 64 columns of the last tile
+    if ((long)a.mtiles * a.ntiles * a.nsplit < min_tiles) {         // too few blocks to fill the chip: keep 256 x 128 ...
+        // ... unless 256 x 192 tiles fit ONE round of the chip where the 256 x 128 tiles need two (fc7 at B = 8, 512 x 512:
+        // 2,312 x 4096 is 10 x 32 = 320 narrow tiles = 1.25 rounds, but 10 x 22 = 220 tiles of 192 couts: 0.117 -> ~0.09 ms)
+        static int ncu = 0, t192 = -1;
+        if (!ncu) {
+            int dev = 0; hipDeviceProp_t p;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+            if (ncu <= 0) ncu = 256;
+        }
+        if (t192 < 0) { const char* e = getenv("SZN_WIDE_192"); t192 = e ? atoi(e) : 1; }
+        const long n192 = (long)a.mtiles * szn_div_up(d->Co, 192), n128 = (long)a.mtiles * szn_div_up(d->Co, 128);
+        const long cost192 = (n192 + ncu - 1) / ncu * 192, cost128 = (n128 + ncu - 1) / ncu * 128;
+        if (!t192 || !szn_is16(d->dtype) || a.nsplit != 1 || cost192 * 100 >= cost128 * 90) return 1;
+        bn = 192; a.ntiles = szn_div_up(d->Co, 192);
+    } else if ((long)a.ntiles * bn - d->Co > 64) return 1;          // would waste > 64 columns of the last tile
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
     a.out = (char*)out; a.colsum = d->colsum;
     a.in_bytes = in_bytes; a.w_bytes = w_bytes;
@@ -659,6 +673,8 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
             return d->dtype == SZN_F16 ? launch_wide_rows<f16_raw>(a, (hipStream_t)stream)
                                        : launch_wide_rows<bf16_raw>(a, (hipStream_t)stream);
     }
+    if (bn == 192)
+        return d->dtype == SZN_F16 ? launch_wide<f16_raw, 6>(a, (hipStream_t)stream) : launch_wide<bf16_raw, 6>(a, (hipStream_t)stream);
     if (bn == 320)
         return d->dtype == SZN_F16 ? launch_wide<f16_raw, 10>(a, (hipStream_t)stream) : launch_wide<bf16_raw, 10>(a, (hipStream_t)stream);
     if (d->dtype == SZN_F16) return launch_wide<f16_raw, 8>(a, (hipStream_t)stream);
