@@ -105,7 +105,37 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][i], xv[s], acc[i], 0, 0, 0);
         }
         const int ow = sx * 16 + r16;
-        if (ow < Wo) {
+        if constexpr (sizeof(T) == 2) {
+            // 16-bit rows are 128 B: lanes r16 < 8 and r16 >= 8 exchange one 16-B piece (row_ror:8), so that ONE store instruction
+            // writes the whole 128-B line of pixels 0..7 (the other one of pixels 8..15) instead of two instructions writing a
+            // 64-B half of every line each
+            u32x4_t v2[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][c]), __float_as_uint(acc[2 * p + 1][c]), false, false);
+                    v[c] = fmaxf(__uint_as_float(r[0]) + bv[p][c], 0.f);
+                    v[4 + c] = fmaxf(__uint_as_float(r[1]) + bv[p][4 + c], 0.f);
+                }
+                T* oe = (T*)&v2[p];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) elem<T>::st(oe + e, v[e]);
+            }
+            const bool lo = r16 < 8;
+            const u32x4_t send = lo ? v2[1] : v2[0];
+            u32x4_t recv;
+            recv.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.x, 0x128, 0xf, 0xf, false);
+            recv.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.y, 0x128, 0xf, 0xf, false);
+            recv.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.z, 0x128, 0xf, 0xf, false);
+            recv.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.w, 0x128, 0xf, 0xf, false);
+            const u32x4_t va = lo ? v2[0] : recv, vb = lo ? recv : v2[1];
+            const int owa = sx * 16 + (r16 & 7), cs = lo ? cst[0] : cst[1];
+            T* op = out + (((long)b * Ho + oh) * Wo + owa) * 64 + cs;
+            if (owa < Wo) *(u32x4_t*)op = va;
+            if (owa + 8 < Wo) *(u32x4_t*)(op + 8 * 64) = vb;
+        } else if (ow < Wo) {
             T* op = out + (((long)b * Ho + oh) * Wo + ow) * 64;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
