@@ -511,16 +511,22 @@ def main():
                 n2 = max(args.steps // 2, 3)
                 for _ in range(2):
                     l2, _ = p2.step(x, target_all)
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                for _ in range(n2):
-                    l2, _ = p2.step(x, target_all)
-                torch.cuda.synchronize()
-                d2 = time.perf_counter() - t2
+                # best of three repeats: on some boxes of the pool this light, host-paced step has been seen ~7x slower for a whole
+                # repeat (26 ms/step against 3.6, phase 1 unaffected in the same process)
+                reps = []
+                for _rep in range(3):
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    for _ in range(n2):
+                        l2, _ = p2.step(x, target_all)
+                    torch.cuda.synchronize()
+                    reps.append(time.perf_counter() - t2)
+                d2 = min(reps)
                 out["phase2"] = {"workload": "BASELINE configs[2]: seen-mask head on the frozen backbone, %dx%d, K=%d (train_unseen "
                                              "= 2 classes), 2-class CE, fwd + head bwd + Adam lr 1e-3" % (H, H, K),
                                  "value": round(B * H * H * n2 / d2 / 1e6, 3), "unit": "Mpixels/s", "steps": n2,
-                                 "ms_per_step": round(d2 / n2 * 1e3, 3), "final_loss": round(float(l2.item()), 5)}
+                                 "ms_per_step": round(d2 / n2 * 1e3, 3), "repeats_ms_per_step": [round(r / n2 * 1e3, 3) for r in reps],
+                                 "final_loss": round(float(l2.item()), 5)}
             except Exception as ex:
                 out["phase2"] = {"error": repr(ex)}
     if rank == 0:
