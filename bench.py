@@ -19,7 +19,11 @@ Prints ONE JSON line: metric train_Mpixels_per_sec (whole job) plus
   kernels       per kernel family, MFMA-class and HBM-class, from 3 extra instrumented steps after the timed region
                 (HIP events around every C-ABI call): ms per step, algorithmic FLOPs or bytes, fraction of the peak
   projection    the three labelled MFMA numbers SURVEY 8-d asks for (true shape, step aggregate, nominal shape)
-  phase2        BASELINE configs[2]: the seen-mask step (frozen backbone, 2-class CE, head-only backward + Adam)
+  phase2        BASELINE configs[2]: the seen-mask step (engine.SeenmaskStep: frozen backbone forward, fused-from-coarse
+                2-class head, head-only backward + Adam), three repeats, its own roofline record
+  fp32, b1      measured in a child process after the headline (a crash there cannot lose the line): the same step at the
+                reference's arithmetic (fp32, B = 8, against the 157.3 TF fp32 MFMA peak) and at the reference's batch size
+                (B = 1, bf16 and fp32, eager and replayed from a captured hipGraph)
   cpu_baseline  the same train step on this host's cores (rank 0, N = 1 only): torch-CPU restatement (what the reference
                 executes; primary) and the C + OpenMP oracle beside it; one 512x512 image each.
 """
@@ -58,7 +62,9 @@ def parse():
                     help="fcn = phase 1 (headline; phase 2 is reported as a sub-record); seenmask = phase 2 as the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the kernels / projection / phase2 sub-records")
+    ap.add_argument("--no-extras", action="store_true", help="skip the kernels / projection / phase2 / fp32 / b1 sub-records")
+    ap.add_argument("--sub-record", choices=["fp32", "b1"], default=None,
+                    help="(internal) measure one sub-record and print it as JSON; run by the main process as a child")
     return ap.parse_args()
 
 
@@ -133,7 +139,8 @@ def cpu_baseline(E, K, H, emb, arch="fcn32s"):
     tgt = synth.make_labels(1, H, H, K)
     cores = os.cpu_count()
     out = {"unit": "Mpixels/s", "cores": cores, "kind": "port"}
-    t = T.timed_train_step(E, K, H, emb, x, tgt, steps=2, arch=arch)  # second step timed (first pays allocation / mkldnn setup)
+    # all host cores; torch's default would be the physical-core count
+    t = T.timed_train_step(E, K, H, emb, x, tgt, steps=2, threads=cores, arch=arch)  # second step timed (first pays allocation / mkldnn setup)
     out["value"] = round(H * H / t["total"] / 1e6, 6)
     out["threads"] = torch.get_num_threads()
     out["sample"] = ("torch-CPU restatement of the %s step (oracle/torch_ref.py; depthwise upscore), 1 image %dx%d, "
@@ -213,8 +220,171 @@ def projection_report(L, torch, step_frac, iters=10):
                     "once from HBM, AI = 300 FLOP/B; operands relu(randn) like fc7's output, randn beside it)"}
 
 
+def _workload(args, torch, rank=0):
+    """(embedding matrix, seen, unseen, images, phase-1 labels, all-class labels) of the configured workload"""
+    from zeroshotsemanticsegmentation_amd import synth, trainer_fcn
+    E, H, B, K = args.embed_dim, args.size, args.batch, args.classes
+    if K == 21 and E in (20, 21, 300):
+        emb_np, seen, unseen = trainer_fcn.load_embeddings("pascal", E), list(range(21)), [16, 18]
+    elif K == 33 and E in (20, 300):
+        emb_np, seen, unseen = trainer_fcn.load_embeddings("context", E), list(range(33)), [16, 18]
+    else:
+        emb_np = synth.make_embeddings(K, E)
+        n_unseen = 10 if K == 59 else max(K // 6, 1)
+        seen, unseen = list(range(K - n_unseen)), list(range(K - n_unseen, K))     # K = 59: seen 0..48, unseen 49..58
+    return emb_np, seen, unseen
+
+
+def _time_steps(torch, fn, steps, warmup):
+    """ms per call of fn(): HIP events on the current stream around `steps` calls"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def _conv_family(torch, L, mods, fn):
+    """one call of fn() with HIP events around every conv forward / dgrad launch -> (TFLOP/s, ms, launches)"""
+    orig = L.call
+    ev = []
+
+    def timed(name, *a):
+        if name not in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm"):
+            return orig(name, *a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); orig(name, *a); e1.record()
+        ev.append((e0, e1, _conv_flops(a[0]._obj)))
+    for mod in mods:
+        mod.L.call = timed
+    L.call = timed
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        L.call = orig
+        for mod in mods:
+            mod.L.call = orig
+    ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+    fl = sum(f for _, _, f in ev)
+    return fl / (ms * 1e-3) / 1e12, ms, len(ev)
+
+
+def sub_record(args):
+    """child process: `fp32` = the headline workload at the reference's arithmetic; `b1` = at the reference's batch size
+    (train.py:82-84), eager and replayed from a captured hipGraph (host pacing out).  Prints one JSON object."""
+    import torch
+    from zeroshotsemanticsegmentation_amd import _lib as L
+    from zeroshotsemanticsegmentation_amd import engine, models, synth
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    L.load()
+    E, H, K = args.embed_dim, args.size, args.classes
+    emb_np, seen, unseen = _workload(args, torch)
+    mflop_px = STEP_MFLOP_PER_PX.get(H) if E == 300 else None
+
+    def build(B, dtype):
+        torch.manual_seed(1337)
+        m = models.FCN32s(n_class=E)
+        m.load_synthetic(1337, device=dev)
+        m.train()
+        ts = engine.TrainStep(m, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=True)
+        x = torch.from_numpy(synth.make_images(B, H, H, seed=1337)).to(dev)
+        t = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337, classes=seen)).to(dev)
+        return m, ts, x, t
+
+    def record(B, dtype, ms, extra=None):
+        peak = PEAK_F32 if dtype == torch.float32 else PEAK_BF16
+        r = {"per_gpu_batch": B, "dtype": "f32" if dtype == torch.float32 else "bf16", "ms_per_step": round(ms, 3),
+             "value": round(B * H * H / (ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s", "peak_TF": peak}
+        if mflop_px:
+            r["step_mfma_frac"] = round(mflop_px * 1e6 * B * H * H / (ms * 1e-3) / 1e12 / peak, 4)
+        r.update(extra or {})
+        return r
+
+    out = {}
+    if args.sub_record == "fp32":
+        B = args.batch
+        m, ts, x, t = build(B, torch.float32)
+        ms = _time_steps(torch, lambda: ts.step(x, t), max(args.steps // 3, 3), 2)
+        tf, fam_ms, n = _conv_family(torch, L, (models, engine), lambda: ts.step(x, t))
+        out = record(B, torch.float32, ms, {
+            "workload": "the headline step at the reference's arithmetic: fp32 operands on v_mfma_f32_16x16x4_f32 (exact fp32 "
+                        "products, the parity-gated path), B=%d, %dx%d, E=%d, K=%d" % (B, H, H, E, K),
+            "roofline": {"bound": "mfma", "kernels": "conv forward + dgrad launches of one step (HIP events)", "achieved": round(tf, 2),
+                         "peak": PEAK_F32, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32, 4), "launches": n,
+                         "ms": round(fam_ms, 3)},
+            "final_loss": round(float(ts.loss.item()), 5)})
+    else:
+        for dtype in (torch.bfloat16, torch.float32):
+            key = "bf16" if dtype == torch.bfloat16 else "fp32"
+            m, ts, x, t = build(1, dtype)
+            steps = 20 if dtype == torch.bfloat16 else 8
+            ms = _time_steps(torch, lambda: ts.step(x, t), steps, 3)
+            rec = record(1, dtype, ms)
+            rec["eager_ms_per_step"] = rec.pop("ms_per_step")
+            rec["eager_value"] = rec.pop("value")
+            eager_frac = rec.pop("step_mfma_frac", None)
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ts.step(x, t)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    ts.step(x, t)
+                gms = _time_steps(torch, g.replay, steps, 3)
+                grec = record(1, dtype, gms)
+                rec.update({"graph": True, "ms_per_step": grec["ms_per_step"], "value": grec["value"]})
+                if "step_mfma_frac" in grec:
+                    rec["step_mfma_frac"] = grec["step_mfma_frac"]
+                rec["graph_note"] = ("one train step captured with torch.cuda.graph (every launch goes through the C-ABI on the "
+                                     "capture stream) and replayed: all kernels of the step run, with the capture-time scalars "
+                                     "(Adam step count, Dropout2d counter)")
+                if not np.isfinite(float(ts.loss.item())):
+                    rec["graph"] = "non-finite loss after replay"
+            except Exception as ex:
+                rec.update({"graph": False, "graph_error": repr(ex)[:300], "ms_per_step": rec["eager_ms_per_step"],
+                            "value": rec["eager_value"]})
+                if eager_frac is not None:
+                    rec["step_mfma_frac"] = eager_frac
+            if eager_frac is not None:
+                rec["eager_step_mfma_frac"] = eager_frac
+            out[key] = rec
+            del m, ts, x, t
+            torch.cuda.empty_cache()
+        out["workload"] = ("the reference's batch size (train.py:82-84: one image per step), %dx%d, E=%d, K=%d; at B=1 fc6 / fc7 "
+                           "stream their weights for 289 pixels and the host enqueues as fast as the GPU executes, hence the "
+                           "hipGraph replay beside the eager number" % (H, H, E, K))
+    print("SUBRECORD " + json.dumps(out))
+
+
+def run_sub_record(kind, args, timeout=240):
+    """run `bench.py --sub-record kind` as a child (the GPU is idle here: the parent has finished measuring)"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--sub-record", kind, "--batch", str(args.batch), "--size", str(args.size),
+           "--embed-dim", str(args.embed_dim), "--classes", str(args.classes), "--steps", str(args.steps)]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        for line in p.stdout.splitlines():
+            if line.startswith("SUBRECORD "):
+                return json.loads(line[len("SUBRECORD "):])
+        return {"error": "rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-400:])}
+    except Exception as ex:
+        return {"error": repr(ex)[:300]}
+
+
 def main():
     args = parse()
+    if args.sub_record:
+        return sub_record(args)
     import torch
     import torch.distributed as dist
     from zeroshotsemanticsegmentation_amd import _lib as L
@@ -241,14 +411,7 @@ def main():
     L.load()
 
     E, H, B, K = args.embed_dim, args.size, args.batch, args.classes
-    if K == 21 and E in (20, 21, 300):
-        emb_np, seen, unseen = trainer_fcn.load_embeddings("pascal", E), list(range(21)), [16, 18]
-    elif K == 33 and E in (20, 300):
-        emb_np, seen, unseen = trainer_fcn.load_embeddings("context", E), list(range(33)), [16, 18]
-    else:
-        emb_np = synth.make_embeddings(K, E)
-        n_unseen = 10 if K == 59 else max(K // 6, 1)
-        seen, unseen = list(range(K - n_unseen)), list(range(K - n_unseen, K))     # K = 59: seen 0..48, unseen 49..58
+    emb_np, seen, unseen = _workload(args, torch)
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.precision]
     peak = PEAK_F32 if dtype == torch.float32 else PEAK_BF16          # fp16 and bf16 MFMA share the dense peak
 
@@ -295,30 +458,10 @@ def main():
 
     def make_phase2():
         # train.py:164-175: everything frozen except seenmask_score (w, b) and seenmask_upscore (w); binary target
-        # "label is a seen class" with unlabelled pixels = 0 (trainer_seenmask.py:55-56); 2-class CE, size_average=True
-        from zeroshotsemanticsegmentation_amd import optim as szn_optim, utils as szn_utils
-        model.set_precision(dtype)
-        for p in model.parameters():
-            p.requires_grad = False
-        head = [model.seenmask_score.weight, model.seenmask_score.bias, model.seenmask_upscore.weight]
-        for p in head:
-            p.requires_grad = True
-        opt2 = szn_optim.FusedAdam(head, lr=1e-3)
-        train_unseen = unseen[:2]                                        # phase 2 trains on train_unseen vs everything else
-        lut = torch.ones(K + 1, dtype=torch.int64, device=dev)
-        lut[train_unseen] = 0
-        lut[K] = 0
-        bin_target = lut[torch.where(target_all >= 0, target_all, torch.full_like(target_all, K))]
-
-        class _Phase2(object):
-            def step(self, xx, tt):
-                score = model(xx, mode="seenmask")
-                loss = szn_utils.cross_entropy2d(score, bin_target, size_average=True)
-                opt2.zero_grad()
-                loss.backward()
-                opt2.step()
-                return loss.detach(), szn_utils.channel_argmax(score)
-        return _Phase2()
+        # "label is a seen class" with unlabelled pixels = 0 (trainer_seenmask.py:55-56); 2-class CE, size_average=True;
+        # phase 2 trains on train_unseen (two of the unseen classes) vs everything else.  engine.SeenmaskStep: no autograd,
+        # no (B,2,H,W) score, head-only flat Adam
+        return engine.SeenmaskStep(model, K, unseen[:2], lr=1e-3, precision=dtype)
 
     if args.phase == "seenmask" and world > 1:
         raise SystemExit("--phase seenmask is a single-GPU line (98 KB of gradients)")
@@ -507,28 +650,58 @@ def main():
                 out["projection"] = {"error": repr(ex)}
         if args.phase == "fcn":
             try:
+                del ts                                         # phase 1 is over: its flat buffers keep the parameters alive
                 p2 = make_phase2()
-                n2 = max(args.steps // 2, 3)
-                for _ in range(2):
+                eng = model._engine
+                n2 = max(args.steps, 10)
+                for _ in range(3):
                     l2, _ = p2.step(x, target_all)
-                # best of three repeats: on some boxes of the pool this light, host-paced step has been seen ~7x slower for a whole
-                # repeat (26 ms/step against 3.6, phase 1 unaffected in the same process)
-                reps = []
-                for _rep in range(3):
+                l_first = float(l2.item())
+                reps = [_time_steps(torch, lambda: p2.step(x, target_all), n2, 1) for _rep in range(3)]
+                l_last = float(p2.loss.item())
+                d2 = sorted(reps)[1]                           # median of three repeats
+                fwd_ms = _time_steps(torch, lambda: eng.forward(x, train=True, keep=False), n2, 2)
+                # head kernels: events around the calls behind the backbone (one extra step)
+                hev = []
+                orig2 = L.call
+
+                def head_timed(name, *a):
+                    if not (name.startswith("szn_seenmask") or name == "szn_adam_step"):
+                        return orig2(name, *a)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); orig2(name, *a); e1.record()
+                    hev.append((name, e0, e1))
+                for mod in (models, engine):
+                    mod.L.call = head_timed
+                try:
+                    p2.step(x, target_all)
                     torch.cuda.synchronize()
-                    t2 = time.perf_counter()
-                    for _ in range(n2):
-                        l2, _ = p2.step(x, target_all)
-                    torch.cuda.synchronize()
-                    reps.append(time.perf_counter() - t2)
-                d2 = min(reps)
+                finally:
+                    for mod in (models, engine):
+                        mod.L.call = orig2
+                head = {}
+                for name, e0, e1 in hev:
+                    head[name] = round(head.get(name, 0.0) + e0.elapsed_time(e1), 4)
+                fwd_gf = {512: 380.01, 768: 724.28}.get(H) if E == 300 else None
                 out["phase2"] = {"workload": "BASELINE configs[2]: seen-mask head on the frozen backbone, %dx%d, K=%d (train_unseen "
-                                             "= 2 classes), 2-class CE, fwd + head bwd + Adam lr 1e-3" % (H, H, K),
-                                 "value": round(B * H * H * n2 / d2 / 1e6, 3), "unit": "Mpixels/s", "steps": n2,
-                                 "ms_per_step": round(d2 / n2 * 1e3, 3), "repeats_ms_per_step": [round(r / n2 * 1e3, 3) for r in reps],
-                                 "final_loss": round(float(l2.item()), 5)}
+                                             "= 2 classes), engine.SeenmaskStep: backbone forward (train mode, nothing kept) + fused "
+                                             "deconv / 2-class CE / argmax / head backward from the 1/32 map + Adam lr 1e-3" % (H, H, K),
+                                 "value": round(B * H * H / (d2 * 1e-3) / 1e6, 3), "unit": "Mpixels/s", "steps": n2,
+                                 "ms_per_step": round(d2, 3), "repeats_ms_per_step": [round(r, 3) for r in reps],
+                                 "repeat_spread": round((max(reps) - min(reps)) / d2, 4),
+                                 "backbone_forward_only_ms": round(fwd_ms, 3), "head_ms": head,
+                                 "loss_first_to_last": [round(l_first, 5), round(l_last, 5)]}
+                if fwd_gf:
+                    tf2 = fwd_gf * 1e9 * B / (d2 * 1e-3) / 1e12
+                    out["phase2"]["roofline"] = {"bound": "mfma", "achieved": round(tf2, 1), "peak": peak, "unit": "TFLOP/s",
+                                                 "frac": round(tf2 / peak, 4),
+                                                 "note": "forward MFMA FLOPs (%.2f GF/image, SURVEY 8-d) over the whole step time; "
+                                                         "the head is 16 B/px of labels in / predictions out" % fwd_gf}
             except Exception as ex:
                 out["phase2"] = {"error": repr(ex)}
+        if args.phase == "fcn" and args.arch == "fcn32s" and not args.unfused_head:
+            out["fp32"] = run_sub_record("fp32", args)
+            out["b1"] = run_sub_record("b1", args)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -180,6 +180,30 @@ int szn_deconv64s32_wgrad(int B, int h, int w, int C, int ldc, int c0, int H, in
                           const float* coarse, const float* dout_nchw, float* dweight,
                           int accumulate, szn_stream_t stream);
 
+/* ---- phase 2 (BASELINE configs[2]): the seen-mask head fused from the 1/32 map -------------------------
+ * Equivalent to szn_deconv64s32_fwd -> [target = np.in1d(label, seen), trainer_seenmask.py:55-56] -> szn_ce2d_fwd
+ * (size_average) -> channel argmax (trainer_seenmask.py:67) -> szn_ce2d_bwd -> szn_deconv64s32_dgrad / _wgrad
+ * (models.py:150-151, utils.py:19-48) without the (B,2,H,W) score or its gradient in HBM.  coarse: NHWC f32
+ * [B][h][w] with pixel stride ldc, the two seen-mask channels at [c0, c0+2); weight: seenmask_upscore.weight
+ * (2,2,64,64) f32.  Binary target of a pixel: n_class > 0: (0 <= label < n_class and bit `label` of seen_bits) ? 1 : 0
+ * -- unlabelled pixels (-1) become 0 and COUNT, like the reference; n_class == 0: `target` already holds {0,1}
+ * (anything else is ignored, cross_entropy2d's mask).  Outputs: loss[1]; stats[2] = {sum of terms, valid pixels}
+ * (may be NULL); conf[4] int64 += confusion counts [target][prediction] (may be NULL; the running train metrics,
+ * trainer_seenmask.py:87); pred int64 (B,H,W) (may be NULL); dscore2 f32 [B*h*w][2] = d loss / d coarse (compact) and
+ * dweight (2,2,64,64) = d loss / d weight -- both NULL for a forward-only call.  Bit-reproducible (fixed-order slabs,
+ * no atomics).  workspace: szn_seenmask_head_workspace_bytes.                                                      */
+size_t szn_seenmask_head_workspace_bytes(int B, int h, int w, int H, int W, int crop);
+int szn_seenmask_head(int B, int h, int w, int ldc, int c0, int H, int W, int crop, const float* coarse,
+                      const float* weight, const int64_t* target, int n_class, uint64_t seen_bits, float* loss,
+                      float* stats, int64_t* conf, int64_t* pred, float* dscore2, float* dweight, void* workspace,
+                      szn_stream_t stream);
+/* seenmask_score = Conv2d(4096, 2, 1) (models.py:97,149) backward from the compact gradient above:
+ * dw[c][k] = sum_m dscore2[m][c] * feat[m][k], db[c] = sum_m dscore2[m][c]; feat [M][ldf] of `dtype` (relu7 after
+ * Dropout2d), F a multiple of 8.  Fixed-order slabs in `workspace` (szn_seenmask_score_wgrad_workspace_bytes).     */
+size_t szn_seenmask_score_wgrad_workspace_bytes(long M, int F);
+int szn_seenmask_score_wgrad(int dtype, long M, int F, int ldf, const void* feat, const float* dscore2, float* dw,
+                             float* db, void* workspace, szn_stream_t stream);
+
 /* ---- losses (utils.py) --------------------------------------------------------------------------
  * score (B,E,H,W) NCHW f32; target (B,H,W) int64, <0 = ignore.  The target embedding of a pixel is
  * either gathered from embed[K][E] by label (target_embed == NULL; ignore pixels use row 0 exactly

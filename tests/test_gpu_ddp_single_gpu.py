@@ -105,3 +105,99 @@ def test_two_ranks_on_one_gpu_equal_one_process_batch2(optname, comm, arch):
             assert big.mean() > 0.5
             assert np.abs(res[0]["w"] - w)[big].max() < 2e-7
         assert np.abs(res[0]["b"] - b).max() < 1e-6
+
+
+# ---- BASELINE configs[3] stand-in at its real per-rank size -----------------------------------------------------------------
+# configs[3] = global batch 64 over 8 GPUs = 8 images per rank, 512x512, E = 300, K = 59, bf16.  Here: TWO ranks of that size
+# on one GPU (fits 288 GB), real 25 MB buckets including the 411 MB fc6 bucket, fp32 and bf16 wire formats, against ONE
+# process stepping on all 16 images.  16-bit activations make the two runs differ by rounding (a layer may pick another tile
+# shape at B = 16, so fp32 sums are rounded to bf16 from slightly different values): the tolerance is a bf16 one.
+E3, K3, H3, B3 = 300, 59, 512, 8
+
+
+def _data3():
+    from zeroshotsemanticsegmentation_amd import synth
+    return (synth.make_images(2 * B3, H3, H3, seed=81), synth.make_labels(2 * B3, H3, H3, K3, seed=82, classes=list(range(49))),
+            synth.make_embeddings(K3, E3))
+
+
+def _layer_digest(ts):
+    """per optimizer-visible layer: (sum, sum |.|, sum of squares) of its weight gradient + a 256-element probe"""
+    out = {}
+    for n in ts.layers:
+        o, cnt = ts.woff[n]
+        g = ts.flat_gw[o:o + cnt].double()
+        idx = (torch.arange(256, device=g.device, dtype=torch.int64) * 2654435761) % cnt
+        out[n] = (torch.stack([g.sum(), g.abs().sum(), (g * g).sum()]).cpu().numpy(), g[idx].cpu().numpy())
+    return out
+
+
+def _worker3(rank, world, port, comm, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from zeroshotsemanticsegmentation_amd import engine, models
+        x, t, emb = _data3()
+        dev = torch.device("cuda", 0)
+        m = models.FCN32s(E3)
+        m.load_synthetic(1337, device=dev)
+        m.eval()
+        ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=torch.bfloat16, fused_head=True, bucket_mb=25,
+                              grad_comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32)
+        sizes = [(e - o) * 4 / 2 ** 20 for o, e, _ in ts.buckets.buckets]
+        sl = slice(rank * B3, (rank + 1) * B3)
+        loss, _ = ts.step(torch.from_numpy(x[sl]).to(dev), torch.from_numpy(t[sl]).to(dev))
+        torch.cuda.synchronize()
+        out = {"rank": rank, "loss": float(loss), "bucket_mb": sizes}
+        if rank == 0:
+            ts.flat_gw.mul_(0.5)                                   # what the optimizer consumed: sum x 1/world
+            out["digest"] = _layer_digest(ts)
+        q.put(out)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as ex:
+        import traceback
+        q.put({"rank": rank, "error": "%r\n%s" % (ex, traceback.format_exc())})
+
+
+@pytest.mark.parametrize("comm", ["fp32", "bf16"])
+def test_configs3_standin_two_ranks_b8_bf16_512(comm):
+    from zeroshotsemanticsegmentation_amd import engine, models
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker3, args=(r, 2, port, comm, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        o = q.get(timeout=900)
+        assert "error" not in o, o.get("error")
+        res[o["rank"]] = o
+    for p in procs:
+        p.join(120)
+    mb = res[0]["bucket_mb"]
+    assert len(mb) >= 4 and max(mb) > 400 and min(mb) < 25, mb      # fc6 alone is 411 MB; the tail bucket is the 2.2 MB rest
+    x, t, emb = _data3()
+    m = models.FCN32s(E3)
+    m.load_synthetic(1337, device=torch.device("cuda", 0))
+    m.eval()
+    ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=torch.bfloat16, fused_head=True)
+    loss, _ = ts.step(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - 0.5 * (res[0]["loss"] + res[1]["loss"])) < 2e-3
+    want = _layer_digest(ts)
+    worst = {}
+    for n, (st, probe) in res[0]["digest"].items():
+        wst, wprobe = want[n]
+        e_abs = abs(st[1] - wst[1]) / wst[1]                         # sum |g|
+        e_sq = abs(st[2] - wst[2]) / wst[2]                          # sum g^2
+        e_probe = float(np.abs(probe - wprobe).max() / (np.abs(wprobe).max() + 1e-30))
+        worst[n] = (e_abs, e_sq, e_probe)
+        # bf16 activations: 2^-9 per rounding, ReLU-gate flips between the two tilings move single elements by more
+        assert e_abs < 2e-2 and e_sq < 4e-2 and e_probe < 0.15, (n, worst[n])
+    print("two ranks x B=8 vs one process B=16 (%s wire): worst layer errors sum|g| %.2e, sum g^2 %.2e, probe %.2e"
+          % (comm, max(v[0] for v in worst.values()), max(v[1] for v in worst.values()), max(v[2] for v in worst.values())))

@@ -113,3 +113,47 @@ def test_fp16_forward_and_train_step():
         # 16-bit activations flip ReLU gates / pooling winners against the fp32 pass, so these are coarse: the point is
         # that the unscaled fp16 gradients are finite, correctly scaled and closer to fp32 than the bf16 ones
         assert e16 < 0.2 and e16 < eb
+
+
+def test_configs4_train_step_as_configured():
+    """BASELINE configs[4] as one train step: 768x768, E = 300, K = 59, IEEE-half activations / weight images with loss scaling
+    + the fp8 (e4m3) projection head, B = 2.  Referees: the fp32 oracle's forward + cosine loss on the same images (first-step
+    loss), the fp32 HIP path (class-assignment agreement rate), and the run itself (finite, decreasing loss, finite gradients).
+    Stated tolerances: |loss - oracle| < 3e-2 (fp16 activations through 16 layers + per-tensor e4m3 head operands, measured
+    ~5e-3), class agreement > 0.97 of the pixels."""
+    E, K, H, B = 300, 59, 768, 2
+    emb = synth.make_embeddings(K, E)
+    m = models.FCN32s(E)
+    m.load_synthetic(1337, device=torch.device("cuda"))
+    m.eval()
+    x = synth.make_images(B, H, H, seed=93)
+    t = synth.make_labels(B, H, H, K, seed=94, classes=list(range(49)))
+    om = O.FCN32sOracle({k: v.detach().cpu().numpy() for k, v in m.named_parameters() if k.split(".")[0] != "upscore"}, E)
+    ol = []
+    for b in range(B):                                    # the reference's loss is per image (n = 1); batched = mean over images
+        of = om.forward(x[b:b + 1], "fcn")
+        ol.append(float(O.cosine_loss(of, t[b:b + 1], embed=emb, want_grad=False)[0]))
+        del of
+    oloss = float(np.mean(ol))
+    xd, td = cu(x), cu(t)
+    loss32, pred32 = m.embed_predict(xd, emb, td)         # fp32 HIP path, fused head
+    assert abs(float(loss32) - oloss) < 1e-4
+    m.set_head_precision("fp8")
+    ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=torch.float16, fused_head=True)
+    assert ts.loss_scale > 1.0 and m._engine.head_fp8
+    losses = []
+    for i in range(3):
+        loss, pred = ts.step(xd, td)
+        losses.append(float(loss))
+        if i == 0:
+            agree = float((pred == pred32).float().mean())
+            assert L.last_kernel() is not None
+            for n in ("conv1_1", "conv3_2", "fc6", "fc7", "score_fr"):
+                g = getattr(m, n).weight.grad
+                assert torch.isfinite(g).all() and float(g.abs().max()) > 0, n
+    print("configs[4] step: loss %s (fp32 oracle %.5f, fp32 HIP %.5f), class agreement with the fp32 path %.4f"
+          % (["%.5f" % l for l in losses], oloss, float(loss32), agree))
+    assert abs(losses[0] - oloss) < 3e-2
+    assert agree > 0.97
+    assert all(np.isfinite(losses)) and losses[2] < losses[0]
+    m.set_head_precision("native")

@@ -65,6 +65,10 @@ SIGNATURES = {
     "szn_deconv64s32_fwd": (_I, [_I] * 9 + [_P, _P, _P, _P]),
     "szn_deconv64s32_dgrad": (_I, [_I] * 9 + [_P, _P, _P, _P]),
     "szn_deconv64s32_wgrad": (_I, [_I] * 9 + [_P, _P, _P, _I, _P]),
+    "szn_seenmask_head_workspace_bytes": (_SZ, [_I] * 6),
+    "szn_seenmask_head": (_I, [_I] * 8 + [_P, _P, _P, _I, _U64] + [_P] * 8),
+    "szn_seenmask_score_wgrad_workspace_bytes": (_SZ, [_L, _I]),
+    "szn_seenmask_score_wgrad": (_I, [_I, _L, _I, _I, _P, _P, _P, _P, _P, _P]),
     "szn_loss_workspace_bytes": (_SZ, [_I, _I, _I]),
     "szn_cosine_loss_fwd": (_I, [_I] * 5 + [_P] * 8),
     "szn_cosine_loss_bwd": (_I, [_I] * 5 + [_P] * 8),

@@ -91,6 +91,147 @@ def allreduce_param_grads(params, group=None):
         off += p.numel()
 
 
+class SeenmaskStep(object):
+    """Phase 2 (BASELINE configs[2]) as one fused step: the body of trainer_seenmask.Trainer.train_epoch
+    (trainer_seenmask.py:72-102) with the optimizer wiring of train.py:164-175, without autograd:
+
+        backbone forward (train mode: Dropout2d on, like the reference's model.train(); no activation is kept -- the
+        backbone is frozen)  ->  szn_seenmask_head: learned 64x64 stride-32 deconv + crop + 2-class cross entropy
+        (size_average) + channel argmax + d(coarse) + d(seenmask_upscore.weight) straight from the 1/32 map, the
+        (B,2,H,W) score never exists  ->  szn_seenmask_score_wgrad (seenmask_score weight / bias)  ->
+        [one 98 KB all-reduce under data parallelism]  ->  Adam on the 24,578 head parameters.
+
+    The three trainable tensors live in one flat fp32 buffer (the module's Parameters and .grads are views of it and of
+    the flat gradient); the engine's fused head image (rows E, E+1 of [CP][4096]) and bias vector are rewritten in place
+    after every update, so no weight image is rebuilt between steps.  Every kernel on this path reduces in a fixed order:
+    two runs give bit-identical losses and weights."""
+
+    def __init__(self, model, n_class, unseen, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, precision=None,
+                 process_group=None):
+        """n_class / unseen: the binary target of a pixel is "its label is one of the n_class classes and not in `unseen`"
+        (trainer_seenmask.py:53-56); n_class = 0: step() is handed {0,1} targets already (other values are ignored)"""
+        if n_class > 64:
+            raise L.SznError("SeenmaskStep: at most 64 classes (seen_bits is a 64-bit mask), got %d" % n_class)
+        self.model, self.eng = model, model._engine
+        if precision is not None:
+            model.set_precision(precision)
+        self.dev = model.conv1_1.weight.device
+        if self.dev.type != "cuda":
+            raise L.SznError("SeenmaskStep needs the model on the GPU")
+        self.n_class = int(n_class)
+        self.seen_bits = 0
+        for k in range(self.n_class):
+            if k not in set(unseen):
+                self.seen_bits |= 1 << k
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.nstep = 0
+        m = model
+        F = m.fc7.out_channels
+        self.F = F
+        ps = (m.seenmask_score.weight, m.seenmask_upscore.weight, m.seenmask_score.bias)
+        n = sum(p.numel() for p in ps)
+        self.flat_p = torch.empty(n, device=self.dev)
+        self.flat_g = torch.zeros(n, device=self.dev)
+        self.m1, self.m2 = torch.zeros(n, device=self.dev), torch.zeros(n, device=self.dev)
+        off = 0
+        self.seg = {}
+        for key, p in zip(("score_w", "up_w", "score_b"), ps):
+            cnt = p.numel()
+            if key == "score_w":             # (2,F,1,1): OHWI order == (2, F) rows
+                src = p.detach().permute(0, 2, 3, 1).reshape(-1)
+                view = lambda t, o=off, c=cnt: t[o:o + c].view(2, 1, 1, F).permute(0, 3, 1, 2)
+            else:
+                src = p.detach().reshape(-1)
+                view = lambda t, o=off, c=cnt, sh=tuple(p.shape): t[o:o + c].view(sh)
+            self.flat_p[off:off + cnt].copy_(src)
+            p.data = view(self.flat_p)
+            p.grad = view(self.flat_g)
+            self.seg[key] = (off, cnt)
+            off += cnt
+        self.eng.mark_dirty()
+        self.loss = torch.zeros(1, device=self.dev)
+        self.stats = torch.zeros(2, device=self.dev)
+        self.conf = torch.zeros(4, dtype=torch.int64, device=self.dev)     # [target][prediction] counts since the last reset
+        self._ws = self._ws2 = None
+
+    def _head_images(self):
+        """(rows E, E+1 of the fused head's weight image in the compute dtype, the same slice of its bias vector)"""
+        m, img = self.model, self.eng._images
+        E, CP, F = m.n_class, m.head_width, self.F
+        return img["head.w"].view(CP, F)[E:E + 2], img["head.b"][E:E + 2]
+
+    def step(self, x, target, dropout_masks=None):
+        """x (B,3,H,W) f32 NCHW, target (B,H,W) int64 class labels (-1 = unlabelled), both on the GPU.
+        -> (loss 0-dim device tensor, pred (B,H,W) int64 device tensor: 1 = "seen")"""
+        m, eng = self.model, self.eng
+        B, _, H, W = x.shape
+        st = L.stream_ptr()
+        ctx = eng.forward(x, train=m.training, masks=dropout_masks, keep=False)
+        E, CP, F = m.n_class, m.head_width, self.F
+        lib = L.load()
+        nb = lib.szn_seenmask_head_workspace_bytes(B, ctx.h, ctx.w, H, W, CROP)
+        if self._ws is None or self._ws.numel() < nb:
+            self._ws = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+        M = B * ctx.h * ctx.w
+        nb2 = lib.szn_seenmask_score_wgrad_workspace_bytes(M, F)
+        if self._ws2 is None or self._ws2.numel() < nb2 + M * 8:
+            self._ws2 = torch.empty(nb2 + M * 8, dtype=torch.uint8, device=self.dev)
+        dsc = self._ws2[nb2:nb2 + M * 8].view(torch.float32)
+        pred = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
+        (ow, nw), (ou, nu), (ob, nbias) = self.seg["score_w"], self.seg["up_w"], self.seg["score_b"]
+        g = self.flat_g
+        L.call("szn_seenmask_head", B, ctx.h, ctx.w, CP, E, H, W, CROP, L.ptr(ctx.coarse), L.ptr(self.flat_p[ou:ou + nu]),
+               L.ptr(target), self.n_class, self.seen_bits, L.ptr(self.loss), L.ptr(self.stats), L.ptr(self.conf), L.ptr(pred),
+               L.ptr(dsc), L.ptr(g[ou:ou + nu]), L.ptr(self._ws), st)
+        feat = ctx.relu7
+        L.call("szn_seenmask_score_wgrad", L.dtype_code(feat.dtype), M, F, F, L.ptr(feat), L.ptr(dsc), L.ptr(g[ow:ow + nw]),
+               L.ptr(g[ob:ob + nbias]), L.ptr(self._ws2), st)
+        if self.world > 1:
+            dist.all_reduce(g, group=self.pg)
+        self._optimizer_step()
+        return self.loss.reshape(()), pred
+
+    def _optimizer_step(self):
+        self.nstep += 1
+        st = L.stream_ptr()
+        gs = 1.0 / self.world
+        rows, bias = self._head_images()
+        (ow, nw) = self.seg["score_w"]
+        n = self.flat_p.numel()
+        lp16 = rows.dtype != torch.float32
+        for o, cnt, lp in ((ow, nw, rows if lp16 else None), (ow + nw, n - ow - nw, None)):
+            L.call("szn_adam_step", cnt, L.ptr(self.flat_p[o:o + cnt]), L.ptr(self.flat_g[o:o + cnt]), L.ptr(self.m1[o:o + cnt]),
+                   L.ptr(self.m2[o:o + cnt]), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                   float(self.wd), self.nstep, gs, L.ptr(lp), L.dtype_code(lp.dtype) if lp is not None else 0, st)
+        if not lp16:
+            rows.copy_(self.flat_p[ow:ow + nw].view(2, self.F))
+        ob, nbias = self.seg["score_b"]
+        bias.copy_(self.flat_p[ob:ob + nbias])
+        # seenmask_upscore.weight is read by the kernels in place (fp32 parameter storage): nothing to refresh
+
+    def metrics(self, reset=True):
+        """running train metrics (trainer_seenmask.py:87: label_accuracy_score on the binary maps with n_class classes)"""
+        import numpy as np
+        from .utils import _hist_to_metrics
+        c = self.conf.cpu().numpy().reshape(2, 2)
+        if reset:
+            self.conf.zero_()
+        h = np.zeros((max(self.n_class, 2), max(self.n_class, 2)))
+        h[:2, :2] = c
+        return _hist_to_metrics(h)
+
+    def export_optimizer_state(self, optim):
+        for key, p in (("score_w", self.model.seenmask_score.weight), ("score_b", self.model.seenmask_score.bias),
+                       ("up_w", self.model.seenmask_upscore.weight)):
+            o, cnt = self.seg[key]
+            shape = lambda t: (t[o:o + cnt].view(2, 1, 1, self.F).permute(0, 3, 1, 2) if key == "score_w" else t[o:o + cnt].view(p.shape))
+            stt = optim.state[p]
+            stt['step'] = torch.tensor(float(self.nstep))
+            stt['exp_avg'], stt['exp_avg_sq'] = shape(self.m1), shape(self.m2)
+
+
 class TrainStep(object):
     def __init__(self, model, embeddings, optimizer="adam", lr=1e-5, momentum=0.99, weight_decay=0.0005,
                  precision=torch.bfloat16, fused_head=True, loss="cos", process_group=None, bucket_mb=25,

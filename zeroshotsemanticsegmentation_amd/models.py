@@ -245,8 +245,10 @@ class _Engine(object):
             masks.append(mk)
         return masks
 
-    def forward(self, x, train=False, masks=None):
-        """x (B,3,H,W) f32 NCHW on the GPU -> ctx with ctx.coarse (B,h,w,CP) f32: projection-head output at 1/32"""
+    def forward(self, x, train=False, masks=None, keep=True):
+        """x (B,3,H,W) f32 NCHW on the GPU -> ctx with ctx.coarse (B,h,w,CP) f32: projection-head output at 1/32.
+        keep=False (frozen backbone: phase 2, inference): the per-layer activations are not kept for a backward pass -- each
+        one goes back to the allocator as soon as the next layer has consumed it; ctx then holds relu7 and coarse only"""
         if x.dim() != 4 or x.shape[1] != 3:
             raise L.SznError("FCN32s expects (B,3,H,W) input, got %s" % (tuple(x.shape),))
         if not x.is_cuda:
@@ -262,7 +264,7 @@ class _Engine(object):
         a = torch.empty(B, H1, W1, 64, device=x.device, dtype=self.dtype)
         L.call("szn_conv1_1_fwd", code, B, H, W, PAD1, L.ptr(x), L.ptr(self._images["conv1_1.w"]),
                L.ptr(self._images["conv1_1.b"]), L.ptr(a), L.stream_ptr())
-        acts, pools = {"conv1_1": a}, []
+        acts, pools = ({"conv1_1": a} if keep else {}), []
         items = _BACKBONE[1:]
         for i, item in enumerate(items):
             if item == "P":
@@ -270,18 +272,24 @@ class _Engine(object):
             name, pad = item
             if i + 1 < len(items) and items[i + 1] == "P":
                 pin, a = self._conv(a, name, pad, pool=True)
-                acts[name] = pin
-                pools.append((pin, a))
+                if keep:
+                    acts[name] = pin
+                    pools.append((pin, a))
+                del pin
             else:
                 a = self._conv(a, name, pad)
-                acts[name] = a
+                if keep:
+                    acts[name] = a
         if train and masks is None:
             masks = self.make_masks(B, m.fc6.out_channels, x.device)
         ctx.masks = masks if train else None
         s6 = ctx.masks[0] if ctx.masks is not None else None
         s7 = ctx.masks[1] if ctx.masks is not None else None
         ctx.relu6 = self._conv(a, "fc6", 0, scale=s6)            # relu -> dropout factor, fused epilogue
+        del a
         ctx.relu7 = self._conv(ctx.relu6, "fc7", 0, scale=s7)
+        if not keep:
+            ctx.relu6 = None
         ctx.acts, ctx.pools = acts, pools
         ctx.coarse = self._head_fp8(ctx.relu7) if self.head_fp8 else self._conv(ctx.relu7, "head", 0, relu=False, out_f32=True)
         ctx.h, ctx.w = ctx.coarse.shape[1:3]
@@ -686,7 +694,7 @@ class FCN32s(nn.Module):
         on pixels whose top-2 cosine margin is < 1e-5).  Used by Trainer.validate."""
         eng = self._engine
         with torch.no_grad():
-            ctx = eng.forward(x.detach() if isinstance(x, torch.Tensor) else x, train=False)
+            ctx = eng.forward(x.detach() if isinstance(x, torch.Tensor) else x, train=False, keep=False)
             emb = torch.as_tensor(embeddings).to(ctx.coarse.device, torch.float32).contiguous()
             K, E = emb.shape
             if E != self.n_class:
