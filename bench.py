@@ -139,8 +139,10 @@ def cpu_baseline(E, K, H, emb, arch="fcn32s"):
     tgt = synth.make_labels(1, H, H, K)
     cores = os.cpu_count()
     out = {"unit": "Mpixels/s", "cores": cores, "kind": "port"}
-    # all host cores; torch's default would be the physical-core count
-    t = T.timed_train_step(E, K, H, emb, x, tgt, steps=2, threads=cores, arch=arch)  # second step timed (first pays allocation / mkldnn setup)
+    # torch's default thread count = the physical cores of the host (128 on the 256-thread GPU boxes).  One thread per LOGICAL
+    # core (BASELINE.md section 3 reads "all host cores") was measured too: 0.0048 Mpx/s against 0.038-0.048 -- oversubscribed
+    # SMT siblings make mkldnn ~10x slower -- so the faster setting is the baseline; `threads` states what was used
+    t = T.timed_train_step(E, K, H, emb, x, tgt, steps=2, arch=arch)  # second step timed (first pays allocation / mkldnn setup)
     out["value"] = round(H * H / t["total"] / 1e6, 6)
     out["threads"] = torch.get_num_threads()
     out["sample"] = ("torch-CPU restatement of the %s step (oracle/torch_ref.py; depthwise upscore), 1 image %dx%d, "

@@ -286,6 +286,25 @@ int szn_sgd_momentum_step(long n, float* param, const float* grad, float* moment
                           float momentum, float weight_decay, int first_step, float grad_scale,
                           void* w_lp, int w_lp_dtype, szn_stream_t stream);
 
+/* ---- dynamic loss scaling for the IEEE-half path (BASELINE configs[4]: "fp16 activations"; the reference is fp32 and has
+ * no counterpart).  scale_state: device float[4] = {loss scale S, found_inf flag, optimizer steps applied, clean steps
+ * since S last changed}.  Per step: d(loss)/d(coarse) is multiplied by S in fp32 before it enters the 16-bit backward pass;
+ * szn_grad_check_finite (after the gradient all-reduce, so every rank sees the same flag: inf / NaN survive a sum) raises
+ * found_inf if any gradient element is not finite; the *_scaled optimizer entry points read S, the flag and the step count
+ * from scale_state: they divide the gradient by S and do NOTHING when the flag is set (masters, moments and the 16-bit
+ * weight image stay as they were); szn_loss_scale_update then backs S off (x backoff, >= min_scale) after an overflow,
+ * or counts the step and grows S (x growth, <= max_scale) after growth_interval clean steps, and clears the flag.
+ * No host synchronisation anywhere: the scale never leaves the device.                                                  */
+int szn_grad_check_finite(long n, const float* grad, float* scale_state, szn_stream_t stream);
+int szn_adam_step_scaled(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, const float* scale_state, float grad_scale,
+                         void* w_lp, int w_lp_dtype, szn_stream_t stream);
+int szn_sgd_momentum_step_scaled(long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum,
+                                 float weight_decay, const float* scale_state, float grad_scale, void* w_lp,
+                                 int w_lp_dtype, szn_stream_t stream);
+int szn_loss_scale_update(float* scale_state, float growth, float backoff, int growth_interval, float min_scale,
+                          float max_scale, szn_stream_t stream);
+
 /* ---- small utilities -------------------------------------------------------------------------------- */
 int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, szn_stream_t stream);
 /* Dropout2d factors: scale[i] = (u_i >= p) ? 1/(1-p) : 0 with a counter-based generator (seed, i)   */

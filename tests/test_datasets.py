@@ -80,3 +80,58 @@ def test_loader_batches_native_samples(tiny):
     loader = torch.utils.data.DataLoader(d, batch_size=2, shuffle=False)
     img, lbl = next(iter(loader))
     assert tuple(img.shape) == (2, 10, 12, 3) and img.dtype == torch.uint8 and tuple(lbl.shape) == (2, 10, 12)
+
+
+def test_presence_cache_is_versioned(tiny, monkeypatch):
+    """a cache written under another schema (label-decoding rules / bit layout / class list) is discarded, not reused"""
+    import json
+    cls = datasets.PascalContext
+    cls(split="train_seen", data_dir="data", train_unseen=[0, 12], val_unseen=[16, 18], native=True)
+    cache = os.path.join("data", cls.name, "label_presence.json")
+    c = json.load(open(cache))
+    assert c["_schema"].startswith("%d:" % datasets.PRESENCE_SCHEMA) and len(c["files"]) == len(G["ids"])
+    # poison every mask and pretend it was written by an older schema: the split must still come out right
+    for k in c["files"]:
+        c["files"][k][2] = 0
+    c["_schema"] = "1:" + c["_schema"].split(":")[1]
+    json.dump(c, open(cache, "w"))
+    d = cls(split="train_seen", data_dir="data", train_unseen=[0, 12], val_unseen=[16, 18], native=True)
+    assert ids_of(d) == [str(s) for s in G["ctx_train_seen_kept"]]
+    assert json.load(open(cache))["_schema"] == d._schema()
+    # the pre-versioning flat format is not trusted either
+    json.dump({k: [1, 1, 0] for k in c["files"]}, open(cache, "w"))
+    d = cls(split="train_seen", data_dir="data", train_unseen=[0, 12], val_unseen=[16, 18], native=True)
+    assert ids_of(d) == [str(s) for s in G["ctx_train_seen_kept"]]
+
+
+def test_pad_collate_ragged_batch():
+    """PASCAL images differ in size (context_dataset.py:143-150): batches > 1 are padded with mean-colour pixels labelled -1"""
+    rs = np.random.RandomState(0)
+    sizes = [(10, 12), (7, 15), (13, 5)]
+    batch = [(torch.from_numpy(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)),
+              torch.from_numpy(rs.randint(0, 33, size=(h, w)).astype(np.int64))) for h, w in sizes]
+    img, lbl = datasets.pad_collate(batch)
+    assert tuple(img.shape) == (3, 13, 15, 3) and img.dtype == torch.uint8
+    assert tuple(lbl.shape) == (3, 13, 15) and lbl.dtype == torch.int64
+    for k, (h, w) in enumerate(sizes):
+        assert torch.equal(img[k, :h, :w], batch[k][0]) and torch.equal(lbl[k, :h, :w], batch[k][1])
+        assert int((lbl[k] >= 0).sum()) == h * w                      # every padded pixel is ignored
+        pad = torch.ones(13, 15, dtype=torch.bool)
+        pad[:h, :w] = False
+        assert (lbl[k][pad] == -1).all()
+        assert (img[k][pad] == torch.tensor(datasets.MEAN_RGB_U8, dtype=torch.uint8)).all()
+    # the padding colour is the mean: at most half a grey level away from zero after the transform
+    bgr = np.array(datasets.MEAN_RGB_U8[::-1], np.float64) - datasets.MEAN_BGR
+    assert np.abs(bgr).max() <= 0.5
+    # the reference's (label, label_embedding) tuple form keeps the label
+    img2, lbl2 = datasets.pad_collate([(b[0], (b[1], torch.zeros(20, *b[1].shape))) for b in batch])
+    assert torch.equal(lbl2, lbl)
+    with pytest.raises(ValueError):
+        datasets.pad_collate([(torch.zeros(3, 4, 4), torch.zeros(4, 4, dtype=torch.int64))])
+
+
+def test_loader_with_pad_collate(tiny):
+    d = datasets.PascalContext(split="val", data_dir="data", native=True)
+    loader = torch.utils.data.DataLoader(d, batch_size=3, shuffle=False, collate_fn=datasets.pad_collate)
+    img, lbl = next(iter(loader))
+    assert tuple(img.shape) == (3, 10, 12, 3) and tuple(lbl.shape) == (3, 10, 12)

@@ -180,7 +180,7 @@ def test_configs3_standin_two_ranks_b8_bf16_512(comm):
     for p in procs:
         p.join(120)
     mb = res[0]["bucket_mb"]
-    assert len(mb) >= 4 and max(mb) > 400 and min(mb) < 25, mb      # fc6 alone is 411 MB; the tail bucket is the 2.2 MB rest
+    assert len(mb) >= 4 and max(mb) > 390 and min(mb) < 25, mb      # MiB: fc6 alone is 411 MB = 392 MiB; the tail bucket is the 2.2 MB rest
     x, t, emb = _data3()
     m = models.FCN32s(E3)
     m.load_synthetic(1337, device=torch.device("cuda", 0))

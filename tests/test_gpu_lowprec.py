@@ -157,3 +157,65 @@ def test_configs4_train_step_as_configured():
     assert agree > 0.97
     assert all(np.isfinite(losses)) and losses[2] < losses[0]
     m.set_head_precision("native")
+
+
+def _fp16_step(loss_scale=None, **kw):
+    E, K, H = 20, 33, 96
+    emb = synth.make_embeddings(K, E)
+    m = models.FCN32s(E)
+    m.load_synthetic(1337, device=torch.device("cuda"))
+    m.eval()
+    ts = engine.TrainStep(m, emb, optimizer=kw.pop("optimizer", "adam"), lr=1e-5, precision=torch.float16, fused_head=True,
+                          loss_scale=loss_scale, **kw)
+    x = cu(synth.make_images(2, H, H, seed=71))
+    t = cu(synth.make_labels(2, H, H, K, seed=72, block=16))
+    return m, ts, x, t
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_dynamic_loss_scale_skips_overflowed_steps_and_recovers(optimizer):
+    """fp16 path: a loss scale far too large makes the 16-bit activation gradients overflow -> the whole optimizer step is
+    skipped on the device (masters, moments, 16-bit weight image untouched), the scale is halved, and once the gradients are
+    finite again steps are applied and counted; after `scale_growth_interval` clean steps the scale doubles"""
+    m, ts, x, t = _fp16_step(loss_scale=2.0 ** 40, optimizer=optimizer, scale_growth_interval=3)
+    assert ts.dynamic and ts.loss_scale == 2.0 ** 40
+    w0, lp0 = ts.flat_w.clone(), ts.flat_w_lp.clone()
+    st0 = [s.clone() for s in ts.state["w"]]
+    loss, _ = ts.step(x, t)
+    assert np.isfinite(float(loss))                                   # the forward pass is unaffected by the scale
+    assert not torch.isfinite(ts.flat_gw).all()                       # the scaled 16-bit backward overflowed
+    assert torch.equal(ts.flat_w, w0) and torch.equal(ts.flat_w_lp, lp0)
+    assert all(torch.equal(a, b) for a, b in zip(ts.state["w"], st0))
+    assert ts.loss_scale == 2.0 ** 39 and ts.applied_steps == 0
+    scales = []
+    for _ in range(40):
+        ts.step(x, t)
+        scales.append(ts.loss_scale)
+        if ts.applied_steps >= 4:
+            break
+    assert ts.applied_steps >= 4, scales
+    assert torch.isfinite(ts.flat_w).all() and not torch.equal(ts.flat_w, w0)
+    assert torch.equal(ts.flat_w_lp.float(), ts.flat_w.half().float())           # the weight image follows the masters
+    k = next(i for i in range(1, len(scales)) if scales[i] == scales[i - 1])    # first clean step
+    assert all(scales[i] == scales[i - 1] / 2 for i in range(1, k))              # halved on every overflow before it
+    assert max(scales[k:]) == 2 * scales[k] or len(scales) - k < 3               # grown after 3 clean steps
+    # checkpoints carry the number of APPLIED steps
+    class _Opt(object):
+        state = __import__("collections").defaultdict(dict)
+    ts.export_optimizer_state(_Opt)
+    if optimizer == "adam":
+        assert all(int(v["step"]) == ts.applied_steps for v in _Opt.state.values())
+
+
+def test_dynamic_loss_scale_equals_static_when_nothing_overflows():
+    ma, tsa, x, t = _fp16_step(dynamic_loss_scale=True)
+    mb, tsb, _, _ = _fp16_step(dynamic_loss_scale=False)
+    assert tsa.dynamic and not tsb.dynamic and tsa.loss_scale == tsb.loss_scale == 4096.0
+    for _ in range(3):
+        la, _ = tsa.step(x, t)
+        lb, _ = tsb.step(x, t)
+        assert float(la) == float(lb)
+    assert tsa.applied_steps == 3
+    assert torch.equal(tsa.flat_gw, tsb.flat_gw)
+    d = (tsa.flat_w - tsb.flat_w).abs().max().item()
+    assert d <= 1e-6 * 3e-5 + 1e-12, d                  # in-kernel bias correction (double pow) vs the host's: rounding only

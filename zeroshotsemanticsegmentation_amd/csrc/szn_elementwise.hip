@@ -349,7 +349,15 @@ template <typename LP>      // element type of the optional 16-bit weight image 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                    float b1, float b2, float eps, float wd, float step_size,
-                                                   float inv_bc2_sqrt, float gscale, uint16_t* __restrict__ wlp, int vec) {
+                                                   float inv_bc2_sqrt, float gscale, uint16_t* __restrict__ wlp, int vec,
+                                                   const float* __restrict__ dyn) {
+    if (dyn) {          // dynamic loss scaling: {scale S, found_inf, steps applied, ...}; see szn_adam_step_scaled
+        if (dyn[1] != 0.f) return;                       // a non-finite gradient somewhere: the whole step is skipped
+        gscale = gscale / dyn[0];
+        const double step = (double)dyn[2] + 1.0;
+        step_size = (float)((double)lr / (1.0 - pow((double)b1, step)));
+        inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)b2, step)));
+    }
     const long n4 = vec ? (n >> 2) : 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4_t pq = ((const f32x4_t*)p)[i], gq = ((const f32x4_t*)g)[i], mq = ((const f32x4_t*)m)[i], vq = ((const f32x4_t*)v)[i];
@@ -385,7 +393,13 @@ __device__ __forceinline__ void sgd_elem(float& pi, float gi, float& bi, float l
 template <typename LP>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ buf, long n, float lr, float mom, float wd,
-                                                  int first, float gscale, uint16_t* __restrict__ wlp, int vec) {
+                                                  int first, float gscale, uint16_t* __restrict__ wlp, int vec,
+                                                  const float* __restrict__ dyn) {
+    if (dyn) {
+        if (dyn[1] != 0.f) return;
+        gscale = gscale / dyn[0];
+        first = dyn[2] == 0.f;
+    }
     const long n4 = vec ? (n >> 2) : 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4_t pq = ((const f32x4_t*)p)[i], gq = ((const f32x4_t*)g)[i];
@@ -604,9 +618,9 @@ extern "C" int szn_image_u8_to_bgr_f32(int B, int H, int W, const uint8_t* rgb_h
     return SZN_OK;
 }
 
-extern "C" int szn_adam_step(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                             void* w_lp, int w_lp_dtype, szn_stream_t stream) {
+static int adam_impl(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* w_lp, int w_lp_dtype,
+                     const float* dyn, szn_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) SZN_FAIL(SZN_ERR_ARG, "adam_step: bad argument");
     if (w_lp && !szn_is16(w_lp_dtype)) SZN_FAIL(SZN_ERR_ARG, "adam_step: the weight image must be SZN_BF16 or SZN_F16");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
@@ -618,27 +632,101 @@ extern "C" int szn_adam_step(long n, float* param, const float* grad, float* exp
     const dim3 grid(grid_for(vec ? (n + 3) / 4 : n, 256, 1 << 24));
     if (w_lp && w_lp_dtype == SZN_F16)
         hipLaunchKernelGGL(adam_kernel<f16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                           beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale, (uint16_t*)w_lp, vec);
+                           beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale, (uint16_t*)w_lp, vec, dyn);
     else
         hipLaunchKernelGGL(adam_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                           beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale, (uint16_t*)w_lp, vec);
+                           beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale, (uint16_t*)w_lp, vec, dyn);
     SZN_CHECK_LAUNCH("adam_kernel");
     return SZN_OK;
 }
 
-extern "C" int szn_sgd_momentum_step(long n, float* param, const float* grad, float* momentum_buf, float lr,
-                                     float momentum, float weight_decay, int first_step, float grad_scale, void* w_lp,
-                                     int w_lp_dtype, szn_stream_t stream) {
+extern "C" int szn_adam_step(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             void* w_lp, int w_lp_dtype, szn_stream_t stream) {
+    return adam_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale, w_lp, w_lp_dtype,
+                     nullptr, stream);
+}
+
+extern "C" int szn_adam_step_scaled(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, const float* scale_state,
+                                    float grad_scale, void* w_lp, int w_lp_dtype, szn_stream_t stream) {
+    if (!scale_state) SZN_FAIL(SZN_ERR_ARG, "adam_step_scaled: scale_state is NULL");
+    return adam_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, 1, grad_scale, w_lp, w_lp_dtype,
+                     scale_state, stream);
+}
+
+static int sgd_impl(long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum, float weight_decay,
+                    int first_step, float grad_scale, void* w_lp, int w_lp_dtype, const float* dyn, szn_stream_t stream) {
     if (!param || !grad || !momentum_buf || n <= 0) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step: bad argument");
     if (w_lp && !szn_is16(w_lp_dtype)) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step: the weight image must be SZN_BF16 or SZN_F16");
     const int vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) == 0 && (((uintptr_t)w_lp) & 7) == 0) ? 1 : 0;
     const dim3 grid(grid_for(vec ? (n + 3) / 4 : n, 256, 1 << 24));
     if (w_lp && w_lp_dtype == SZN_F16)
         hipLaunchKernelGGL(sgd_kernel<f16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, n, lr, momentum,
-                           weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec);
+                           weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec, dyn);
     else
         hipLaunchKernelGGL(sgd_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, n, lr, momentum,
-                           weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec);
+                           weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec, dyn);
     SZN_CHECK_LAUNCH("sgd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_sgd_momentum_step(long n, float* param, const float* grad, float* momentum_buf, float lr,
+                                     float momentum, float weight_decay, int first_step, float grad_scale, void* w_lp,
+                                     int w_lp_dtype, szn_stream_t stream) {
+    return sgd_impl(n, param, grad, momentum_buf, lr, momentum, weight_decay, first_step, grad_scale, w_lp, w_lp_dtype, nullptr, stream);
+}
+
+extern "C" int szn_sgd_momentum_step_scaled(long n, float* param, const float* grad, float* momentum_buf, float lr,
+                                            float momentum, float weight_decay, const float* scale_state, float grad_scale,
+                                            void* w_lp, int w_lp_dtype, szn_stream_t stream) {
+    if (!scale_state) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step_scaled: scale_state is NULL");
+    return sgd_impl(n, param, grad, momentum_buf, lr, momentum, weight_decay, 0, grad_scale, w_lp, w_lp_dtype, scale_state, stream);
+}
+
+// ---- dynamic loss scaling (fp16 path) ------------------------------------------------------------------------------------------
+// state = {scale S, found_inf, optimizer steps applied, clean steps since S last changed}
+__global__ __launch_bounds__(256) void grad_finite_kernel(const float* __restrict__ g, long n, float* __restrict__ state, int vec) {
+    const long n4 = vec ? (n >> 2) : 0;
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4_t q = ((const f32x4_t*)g)[i];
+        // x - x is 0 for every finite x and NaN for +-inf / NaN
+        const float z = (q[0] - q[0]) + (q[1] - q[1]) + (q[2] - q[2]) + (q[3] - q[3]);
+        bad |= !(z == 0.f);
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) bad |= !((g[i] - g[i]) == 0.f);
+    if (__any(bad) && (threadIdx.x & 63) == 0) state[1] = 1.f;      // every writer stores the same value
+}
+
+__global__ void loss_scale_update_kernel(float* __restrict__ st, float growth, float backoff, int interval, float lo, float hi) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st[1] != 0.f) {                                  // overflow: the optimizer kernels skipped this step
+        st[0] = fmaxf(st[0] * backoff, lo);
+        st[3] = 0.f;
+    } else {
+        st[2] += 1.f;
+        st[3] += 1.f;
+        if (st[3] >= (float)interval) { st[0] = fminf(st[0] * growth, hi); st[3] = 0.f; }
+    }
+    st[1] = 0.f;
+}
+
+extern "C" int szn_grad_check_finite(long n, const float* grad, float* scale_state, szn_stream_t stream) {
+    if (!grad || !scale_state || n <= 0) SZN_FAIL(SZN_ERR_ARG, "grad_check_finite: bad argument");
+    const int vec = (((uintptr_t)grad) & 15) == 0 ? 1 : 0;
+    hipLaunchKernelGGL(grad_finite_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, grad,
+                       n, scale_state, vec);
+    SZN_CHECK_LAUNCH("grad_finite_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_loss_scale_update(float* scale_state, float growth, float backoff, int growth_interval, float min_scale,
+                                     float max_scale, szn_stream_t stream) {
+    if (!scale_state || growth < 1.f || backoff <= 0.f || backoff > 1.f || growth_interval < 1)
+        SZN_FAIL(SZN_ERR_ARG, "loss_scale_update: bad argument");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale_state, growth, backoff,
+                       growth_interval, min_scale, max_scale);
+    SZN_CHECK_LAUNCH("loss_scale_update_kernel");
     return SZN_OK;
 }

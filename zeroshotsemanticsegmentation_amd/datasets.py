@@ -34,6 +34,10 @@ CONTEXT33_CLASSES = ['aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'bus', 'c
                      'grass', 'ground', 'road', 'building', 'tree', 'water', 'mountain', 'wall', 'floor', 'track',
                      'keyboard', 'ceiling']
 INVALID_BIT = 63          # "the label file contains invalid / unlabelled pixels" in the presence mask
+# version of everything a cached presence mask depends on besides the file itself: the label decoding rules of the
+# _read_label hooks (context: png - 1; voc: 255 -> -1) and the bit layout above.  Bump it when any of them changes: a cache
+# written under another version (or for another class list) is discarded, never reused.
+PRESENCE_SCHEMA = 2
 
 
 def _open_image(path):
@@ -105,12 +109,18 @@ class _SegmentationDataset(torch.utils.data.Dataset):
             m |= 1 << (INVALID_BIT if c < 0 else int(c))
         return m
 
+    def _schema(self):
+        import hashlib
+        return "%d:%s" % (PRESENCE_SCHEMA, hashlib.sha1("|".join(self.class_names).encode()).hexdigest()[:12])
+
     def _load_cache(self):
         if self._cache_path and osp.exists(self._cache_path):
             try:
-                return json.load(open(self._cache_path))
+                c = json.load(open(self._cache_path))
             except (OSError, ValueError):
                 return {}
+            if isinstance(c, dict) and c.get("_schema") == self._schema() and isinstance(c.get("files"), dict):
+                return c["files"]
         return {}
 
     def _save_cache(self):
@@ -119,7 +129,7 @@ class _SegmentationDataset(torch.utils.data.Dataset):
         try:
             os.makedirs(osp.dirname(self._cache_path), exist_ok=True)
             tmp = self._cache_path + '.tmp%d' % os.getpid()
-            json.dump(self._presence, open(tmp, 'w'))
+            json.dump({"_schema": self._schema(), "files": self._presence}, open(tmp, 'w'))
             os.replace(tmp, self._cache_path)
         except OSError:
             pass                                      # read-only dataset directory: scan again next time
@@ -218,6 +228,38 @@ class PascalVOC(_SegmentationDataset):
     def _banned_mask(self):
         extra = {'train': self.val_unseen, 'train_seen': self.train_unseen + self.val_unseen, 'val': []}[self.split]
         return self._bits(list(extra))
+
+
+MEAN_RGB_U8 = tuple(int(round(v)) for v in utils.MEAN_BGR[::-1])       # the uint8 colour closest to the mean: ~0 after the transform
+
+
+def pad_collate(batch):
+    """collate_fn for NATIVE samples (uint8 (H,W,3) RGB image, int64 (H,W) label) of different sizes -- PASCAL images differ in
+    size (context_dataset.py:143-150 never resizes; the reference therefore trains at batch size 1, train.py:82-84).  Every
+    sample is padded at the bottom / right to the largest height / width of the batch: image pixels with the mean colour (zero
+    after the BGR - mean transform, i.e. what conv1_1's own zero padding continues with), labels with -1, which every loss,
+    class-assignment and histogram kernel of this path already ignores (utils.py:33,60,84: `target >= 0`).  Per-image losses
+    keep their own valid-pixel counts, so a padded batch is the mean of its images' losses.  -> ((B,Hm,Wm,3) uint8, (B,Hm,Wm)
+    int64).  Samples that carry the reference's (label, label_embedding) tuple keep the label only (the embedding is gathered
+    on the GPU)."""
+    imgs, lbls = [], []
+    for img, lbl in batch:
+        if isinstance(lbl, (tuple, list)):
+            lbl = lbl[0]
+        img, lbl = torch.as_tensor(img), torch.as_tensor(lbl)
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+            raise ValueError("pad_collate expects native samples: uint8 (H,W,3) images (datasets built with native=True)")
+        imgs.append(img)
+        lbls.append(lbl.long())
+    Hm, Wm = max(i.shape[0] for i in imgs), max(i.shape[1] for i in imgs)
+    out_i = torch.empty(len(imgs), Hm, Wm, 3, dtype=torch.uint8)
+    out_i[:] = torch.tensor(MEAN_RGB_U8, dtype=torch.uint8)
+    out_l = torch.full((len(imgs), Hm, Wm), -1, dtype=torch.int64)
+    for k, (img, lbl) in enumerate(zip(imgs, lbls)):
+        h, w = img.shape[:2]
+        out_i[k, :h, :w] = img
+        out_l[k, :h, :w] = lbl
+    return out_i, out_l
 
 
 def download(data_dir):

@@ -236,7 +236,8 @@ class TrainStep(object):
     def __init__(self, model, embeddings, optimizer="adam", lr=1e-5, momentum=0.99, weight_decay=0.0005,
                  precision=torch.bfloat16, fused_head=True, loss="cos", process_group=None, bucket_mb=25,
                  train_metrics=True, betas=(0.9, 0.999), eps=1e-8, bias_lr=None, bias_weight_decay=0.0,
-                 adam_weight_decay=0.0, grad_comm_dtype=None, loss_scale=None):
+                 adam_weight_decay=0.0, grad_comm_dtype=None, loss_scale=None, dynamic_loss_scale=None,
+                 scale_growth=2.0, scale_backoff=0.5, scale_growth_interval=2000):
         if loss not in ("cos", "mse") or (fused_head and loss != "cos"):
             raise L.SznError("TrainStep: fused head supports the cosine loss; use fused_head=False for mse")
         self.model = model
@@ -268,19 +269,44 @@ class TrainStep(object):
         # static loss scaling for the fp16 path: gradients below 6e-8 vanish in IEEE half, so d(loss)/d(coarse) is multiplied
         # by loss_scale in fp32 before it enters the 16-bit backward pass and the optimizer kernel divides it out again
         # (grad_scale).  The .grad views then hold loss_scale x gradient.  bf16 / fp32 need none.
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if precision == torch.float16 else 1.0)
+        self._loss_scale0 = float(loss_scale) if loss_scale is not None else (4096.0 if precision == torch.float16 else 1.0)
+        # dynamic loss scaling (default for fp16): the scale, the overflow flag and the count of APPLIED optimizer steps live
+        # on the device (include/szn.h, szn_grad_check_finite / szn_*_step_scaled / szn_loss_scale_update); a step whose
+        # gradients contain inf / NaN leaves masters, moments and weight images untouched and halves the scale -- no host
+        # synchronisation, identical decisions on every data-parallel rank (the flag is read from the all-reduced gradient)
+        self.dynamic = (precision == torch.float16) if dynamic_loss_scale is None else bool(dynamic_loss_scale)
+        self.scale_cfg = (float(scale_growth), float(scale_backoff), int(scale_growth_interval), 1.0, 65536.0)
+        self.scale_state = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.train_metrics = train_metrics
         self.nstep = 0
         self._flatten()
         self._buckets(bucket_mb)
+        if self.dynamic:
+            self.scale_state = torch.tensor([self._loss_scale0, 0.0, 0.0, 0.0], device=self.dev)
         self.hist = torch.zeros(3, self.K, self.K, dtype=torch.int64, device=self.dev)
         self.loss = torch.zeros(1, device=self.dev)
         self.stats = None
         self._ws = None
         self.keep_ctx = False        # tests: keep the forward state of the last step (activations stay alive one step longer)
         self.last_ctx = None
+
+    @property
+    def loss_scale(self):
+        """the factor the .grad views currently carry (dynamic scaling: read back from the device -- a host sync; tests only)"""
+        return float(self.scale_state[0].item()) if self.dynamic else self._loss_scale0
+
+    def _scale(self, t):
+        """t (fp32 d loss / d head input) x loss scale, as the compute dtype"""
+        if self.dynamic:
+            return (t.float() * self.scale_state[0]).to(self.eng.dtype)
+        return (t.float() * self._loss_scale0).to(self.eng.dtype)
+
+    @property
+    def applied_steps(self):
+        """optimizer steps that were actually applied (dynamic loss scaling skips overflowed ones)"""
+        return int(self.scale_state[2].item()) if self.dynamic else self.nstep
 
     # ---- flat parameter / gradient / moment storage ----------------------------------------------------
     def _flatten(self):
@@ -391,7 +417,7 @@ class TrainStep(object):
         code = L.dtype_code(eng.dtype)
         pred = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
         stats = torch.empty(B, 2, device=self.dev)
-        scaled = self.loss_scale != 1.0
+        scaled = self.dynamic or self._loss_scale0 != 1.0
         dcoarse = torch.zeros(B, ctx.h, ctx.w, CP, device=self.dev, dtype=torch.float32 if scaled else eng.dtype)
         code = L.dtype_code(dcoarse.dtype)
         if self.fused_head:
@@ -413,7 +439,7 @@ class TrainStep(object):
             dc32, _ = eng.head_backward(ctx, df=df)
             dcoarse = dc32
         if scaled:
-            dcoarse = (dcoarse.float() * self.loss_scale).to(eng.dtype)
+            dcoarse = self._scale(dcoarse)
         self.stats = stats
         self._backward(ctx, dcoarse, self.buckets.layer_done)
         self.buckets.finish()
@@ -477,8 +503,10 @@ class TrainStep(object):
         L.call("szn_fused_head_strided", 8, B, n3, m3, E, CP, 0, H, W, CROP_UP8, K, L.ptr(fuse3), L.ptr(self.emb), L.ptr(target),
                L.ptr(self.loss), L.ptr(stats), L.ptr(pred), L.SZN_F32, L.ptr(dfuse3), L.ptr(self._ws), st)
         self.stats = stats
-        if self.loss_scale != 1.0:
-            dfuse3 = dfuse3 * self.loss_scale
+        if self.dynamic:
+            dfuse3 = dfuse3 * self.scale_state[0]
+        elif self._loss_scale0 != 1.0:
+            dfuse3 = dfuse3 * self._loss_scale0
         # backward of the head chain; the skip gradients join the backbone chain at the pool3 / pool4 outputs
         skips = {}
         dmap = dfuse3
@@ -488,9 +516,11 @@ class TrainStep(object):
             nn, mm = dmap.shape[1:3]
             dsp = torch.zeros(Bp, hp, wp, CP, device=self.dev, dtype=dt)
             dsp[:, crop:crop + nn, crop:crop + mm] = dmap
-            eng._wgrad(pool, dsp, s["gw"], s["gb"], ci, CP, 1, 0)
             o, cnt = self.woff[name]
-            self.flat_gw[o:o + cnt].view(E, 1, 1, ci).copy_(s["gw"][:E])
+            # the copy into the flat gradient runs as the wgrad's `after` hook: on the weight-gradient stream when
+            # SZN_WGRAD_STREAM=1 moves these launches off the main stream (a copy queued on the main stream would race them)
+            eng._wgrad(pool, dsp, s["gw"], s["gb"], ci, CP, 1, 0,
+                       after=lambda o=o, cnt=cnt, s=s, ci=ci: self.flat_gw[o:o + cnt].view(E, 1, 1, ci).copy_(s["gw"][:E]))
             skips[pi] = eng._dgrad(dsp, None, pool.shape, 0, wT=s["wT"])
             dmap = self._up2(dmap, fwd=False, shape=tuple(up_shape))
         eng._join_wgrad()
@@ -522,20 +552,35 @@ class TrainStep(object):
     def _optimizer_step(self):
         self.nstep += 1
         st = L.stream_ptr()
-        gs = 1.0 / (self.world * self.loss_scale)
+        dyn = self.scale_state
+        gs = 1.0 / self.world if self.dynamic else 1.0 / (self.world * self._loss_scale0)
         lp_code = L.dtype_code(self.flat_w_lp.dtype) if self.flat_w_lp is not None else 0
+        if self.dynamic:                 # raise the overflow flag from the (already all-reduced) gradients
+            L.call("szn_grad_check_finite", self.flat_gw.numel(), L.ptr(self.flat_gw), L.ptr(dyn), st)
+            L.call("szn_grad_check_finite", self.flat_gb.numel(), L.ptr(self.flat_gb), L.ptr(dyn), st)
         for key, flat, grad, lr, wd in (("w", self.flat_w, self.flat_gw, self.lr, self.wd),
                                         ("b", self.flat_b, self.flat_gb, self.bias_lr, self.bias_wd)):
             lp = L.ptr(self.flat_w_lp) if (key == "w" and self.flat_w_lp is not None) else None
             if self.opt == "adam":       # train.py:130-133 (Adam has no weight decay in the reference wiring)
                 m1, m2 = self.state[key]
-                L.call("szn_adam_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr),
-                       float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.bias_wd if key == "b" else self.adam_wd),
-                       self.nstep, gs, lp, lp_code, st)
+                awd = float(self.bias_wd if key == "b" else self.adam_wd)
+                if self.dynamic:
+                    L.call("szn_adam_step_scaled", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr),
+                           float(self.betas[0]), float(self.betas[1]), float(self.eps), awd, L.ptr(dyn), gs, lp, lp_code, st)
+                else:
+                    L.call("szn_adam_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr),
+                           float(self.betas[0]), float(self.betas[1]), float(self.eps), awd, self.nstep, gs, lp, lp_code, st)
             else:                        # train.py:126-129
                 (buf,) = self.state[key]
-                L.call("szn_sgd_momentum_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(buf), float(lr),
-                       float(self.momentum), float(wd), int(self.nstep == 1), gs, lp, lp_code, st)
+                if self.dynamic:
+                    L.call("szn_sgd_momentum_step_scaled", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(buf), float(lr),
+                           float(self.momentum), float(wd), L.ptr(dyn), gs, lp, lp_code, st)
+                else:
+                    L.call("szn_sgd_momentum_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(buf), float(lr),
+                           float(self.momentum), float(wd), int(self.nstep == 1), gs, lp, lp_code, st)
+        if self.dynamic:
+            g, b, iv, lo, hi = self.scale_cfg
+            L.call("szn_loss_scale_update", L.ptr(dyn), g, b, iv, lo, hi, st)
         self.eng.mark_dirty()
 
     # ---- checkpoint compatibility (reference dict keys: trainer_fcn.py:281-288) ------------------------------
@@ -556,11 +601,11 @@ class TrainStep(object):
         for p, key, view in self._param_slots():
             st = optim.state[p]
             if self.opt == "adam":
-                st['step'] = torch.tensor(float(self.nstep))
+                st['step'] = torch.tensor(float(self.applied_steps))
                 st['exp_avg'] = view(self.state[key][0])
                 st['exp_avg_sq'] = view(self.state[key][1])
             else:
-                st['momentum_buffer'] = view(self.state[key][0]) if self.nstep > 0 else None
+                st['momentum_buffer'] = view(self.state[key][0]) if self.applied_steps > 0 else None
 
     def import_optimizer_state(self, optim):
         """inverse of export_optimizer_state (resume: train.py:135-136 loads `optim_state_dict` into the optimizer)"""
@@ -576,6 +621,8 @@ class TrainStep(object):
                 steps.append(1)
         if steps:
             self.nstep = max(steps)
+            if self.dynamic:
+                self.scale_state[2] = float(self.nstep)
 
     def metrics(self, reset=True):
         """running train metrics from the device histogram (trainer_fcn.py:164)"""

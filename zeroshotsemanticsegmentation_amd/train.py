@@ -175,6 +175,12 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     cfg = update_cfg_with_args(configurations[args.config], args)
     validate_cfg(cfg)
+    if args.precision == 'fp16' and cfg['mode'] == 'train' and cfg['fcn_epochs'] > 0 and \
+            (cfg['fcn_loss'] != 'cos' or not cfg['embed_dim'] or cfg['forced_unseen']):
+        # loss scaling lives in the fused steps only (engine.TrainStep / SeenmaskStep); see trainer_fcn.Trainer.train_epoch
+        raise Exception("--precision fp16 needs the fused training step: embedding configuration with fcn_loss 'cos' and no "
+                        "forced_unseen (got loss %r, embed_dim %r, forced_unseen %r); use bf16 or fp32"
+                        % (cfg['fcn_loss'], cfg['embed_dim'], cfg['forced_unseen']))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
@@ -213,6 +219,7 @@ def main(argv=None):
 
     # 1. dataset
     all_unseen = cfg['train_unseen'] + cfg['val_unseen']
+    collate = None
     if args.synthetic:
         n_img, H, W = args.synthetic
         n_class = 21 if cfg['dataset'] == 'pascal' else 33
@@ -225,10 +232,11 @@ def main(argv=None):
         val_dataset = mk('val', [], max(n_img // 4, 1))
     else:
         # real data under <data_dir> (reference layout, train.py:64-80); samples travel raw (uint8 image + label), the BGR /
-        # mean transform and the target-embedding gather run on the GPU; images differ in size, so batch size stays 1
-        from .datasets import PascalContext, PascalVOC
-        if args.batch_size != 1:
-            raise SystemExit("real PASCAL images differ in size: --batch-size must be 1 (like the reference)")
+        # mean transform and the target-embedding gather run on the GPU; images differ in size: batches > 1 are padded to the
+        # largest image of the batch with ignored (-1) pixels (datasets.pad_collate; the reference trains at batch size 1)
+        from .datasets import PascalContext, PascalVOC, pad_collate
+        if args.batch_size > 1:
+            collate = pad_collate
         cls = PascalVOC if cfg['dataset'] == 'pascal' else PascalContext
         mkr = lambda split: cls(split=split, embed_dim=cfg['embed_dim'], one_hot_embed=cfg['one_hot_embed'],
                                 data_dir=args.data_dir, train_unseen=cfg['train_unseen'], val_unseen=cfg['val_unseen'],
@@ -237,18 +245,22 @@ def main(argv=None):
     kwargs = {'num_workers': args.workers, 'pin_memory': True}
 
     def loader(ds, bs, shuffle):
+        kw = dict(kwargs, collate_fn=collate) if (collate is not None and bs > 1) else kwargs
         if world > 1 and shuffle:       # every rank holds the same dataset; the sampler deals disjoint shards per epoch
             sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=1337)
-            return torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler, **kwargs)
-        return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=shuffle, **kwargs)
+            return torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler, **kw)
+        if world > 1:                   # validation: rank r evaluates images r, r + world, ... and loads ONLY those
+            ds = torch.utils.data.Subset(ds, list(range(rank, len(ds), world)))
+        return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=shuffle, **kw)
     train_loader = loader(train_dataset, args.batch_size, True)
     train_seen_loader = loader(train_seen_dataset, args.batch_size, True)
-    val_loader = loader(val_dataset, 1, False)            # validation shards by batch index inside Trainer.validate
+    val_loader = loader(val_dataset, 1, False)            # sharded by rank above; Trainer.validate all-reduces the sums
+    val_loader.szn_sharded = world > 1                    # tells the trainers not to skip batches by index on top of it
     label_names = train_dataset.class_names
     if rank == 0 and not osp.exists(osp.join(log_dir, 'counts.csv')):
         with open(osp.join(log_dir, 'counts.csv'), 'w') as f:
             f.write('train_seen,train_unseen,val\n%d,%d,%d\n' % (len(train_seen_loader), len(train_loader) - len(train_seen_loader),
-                                                                 len(val_loader)))
+                                                                 len(val_dataset)))
 
     # 2. model
     model = {'fcn32s': models.FCN32s, 'fcn8s': models.FCN8s}[args.arch](n_class=cfg['embed_dim'] if cfg['embed_dim'] else 21)

@@ -196,6 +196,12 @@ class Trainer(object):
     def train_epoch(self):
         self.model.train()
         step = self._fast_step()
+        if step is None and self.model._engine.dtype == torch.float16:
+            # IEEE-half gradients need loss scaling, which only engine.TrainStep applies (d(coarse) is multiplied in fp32 before
+            # it enters the 16-bit backward pass); the autograd paths (mse / cross_entropy losses, forced_unseen, non-reference
+            # optimizer wiring) would push ~1e-7-sized activation gradients through fp16 unscaled and lose them silently
+            raise RuntimeError("precision fp16 is only supported on the fused training step (embedding cosine loss, reference "
+                               "optimizer wiring, no forced_unseen); use bf16 or fp32 for this configuration")
         for batch_idx, (data, target) in enumerate(self.train_loader):
             if step is not None:
                 data, target, _ = self._unpack(data, target)
@@ -284,7 +290,8 @@ class Trainer(object):
         acc = torch.zeros(2, dtype=torch.float64, device=self.device)          # loss sum, image-batch count
         with torch.no_grad():
             for batch_idx, (data, target) in enumerate(self.val_loader):
-                if world > 1 and batch_idx % world != self.rank:
+                # a loader that is not already sharded per rank (train.py shards it: each rank decodes only its own images)
+                if world > 1 and not getattr(self.val_loader, 'szn_sharded', False) and batch_idx % world != self.rank:
                     continue
                 score, loss, pred, tgt = self._predict_device(data, target, both_fcn_and_seenmask)
                 acc[0] += loss.double()

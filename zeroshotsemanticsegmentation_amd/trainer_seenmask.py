@@ -118,6 +118,11 @@ class Trainer(object):
         from .engine import allreduce_param_grads
         self.model.train()
         step = self._fast_step()
+        if step is None and self.model._engine.dtype == torch.float16:
+            # the autograd path rounds the unscaled ~1e-5-sized d(coarse) to IEEE half before the weight gradient (subnormals);
+            # engine.SeenmaskStep keeps it in fp32
+            raise RuntimeError("precision fp16 in phase 2 needs the fused seen-mask step (the reference's single Adam group over "
+                               "seenmask_score / seenmask_upscore); use bf16 or fp32 with this optimizer")
         for batch_idx, (data, target) in enumerate(self.train_loader):
             if step is not None:
                 if isinstance(target, (tuple, list)):
@@ -160,7 +165,8 @@ class Trainer(object):
         acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         with torch.no_grad():
             for batch_idx, (data, target) in enumerate(self.val_loader):
-                if world > 1 and batch_idx % world != self.rank:
+                # a loader that is not already sharded per rank (train.py shards it: each rank decodes only its own images)
+                if world > 1 and not getattr(self.val_loader, 'szn_sharded', False) and batch_idx % world != self.rank:
                     continue
                 score, loss, pred, tgt = self._forward_device(data, target)
                 acc[0] += loss.double()
