@@ -11,6 +11,7 @@
 //     OOB offsets for padding, bias / ReLU / gate / dropout / column-sum epilogue on whole output rows.
 #include "szn_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((address_space(3))) void* ldsptr_t;
@@ -27,6 +28,7 @@ struct WideArgs {
     float* ws;                 // split-K: fp32 slabs [nsplit][M][Co] (plain stores, no epilogue); nullptr = single pass
     int nsplit, chunks_per_split;
     int stagger;               // 1: wave pairs take turns issuing the LDS-DMA loads of a chunk (SZN_WIDE_STAGGER=0: all at once)
+    int shift;                 // 1: waves 4-7 run half a K step behind waves 0-3 (SZN_WIDE_SHIFT=0: lockstep)
 };
 
 constexpr unsigned kOOBx = 0x80000000u;
@@ -256,33 +258,21 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
     set_tap();
     issue(0);
     const int offs0 = ((g ^ (r16 & 7)) << 4), offs1 = (((4 + g) ^ (r16 & 7)) << 4);
-    int stage = 0;
-    for (int kc = kbeg; kc < nK; ++kc) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunk kc landed (the only one outstanding)
-        __builtin_amdgcn_s_barrier();                             // ... for every wave; everyone left the other stage
-        // The eight LDS-DMA loads of a wave stall it at VMEM issue (a CU ingests ~64 B of LDS-DMA per clock: 64 KiB = ~1000
-        // cycles per chunk, half of the chunk's MFMA time): wave pair k issues behind its k-th pair of weight fragments of
-        // the first K half, so the eight waves are never all stalled at once and their SIMD partners keep the MFMA pipe busy.
-        const bool fill = ABL != 1 && kc + 1 < nK;
-        // turn = the weight-fragment index (of the first K half) behind which this wave issues: stagger 1 -> pairs at
-        // 0, 2, 4, 6; stagger 2 -> every wave its own slot
-        // (WNF < 8, the 192-wide tile: pairs at 0, 1, 2, 3 -- every slot has to be below WNF)
-        const int turn = WNF < 8 ? (a.stagger ? (w >> 1) : 0) : a.stagger == 2 ? w : (a.stagger ? 2 * (w >> 1) : 0);
-        if (fill && turn == 0) issue(stage ^ 1);
-        const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
-        const char* sw = smem + stage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
-        if constexpr (ABL == 2) { if (fill && turn != 0) issue(stage ^ 1); } else
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int off = s ? offs1 : offs0;
-            u32x4_t wf[WNF], pf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pf[j] = *(const u32x4_t*)(sp + j * 16 * 128 + off);
-#pragma unroll
-            for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + off);
+    // turn = the weight-fragment index behind which this wave issues its LDS-DMA loads: stagger 1 -> pairs at 0, 2, 4, 6;
+    // stagger 2 -> every wave its own slot (WNF < 8, the 192-wide tile: pairs at 0, 1, 2, 3 -- every slot has to be below WNF).
+    // The eight loads of a wave stall it at VMEM issue (a CU ingests ~64 B of LDS-DMA per clock: 64 KiB = ~1000 cycles per
+    // chunk): spread over the wave pairs, the eight waves are never all stalled at once.
+    const int turn = WNF < 8 ? (a.stagger ? (w >> 1) : 0) : a.stagger == 2 ? w : (a.stagger ? 2 * (w >> 1) : 0);
+    // phase-shifted wave groups, one barrier per chunk: see conv3x3_wide_rows (waves 4-7 carry the MFMAs of their second K half
+    // across the barrier, so that on every SIMD one wave reads fragments while its partner multiplies)
+    const bool late = a.shift && w >= 4 && ABL == 0;
+    auto run = [&](auto late_tag) {
+        constexpr bool LATE = decltype(late_tag)::value;
+        u32x4_t wf[WNF], pf[4];
+        auto math = [&](int issue_at, int stage_to_fill) {
 #pragma unroll
             for (int i = 0; i < WNF; ++i) {
-                if (s == 0 && i > 0 && i < 8 && fill && turn == i) issue(stage ^ 1);
+                if (i == issue_at) issue(stage_to_fill);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if constexpr (ES == 2) {
@@ -295,9 +285,40 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
                     }
                 }
             }
+        };
+        int stage = 0;
+        for (int kc = kbeg; kc < nK; ++kc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunk kc landed (the only one outstanding)
+            __builtin_amdgcn_s_barrier();                             // ... for every wave; everyone left the other stage
+            int issue_at = (ABL != 1 && kc + 1 < nK) ? turn : -1;
+            if constexpr (LATE) {
+                if (kc > kbeg) { math(issue_at, stage ^ 1); issue_at = -1; }     // second half of chunk kc - 1
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const char* sp = smem + stage * STAGE + (wm * 64 + r16) * 128;
+            const char* sw = smem + stage * STAGE + BM * 128 + (wn * (BN / 2) + r16) * 128;
+            if constexpr (ABL == 2) { if (issue_at >= 0) issue(stage ^ 1); } else
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int off = s ? offs1 : offs0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pf[j] = *(const u32x4_t*)(sp + j * 16 * 128 + off);
+#pragma unroll
+                for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + off);
+                if (s == 0) {
+                    math(issue_at, stage ^ 1);
+                    if constexpr (LATE) __builtin_amdgcn_sched_barrier(0);
+                } else if constexpr (!LATE) {
+                    math(-1, 0);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the held fragments have left the stage before the barrier
+                }
+            }
+            stage ^= 1;
         }
-        stage ^= 1;
-    }
+        if constexpr (LATE) { if (nK > kbeg) math(-1, 0); }
+    };
+    if (late) run(std::true_type{}); else run(std::false_type{});
 
     wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, split);
 #endif
@@ -336,17 +357,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_rows(WideArgs a) {
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
 
     const int chunkA = (lane & 7) ^ (lane >> 3);
-    const long npix = (long)a.B * a.Hi * a.Wi;
+    const int npix = a.B * a.Hi * a.Wi;                 // (the operand is below 2 GB: 32-bit pixel arithmetic throughout)
     // LDS row r of the pixel buffer <-> flattened input pixel m0 - 1 + (kh - 1) Wi + r.  Wave w fills row groups 4w .. 4w+3,
     // wave 0 also group 32 (rows 256 .. 263, of which 256 and 257 are used)
     unsigned voffA[5], voffB[NBW];
+    const unsigned laneoffA = (unsigned)(((lane >> 3) * a.ldi + chunkA * 8) * ES);
     auto set_kh = [&](int kh) {
+        const int pbase = m0 - 1 + (kh - 1) * a.Wi;     // wave-uniform
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const int row = (i < 4 ? 32 * w + 8 * i : 256) + (lane >> 3);
-            const long p = (long)m0 - 1 + (long)(kh - 1) * a.Wi + row;
-            const bool ok = p >= 0 && p < npix && row < BM + 2;
-            voffA[i] = ok ? (unsigned)((p * a.ldi + chunkA * 8) * ES) : kOOBx;
+            const int row0 = (i < 4 ? 32 * w + 8 * i : 256);
+            const int p = pbase + row0 + (lane >> 3);
+            const bool ok = (unsigned)p < (unsigned)npix && row0 + (lane >> 3) < BM + 2;
+            voffA[i] = ok ? (unsigned)((pbase + row0) * a.ldi * ES) + laneoffA : kOOBx;
         }
     };
 #pragma unroll
@@ -421,38 +444,67 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_rows(WideArgs a) {
 
     const int turn = a.stagger == 2 ? w : (a.stagger ? 2 * (w >> 1) : 0);
     int ckw = 0, cgrp = 0, ctap_base = 0, cic = 0;       // the step being computed: tap = ctap_base + ckw
-    for (int kc = 0; kc < nK; ++kc) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const bool fill = kc + 1 < nK;
-        if (fill && turn == 0) issue(kc + 1);
-        const int rsh = (r16 + ckw) & 7;
-        const char* sp = sA + (cgrp & 1) * ABYTES + (wm * 64 + r16 + ckw) * 128;
-        const char* sw = sB + (kc & 1) * BBYTES + (wn * (BN / 2) + r16) * 128;
-        const int tap = ctap_base + ckw;
-        bool keep[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) keep[j] = (vmask[j] >> tap) & 1u;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int offp = (((4 * s + g) ^ rsh) << 4), offw = (((4 * s + g) ^ (r16 & 7)) << 4);
-            u32x4_t wf[WNF], pf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u32x4_t v = *(const u32x4_t*)(sp + j * 16 * 128 + offp);
-                pf[j].x = keep[j] ? v.x : 0u; pf[j].y = keep[j] ? v.y : 0u; pf[j].z = keep[j] ? v.z : 0u; pf[j].w = keep[j] ? v.w : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + offw);
+    // Phase-shifted wave groups, ONE barrier per K step (a.shift; SZN_WIDE_SHIFT=0: lockstep).  A K step is two halves of
+    // 12 fragment reads (R) + 32 MFMA (M).  In lockstep every wave runs R0 M0 R1 M1 behind the barrier, so all eight waves sit
+    // in R0 at the same time and the matrix pipes idle until the first fragments arrive (~a fifth of the step).  With the
+    // shift, waves 4-7 -- the SIMD partners of waves 0-3 -- carry the MFMAs of their second half across the barrier:
+    //     waves 0-3:  | R0 M0 R1 M1 | R0 M0 R1 M1 |          (| = s_barrier)
+    //     waves 4-7:  | M1' R0 M0 R1 | M1' R0 M0 R1 |        (M1' = second half of the PREVIOUS step, fragments held in registers)
+    // so on every SIMD one wave reads while the other multiplies.  Stage safety is unchanged: every read of a stage is
+    // complete (lgkmcnt(0)) before the barrier behind which that stage is refilled.
+    const bool late = a.shift && w >= 4;
+    // two copies of the loop (LATE is a compile-time property of each): in the lockstep copy the fragment registers are dead at
+    // the back edge, in the late copy they are carried across it
+    auto run = [&](auto late_tag) {
+        constexpr bool LATE = decltype(late_tag)::value;
+        u32x4_t wf[WNF], pf[4];
+        auto math = [&](int issue_at, int next_step) {
 #pragma unroll
             for (int i = 0; i < WNF; ++i) {
-                if (s == 0 && i > 0 && fill && turn == i) issue(kc + 1);
+                if (i == issue_at) issue(next_step);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(wf[i], pf[j], acc[i][j]);
             }
+        };
+        for (int kc = 0; kc < nK; ++kc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int issue_at = (kc + 1 < nK) ? turn : -1;
+            if constexpr (LATE) {
+                if (kc > 0) { math(issue_at, kc + 1); issue_at = -1; }            // M1 of step kc - 1
+                __builtin_amdgcn_sched_barrier(0);  // the next reads reuse the fragment registers: no hoisting above the MFMAs
+            }
+            const int rsh = (r16 + ckw) & 7;
+            const char* sp = sA + (cgrp & 1) * ABYTES + (wm * 64 + r16 + ckw) * 128;
+            const char* sw = sB + (kc & 1) * BBYTES + (wn * (BN / 2) + r16) * 128;
+            const int tap = ctap_base + ckw;
+            bool keep[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep[j] = (vmask[j] >> tap) & 1u;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int offp = (((4 * s + g) ^ rsh) << 4), offw = (((4 * s + g) ^ (r16 & 7)) << 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4_t v = *(const u32x4_t*)(sp + j * 16 * 128 + offp);
+                    pf[j].x = keep[j] ? v.x : 0u; pf[j].y = keep[j] ? v.y : 0u; pf[j].z = keep[j] ? v.z : 0u; pf[j].w = keep[j] ? v.w : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + offw);
+                if (s == 0) {
+                    math(issue_at, kc + 1);
+                    if constexpr (LATE) __builtin_amdgcn_sched_barrier(0);
+                } else if constexpr (!LATE) {
+                    math(-1, 0);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the held fragments have left the stage before the barrier
+                }
+            }
+            if (++ckw == 3) { ckw = 0; ++cgrp; if (++cic == cpt) { cic = 0; ctap_base += 3; } }
         }
-        if (++ckw == 3) { ckw = 0; ++cgrp; if (++cic == cpt) { cic = 0; ctap_base += 3; } }
-    }
+        if constexpr (LATE) math(-1, 0);
+    };
+    if (late) run(std::true_type{}); else run(std::false_type{});
 
     wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, 0);
 #endif
@@ -637,6 +689,7 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     WideArgs a;
     a.ws = nsplit > 1 ? ws : nullptr; a.nsplit = nsplit > 1 ? nsplit : 1;
     { static int stg = -1; if (stg < 0) { const char* e = getenv("SZN_WIDE_STAGGER"); stg = e ? atoi(e) : 1; } a.stagger = stg; }
+    { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_WIDE_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
     a.chunks_per_split = nsplit > 1 ? chunks_per_split : (1 << 30);
     a.M = d->B * d->Ho * d->Wo;
     // cout tile 256, or 320 (bf16) when that wastes fewer columns: the 300-d projection is one 320-wide tile
@@ -699,7 +752,7 @@ int szn_proj_stream_try(const szn_conv_desc_t* d, const void* in, const void* w,
     a.M = d->B * d->Ho * d->Wo;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = 1; a.nmajor = 0;
     if (a.mtiles < min_tiles) return 1;
-    a.ws = nullptr; a.nsplit = 1; a.chunks_per_split = 1 << 30; a.stagger = 0;
+    a.ws = nullptr; a.nsplit = 1; a.chunks_per_split = 1 << 30; a.stagger = 0; a.shift = 0;
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = nullptr; a.cscale = nullptr;
     a.out = (char*)out; a.colsum = nullptr;
     a.in_bytes = 0; a.w_bytes = (unsigned)((size_t)d->Co * d->Ci * 2);

@@ -707,7 +707,7 @@ __global__ void loss_scale_update_kernel(float* __restrict__ st, float growth, f
     } else {
         st[2] += 1.f;
         st[3] += 1.f;
-        if (st[3] >= (float)interval) { st[0] = fminf(st[0] * growth, hi); st[3] = 0.f; }
+        if (st[3] >= (float)interval) { if (st[0] < hi) st[0] = fminf(st[0] * growth, hi); st[3] = 0.f; }   // growth never lowers S
     }
     st[1] = 0.f;
 }

@@ -275,7 +275,7 @@ class TrainStep(object):
         # gradients contain inf / NaN leaves masters, moments and weight images untouched and halves the scale -- no host
         # synchronisation, identical decisions on every data-parallel rank (the flag is read from the all-reduced gradient)
         self.dynamic = (precision == torch.float16) if dynamic_loss_scale is None else bool(dynamic_loss_scale)
-        self.scale_cfg = (float(scale_growth), float(scale_backoff), int(scale_growth_interval), 1.0, 65536.0)
+        self.scale_cfg = (float(scale_growth), float(scale_backoff), int(scale_growth_interval), 1.0, 2.0 ** 32)
         self.scale_state = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
