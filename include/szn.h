@@ -314,8 +314,21 @@ int szn_dropout2d_mask(long n, float p, uint64_t seed, uint64_t offset, float* s
  * 93,97,145,149).  x [M][K] (x_dtype) and w [N][K] (w_dtype) are quantised to OCP e4m3 with per-tensor scales
  * amax/448 (round to nearest even), multiplied on the fp8 matrix cores with fp32 accumulation and rescaled:
  * out[m][n] = (sum_k xq wq) * sx * sw + bias[n], fp32, row stride ldo.  K must be a multiple of 128.  workspace:
- * szn_proj_fp8_workspace_bytes(M, K, N) bytes, 16-B aligned.  Forward only (the backward pass keeps 16-bit operands). */
+ * szn_proj_fp8_workspace_bytes(M, K, N) bytes, 16-B aligned.                                                       */
 size_t szn_proj_fp8_workspace_bytes(long M, int K, int N);
+/* Backward of that layer on the fp8 matrix cores (the e4m3-forward / e5m2-gradient recipe; no reference counterpart):
+ *   dgrad: dx[m][k] = epi( sum_n g[m][n] * w[n][k] ),  wgrad: dw[n][k] = sum_m g[m][n] * x[m][k]
+ * g (the gradient wrt the projection output, row stride ldg) is quantised to OCP e5m2 with the per-tensor scale
+ * amax / 57344, w [N][K] and x [M][ldx] to e4m3 (amax / 448); products exact in fp32, fp32 accumulation, one rescale.
+ * dgrad epilogue like szn_conv2d_dgrad: optional gate (gate[m][k] > 0 ? v : 0; element type gate_dtype, row stride ldgate),
+ * optional chan_scale[image][k] (image = m / rows_per_image), output element type out_dtype, row stride ldx.
+ * dw is fp32 [N][K], dense.  workspace: szn_proj_fp8_bwd_workspace_bytes(M, K, N), 16-B aligned.                      */
+size_t szn_proj_fp8_bwd_workspace_bytes(long M, int K, int N);
+int szn_proj_fp8_dgrad(int g_dtype, int w_dtype, long M, int K, int N, int ldg, const void* g, const void* w,
+                       const void* gate, int gate_dtype, int ldgate, const float* chan_scale, int rows_per_image,
+                       int out_dtype, void* dx, int ldx, void* workspace, szn_stream_t stream);
+int szn_proj_fp8_wgrad(int g_dtype, int x_dtype, long M, int K, int N, int ldg, int ldx, const void* g, const void* x,
+                       float* dw, void* workspace, szn_stream_t stream);
 int szn_proj_fp8_fwd(int x_dtype, int w_dtype, long M, int K, int N, int ldo, const void* x, const void* w,
                      const float* bias, float* out_f32, void* workspace, szn_stream_t stream);
 /* Dataset transform on the device (context_dataset.py:143-150, pascal_dataset.py:138-145): RGB uint8 HWC image(s)

@@ -387,6 +387,45 @@ def proj_fp8(x, w, bias=None):
     return out.astype(np.float32)
 
 
+def e5m2_round(x):
+    """round float32 values to the nearest OCP e5m2 value, ties to even, saturating at +-57344 (gfx950's v_cvt_pk_bf8_f32 for
+    in-range inputs): 2 mantissa bits, normal exponents 2^-14 .. 2^15, subnormal step 2^-16"""
+    x = np.asarray(x, dtype=np.float64)
+    a = np.abs(x)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    e = np.maximum(e, -14.0)
+    step = np.exp2(e - 2.0)
+    q = np.minimum(np.rint(a / step) * step, 57344.0)
+    return (np.sign(x) * q).astype(np.float32)
+
+
+def _fp8_scale(t, fmax):
+    a = np.float32(np.abs(t).max()) if t.size else np.float32(0)
+    inv = np.float32(fmax) / a if a > 0 else np.float32(1.0)
+    sc = a / np.float32(fmax) if a > 0 else np.float32(1.0)
+    return inv, sc
+
+
+def proj_fp8_dgrad(g, w):
+    """csrc/szn_proj_fp8.hip backward restated: dx = g . w with the gradient g (M,N) in e5m2 and the weights w (N,K) in e4m3,
+    per-tensor scales amax / 57344 and amax / 448, exact products, fp32 rescale -> (M,K) float32 (before gate / dropout)"""
+    g, w = np.asarray(g, np.float32), np.asarray(w, np.float32)
+    ig, sg = _fp8_scale(g, 57344.0)
+    iw, sw = _fp8_scale(w, 448.0)
+    gq, wq = e5m2_round(g * ig), e4m3_round(w * iw)
+    return ((gq.astype(np.float64) @ wq.astype(np.float64)) * np.float64(sg * sw)).astype(np.float32)
+
+
+def proj_fp8_wgrad(g, x):
+    """dw = g^T . x with g (M,N) in e5m2 and the activations x (M,K) in e4m3 -> (N,K) float32"""
+    g, x = np.asarray(g, np.float32), np.asarray(x, np.float32)
+    ig, sg = _fp8_scale(g, 57344.0)
+    ix, sx = _fp8_scale(x, 448.0)
+    gq, xq = e5m2_round(g * ig), e4m3_round(x * ix)
+    return ((gq.astype(np.float64).T @ xq.astype(np.float64)) * np.float64(sg * sx)).astype(np.float32)
+
+
 def confusion_hist(label_trues, label_preds, n_class, unseen=None):
     lt = _c(np.asarray(label_trues).reshape(-1), np.int64)
     lp = _c(np.asarray(label_preds).reshape(-1), np.int64)

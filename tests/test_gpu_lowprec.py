@@ -219,3 +219,75 @@ def test_dynamic_loss_scale_equals_static_when_nothing_overflows():
     assert torch.equal(tsa.flat_gw, tsb.flat_gw)
     d = (tsa.flat_w - tsb.flat_w).abs().max().item()
     assert d <= 1e-6 * 3e-5 + 1e-12, d                  # in-kernel bias correction (double pow) vs the host's: rounding only
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+def test_proj_fp8_backward_kernels_match_oracle_restatement(dt):
+    """the e5m2-gradient x e4m3-operand backward GEMMs of the projection layer (szn_proj_fp8_dgrad / _wgrad) against the
+    oracle's restatement of the same quantisation, and against the fp32 products"""
+    M, K, N, ldg = 2 * 25 * 25 + 3, 4096, 302, 320
+    gen = torch.Generator().manual_seed(11)
+    g = torch.zeros(M, ldg)
+    g[:, :N] = torch.randn(M, N, generator=gen) * torch.exp(torch.randn(M, 1, generator=gen) * 2.0) * 1e-4    # wide dynamic range
+    x = torch.relu(torch.randn(M, K, generator=gen)) * 3.0
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    gd, xd, wd = g.to(dt).cuda(), x.to(dt).cuda(), w.to(dt).cuda()
+    gs, xs, ws_ = gd.float().cpu().numpy()[:, :N], xd.float().cpu().numpy(), wd.float().cpu().numpy()
+    code = L.dtype_code(dt)
+    wsb = torch.empty(L.load().szn_proj_fp8_bwd_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
+    # dgrad, no epilogue, fp32 output
+    dx = torch.full((M, K), 7.0, device="cuda")
+    L.call("szn_proj_fp8_dgrad", code, code, M, K, N, ldg, L.ptr(gd), L.ptr(wd), None, 0, 0, None, 1, L.SZN_F32, L.ptr(dx), K,
+           L.ptr(wsb), L.stream_ptr())
+    want = O.proj_fp8_dgrad(gs, ws_)
+    got = dx.cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+    ref = gs.astype(np.float64) @ ws_.astype(np.float64)
+    e_d = np.abs(got - ref).max() / np.abs(ref).max()
+    # with the epilogue of the training step: ReLU gate of the producing layer, Dropout2d factor per (image, channel), 16-bit output
+    scale = (torch.rand(3, K, generator=gen) > 0.5).float().cuda() * 2.0
+    rows = (M + 2) // 3
+    odt = dt if dt != torch.float32 else torch.bfloat16
+    dx2 = torch.empty(M, K, device="cuda", dtype=odt)
+    L.call("szn_proj_fp8_dgrad", code, code, M, K, N, ldg, L.ptr(gd), L.ptr(wd), L.ptr(xd), code, K, L.ptr(scale), rows,
+           L.dtype_code(odt), L.ptr(dx2), K, L.ptr(wsb), L.stream_ptr())
+    img = np.minimum(np.arange(M) // rows, 2)
+    want2 = torch.from_numpy(np.where(xs > 0, want, 0.0) * scale.cpu().numpy()[img]).to(odt).float().numpy()
+    ulp = 2.0 ** -7 if odt == torch.bfloat16 else 2.0 ** -10           # one unit of the 16-bit output format (relative)
+    diff = np.abs(dx2.float().cpu().numpy() - want2)
+    assert (diff <= ulp * np.abs(want2) + 4e-5 * np.abs(want2).max()).all()
+    # wgrad
+    dw = torch.full((N, K), 7.0, device="cuda")
+    L.call("szn_proj_fp8_wgrad", code, code, M, K, N, ldg, K, L.ptr(gd), L.ptr(xd), L.ptr(dw), L.ptr(wsb), L.stream_ptr())
+    wantw = O.proj_fp8_wgrad(gs, xs)
+    gotw = dw.cpu().numpy()
+    assert np.abs(gotw - wantw).max() < 2e-5 * np.abs(wantw).max()
+    refw = gs.astype(np.float64).T @ xs.astype(np.float64)
+    e_w = np.abs(gotw - refw).max() / np.abs(refw).max()
+    print("fp8 backward vs fp32 products (%s operands): dgrad %.3e, wgrad %.3e of the output scale" % (dt, e_d, e_w))
+    assert e_d < 0.15 and e_w < 0.15                       # e5m2 keeps 2 mantissa bits of a gradient spanning ~6 decades
+
+
+def test_fp8_backward_train_step_tracks_the_16bit_head():
+    """TrainStep with set_head_precision('fp8_bwd'): score_fr / fc7 gradients against the straight-through ('fp8') step on the
+    same batch, and a decreasing loss"""
+    E, K, H = 300, 59, 256
+    emb = synth.make_embeddings(K, E)
+    x = cu(synth.make_images(2, H, H, seed=75))
+    t = cu(synth.make_labels(2, H, H, K, seed=76, classes=list(range(49))))
+    grads = {}
+    for kind in ("fp8", "fp8_bwd"):
+        m = models.FCN32s(E)
+        m.load_synthetic(1337, device=torch.device("cuda"))
+        m.eval()
+        m.set_head_precision(kind)
+        ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=torch.bfloat16, fused_head=True)
+        losses = [float(ts.step(x, t)[0])]
+        grads[kind] = {n: getattr(m, n).weight.grad.detach().float().clone() for n in ("score_fr", "fc7", "fc6", "conv3_2")}
+        losses += [float(ts.step(x, t)[0]) for _ in range(2)]
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], (kind, losses)
+        assert L.last_kernel() is not None
+    for n, ref in grads["fp8"].items():
+        err = float((grads["fp8_bwd"][n] - ref).norm() / ref.norm())
+        print("%s weight gradient, fp8 backward vs 16-bit backward of the head: relative l2 error %.3e" % (n, err))
+        assert torch.isfinite(grads["fp8_bwd"][n]).all() and err < 0.25, (n, err)

@@ -91,6 +91,9 @@ SIGNATURES = {
     "szn_dropout2d_mask": (_I, [_L, _F, _U64, _U64, _P, _P]),
     "szn_proj_fp8_workspace_bytes": (_SZ, [_L, _I, _I]),
     "szn_proj_fp8_fwd": (_I, [_I, _I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "szn_proj_fp8_bwd_workspace_bytes": (_SZ, [_L, _I, _I]),
+    "szn_proj_fp8_dgrad": (_I, [_I, _I, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P]),
+    "szn_proj_fp8_wgrad": (_I, [_I, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "szn_image_u8_to_bgr_f32": (_I, [_I, _I, _I, _P, C.POINTER(C.c_double), _P, _P]),
 }
 

@@ -32,6 +32,7 @@ struct WtArgs {
     int tiles_x, tiles_y, ntiles;      // ntiles = B * tiles_y * tiles_x
     int cotiles, citiles, nsplit;
     int accumulate;
+    int xcd_mode;              // block -> (split, combo) mapping, see the kernel
     int ablate;                // debug (env SZN_WGT_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no reads / MFMA
 };
 
@@ -54,10 +55,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
     const int h = w >> 2, c = w & 3;
     const int g = lane >> 4, r16 = lane & 15;
 
-    // block -> (pixel split, cout tile, cin slice); the combos of one pixel range are neighbours in launch order
-    int bid = blockIdx.x;
-    const int cit = bid % a.citiles; bid /= a.citiles;
-    const int cot = bid % a.cotiles; const int split = bid / a.cotiles;
+    // block -> (pixel split, cout tile, cin slice).  The cotiles x citiles combos of one pixel split read the SAME dout tiles
+    // (citiles times) and input patches (cotiles times); a.xcd_mode places them on as few XCDs as possible (block b runs on
+    // XCD b % 8 -- observed placement, used for speed only), so that the repeats are hits in that XCD's L2 instead of one
+    // fabric fetch per XCD: 1 = the split count is a multiple of 8 (split = b % nsplit lives on XCD split % 8),
+    // 2 = the split count divides 8 (a split owns 8 / nsplit XCDs), 0 = launch order (combos of a split are neighbours).
+    const int ncombo_k = a.cotiles * a.citiles;
+    int split, combo;
+    if (a.xcd_mode == 1) { split = blockIdx.x % a.nsplit; combo = blockIdx.x / a.nsplit; }
+    else if (a.xcd_mode == 2) {
+        const int xps = 8 / a.nsplit, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        split = xcd / xps; combo = (xcd % xps) * (ncombo_k / xps) + idx;
+    } else { combo = blockIdx.x % ncombo_k; split = blockIdx.x / ncombo_k; }
+    const int cit = combo % a.citiles, cot = combo / a.citiles;
+    const int slab_id = split * ncombo_k + combo;                  // what wgrad_taps_reduce expects
     const int first = (int)((long)a.ntiles * split / a.nsplit), last = (int)((long)a.ntiles * (split + 1) / a.nsplit);
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, (int)a.dout_bytes, 0x00020000);
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
     }
 
     // ---- partial -> slab [wave][fragment f = 9 i + tap][e][lane], 256 contiguous bytes per store instruction ----
-    float* slab = a.ws + (size_t)blockIdx.x * SLAB + (size_t)w * (18 * 256) + lane;
+    float* slab = a.ws + (size_t)slab_id * SLAB + (size_t)w * (18 * 256) + lane;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) slab[((i * 9 + k) * 4 + e) * 64] = acc[i][k][e];
     if (a.ablate == 9 && tid == 0) {                  // debug: the block's cycle split replaces the head of its slab
-        float* dbg = a.ws + (size_t)blockIdx.x * SLAB;
+        float* dbg = a.ws + (size_t)slab_id * SLAB;
         dbg[0] = (float)tw; dbg[1] = (float)ti; dbg[2] = (float)tc; dbg[3] = (float)(last - first);
     }
 #endif
@@ -316,6 +327,15 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     if (ns > (long)(d->workspace_bytes / slab_bytes)) ns = (long)(d->workspace_bytes / slab_bytes);
     if (ns < 1 || ns * ncombo < 32) return 1;
     a.nsplit = (int)ns;
+    {
+        static int xm = -1;
+        if (xm < 0) { const char* e = getenv("SZN_WGT_XCD"); xm = e ? atoi(e) : 1; }
+        a.xcd_mode = 0;
+        if (xm && ncombo > 1) {
+            if (ns % 8 == 0) a.xcd_mode = 1;
+            else if (ns <= 8 && 8 % ns == 0 && ncombo % (8 / ns) == 0) a.xcd_mode = 2;
+        }
+    }
     a.dout = (const char*)dout; a.in = (const char*)in; a.dw = dw; a.ws = (float*)d->workspace;
     a.dout_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->ldo * 2);
     a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->ldi * 2);

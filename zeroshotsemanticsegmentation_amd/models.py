@@ -75,7 +75,9 @@ class _Engine(object):
         self._wg_ws = None            # slab workspace of the wgrad kernels (they run on their own stream)
         self._wg_stream = None        # torch.cuda.Stream, or False when disabled (SZN_WGRAD_STREAM=0)
         self.head_fp8 = False         # forward of the projection head on the fp8 matrix cores (set_head_precision)
+        self.head_fp8_bwd = False     # ... and its dgrad / wgrad (e5m2 gradient x e4m3 operands)
         self._fp8_ws = None
+        self._fp8_bws = None
         self.lp_views = {}          # layer -> compute-dtype OHWI weight image maintained by the optimizer kernel (TrainStep)
         self._seen_versions = None    # versions of seenmask_score mirrored into the TrainStep-owned head image
 
@@ -297,7 +299,7 @@ class _Engine(object):
 
     def _head_fp8(self, feat):
         """score_fr || seenmask_score as ONE fp8 (e4m3) GEMM with per-tensor scales (szn_proj_fp8_fwd; BASELINE configs[4]).
-        Forward only: the backward pass differentiates the 16-bit / fp32 head (straight-through)."""
+        The backward pass differentiates the 16-bit / fp32 head (straight-through) unless head_fp8_bwd is set."""
         B, h, w, F = feat.shape
         CP = self.model.head_width
         wimg, bimg = self._images["head.w"], self._images["head.b"]
@@ -308,6 +310,40 @@ class _Engine(object):
         L.call("szn_proj_fp8_fwd", L.dtype_code(feat.dtype), L.dtype_code(wimg.dtype), B * h * w, F, CP, CP, L.ptr(feat),
                L.ptr(wimg), L.ptr(bimg), L.ptr(out), L.ptr(self._fp8_ws), L.stream_ptr())
         return out
+
+    def _fp8_bwd_ws(self, M, F, CP, dev):
+        nb = L.load().szn_proj_fp8_bwd_workspace_bytes(M, F, CP)
+        if self._fp8_bws is None or self._fp8_bws.numel() < nb or self._fp8_bws.device != dev:
+            self._fp8_bws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        return self._fp8_bws
+
+    def _head_wgrad_fp8(self, feat, dc, dwh, dbh):
+        """d(score_fr || seenmask_score weight) = dc^T . feat with the gradient in e5m2 and the features in e4m3
+        (szn_proj_fp8_wgrad); the bias gradient is the plain column sum of dc"""
+        B, h, w, F = feat.shape
+        CP, M = self.model.head_width, B * h * w
+        ws = self._fp8_bwd_ws(M, F, CP, feat.device)
+        st = L.stream_ptr()
+        L.call("szn_proj_fp8_wgrad", L.dtype_code(dc.dtype), L.dtype_code(feat.dtype), M, F, CP, CP, F, L.ptr(dc), L.ptr(feat),
+               L.ptr(dwh), L.ptr(ws), st)
+        if dbh is not None:
+            L.call("szn_bias_grad", L.dtype_code(dc.dtype), M, CP, CP, L.ptr(dc), L.ptr(dbh), 0, st)
+
+    def _head_dgrad_fp8(self, dc, feat, scale, colsum):
+        """d(fc7 output) = dc . W_head on the fp8 matrix cores (szn_proj_fp8_dgrad) with the ReLU gate / Dropout2d factor of fc7
+        in the epilogue; `colsum` (fc7's bias gradient, pre-zeroed) receives the column sums of the result"""
+        B, h, w, F = feat.shape
+        CP, M = self.model.head_width, B * h * w
+        ws = self._fp8_bwd_ws(M, F, CP, feat.device)
+        wimg = self._images["head.w"]
+        code = L.dtype_code(self.dtype)
+        d = torch.empty(B, h, w, F, device=feat.device, dtype=self.dtype)
+        st = L.stream_ptr()
+        L.call("szn_proj_fp8_dgrad", L.dtype_code(dc.dtype), L.dtype_code(wimg.dtype), M, F, CP, CP, L.ptr(dc), L.ptr(wimg),
+               L.ptr(feat), L.dtype_code(feat.dtype), F, L.ptr(scale), h * w, code, L.ptr(d), F, L.ptr(ws), st)
+        if colsum is not None:
+            L.call("szn_bias_grad", code, M, F, F, L.ptr(d), L.ptr(colsum), 1, st)
+        return d
 
     def upscore(self, ctx):
         """coarse -> f (B,E,H,W) f32 NCHW: fixed bilinear ConvTranspose2d + crop (models.py:146-147)"""
@@ -433,9 +469,15 @@ class _Engine(object):
         flat_bias = grads.get("_flat_bias")          # TrainStep: every bias gradient is a view of one flat buffer:
         if flat_bias is not None and backbone:       # one fill, BEFORE the head hook copies score_fr's gradient into it
             flat_bias.zero_()
+        fp8b = self.head_fp8_bwd and self.head_fp8
         if "head" in grads:
             dwh, dbh = grads["head"]
-            self._wgrad(feat, dc, dwh, dbh, F, m.head_width, 1, 0, after=head_first)
+            if fp8b:
+                self._head_wgrad_fp8(feat, dc, dwh, dbh)
+                if head_first is not None:
+                    head_first()
+            else:
+                self._wgrad(feat, dc, dwh, dbh, F, m.head_width, 1, 0, after=head_first)
         if not backbone:
             self._join_wgrad()
             return
@@ -449,7 +491,10 @@ class _Engine(object):
                 if name != "head":
                     grads[name][1].zero_()
         # d(fc7 pre-activation): ReLU gate (feat > 0) and dropout factor fused into the dgrad epilogue
-        d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7, colsum=grads["fc7"][1])
+        if fp8b:
+            d = self._head_dgrad_fp8(dc, feat, s7, grads["fc7"][1])
+        else:
+            d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7, colsum=grads["fc7"][1])
         self._wgrad(ctx.relu6, d, grads["fc7"][0], None, F, F, 1, 0, after=lambda: done("fc7"))
         d = self._dgrad(d, "fc7", ctx.relu6.shape, 0, gate=ctx.relu6, scale=s6, colsum=grads["fc6"][1])
         pool5 = ctx.pools[4][1]
@@ -642,10 +687,13 @@ class FCN32s(nn.Module):
         return self
 
     def set_head_precision(self, kind):
-        """'native' (the compute dtype) or 'fp8': projection head forward on the fp8 matrix cores (BASELINE configs[4])"""
-        if kind not in ("native", "fp8"):
-            raise L.SznError("head precision must be 'native' or 'fp8'")
-        self._engine.head_fp8 = (kind == "fp8")
+        """'native' (the compute dtype); 'fp8': projection head forward on the fp8 matrix cores (e4m3 operands, BASELINE
+        configs[4]), backward on the 16-bit head (straight-through); 'fp8_bwd': forward as 'fp8' AND the layer's dgrad / wgrad
+        on the fp8 matrix cores (gradient in e5m2, weights / features in e4m3)"""
+        if kind not in ("native", "fp8", "fp8_bwd"):
+            raise L.SznError("head precision must be 'native', 'fp8' or 'fp8_bwd'")
+        self._engine.head_fp8 = kind in ("fp8", "fp8_bwd")
+        self._engine.head_fp8_bwd = kind == "fp8_bwd"
         return self
 
     def load_synthetic(self, seed=1337, device=None):
