@@ -331,7 +331,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
         static int xm = -1;
         if (xm < 0) { const char* e = getenv("SZN_WGT_XCD"); xm = e ? atoi(e) : 1; }
         a.xcd_mode = 0;
-        if (xm && ncombo > 1) {
+        if (xm && ncombo >= 4) {        // (two combos: measured 3 % slower than launch order, conv2_1)
             if (ns % 8 == 0) a.xcd_mode = 1;
             else if (ns <= 8 && 8 % ns == 0 && ncombo % (8 / ns) == 0) a.xcd_mode = 2;
         }

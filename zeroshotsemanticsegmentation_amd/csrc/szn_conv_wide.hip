@@ -39,7 +39,7 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int nwg) {
 // ---- epilogue staged through LDS in four 64-pixel passes ----
 template <typename T, int WNF>
 __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[WNF][4], char* smem, int tid, int wm, int wn,
-                                              int g, int r16, int m0, int n0, int split, int mvalid = 256) {
+                                              int g, int r16, int m0, int n0, int split) {
     constexpr int ES = sizeof(T);
     constexpr int BN = 32 * WNF;
     constexpr int P = BN + 4;                          // tile pitch (floats): 64 x 260 x 4 B = 66,560 B per pass
@@ -75,7 +75,7 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
                 for (int k = 0; k < NIT; ++k) {
                     const int row = row0 + k * RG;
                     const int m = m0 + pass * 64 + row;
-                    if (row < 64 && m < a.M && pass * 64 + row < mvalid) {
+                    if (row < 64 && m < a.M) {
                         const float* tp = tile + row * P + cc * 8;
                         float* o = slab + (size_t)m * a.Co + n;
                         if (full && (a.Co & 3) == 0) {
@@ -95,7 +95,7 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
             for (int k = 0; k < NIT; ++k) {
                 const int row = row0 + k * RG;
                 const int m = m0 + pass * 64 + row;
-                if (row < 64 && m < a.M && pass * 64 + row < mvalid) {
+                if (row < 64 && m < a.M) {
                     const float* tp = tile + row * P + cc * 8;
                     float v[8];
                     *(f32x4_t*)&v[0] = *(const f32x4_t*)tp;
@@ -458,168 +458,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_rows(WideArgs a) {
 #endif
 }
 
-// ---- the same with a THREE-stage weight ring (conv3x3_wide_rows3; SZN_WIDE_ROWS=1 keeps the two-stage kernel) --------------------
-// The two-stage kernel issues the weights of step k + 1 behind the barrier of step k and drains them (vmcnt(0)) at the next
-// barrier: one K step (~1.7 us) of flight time, and every wave of the block waits when a piece is late -- the ablation without the
-// LDS-DMA (reads + MFMA + barriers only) runs 27 % faster, while moving a third FEWER bytes (the row-resident operand above) bought
-// 2-3 %: the stream is latency-, not bandwidth-bound.  Here the weights of step k + 2 are issued during step k (counted
-// s_waitcnt vmcnt(N): the loads issued during step k - 1 may still be in flight at the barrier of step k) and the pixel rows of
-// the next (kh, cin chunk) group during the group's kw = 0 / 1 steps (three / two steps ahead).
-// LDS: 3 x 32 KiB of weights leave 2 x 32 KiB for the pixel groups -- 256 rows each, no room for the two halo rows -- so a
-// tile is 254 output pixels: LDS row r <-> flattened input pixel m0 - 1 + (kh - 1) Wi + r, r = 0 .. 255, covers every tap of
-// pixels m0 .. m0 + 253; the last two MFMA rows of a block are masked out (0.8 % of the MFMAs) and not stored.
-template <typename T>
-__global__ __launch_bounds__(512, 2) void conv3x3_wide_rows3(WideArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(sizeof(T) == 2, "16-bit storage only");
-    constexpr int ES = 2, BMV = 254, BN = 256, WNF = 8, NBW = 4;
-    constexpr int ABYTES = 256 * 128, BBYTES = BN * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // pixels [2][256 x 128 B] | weights [3][256 x 128 B] = 160 KiB
-    char* const sA = smem;
-    char* const sB = smem + 2 * ABYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
-    const int g = lane >> 4, r16 = lane & 15;
-
-    const int nwg = a.mtiles * a.ntiles;
-    const int lid = xcd_remap_w(blockIdx.x, nwg);
-    const int nt = lid % a.ntiles, mt = lid / a.ntiles;
-    const int m0 = mt * BMV, n0 = nt * BN;
-
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
-
-    const int chunkA = (lane & 7) ^ (lane >> 3);
-    const int npix = a.B * a.Hi * a.Wi;                 // (the operand is below 2 GB: 32-bit pixel arithmetic)
-    unsigned voffA[4], voffB[NBW];
-    const unsigned laneoffA = (unsigned)(((lane >> 3) * a.ldi + chunkA * 8) * ES);
-    auto set_kh = [&](int kh) {
-        const int pbase = m0 - 1 + (kh - 1) * a.Wi + 32 * w;        // wave-uniform
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = pbase + 8 * i + (lane >> 3);
-            voffA[i] = ((unsigned)p < (unsigned)npix) ? (unsigned)((pbase + 8 * i) * a.ldi * ES) + laneoffA : kOOBx;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-        const int n = n0 + (NBW * w + i) * 8 + (lane >> 3);
-        voffB[i] = (n < a.Co) ? (unsigned)(((long)n * 9 * a.Ci + chunkA * 8) * ES) : kOOBx;
-    }
-    // tap validity of the four pixels this lane supplies (pixel fragment j, row r16): bit kh * 3 + kw
-    unsigned vmask[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int local = wm * 64 + 16 * j + r16;
-        const int m = m0 + local;
-        unsigned mk = 0;
-        if (m < a.M && local < BMV) {
-            const int r = m % a.HoWo;
-            const int oh = r / a.Wo, ow = r - oh * a.Wo;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-                    if ((unsigned)(oh + kh - 1) < (unsigned)a.Hi && (unsigned)(ow + kw - 1) < (unsigned)a.Wi) mk |= 1u << (kh * 3 + kw);
-        }
-        vmask[j] = mk;
-    }
-
-    const int cpt = a.Ci / 64;
-    const int nK = 9 * cpt;
-    // weights: the step being issued FOR runs two ahead of the step being computed
-    int wkh = 0, wic = 0, wkw = 0, wstep = 0;
-    auto issue_w = [&]() {
-        const int soffB = ((wkh * 3 + wkw) * a.Ci) * ES + wic * 128;
-        char* sb = sB + (wstep % 3) * BBYTES;
-#pragma unroll
-        for (int i = 0; i < NBW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + (NBW * w + i) * 1024), 16, voffB[i], soffB, 0, 0);
-        ++wstep;
-        if (++wkw == 3) { wkw = 0; if (++wic == cpt) { wic = 0; ++wkh; } }
-    };
-    // pixels of group (kh, ic): half 0 = this wave's row groups 0, 1, half 1 = groups 2, 3
-    int voff_kh = 0;
-    auto issue_p = [&](int kh, int ic, int grp, int half) {
-        if (kh != voff_kh) { set_kh(kh); voff_kh = kh; }
-        char* sa = sA + (grp & 1) * ABYTES;
-        const int soffA = ic * 128;
-        if (half == 0) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + (32 * w + 0) * 128), 16, voffA[0], soffA, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + (32 * w + 8) * 128), 16, voffA[1], soffA, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + (32 * w + 16) * 128), 16, voffA[2], soffA, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sa + (32 * w + 24) * 128), 16, voffA[3], soffA, 0, 0);
-        }
-    };
-
-    f32x4_t acc[WNF][4];
-#pragma unroll
-    for (int i = 0; i < WNF; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // prologue: the pixels of group 0, the weights of steps 0 and 1
-    set_kh(0);
-    issue_p(0, 0, 0, 0);
-    issue_p(0, 0, 0, 1);
-    issue_w();
-    if (nK > 1) issue_w();
-    int prev_issued = nK > 1 ? 4 : 0;      // loads issued AFTER the weights the next barrier needs
-
-    const int turn = a.stagger == 2 ? w : (a.stagger ? 2 * (w >> 1) : 0);
-    int ckw = 0, cgrp = 0, ckh = 0, cic = 0;              // the step being computed: group (ckh, cic), tap ckh * 3 + ckw
-    for (int kc = 0; kc < nK; ++kc) {
-        // the weights of step kc (and, in front of them, the pixels of its group) have landed; what was issued during step kc - 1 may fly on
-        if (prev_issued >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (prev_issued == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (prev_issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // this step's loads: [pixel half of the NEXT group at kw 0 / 1] then [weights of step kc + 2]
-        int nkh = ckh, nic = cic + 1;
-        if (nic == cpt) { nic = 0; ++nkh; }
-        const bool pix = ckw < 2 && nkh < 3, wts = kc + 2 < nK;
-        prev_issued = (pix ? 2 : 0) + (wts ? 4 : 0);
-        auto issue = [&]() {
-            if (pix) issue_p(nkh, nic, cgrp + 1, ckw);
-            if (wts) issue_w();
-        };
-        if (turn == 0) issue();
-        const int rsh = (r16 + ckw) & 7;
-        const char* sp = sA + (cgrp & 1) * ABYTES + (wm * 64 + r16 + ckw) * 128;
-        const char* sw = sB + (kc % 3) * BBYTES + (wn * (BN / 2) + r16) * 128;
-        const int tap = ckh * 3 + ckw;
-        bool keep[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) keep[j] = (vmask[j] >> tap) & 1u;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int offp = (((4 * s + g) ^ rsh) << 4), offw = (((4 * s + g) ^ (r16 & 7)) << 4);
-            u32x4_t wf[WNF], pf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u32x4_t v = *(const u32x4_t*)(sp + j * 16 * 128 + offp);
-                pf[j].x = keep[j] ? v.x : 0u; pf[j].y = keep[j] ? v.y : 0u; pf[j].z = keep[j] ? v.z : 0u; pf[j].w = keep[j] ? v.w : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < WNF; ++i) wf[i] = *(const u32x4_t*)(sw + i * 16 * 128 + offw);
-#pragma unroll
-            for (int i = 0; i < WNF; ++i) {
-                if (s == 0 && i > 0 && turn == i) issue();
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(wf[i], pf[j], acc[i][j]);
-            }
-        }
-        if (++ckw == 3) { ckw = 0; ++cgrp; if (++cic == cpt) { cic = 0; ++ckh; } }
-    }
-
-    wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, 0, BMV);
-#endif
-}
-
 // ---- pixel projection (1x1, K >> N, N <= 320): activation operand streamed from HBM ----------------------------------------------
 // score_fr is M x 4096 x 300: every activation row is used by ONE block, once (AI = 300 FLOP per activation byte -- at the HBM
 // ridge), while the 2.6 MB filter matrix is re-read by every block from its XCD's L2.  conv_igemm_wide<T, 10> keeps one 72 KiB chunk
@@ -763,20 +601,6 @@ int launch_wide_rows(const WideArgs& a, hipStream_t st) {
     return SZN_OK;
 }
 
-template <typename T>
-int launch_wide_rows3(WideArgs a, hipStream_t st) {
-    const size_t lds = 5 * 256 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wide_rows3<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    a.mtiles = szn_div_up(a.M, 254);                       // 254 output pixels per tile (see the kernel)
-    hipLaunchKernelGGL((conv3x3_wide_rows3<T>), dim3(a.mtiles * a.ntiles), dim3(512), lds, st, a);
-    SZN_CHECK_LAUNCH("conv3x3_wide_rows3");
-    return SZN_OK;
-}
-
 template <typename T, int WNF>
 int launch_wide(const WideArgs& a, hipStream_t st) {
     const size_t lds = 2 * (256 + 32 * WNF) * 128;
@@ -843,15 +667,11 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.relu = d->relu; a.out_f32 = d->out_f32; a.HoWo = d->Ho * d->Wo;
     {
         static int rows = -1;
-        if (rows < 0) { const char* e = getenv("SZN_WIDE_ROWS"); rows = e ? atoi(e) : 2; }
+        if (rows < 0) { const char* e = getenv("SZN_WIDE_ROWS"); rows = e ? atoi(e) : 1; }
         if (rows && bn == 256 && szn_is16(d->dtype) && a.nsplit == 1 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->Hi == d->Ho &&
-            d->Wi == d->Wo && (d->Ci % 64) == 0) {
-            if (rows >= 2)       // three-stage weight ring, 254-pixel tiles
-                return d->dtype == SZN_F16 ? launch_wide_rows3<f16_raw>(a, (hipStream_t)stream)
-                                           : launch_wide_rows3<bf16_raw>(a, (hipStream_t)stream);
+            d->Wi == d->Wo && (d->Ci % 64) == 0)
             return d->dtype == SZN_F16 ? launch_wide_rows<f16_raw>(a, (hipStream_t)stream)
                                        : launch_wide_rows<bf16_raw>(a, (hipStream_t)stream);
-        }
     }
     if (bn == 192)
         return d->dtype == SZN_F16 ? launch_wide<f16_raw, 6>(a, (hipStream_t)stream) : launch_wide<bf16_raw, 6>(a, (hipStream_t)stream);
