@@ -227,15 +227,14 @@ int szn_mse_loss_fwd(int B, int E, int H, int W, int K, const float* score, cons
 int szn_mse_loss_bwd(int B, int E, int H, int W, int K, const float* score, const int64_t* target,
                      const float* embed, const float* target_embed, const float* stats,
                      const float* gout, float* dscore, szn_stream_t stream);
-/* utils.py:19-48  cross_entropy2d: sum over ALL valid pixels of the batch of -log_softmax[target];
- * size_average divides by the number of valid pixels.  pred (may be NULL) receives the channel
- * argmax (score.data.max(1)[1], trainer_fcn.py:117 / trainer_seenmask.py:67) as int64 (B,H,W).     */
-int szn_ce2d_fwd(int B, int C, int H, int W, const float* score, const int64_t* target,
-                 int size_average, float* loss, float* stats, int64_t* pred, void* workspace,
-                 szn_stream_t stream);
-int szn_ce2d_bwd(int B, int C, int H, int W, const float* score, const int64_t* target,
-                 int size_average, const float* stats, const float* gout, float* dscore,
-                 szn_stream_t stream);
+/* utils.py:19-48  cross_entropy2d: sum over ALL valid pixels of the batch of -weight[target] * log_softmax[target]
+ * (weight: optional f32 [C] class weights, NULL = 1; F.nll_loss(weight=, size_average=False), utils.py:46);
+ * size_average divides by the NUMBER of valid pixels (utils.py:47-48, not by the weight sum).  pred (may be NULL) receives
+ * the channel argmax (score.data.max(1)[1], trainer_fcn.py:117 / trainer_seenmask.py:67) as int64 (B,H,W).           */
+int szn_ce2d_fwd(int B, int C, int H, int W, const float* score, const int64_t* target, const float* weight,
+                 int size_average, float* loss, float* stats, int64_t* pred, void* workspace, szn_stream_t stream);
+int szn_ce2d_bwd(int B, int C, int H, int W, const float* score, const int64_t* target, const float* weight,
+                 int size_average, const float* stats, const float* gout, float* dscore, szn_stream_t stream);
 
 /* ---- nearest-class-embedding inference (utils.py:159-205) --------------------------------------
  * sim[k] = (score_px . embed[k]) / (||score_px|| * (||embed[k]|| == 0 ? 1 : ||embed[k]||)),

@@ -294,15 +294,17 @@ def mse_loss(score, target, embed=None, target_embed=None, want_grad=True):
     return _loss(lib().szo_mse_loss, score, target, embed, target_embed, want_grad)
 
 
-def cross_entropy2d(score, target, size_average=False, want_grad=True):
-    """utils.py:19-48; also returns the channel argmax (trainer_fcn.py:117)."""
+def cross_entropy2d(score, target, size_average=False, want_grad=True, weight=None):
+    """utils.py:19-48 (weight = the optional (C,) class weights of utils.py:46); also returns the channel argmax
+    (trainer_fcn.py:117)."""
     score = _c(score)
     target = _c(target, np.int64)
     B, Cc, H, W = score.shape
     stats = np.zeros((B, 2), np.float32)
     dscore = np.empty_like(score) if want_grad else None
     pred = np.empty((B, H, W), np.int64)
-    loss = lib().szo_ce2d(B, Cc, H * W, _p(score), _p(target), int(size_average), _p(stats), _p(dscore), _p(pred))
+    weight = None if weight is None else _c(weight)
+    loss = lib().szo_ce2d(B, Cc, H * W, _p(score), _p(target), _p(weight), int(size_average), _p(stats), _p(dscore), _p(pred))
     return np.float32(loss), dscore, pred
 
 

@@ -92,10 +92,11 @@ double szo_mse_loss(int B, int E, int HW, int K, const float* score, const int64
     return embed_loss(1, B, E, HW, K, score, target, embed, tembed, stats, dscore);
 }
 
-/* cross_entropy2d: sum over all valid pixels of -log_softmax(score)[target]; /N_valid if size_average.
+/* cross_entropy2d (utils.py:19-48): sum over all valid pixels of -weight[target] * log_softmax(score)[target] (weight may be
+ * NULL); /N_valid (the pixel count, utils.py:47-48) if size_average.
  * pred = first channel argmax (score.data.max(1)[1]).                                                 */
-double szo_ce2d(int B, int C, int HW, const float* score, const int64_t* target, int size_average, float* stats,
-                float* dscore, int64_t* pred) {
+double szo_ce2d(int B, int C, int HW, const float* score, const int64_t* target, const float* weight, int size_average,
+                float* stats, float* dscore, int64_t* pred) {
     double total = 0.0, ntot = 0.0;
     for (int b = 0; b < B; ++b) {
         double s_sum = 0.0, n = 0.0;
@@ -109,7 +110,9 @@ double szo_ce2d(int B, int C, int HW, const float* score, const int64_t* target,
             if (lbl < 0 || lbl >= C) continue;
             float se = 0.f;
             for (int c = 0; c < C; ++c) se += expf(sp[(size_t)c * HW] - mx);
-            s_sum += (double)(-(sp[(size_t)lbl * HW] - mx - logf(se)));
+            float term = -(sp[(size_t)lbl * HW] - mx - logf(se));
+            if (weight) term = weight[lbl] * term;          /* F.nll_loss(weight=, size_average=False): utils.py:46 */
+            s_sum += (double)term;
             n += 1.0;
         }
         stats[2 * b] = (float)s_sum; stats[2 * b + 1] = (float)n;
@@ -127,8 +130,9 @@ double szo_ce2d(int B, int C, int HW, const float* score, const int64_t* target,
                 for (int c = 1; c < C; ++c) mx = fmaxf(mx, sp[(size_t)c * HW]);
                 float se = 0.f;
                 for (int c = 0; c < C; ++c) se += expf(sp[(size_t)c * HW] - mx);
+                const float gw = weight ? g * weight[lbl] : g;
                 for (int c = 0; c < C; ++c)
-                    dp[(size_t)c * HW] = g * (expf(sp[(size_t)c * HW] - mx) / se - (c == lbl ? 1.f : 0.f));
+                    dp[(size_t)c * HW] = gw * (expf(sp[(size_t)c * HW] - mx) / se - (c == lbl ? 1.f : 0.f));
             }
     }
     return size_average ? total / ntot : total;

@@ -134,6 +134,19 @@ def test_g4_ce2d(name):
     assert np.array_equal(utils.channel_argmax(s).cpu().numpy(), g["pred"])
 
 
+@pytest.mark.parametrize("name", ["C21_n1", "C2_n3"])
+def test_g4_ce2d_weighted(name):
+    """utils.cross_entropy2d(weight=...) (reference utils.py:19,46) against the fixture captured from the reference"""
+    g = gold("g4_ce2d_weighted_" + name)
+    s = cu(g["score"]).requires_grad_(True)
+    loss = utils.cross_entropy2d(s, cu(g["target"]), weight=cu(g["weight"]), size_average=bool(g["size_average"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    assert rel(s.grad, g["dscore"]) < 1e-4
+    with pytest.raises(Exception):
+        utils.cross_entropy2d(s, cu(g["target"]), weight=cu(g["weight"][:-1]))
+
+
 @pytest.mark.parametrize("name", ["context_E20", "pascal_E20", "context_E300"])
 def test_g5_infer(name):
     g = gold("g5_infer_" + name)

@@ -108,6 +108,18 @@ def test_g4_ce2d(name):
     assert np.array_equal(pred, g["pred"])
 
 
+@pytest.mark.parametrize("name", ["C21_n1", "C2_n3"])
+def test_g4_ce2d_weighted(name):
+    """cross_entropy2d(weight=...) (reference utils.py:19,46), fixture captured from the reference"""
+    g = gold("g4_ce2d_weighted_" + name)
+    loss, ds, _ = O.cross_entropy2d(g["score"], g["target"], size_average=bool(g["size_average"]), weight=g["weight"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    assert rel(ds, g["dscore"]) < 1e-4
+    # the weights matter: the unweighted loss is a different number
+    l0, _, _ = O.cross_entropy2d(g["score"], g["target"], size_average=bool(g["size_average"]))
+    assert abs(float(l0) - float(g["loss"])) > 1e-3 * abs(float(g["loss"]))
+
+
 @pytest.mark.parametrize("name", ["context_E20", "pascal_E20", "context_E300"])
 def test_g5_infer(name):
     g = gold("g5_infer_" + name)

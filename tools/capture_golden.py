@@ -157,6 +157,22 @@ def g4_losses():
              loss=np.array(loss.item(), dtype=np.float64), dscore=s.grad.numpy(), pred=pred.astype(np.int64))
 
 
+def g4w_weighted_ce():
+    """cross_entropy2d with class weights (reference utils.py:19,46: F.nll_loss(weight=...)); kept apart from g4 so that the
+    existing fixtures stay byte-identical"""
+    for (C, H, W, avg, n) in [(21, 16, 20, False, 1), (2, 8, 8, True, 3)]:
+        score = synth.uniform(6200 + C + n, (n, C, H, W), -3.0, 3.0)
+        target = synth.make_labels(n, H, W, C, seed=6300 + C + n, block=2, ignore_frac=0.1)
+        weight = synth.uniform(6400 + C, (C,), 0.25, 2.0)
+        if C > 2:
+            weight[3] = 0.0                                   # a class that does not count at all
+        s = torch.from_numpy(score).clone().requires_grad_(True)
+        loss = ref_utils.cross_entropy2d(s, torch.from_numpy(target), weight=torch.from_numpy(weight), size_average=avg)
+        loss.backward()
+        save("g4_ce2d_weighted_C%d_n%d" % (C, n), score=score, target=target, weight=weight, size_average=np.array(int(avg)),
+             loss=np.array(loss.item(), dtype=np.float64), dscore=s.grad.numpy())
+
+
 # ---------------------------------------------------------------------------------------- G5
 def masked(emb, rows):
     out = np.zeros_like(emb)
@@ -431,6 +447,7 @@ def main():
     if run("g1"): g1_upsampling()
     if run("g9"): g9_embeddings()
     if run("g4"): g4_losses()
+    if run("g4w"): g4w_weighted_ce()
     if run("g5"): g5_infer()
     if run("g6"): g6_metrics()
     if run("g2") or run("g3"):

@@ -74,8 +74,8 @@ SIGNATURES = {
     "szn_cosine_loss_bwd": (_I, [_I] * 5 + [_P] * 8),
     "szn_mse_loss_fwd": (_I, [_I] * 5 + [_P] * 8),
     "szn_mse_loss_bwd": (_I, [_I] * 5 + [_P] * 8),
-    "szn_ce2d_fwd": (_I, [_I] * 4 + [_P, _P, _I, _P, _P, _P, _P, _P]),
-    "szn_ce2d_bwd": (_I, [_I] * 4 + [_P, _P, _I, _P, _P, _P, _P]),
+    "szn_ce2d_fwd": (_I, [_I] * 4 + [_P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "szn_ce2d_bwd": (_I, [_I] * 4 + [_P, _P, _P, _I, _P, _P, _P, _P]),
     "szn_embed_argmax": (_I, [_I] * 5 + [_P, _P, _I, _U64, _P, _P, _P, _P]),
     "szn_confusion_hist": (_I, [_L, _I, _P, _P, _U64, _P, _P]),
     "szn_fused_head_workspace_bytes": (_SZ, [_I] * 5),

@@ -388,7 +388,8 @@ __global__ __launch_bounds__(256) void embed_loss_bwd_kernel(const float* __rest
 
 // ---- cross_entropy2d --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
-                                                     double* __restrict__ part, int64_t* __restrict__ pred, int C, int HW) {
+                                                     const float* __restrict__ cweight, double* __restrict__ part,
+                                                     int64_t* __restrict__ pred, int C, int HW) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     double term = 0.0, cnt = 0.0;
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ s
             float se = 0.f;
             for (int c = 0; c < C; ++c) se += expf(sp[(long)c * HW] - mx);
             term = (double)(-(sp[lbl * (long)HW] - mx - logf(se)));
+            if (cweight) term = (double)(cweight[lbl] * (float)term);      // F.nll_loss(weight=): w[target] * nll, fp32 product
             cnt = 1.0;
         }
     }
@@ -410,8 +412,9 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ s
 }
 
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
-                                                     const float* __restrict__ stats, const float* __restrict__ gout,
-                                                     float* __restrict__ dscore, int B, int C, int HW, int size_average) {
+                                                     const float* __restrict__ cweight, const float* __restrict__ stats,
+                                                     const float* __restrict__ gout, float* __restrict__ dscore, int B, int C,
+                                                     int HW, int size_average) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
         for (int i = 0; i < B; ++i) n += stats[2 * i + 1];
         g /= n;
     }
+    if (cweight) g *= cweight[lbl];
     float mx = sp[0];
     for (int c = 1; c < C; ++c) mx = fmaxf(mx, sp[(long)c * HW]);
     float se = 0.f;
@@ -760,13 +764,13 @@ extern "C" int szn_mse_loss_bwd(int B, int E, int H, int W, int K, const float* 
                              "mse_loss_bwd");
 }
 
-extern "C" int szn_ce2d_fwd(int B, int C, int H, int W, const float* score, const int64_t* target, int size_average,
-                            float* loss, float* stats, int64_t* pred, void* ws, szn_stream_t stream) {
+extern "C" int szn_ce2d_fwd(int B, int C, int H, int W, const float* score, const int64_t* target, const float* weight,
+                            int size_average, float* loss, float* stats, int64_t* pred, void* ws, szn_stream_t stream) {
     if (!score || !target || !loss || !stats || !ws || B <= 0 || C <= 0 || H <= 0 || W <= 0)
         SZN_FAIL(SZN_ERR_ARG, "ce2d_fwd: bad argument");
     const int HW = H * W, nblk = (HW + 255) / 256;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk, B), dim3(256), 0, st, score, target, (double*)ws, pred, C, HW);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk, B), dim3(256), 0, st, score, target, weight, (double*)ws, pred, C, HW);
     SZN_CHECK_LAUNCH("ce_fwd_kernel");
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, B, nblk, 2, size_average, loss,
                        stats);
@@ -774,12 +778,12 @@ extern "C" int szn_ce2d_fwd(int B, int C, int H, int W, const float* score, cons
     return SZN_OK;
 }
 
-extern "C" int szn_ce2d_bwd(int B, int C, int H, int W, const float* score, const int64_t* target, int size_average,
-                            const float* stats, const float* gout, float* dscore, szn_stream_t stream) {
+extern "C" int szn_ce2d_bwd(int B, int C, int H, int W, const float* score, const int64_t* target, const float* weight,
+                            int size_average, const float* stats, const float* gout, float* dscore, szn_stream_t stream) {
     if (!score || !target || !stats || !dscore || B <= 0 || C <= 0 || H <= 0 || W <= 0)
         SZN_FAIL(SZN_ERR_ARG, "ce2d_bwd: bad argument");
     const int HW = H * W, nblk = (HW + 255) / 256;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, score, target, stats, gout, dscore, B,
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, score, target, weight, stats, gout, dscore, B,
                        C, HW, size_average);
     SZN_CHECK_LAUNCH("ce_bwd_kernel");
     return SZN_OK;

@@ -193,16 +193,23 @@ __global__ __launch_bounds__(256) void smh_finalize_kernel(const double* __restr
         if (conf && t < 4) conf[t] += (int64_t)((sh[0][2 + t] + sh[1][2 + t]) + (sh[2][2 + t] + sh[3][2 + t]));
     }
     const float gs = (float)(1.0 / N);
-    const long e = (long)blockIdx.x * 256 + t;
-    if (e < kTaps) {
+    // weight gradient: 64 elements per block, the G slabs split over four thread groups (four independent chains of loads per
+    // element instead of one 256-long one; 256 blocks instead of 64), combined in a fixed order
+    __shared__ float wsum[4][64];
+    const int nwblk = kTaps / 64;
+    if ((int)blockIdx.x < nwblk) {
         if (dweight) {
+            const int e = blockIdx.x * 64 + (t & 63), q = t >> 6;
+            const int k0 = q * ((G + 3) / 4), k1 = min(G, k0 + (G + 3) / 4);
             float a = 0.f;
-            for (int k = 0; k < G; ++k) a += slab[(long)k * kTaps + e];
-            dweight[e] = a * gs;
+            for (int k = k0; k < k1; ++k) a += slab[(long)k * kTaps + e];
+            wsum[q][t & 63] = a;
+            __syncthreads();
+            if (t < 64) dweight[blockIdx.x * 64 + t] = ((wsum[0][t] + wsum[1][t]) + (wsum[2][t] + wsum[3][t])) * gs;
         }
         return;
     }
-    const long e2 = e - kTaps;
+    const long e2 = (long)(blockIdx.x - nwblk) * 256 + t;
     if (!dsc || e2 >= (long)g.B * g.h * g.w * 2) return;
     const int ci = (int)(e2 & 1);
     long m = e2 >> 1;
@@ -264,18 +271,23 @@ __global__ __launch_bounds__(512) void smh_score_wgrad_kernel(const T* __restric
 __global__ __launch_bounds__(256) void smh_score_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ dsc,
                                                                float* __restrict__ dw, float* __restrict__ db, long M, int F,
                                                                int S) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e < 2L * F) {
-        float a = 0.f;
-        for (int s = 0; s < S; ++s) a += slab[(long)s * 2 * F + e];
-        dw[e] = a;
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 128 && db) {     // bias: one wave per channel, fixed order
-        const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        float a = 0.f;
-        for (long m = lane; m < M; m += 64) a += dsc[2 * m + c];
-        a = wave_sum(a);
-        if (lane == 0) db[c] = a;
+    // 64 outputs per block, the S slabs split over four thread groups, combined in a fixed order
+    __shared__ float part[4][64];
+    const int t = threadIdx.x, q = t >> 6;
+    const long e = (long)blockIdx.x * 64 + (t & 63);
+    const int s0 = q * ((S + 3) / 4), s1 = min(S, s0 + (S + 3) / 4);
+    float a = 0.f;
+    if (e < 2L * F)
+        for (int s = s0; s < s1; ++s) a += slab[(long)s * 2 * F + e];
+    part[q][t & 63] = a;
+    __syncthreads();
+    if (t < 64 && e < 2L * F) dw[e] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    if (blockIdx.x == gridDim.x - 1 && t < 128 && db) {     // bias: one wave per channel, fixed order
+        const int c = t >> 6, lane = t & 63;
+        float b = 0.f;
+        for (long m = lane; m < M; m += 64) b += dsc[2 * m + c];
+        b = wave_sum(b);
+        if (lane == 0) db[c] = b;
     }
 }
 
@@ -326,8 +338,8 @@ extern "C" int szn_seenmask_head(int B, int h, int w, int ldc, int c0, int H, in
     if (grad) smh_cell_kernel<true><<<G, 256, 0, st>>>(coarse, weight, target, n_class, seen_bits, pred, part, cellpart, slab, g);
     else smh_cell_kernel<false><<<G, 256, 0, st>>>(coarse, weight, target, n_class, seen_bits, pred, part, cellpart, slab, g);
     SZN_CHECK_LAUNCH("smh_cell_kernel");
-    const long work = grad ? kTaps + (long)B * h * w * 2 : 1;
-    smh_finalize_kernel<<<szn_div_up(work, 256), 256, 0, st>>>(part, G, cellpart, slab, loss, stats, conf, grad ? dscore2 : nullptr,
+    const int fblocks = grad ? kTaps / 64 + szn_div_up((long)B * h * w * 2, 256) : 1;
+    smh_finalize_kernel<<<fblocks, 256, 0, st>>>(part, G, cellpart, slab, loss, stats, conf, grad ? dscore2 : nullptr,
                                                                grad ? dweight : nullptr, g);
     SZN_CHECK_LAUNCH("smh_finalize_kernel");
     return SZN_OK;
@@ -352,7 +364,7 @@ extern "C" int szn_seenmask_score_wgrad(int dtype, long M, int F, int ldf, const
     else if (dtype == SZN_F16) smh_score_wgrad_kernel<f16_raw><<<grid, 512, 0, st>>>((const f16_raw*)feat, dscore2, slab, M, F, ldf, rows);
     else SZN_FAIL(SZN_ERR_ARG, "szn_seenmask_score_wgrad: dtype %d", dtype);
     SZN_CHECK_LAUNCH("smh_score_wgrad_kernel");
-    smh_score_reduce_kernel<<<szn_div_up(2L * F, 256), 256, 0, st>>>(slab, dscore2, dw, db, M, F, S);
+    smh_score_reduce_kernel<<<szn_div_up(2L * F, 64), 256, 0, st>>>(slab, dscore2, dw, db, M, F, S);
     SZN_CHECK_LAUNCH("smh_score_reduce_kernel");
     return SZN_OK;
 }

@@ -127,16 +127,16 @@ def mse_loss(score, target, target_embed):
 
 class _CE2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, score, target, size_average):
+    def forward(ctx, score, target, size_average, weight):
         B, Cc, H, W = score.shape
         dev = score.device
         loss = torch.empty(1, device=dev)
         stats = torch.empty(B, 2, device=dev)
         ws = torch.empty(L.load().szn_loss_workspace_bytes(B, H, W), dtype=torch.uint8, device=dev)
-        L.call("szn_ce2d_fwd", B, Cc, H, W, L.ptr(score), L.ptr(target), int(size_average), L.ptr(loss), L.ptr(stats),
-               None, L.ptr(ws), L.stream_ptr())
+        L.call("szn_ce2d_fwd", B, Cc, H, W, L.ptr(score), L.ptr(target), L.ptr(weight), int(size_average), L.ptr(loss),
+               L.ptr(stats), None, L.ptr(ws), L.stream_ptr())
         ctx.save_for_backward(score, target, stats)
-        ctx.size_average = size_average
+        ctx.size_average, ctx.weight = size_average, weight
         return loss.reshape(())
 
     @staticmethod
@@ -145,17 +145,22 @@ class _CE2d(torch.autograd.Function):
         B, Cc, H, W = score.shape
         dscore = torch.empty_like(score)
         g = gout.contiguous().float().reshape(1)
-        L.call("szn_ce2d_bwd", B, Cc, H, W, L.ptr(score), L.ptr(target), int(ctx.size_average), L.ptr(stats), L.ptr(g),
-               L.ptr(dscore), L.stream_ptr())
-        return dscore, None, None
+        L.call("szn_ce2d_bwd", B, Cc, H, W, L.ptr(score), L.ptr(target), L.ptr(ctx.weight), int(ctx.size_average), L.ptr(stats),
+               L.ptr(g), L.ptr(dscore), L.stream_ptr())
+        return dscore, None, None, None
 
 
 def cross_entropy2d(score, target, weight=None, size_average=False):
-    """log-softmax over channels + masked NLL sum, optionally / #valid (reference utils.py:19-48)."""
-    if weight is not None:
-        raise L.SznError("cross_entropy2d: class weights are not used anywhere on the SZN path and are unsupported")
+    """log-softmax over channels + masked, optionally class-weighted NLL sum, optionally / #valid pixels (reference
+    utils.py:19-48; `weight` = the (C,) tensor handed to F.nll_loss at utils.py:46; size_average divides by the number of
+    valid pixels, not by the weight sum, utils.py:47-48)."""
     score, target = _prep(score, target)
-    return _CE2d.apply(score, target, bool(size_average))
+    if weight is not None:
+        weight = torch.as_tensor(weight).detach().to(device=score.device, dtype=torch.float32).contiguous()
+        if weight.dim() != 1 or weight.numel() != score.shape[1]:
+            raise L.SznError("cross_entropy2d: weight must have one entry per class (%d), got %s"
+                             % (score.shape[1], tuple(weight.shape)))
+    return _CE2d.apply(score, target, bool(size_average), weight)
 
 
 def channel_argmax(score):
@@ -168,7 +173,7 @@ def channel_argmax(score):
     dummy_t = torch.full((B, H, W), -1, dtype=torch.int64, device=dev)
     loss = torch.empty(1, device=dev); stats = torch.empty(B, 2, device=dev)
     ws = torch.empty(L.load().szn_loss_workspace_bytes(B, H, W), dtype=torch.uint8, device=dev)
-    L.call("szn_ce2d_fwd", B, Cc, H, W, L.ptr(score), L.ptr(dummy_t), 0, L.ptr(loss), L.ptr(stats), L.ptr(pred), L.ptr(ws),
+    L.call("szn_ce2d_fwd", B, Cc, H, W, L.ptr(score), L.ptr(dummy_t), None, 0, L.ptr(loss), L.ptr(stats), L.ptr(pred), L.ptr(ws),
            L.stream_ptr())
     return pred
 
