@@ -69,6 +69,13 @@ typedef struct {
                          (models.py:47,54,63,72,81 follow a ReLU'd conv): [B][ceil(Ho/2)][ceil(Wo/2)][Co], same element
                          type as out, dense (needs ldo == Co, relu != 0).  Fused into the conv epilogue where the
                          kernel supports it (the 710^2 / 355^2 layers), else szn_maxpool2x2_ceil_fwd runs behind it */
+    float* colsum_slab; /* optional fp32 workspace [colsum_slab_rows][Co] (dgrad: [..][Ci]), 16-B aligned, declared at the END of
+                         the struct.  With it the kernel does NOT touch colsum: every pixel tile / persistent block writes its
+                         partial column sums into its own row (szn_last_colsum_rows() rows, a function of the kernel the
+                         dispatcher picked) and the caller adds them with szn_colsum_reduce_batch in a fixed order --
+                         bit-reproducible bias gradients.  Without it the partials are added to colsum with fp32 atomics
+                         (same value up to the order of the additions).                                            */
+    int colsum_slab_rows; /* rows the slab can hold; an error is returned if the kernel needs more                  */
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
@@ -115,6 +122,18 @@ int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const void* dout,
 /* db[n] (+)= sum_m dout[m][n], m < M rows with pixel stride ldd.                                  */
 int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
                   szn_stream_t stream);
+/* the same with a slab for the per-block partial rows ([colsum_slab_rows][Co] fp32, see szn_conv_desc_t.colsum_slab): db is
+ * only zeroed (accumulate == 0), the sums arrive through szn_colsum_reduce_batch.  colsum_slab == NULL: as szn_bias_grad. */
+int szn_bias_grad_slab(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
+                       float* colsum_slab, int colsum_slab_rows, szn_stream_t stream);
+/* Deterministic bias gradients.  The kernels that produce column sums (szn_conv2d_fwd / _dgrad with colsum,
+ * szn_maxpool2x2_ceil_bwd, szn_bias_grad_slab) write partial rows into the caller's slab when one is given;
+ * szn_last_colsum_rows() = the number of rows the LAST such call on this thread wrote (0: it used no slab), and
+ * szn_colsum_reduce_batch adds out[j][c] += sum_{r < rows[j]} slabs[j][r * C[j] + c] for n jobs in one launch, rows in
+ * ascending order (host arrays of length n; every bias gradient of a backward pass in ONE launch).                  */
+int szn_last_colsum_rows(void);
+int szn_colsum_reduce_batch(int n, const float* const* slabs, const int* rows, const int* C, float* const* out,
+                            szn_stream_t stream);
 
 /* the "pixel projection" of the north star: score_fr (|| seenmask_score) 1x1 conv, models.py:93,97,
  * 145,149.  Thin aliases of the conv entry points with KH=KW=1, pad=0 (M = B*h*w rows).           */
@@ -144,6 +163,7 @@ int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void*
  * scan order) and is then gated by in > 0 (the ReLU that precedes every pool).                    */
 int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void* in,
                             const void* out, const void* dout, void* din, float* colsum /* [C] += sum of din, or NULL */,
+                            float* colsum_slab /* optional, see szn_conv_desc_t.colsum_slab */, int colsum_slab_rows,
                             szn_stream_t stream);
 
 /* ---- upscore: ConvTranspose2d(E,E,64,stride 32,bias=False) with the fixed bilinear kernel of

@@ -164,13 +164,41 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
         assert relerr(din2.float().cpu().permute(0, 3, 1, 2), dx_ref) < tol
         # the sums are taken on the fp32 values before the bf16 rounding of din
         assert relerr(cs.cpu(), dx_ref.sum((0, 2, 3))) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+        # deterministic form: partial rows in a slab (NaN-filled: every row the kernel reports must be written completely) +
+        # szn_colsum_reduce_batch; equal to the atomics to rounding, bit-identical from run to run
+        def slab_colsum():
+            cs2 = torch.zeros(Ci, device=dev)
+            cap = max((B * Hi * Wi + 255) // 256, 2048)
+            slab = torch.full((cap * Ci,), float("nan"), device=dev)
+            dgs, _, _ = conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad, ldg=Ci)
+            dgs.colsum, dgs.colsum_slab, dgs.colsum_slab_rows = cs2.data_ptr(), slab.data_ptr(), cap
+            L.call("szn_conv2d_dgrad", C.byref(dgs), L.ptr(doutd), L.ptr(wT), L.ptr(xd), None, L.ptr(din2), L.stream_ptr())
+            rows = L.load().szn_last_colsum_rows()
+            assert 0 < rows <= cap
+            assert float(cs2.abs().max()) == 0.0                    # the kernel itself leaves colsum alone
+            L.call("szn_colsum_reduce_batch", 1, (C.c_void_p * 1)(slab.data_ptr()), (C.c_int * 1)(rows), (C.c_int * 1)(Ci),
+                   (C.c_void_p * 1)(cs2.data_ptr()), L.stream_ptr())
+            torch.cuda.synchronize()
+            return cs2
+        ca, cb = slab_colsum(), slab_colsum()
+        assert torch.equal(ca, cb)
+        assert relerr(ca.cpu(), cs.cpu()) < 1e-5
     dw = torch.full((Co, K, K, Ci), float("nan"), device=dev)
     db = torch.full((Co,), float("nan"), device=dev)
     L.call("szn_conv2d_wgrad", C.byref(dgd), L.ptr(xd), L.ptr(doutd), L.ptr(dw), 0, L.stream_ptr())
     if expect[2]:
         assert L.last_kernel() == expect[2], ("wgrad kernel", L.last_kernel())
     L.call("szn_bias_grad", dt, B * Ho * Wo, Co, d.ldo, L.ptr(doutd), L.ptr(db), 0, L.stream_ptr())
+    # ... and its deterministic form
+    db2 = torch.full((Co,), float("nan"), device=dev)
+    bslab = torch.full((2048 * Co,), float("nan"), device=dev)
+    L.call("szn_bias_grad_slab", dt, B * Ho * Wo, Co, d.ldo, L.ptr(doutd), L.ptr(db2), 0, L.ptr(bslab), 2048, L.stream_ptr())
+    brows = L.load().szn_last_colsum_rows()
+    L.call("szn_colsum_reduce_batch", 1, (C.c_void_p * 1)(bslab.data_ptr()), (C.c_int * 1)(brows), (C.c_int * 1)(Co),
+           (C.c_void_p * 1)(db2.data_ptr()), L.stream_ptr())
     torch.cuda.synchronize()
+    assert 0 < brows <= 2048 and relerr(db2.cpu(), db_ref) < 1e-4
     got = dw.cpu().permute(0, 3, 1, 2)
     # a weight gradient sums B*Ho*Wo products per entry: the fp32 reduction-order noise (vs torch's own order) grows with the
     # pixel count (1.1e-5 at 66 k pixels)
@@ -306,11 +334,25 @@ def test_maxpool(dtype, hw):
     din = torch.empty(B, Hi, Wi, Cc, device="cuda", dtype=dtype)
     doutd = nhwc(dout).cuda().to(dtype)
     cs = torch.zeros(Cc, device="cuda")
-    L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.ptr(cs),
+    L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.ptr(cs), None, 0,
            L.stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(din.float().cpu().permute(0, 3, 1, 2), dref)
     assert relerr(cs.cpu(), dref.sum((0, 2, 3))) < 1e-5          # fused bias gradient = column sums of din
+    # deterministic form of the column sums: partial rows + fixed-order reduce
+    cs2 = torch.zeros(Cc, device="cuda")
+    slab = torch.full((2048 * Cc,), float("nan"), device="cuda")
+    L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.ptr(cs2), L.ptr(slab),
+           2048, L.stream_ptr())
+    rows = L.load().szn_last_colsum_rows()
+    assert 0 < rows <= 2048 and float(cs2.abs().max()) == 0.0
+    L.call("szn_colsum_reduce_batch", 1, (C.c_void_p * 1)(slab.data_ptr()), (C.c_int * 1)(rows), (C.c_int * 1)(Cc),
+           (C.c_void_p * 1)(cs2.data_ptr()), L.stream_ptr())
+    torch.cuda.synchronize()
+    assert relerr(cs2.cpu(), dref.sum((0, 2, 3))) < 1e-5
+    with pytest.raises(L.SznError):
+        L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.ptr(cs2), L.ptr(slab),
+               0, L.stream_ptr())
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -162,3 +162,48 @@ def test_fused_optimizer_resumes_from_nchw_contiguous_state(kind):
         p.grad = gr.cuda().contiguous(memory_format=torch.channels_last); opt.step()
     torch.cuda.synchronize()
     assert float((p.detach().cpu() - pr.detach()).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("precision,size,B", [(torch.float32, 96, 2), (torch.bfloat16, 96, 2), (torch.bfloat16, 512, 4)])
+def test_train_step_is_bit_reproducible(precision, size, B):
+    """two identically seeded TrainStep runs give bit-identical gradients (weights AND biases) and parameters: the bias
+    gradients come from fixed-order partial rows (szn_colsum_reduce_batch), the head / f32 weight gradients from fixed-order
+    slabs -- no fp32 atomics anywhere on the step (SZN_DETERMINISTIC, default on)"""
+    E, K = (300, 59) if size == 512 else (20, 33)
+    emb = synth.make_embeddings(K, E)
+    x = cu(synth.make_images(B, size, size, seed=91))
+    t = cu(synth.make_labels(B, size, size, K, seed=92, block=16))
+    runs = []
+    for _rep in range(2):
+        m = models.FCN32s(E)
+        m.load_synthetic(1337, device=torch.device("cuda"))
+        m.train()                                               # Dropout2d on: the mask generator is counter-based, so seeded too
+        assert m._engine.deterministic
+        ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=precision, fused_head=True)
+        for _ in range(2):
+            loss, pred = ts.step(x, t)
+        torch.cuda.synchronize()
+        runs.append((float(loss), pred.clone(), ts.flat_gw.clone(), ts.flat_gb.clone(), ts.flat_w.clone(), ts.flat_b.clone()))
+    a, b = runs
+    assert a[0] == b[0] and torch.equal(a[1], b[1])
+    for i, what in ((2, "weight gradients"), (3, "bias gradients"), (4, "weights"), (5, "biases")):
+        assert torch.equal(a[i], b[i]), what
+    assert float(a[3].abs().max()) > 0                          # the bias gradients are really there
+
+
+def test_deterministic_bias_gradients_equal_the_atomic_ones(monkeypatch):
+    """SZN_DETERMINISTIC=0 (fp32 atomics, the round-2 behaviour) and the slab form agree to rounding"""
+    E, K, H = 20, 33, 96
+    emb = synth.make_embeddings(K, E)
+    x = cu(synth.make_images(2, H, H, seed=93))
+    t = cu(synth.make_labels(2, H, H, K, seed=94, block=16))
+    out = {}
+    for det in (True, False):
+        m = models.FCN32s(E)
+        m.load_synthetic(1337, device=torch.device("cuda"))
+        m.eval()
+        m._engine.deterministic = det
+        ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=torch.float32, fused_head=True)
+        ts.step(x, t)
+        out[det] = (ts.flat_gb.clone(), ts.flat_gw.clone())
+    assert rel(out[True][0], out[False][0]) < 1e-5 and rel(out[True][1], out[False][1]) < 1e-5

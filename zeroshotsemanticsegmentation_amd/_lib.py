@@ -21,7 +21,8 @@ class SznError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")] + [
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p)]
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p),
+        ("colsum_slab", C.c_void_p), ("colsum_slab_rows", C.c_int)]
 
 
 class DeviceInfo(C.Structure):
@@ -48,6 +49,9 @@ SIGNATURES = {
     "szn_conv2d_dgrad_gemm": (_I, [_D, _P, _P, _P, _P]),
     "szn_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "szn_bias_grad": (_I, [_I, _L, _I, _I, _P, _P, _I, _P]),
+    "szn_bias_grad_slab": (_I, [_I, _L, _I, _I, _P, _P, _I, _P, _I, _P]),
+    "szn_last_colsum_rows": (_I, []),
+    "szn_colsum_reduce_batch": (_I, [_I, _P, _P, _P, _P, _P]),
     "szn_gemm_proj_fwd": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "szn_gemm_proj_dgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "szn_gemm_proj_wgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _I, _P]),
@@ -55,7 +59,7 @@ SIGNATURES = {
     "szn_conv1_1_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "szn_conv1_1_wgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "szn_maxpool2x2_ceil_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
-    "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "szn_bilinear_up32_crop_fwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_bilinear_up32_crop_bwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_bilinear_up_crop_fwd": (_I, [_I] * 10 + [_P, _P, _P]),

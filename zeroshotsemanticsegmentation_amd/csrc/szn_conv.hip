@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad(WgradArgs a) {
 // (block, channel)
 template <typename T>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dout, float* __restrict__ db, long M, int Co,
-                                                        int ldd, int rows_per_block) {
+                                                        int ldd, int rows_per_block, float* __restrict__ slab) {
     constexpr int CH = elem<T>::kPer16B;
     __shared__ float red[256 * CH];
     const int cpr = (Co + CH - 1) / CH;                  // 16-B chunks per row
@@ -500,7 +500,10 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ do
             float s = 0.f;
             for (int l = 0; l < rl; ++l) s += red[l * ncg * CH + i];
             const int n = cg * CH + i;
-            if (n < Co && s != 0.f) atomicAdd(db + n, s);
+            if (n < Co) {
+                if (slab) slab[(long)blockIdx.x * Co + n] = s;       // one partial row per block (fixed-order reduce later)
+                else if (s != 0.f) atomicAdd(db + n, s);
+            }
         }
     }
 }
@@ -556,7 +559,7 @@ int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, c
        : d->dtype == SZN_F16 ? launch_conv<f16_raw>(a, (hipStream_t)stream) : launch_conv<float>(a, (hipStream_t)stream);
     if (rc || !d->colsum) return rc;
     if (d->out_f32 && szn_is16(d->dtype)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_fwd(v1): colsum with out_f32 is unsupported");
-    return szn_bias_grad(d->dtype, a.M, d->Co, d->ldo, out, d->colsum, 1, stream);   // fallback path: separate pass
+    return szn_bias_grad_slab(d->dtype, a.M, d->Co, d->ldo, out, d->colsum, 1, d->colsum_slab, d->colsum_slab_rows, stream);   // fallback path: separate pass
 }
 
 extern "C" int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, const void* w, void* wT,
@@ -738,8 +741,15 @@ int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* do
     return SZN_OK;
 }
 
+extern "C" int szn_bias_grad_slab(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
+                                  float* colsum_slab, int colsum_slab_rows, szn_stream_t stream);
 extern "C" int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
                              szn_stream_t stream) {
+    return szn_bias_grad_slab(dtype, M, Co, ldd, dout, db, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int szn_bias_grad_slab(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
+                                  float* slab, int slab_rows, szn_stream_t stream) {
     if (!dout || !db || M <= 0 || Co <= 0 || ldd < Co) SZN_FAIL(SZN_ERR_ARG, "bias_grad: bad argument");
     if (ldd % (szn_is16(dtype) ? 8 : 4) || ((uintptr_t)dout & 15))
         SZN_FAIL(SZN_ERR_UNSUPPORTED, "bias_grad: rows must be 16-B aligned (ldd multiple of %d)", szn_is16(dtype) ? 8 : 4);
@@ -751,15 +761,17 @@ extern "C" int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dou
     long rpb = (M + 2047) / 2048;
     if (rpb < 32) rpb = 32;
     const int blocks = szn_div_up(M, rpb);
+    if (slab && slab_rows < blocks) SZN_FAIL(SZN_ERR_ARG, "bias_grad: colsum_slab holds %d rows, %d needed", slab_rows, blocks);
+    szn_note_colsum_rows(slab ? blocks : 0);
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(bias_grad_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)dout, db, M, Co, ldd,
-                           (int)rpb);
+                           (int)rpb, slab);
     else if (dtype == SZN_F16)
         hipLaunchKernelGGL(bias_grad_kernel<f16_raw>, dim3(blocks), dim3(256), 0, st, (const f16_raw*)dout, db, M, Co, ldd,
-                           (int)rpb);
+                           (int)rpb, slab);
     else if (dtype == SZN_F32)
         hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, db, M, Co, ldd,
-                           (int)rpb);
+                           (int)rpb, slab);
     else
         SZN_FAIL(SZN_ERR_ARG, "bias_grad: bad dtype %d", dtype);
     SZN_CHECK_LAUNCH("bias_grad_kernel");

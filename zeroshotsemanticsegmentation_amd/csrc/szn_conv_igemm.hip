@@ -60,6 +60,7 @@ struct Conv2Args {
     const char* in; const char* w; const float* bias; const char* gate; const float* cscale; char* out;
     float* ws;                 // split-K accumulator [M][Co] (nsplit > 1)
     float* colsum;             // optional [Co]: += column sums of the stored tensor (bias gradient of the producer layer)
+    float* cslab;              // optional [mtiles][Co]: per-tile partial rows instead of atomics on colsum (fixed-order reduce later)
     unsigned in_bytes, w_bytes;
     int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
     int ldi, ldo, ldg, relu, out_f32;
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
         if (tid < BN && n0 + tid < a.Co) {
             float t = 0.f;
             for (int r = 0; r < 512 / CPR; ++r) t += red[r * BN + tid];
-            if (t != 0.f) atomicAdd(a.colsum + n0 + tid, t);
+            if (a.cslab) a.cslab[(long)(m0 >> 8) * a.Co + n0 + tid] = t;
+            else if (t != 0.f) atomicAdd(a.colsum + n0 + tid, t);
         }
     }
 #endif
@@ -468,6 +470,8 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
 extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias,
                               const void* gate, const float* chan_scale, void* out, szn_stream_t stream) {
     if (!d) SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: null descriptor");
+    szn_note_colsum_rows(0);
+    if (d->colsum_slab && ((uintptr_t)d->colsum_slab & 15)) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab must be 16-B aligned");
     if (d->pool_out && (!d->relu || d->ldo != d->Co || gate || chan_scale))
         SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: pool_out needs relu, ldo == Co and no gate / chan_scale");
     int pooled = 0;
@@ -523,6 +527,9 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     const bool narrow = d->Co <= 64;
     const int BN = narrow ? 64 : 128;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(a.Co, BN);
+    a.cslab = d->colsum ? d->colsum_slab : nullptr;
+    if (a.cslab && d->colsum_slab_rows < a.mtiles) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab holds %d rows, %d needed", d->colsum_slab_rows, a.mtiles);
+    szn_note_colsum_rows(a.cslab ? a.mtiles : 0);
     const int nK = d->KH * d->KW * (d->Ci / bke);
     a.nsplit = 1; a.chunks_per_split = nK;
     const long tiles = (long)a.mtiles * a.ntiles;

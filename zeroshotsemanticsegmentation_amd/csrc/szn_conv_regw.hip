@@ -29,6 +29,7 @@ namespace {
 
 struct RwArgs {
     const char* in; const char* w; const float* bias; const char* gate; char* out; float* colsum;
+    float* cslab;              // optional [grid][Co]: this block's column sums go to row blockIdx.x (fixed-order reduce later)
     char* pool;                        // optional: MaxPool2d(2,2,ceil) of the (ReLU'd) output, [B][Hp][Wp][Co] dense
     unsigned in_bytes, gate_bytes;
     int Hp, Wp;
@@ -96,7 +97,10 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
     const int G = gridDim.x;
     const int vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     const int first = (int)((long)a.ntiles * vb / G), last = (int)((long)a.ntiles * (vb + 1) / G);
-    if (first >= last) return;
+    if (first >= last) {
+        if constexpr (COLSUM) { if (a.cslab && tid < CO) a.cslab[(long)blockIdx.x * CO + tid] = 0.f; }
+        return;
+    }
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
     const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)(GATED ? a.gate : a.in), 0, (int)(GATED ? a.gate_bytes : 0u), 0x00020000);
@@ -175,6 +179,11 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
     // waited for its own pieces of patch first + k), no extra registers.  CIG = 2 keeps the lockstep order: its mid-tile partner
     // exchange needs a block barrier that both groups reach at the same point.
     const bool grpB = CIG == 1 && a.shift && w >= 4;
+    // column sums (bias gradient of the producer layer): each lane keeps running sums of its 8 couts over all the tiles of the
+    // block; they are combined once, in a fixed order, behind the tile loop (no LDS atomics: bit-reproducible)
+    float cst[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cst[e] = 0.f;
     int buf = 0;
     for (int t = first; t < last; ++t) {
         const bool more = t + NBUF - 1 < last;
@@ -275,10 +284,9 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        float cs[8];
         float pm[8];                                                       // pooling: the even row of the current row pair
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { cs[e] = 0.f; pm[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) pm[e] = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const bool ok = okw && oh0 + j < a.Ho;
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                     x = (gv > 0.f) ? x : 0.f;
                 }
                 v[e] = x;
-                if constexpr (COLSUM) cs[e] += ok ? x : 0.f;
+                if constexpr (COLSUM) cst[e] += ok ? x : 0.f;
             }
             u32x4_t pk;
             pk.x = pack2<T>(v[0], v[1]);
@@ -337,29 +345,34 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                 }
             }
         }
-        if constexpr (COLSUM) {
-            float* red = (float*)(smem + G_::OFF_RED) + cstart;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = row16_sum(cs[e]);
-                if (r16 == 0) __hip_atomic_fetch_add(red + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f32
-            }
-        }
         if (!grpB) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         buf = (buf == NBUF - 1) ? 0 : buf + 1;
     }
-    if constexpr (COLSUM && CIG == 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // group B's last column sums are in LDS before the flush below
-    }
-
     if constexpr (COLSUM) {
+        // lane (g, r16 == 0) of wave w holds, after the row sum, the 8 couts cstart .. cstart + 7 of its wave: 8 waves x 4 rows x 8
+        // values go to LDS (the patch buffers are free behind the barrier) and thread c adds the waves that own cout c in
+        // ascending wave order
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* pw = (float*)smem;                           // [8 waves][4 g][8]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = row16_sum(cst[e]);
+            if (r16 == 0) pw[(w * 4 + g) * 8 + e] = x;
+        }
+        __syncthreads();
         if (tid < CO) {
-            const float s = ((const float*)(smem + G_::OFF_RED))[tid];     // complete: behind the last barrier
-            if (s != 0.f) atomicAdd(a.colsum + tid, s);
+            const int cogc = tid >> 5, rem = tid & 31;
+            const int gc = (((rem & 15) >> 3) << 1) | (rem >> 4), ec = rem & 7;     // inverse of cstart = 32 cog + 16 (g & 1) + 8 (g >> 1)
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww)
+                if ((ww / CIG) % COG == cogc) s += pw[(ww * 4 + gc) * 8 + ec];
+            if (a.cslab) a.cslab[(long)blockIdx.x * CO + tid] = s;
+            else if (s != 0.f) atomicAdd(a.colsum + tid, s);
         }
     }
 #endif
@@ -402,6 +415,7 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     RwArgs a;
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.out = (char*)out;
     a.colsum = d->colsum;
+    a.cslab = d->colsum ? d->colsum_slab : nullptr;
     a.pool = (char*)d->pool_out; a.Hp = (d->Ho + 1) / 2; a.Wp = (d->Wo + 1) / 2;
     a.in_bytes = (unsigned)in_bytes; a.gate_bytes = (unsigned)gate_bytes;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.pad = d->pad;
@@ -421,6 +435,8 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
         if (ncu < 8) ncu = 8;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (a.cslab && d->colsum_slab_rows < ncu) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab holds %d rows, %d needed", d->colsum_slab_rows, ncu);
+    szn_note_colsum_rows(a.cslab ? ncu : 0);
     if (d->dtype == SZN_F16) {
         if (cog == 2 && cig == 1) return launch_regw_flags<f16_raw, 2, 1>(a, ncu, st);
         if (cog == 4 && cig == 1) return launch_regw_flags<f16_raw, 4, 1>(a, ncu, st);

@@ -13,6 +13,7 @@
 //   * 3-stage LDS ring (<= 48 KiB, 3 blocks per CU), counted vmcnt, one raw s_barrier per K step;
 //   * split over pixels; partial tiles are added to the fp32 OHWI gradient with global atomics.
 #include "szn_common.h"
+#include <algorithm>
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -38,6 +39,8 @@ struct Wg2Args {
     int M;
     int kspan, nsplit, cotiles, citiles;
     int plain_store;           // single split and no accumulation: write the tile instead of atomically adding it
+    float* slab;               // pixel splits > 1 with a workspace: split s stores its partial into slab[s][Co*KH*KW*Ci] (plain
+                               // stores; wgrad_slab_reduce adds the splits in a fixed order: deterministic, no atomics / memset)
     int ablate;                // debug (env SZN_WG_ABLATE=1): skip the output epilogue (wrong results)
 };
 
@@ -248,14 +251,31 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_v2(Wg2Args a) {
             const int r = idx / CI_T, c = idx - r * CI_T;
             const int co = co0 + half * HR + r, ci = ci0 + c;
             if (co < a.Co && ci < a.Ci) {
-                float* dst = a.dw + ((long)(co * a.KH + kh) * a.KW + kw) * a.Ci + ci;
+                const long off = ((long)(co * a.KH + kh) * a.KW + kw) * a.Ci + ci;
                 const float v = tile[r * PT + c];
-                if (a.plain_store) *dst = v;
-                else atomicAdd(dst, v);
+                if (a.slab) a.slab[(long)split * ((long)a.Co * a.KH * a.KW * a.Ci) + off] = v;
+                else if (a.plain_store) a.dw[off] = v;
+                else atomicAdd(a.dw + off, v);
             }
         }
     }
 #endif
+}
+
+// dw[i] (+)= sum_s slab[s][i], four elements per thread, splits added in ascending order
+__global__ __launch_bounds__(256) void wgrad_slab_reduce(const float* __restrict__ slab, float* __restrict__ dw, long nw, int nsplit,
+                                                         int accumulate) {
+    const long n4 = nw >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4_t s = accumulate ? ((const f32x4_t*)dw)[i] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nsplit; ++k) s += ((const f32x4_t*)(slab + (long)k * nw))[i];
+        ((f32x4_t*)dw)[i] = s;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < nw; i += (long)gridDim.x * 256) {
+        float s = accumulate ? dw[i] : 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slab[(long)k * nw + i];
+        dw[i] = s;
+    }
 }
 
 template <typename T, int FA, int FB>
@@ -314,15 +334,24 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
     if (span < 1024) span = 1024;
     span = (span + 63) / 64 * 64;
     if (tiles >= 512) span = (a.M + 63) / 64 * 64;       // enough tiles to fill the chip: one split, plain stores (fc6, fc7)
-    a.kspan = (int)span;
     a.nsplit = szn_div_up(a.M, span);
+    // a workspace turns the split reduction into fixed-order slabs (deterministic): fewer splits if it is too small for all
+    a.slab = nullptr;
+    if (a.nsplit > 1 && d->workspace && !((uintptr_t)d->workspace & 15) && (nw & 3) == 0 && !((uintptr_t)dw & 15)) {
+        const long fit = (long)(d->workspace_bytes / ((size_t)nw * sizeof(float)));
+        if (fit >= 2) {
+            if (fit < a.nsplit) { span = ((a.M + fit - 1) / fit + 63) / 64 * 64; a.nsplit = szn_div_up(a.M, span); }
+            if (a.nsplit > 1) a.slab = (float*)d->workspace;
+        }
+    }
+    a.kspan = (int)span;
     const long blocks = tiles * a.nsplit;
     if (blocks >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad: grid too large");
     a.plain_store = (a.nsplit == 1 && !accumulate) ? 1 : 0;      // fc6: 411 MB written once instead of memset + atomics
     static int wg_abl = -1;
     if (wg_abl < 0) { wg_abl = szn_ablate_env("SZN_WG_ABLATE"); }
     a.ablate = wg_abl;
-    if (!accumulate && !a.plain_store) {
+    if (!accumulate && !a.plain_store && !a.slab) {
         hipError_t e = hipMemsetAsync(dw, 0, nw * sizeof(float), st);
         if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "conv2d_wgrad memset: %s", hipGetErrorString(e));
     }
@@ -343,5 +372,11 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
         else launch_wg2<float, 2, 2>(a, blocks, st);
     }
     SZN_CHECK_LAUNCH("conv_wgrad_v2");
+    if (a.slab) {
+        const long n4 = (nw + 3) / 4;
+        hipLaunchKernelGGL(wgrad_slab_reduce, dim3((unsigned)std::min<long>((n4 + 255) / 256, 4096L)), dim3(256), 0, st,
+                           (const float*)a.slab, dw, nw, a.nsplit, accumulate);
+        SZN_CHECK_LAUNCH("wgrad_slab_reduce");
+    }
     return SZN_OK;
 }

@@ -20,6 +20,7 @@ namespace {
 struct WideArgs {
     const char* in; const char* w; const float* bias; const char* gate; const float* cscale; char* out;
     float* colsum;
+    float* cslab;              // optional [mtiles][Co]: the column sums of a pixel tile go to its row instead of fp32 atomics on colsum
     unsigned in_bytes, w_bytes;
     int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
     int ldi, ldo, ldg, relu, out_f32;
@@ -166,7 +167,8 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
         if (tid < BN && n0 + tid < a.Co) {
             float t = 0.f;
             for (int r = 0; r < RG; ++r) t += red[r * BN + tid];
-            if (t != 0.f) atomicAdd(a.colsum + n0 + tid, t);
+            if (a.cslab) a.cslab[(long)(m0 >> 8) * a.Co + n0 + tid] = t;         // tile row m0 / 256: reduced in a fixed order later
+            else if (t != 0.f) atomicAdd(a.colsum + n0 + tid, t);
         }
     }
 }
@@ -661,6 +663,9 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     } else if ((long)a.ntiles * bn - d->Co > 64) return 1;          // would waste > 64 columns of the last tile
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
     a.out = (char*)out; a.colsum = d->colsum;
+    a.cslab = (d->colsum && !a.ws) ? d->colsum_slab : nullptr;
+    if (a.cslab && d->colsum_slab_rows < a.mtiles) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab holds %d rows, %d needed", d->colsum_slab_rows, a.mtiles);
+    szn_note_colsum_rows(a.cslab ? a.mtiles : 0);
     a.in_bytes = in_bytes; a.w_bytes = w_bytes;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
@@ -701,7 +706,7 @@ int szn_proj_stream_try(const szn_conv_desc_t* d, const void* in, const void* w,
     if (a.mtiles < min_tiles) return 1;
     a.ws = nullptr; a.nsplit = 1; a.chunks_per_split = 1 << 30; a.stagger = 0;
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = nullptr; a.cscale = nullptr;
-    a.out = (char*)out; a.colsum = nullptr;
+    a.out = (char*)out; a.colsum = nullptr; a.cslab = nullptr;
     a.in_bytes = 0; a.w_bytes = (unsigned)((size_t)d->Co * d->Ci * 2);
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.KH = 1; a.KW = 1; a.pad = 0; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = 0;

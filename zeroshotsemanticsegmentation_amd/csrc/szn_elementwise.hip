@@ -4,6 +4,7 @@
 // Reference sites: models.py:43-47 (conv1_1, pools), models.py:86,91 (Dropout2d), train.py:126-133,174-175
 // (torch.optim.SGD / Adam with two parameter groups).
 #include "szn_common.h"
+#include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -24,6 +25,9 @@ static thread_local const char* g_prev_kernel = "";
 void szn_note_kernel(const char* name) { g_prev_kernel = g_last_kernel; g_last_kernel = name; }
 extern "C" const char* szn_last_kernel(void) { return g_last_kernel; }
 extern "C" const char* szn_prev_kernel(void) { return g_prev_kernel; }
+static thread_local int g_colsum_rows = 0;
+void szn_note_colsum_rows(int rows) { g_colsum_rows = rows; }
+extern "C" int szn_last_colsum_rows(void) { return g_colsum_rows; }
 
 extern "C" int szn_version(void) { return 100; /* 0.1.0 */ }
 extern "C" int szn_device_info(int device, szn_device_info_t* out) {
@@ -244,7 +248,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ in, const T* __restrict__ out,
                                                           const T* __restrict__ dout, T* __restrict__ din, int B, int Hi,
-                                                          int Wi, int C, int Ho, int Wo, float* __restrict__ colsum) {
+                                                          int Wi, int C, int Ho, int Wo, float* __restrict__ colsum,
+                                                          float* __restrict__ cslab) {
     constexpr int CH = elem<T>::kPer16B;
     __shared__ float red[256 * CH];
     (void)out;
@@ -305,7 +310,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
             const int cc = c / CH, e = c - cc * CH;
             float t = 0.f;
             for (int r = cc; r < 256; r += cpp) t += red[r * CH + e];
-            if (t != 0.f) atomicAdd(colsum + c, t);
+            if (cslab) cslab[(long)blockIdx.x * C + c] = t;      // one partial row per block, reduced in a fixed order later
+            else if (t != 0.f) atomicAdd(colsum + c, t);
         }
     }
 }
@@ -534,7 +540,8 @@ extern "C" int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, 
 }
 
 extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void* in, const void* out,
-                                       const void* dout, void* din, float* colsum, szn_stream_t stream) {
+                                       const void* dout, void* din, float* colsum, float* colsum_slab, int colsum_slab_rows,
+                                       szn_stream_t stream) {
     if (!in || !out || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0)
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad argument");
     const int ch = szn_is16(dtype) ? 8 : 4;
@@ -547,17 +554,21 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
     static int capx = -1;
     if (capx < 0) { const char* e = getenv("SZN_POOLBWD_BLOCKS"); capx = e ? atoi(e) : 512; if (capx < 1) capx = 1; }
     const int grid = grid_for(total, 256, colsum ? capx : 65536);
+    float* cslab = colsum ? colsum_slab : nullptr;
+    if (cslab && colsum_slab_rows < grid)
+        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: colsum_slab holds %d rows, %d needed", colsum_slab_rows, grid);
+    szn_note_colsum_rows(cslab ? grid : 0);
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_raw*)in, (const bf16_raw*)out, (const bf16_raw*)dout, (bf16_raw*)din, B, Hi, Wi, C,
-                           Ho, Wo, colsum);
+                           Ho, Wo, colsum, cslab);
     else if (dtype == SZN_F16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<f16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const f16_raw*)in, (const f16_raw*)out, (const f16_raw*)dout, (f16_raw*)din, B, Hi, Wi, C,
-                           Ho, Wo, colsum);
+                           Ho, Wo, colsum, cslab);
     else if (dtype == SZN_F32)
         hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)in, (const float*)out, (const float*)dout, (float*)din, B, Hi, Wi, C, Ho, Wo, colsum);
+                           (const float*)in, (const float*)out, (const float*)dout, (float*)din, B, Hi, Wi, C, Ho, Wo, colsum, cslab);
     else
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad dtype %d", dtype);
     SZN_CHECK_LAUNCH("maxpool_bwd_kernel");
@@ -728,5 +739,64 @@ extern "C" int szn_loss_scale_update(float* scale_state, float growth, float bac
     hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale_state, growth, backoff,
                        growth_interval, min_scale, max_scale);
     SZN_CHECK_LAUNCH("loss_scale_update_kernel");
+    return SZN_OK;
+}
+
+// ---- fixed-order reduction of the column-sum partial rows (bias gradients) ------------------------------------------------------
+// job j: out[c] += sum_{r < rows} slab[r][c], c < C.  One block = 64 channels of one job (16 float4 columns x 16 row groups): each
+// thread adds every 16th row (independent 16-B loads, eight in flight), the 16 groups are combined in ascending order.
+struct ColsumJobs { const float* slab[32]; float* out[32]; int rows[32]; int C[32]; int first_block[33]; };
+
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(ColsumJobs jb, int njobs) {
+    __shared__ f32x4_t part[16][16];
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jb.first_block[j + 1]) ++j;
+    const int c0 = ((int)blockIdx.x - jb.first_block[j]) * 64;
+    const int C = jb.C[j], rows = jb.rows[j];
+    const float* slab = jb.slab[j];
+    const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = c0 + q * 4;
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        if ((C & 3) == 0) {
+            for (int r = rg; r < rows; r += 16) a += *(const f32x4_t*)(slab + (long)r * C + c);
+        } else {
+            for (int r = rg; r < rows; r += 16)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < C) a[e] += slab[(long)r * C + c + e];
+        }
+    }
+    part[rg][q] = a;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cc = c0 + threadIdx.x;
+        if (cc < C) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += part[g][threadIdx.x >> 2][threadIdx.x & 3];
+            jb.out[j][cc] += s;
+        }
+    }
+}
+
+extern "C" int szn_colsum_reduce_batch(int n, const float* const* slabs, const int* rows, const int* C, float* const* out,
+                                       szn_stream_t stream) {
+    if (n < 0 || (n > 0 && (!slabs || !rows || !C || !out))) SZN_FAIL(SZN_ERR_ARG, "colsum_reduce_batch: bad argument");
+    for (int base = 0; base < n; base += 32) {
+        ColsumJobs jb;
+        const int m = std::min(32, n - base);
+        int blocks = 0;
+        for (int j = 0; j < m; ++j) {
+            if (!slabs[base + j] || !out[base + j] || rows[base + j] < 0 || C[base + j] <= 0 || ((uintptr_t)slabs[base + j] & 15))
+                SZN_FAIL(SZN_ERR_ARG, "colsum_reduce_batch: bad job %d", base + j);
+            jb.slab[j] = slabs[base + j]; jb.out[j] = out[base + j]; jb.rows[j] = rows[base + j]; jb.C[j] = C[base + j];
+            jb.first_block[j] = blocks;
+            blocks += (C[base + j] + 63) / 64;
+        }
+        jb.first_block[m] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jb, m);
+        SZN_CHECK_LAUNCH("colsum_reduce_kernel");
+    }
     return SZN_OK;
 }

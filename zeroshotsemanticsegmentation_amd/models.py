@@ -79,6 +79,11 @@ class _Engine(object):
         self._fp8_ws = None
         self._fp8_bws = None
         self.lp_views = {}          # layer -> compute-dtype OHWI weight image maintained by the optimizer kernel (TrainStep)
+        # bias gradients = column sums of the tensors the backward kernels write.  deterministic (default, SZN_DETERMINISTIC=0
+        # turns it off): every producing kernel writes per-tile partial rows into a slab of this pool and ONE
+        # szn_colsum_reduce_batch launch at the end of the backward pass adds them in a fixed order; otherwise fp32 atomics
+        self.deterministic = os.environ.get("SZN_DETERMINISTIC", "1") != "0"
+        self._cs_pool, self._cs_off, self._cs_jobs = None, 0, []
         self._seen_versions = None    # versions of seenmask_score mirrored into the TrainStep-owned head image
 
     def _workspace(self, desc, nbytes, device):
@@ -215,6 +220,38 @@ class _Engine(object):
             if not any(wt is b[1] for b in batch):
                 L.call("szn_pack_weight_dgrad", code, co, k, k, ci, L.ptr(wc), L.ptr(wt), st)
 
+    # ---- deterministic column sums (bias gradients) ------------------------------------------------
+    def _cs_slab(self, M, Cc, device):
+        """-> (fp32 slab tensor, rows it can hold) for a kernel that writes an (M, Cc) tensor, or (None, 0)"""
+        if not self.deterministic:
+            return None, 0
+        rows = max((M + 255) // 256, min(2048, (M + 31) // 32), 512)
+        n = (rows * Cc + 63) // 64 * 64
+        if self._cs_pool is None or self._cs_pool.device != device or self._cs_off + n > self._cs_pool.numel():
+            self._cs_pool = torch.empty(max(32 << 20, 2 * n), dtype=torch.float32, device=device)   # (jobs keep the old pool alive)
+            self._cs_off = 0
+        slab = self._cs_pool[self._cs_off:self._cs_off + rows * Cc]
+        self._cs_off += n
+        return slab, rows
+
+    def _cs_register(self, slab, Cc, out):
+        """after a call that was handed `slab`: remember how many rows it wrote"""
+        if slab is None:
+            return
+        rows = L.load().szn_last_colsum_rows()
+        if rows > 0:
+            self._cs_jobs.append((slab, rows, Cc, out))
+
+    def _flush_colsum(self):
+        """out[c] += the partial rows of every pending job, one launch, fixed order"""
+        jobs, self._cs_jobs, self._cs_off = self._cs_jobs, [], 0
+        if not jobs:
+            return
+        n = len(jobs)
+        VP, IA = C.c_void_p * n, C.c_int * n
+        L.call("szn_colsum_reduce_batch", n, VP(*[j[0].data_ptr() for j in jobs]), IA(*[j[1] for j in jobs]),
+               IA(*[j[2] for j in jobs]), VP(*[j[3].data_ptr() for j in jobs]), L.stream_ptr())
+
     # ---- kernels ---------------------------------------------------------------------------------
     def _conv(self, x, name, pad, relu=True, scale=None, out_f32=False, w=None, b=None, co=None, k=None, pool=False):
         """conv (+ bias, ReLU, dropout factor) through szn_conv2d_fwd; pool=True also returns MaxPool2d(2,2,ceil) of the
@@ -327,7 +364,9 @@ class _Engine(object):
         L.call("szn_proj_fp8_wgrad", L.dtype_code(dc.dtype), L.dtype_code(feat.dtype), M, F, CP, CP, F, L.ptr(dc), L.ptr(feat),
                L.ptr(dwh), L.ptr(ws), st)
         if dbh is not None:
-            L.call("szn_bias_grad", L.dtype_code(dc.dtype), M, CP, CP, L.ptr(dc), L.ptr(dbh), 0, st)
+            slab, rows = self._cs_slab(M, CP, dc.device)
+            L.call("szn_bias_grad_slab", L.dtype_code(dc.dtype), M, CP, CP, L.ptr(dc), L.ptr(dbh), 0, L.ptr(slab), rows, st)
+            self._cs_register(slab, CP, dbh)
 
     def _head_dgrad_fp8(self, dc, feat, scale, colsum):
         """d(fc7 output) = dc . W_head on the fp8 matrix cores (szn_proj_fp8_dgrad) with the ReLU gate / Dropout2d factor of fc7
@@ -342,7 +381,9 @@ class _Engine(object):
         L.call("szn_proj_fp8_dgrad", L.dtype_code(dc.dtype), L.dtype_code(wimg.dtype), M, F, CP, CP, L.ptr(dc), L.ptr(wimg),
                L.ptr(feat), L.dtype_code(feat.dtype), F, L.ptr(scale), h * w, code, L.ptr(d), F, L.ptr(ws), st)
         if colsum is not None:
-            L.call("szn_bias_grad", code, M, F, F, L.ptr(d), L.ptr(colsum), 1, st)
+            slab, rows = self._cs_slab(M, F, d.device)
+            L.call("szn_bias_grad_slab", code, M, F, F, L.ptr(d), L.ptr(colsum), 1, L.ptr(slab), rows, st)
+            self._cs_register(slab, F, colsum)
         return d
 
     def upscore(self, ctx):
@@ -403,8 +444,10 @@ class _Engine(object):
             t.record_stream(side)
 
     def _join_wgrad(self):
+        """end of a backward pass: the weight-gradient stream (if any) rejoins, the pending bias-gradient rows are reduced"""
         if self._wg_stream:
             torch.cuda.current_stream().wait_stream(self._wg_stream)
+        self._flush_colsum()
 
     def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None):
         """dw (OHWI f32) = wgrad of one layer, on the wgrad stream; `after` (e.g. the DDP bucket hook) runs there too"""
@@ -413,16 +456,20 @@ class _Engine(object):
         ldo = dout.shape[3] if ldo is None else ldo
         code = L.dtype_code(self.dtype)
         d = L.ConvDesc(code, B, Hi, Wi, ci, Ho, Wo, co, k, k, pad, ci, ldo, 0, 0, 0)
-        if k == 3:      # slabs of the all-taps kernel (szn_conv_wgrad_taps.hip): <= 256 blocks x 64*9*64 fp32
-            nb = 2 * 256 * 64 * 9 * 64 * 4      # (room for SZN_WGT_OVERSUB=2: two blocks per CU)
-            if self._wg_ws is None or self._wg_ws.device != x.device:
-                self._wg_ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
-            d.workspace, d.workspace_bytes = self._wg_ws.data_ptr(), nb
+        # slab workspace of the weight-gradient kernels: the all-taps kernel (szn_conv_wgrad_taps.hip: <= 256 blocks x 64*9*64
+        # fp32, room for SZN_WGT_OVERSUB=2) and the pixel splits of conv_wgrad_v2 (head / skip layers, every f32 layer: fixed-order
+        # slabs instead of fp32 atomics -- it takes as many splits as fit)
+        nb = 2 * 256 * 64 * 9 * 64 * 4
+        if self._wg_ws is None or self._wg_ws.device != x.device:
+            self._wg_ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        d.workspace, d.workspace_bytes = self._wg_ws.data_ptr(), nb
         with self._wgrad_stream(x, dout):
             st = L.stream_ptr()
             L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
             if db is not None:
-                L.call("szn_bias_grad", code, B * Ho * Wo, co, ldo, L.ptr(dout), L.ptr(db), 0, st)
+                slab, rows = self._cs_slab(B * Ho * Wo, co, dout.device)
+                L.call("szn_bias_grad_slab", code, B * Ho * Wo, co, ldo, L.ptr(dout), L.ptr(db), 0, L.ptr(slab), rows, st)
+                self._cs_register(slab, co, db)
             if after is not None:
                 after()
 
@@ -447,11 +494,16 @@ class _Engine(object):
         wT = self._images[name + ".wT"] if wT is None else wT
         k = wT.shape[1]
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, Ci, 0, 0)
+        slab = None
         if colsum is not None:
             d.colsum = colsum.data_ptr()
+            slab, rows = self._cs_slab(B * Hi * Wi, Ci, dout.device)
+            if slab is not None:
+                d.colsum_slab, d.colsum_slab_rows = slab.data_ptr(), rows
         else:
             self._workspace(d, B * Hi * Wi * Ci * 4, dout.device)
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
+        self._cs_register(slab, Ci, colsum)
         return din
 
     def backward(self, ctx, dcoarse, grads, backbone=True, layer_done=None, head_first=None, skips=None):
@@ -511,8 +563,10 @@ class _Engine(object):
                 B, Hi, Wi, Cc = pin.shape
                 dn = torch.empty_like(pin)
                 producer = items[idx - 1][0]                   # the conv whose (ReLU'd) output this pool reads
+                slab, rows = self._cs_slab(B * Hi * Wi, Cc, d.device)
                 L.call("szn_maxpool2x2_ceil_bwd", code, B, Hi, Wi, Cc, L.ptr(pin), L.ptr(pout), L.ptr(d), L.ptr(dn),
-                       L.ptr(grads[producer][1]), st)
+                       L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
+                self._cs_register(slab, Cc, grads[producer][1])
                 d = dn
                 continue
             name, pad = item
