@@ -206,3 +206,20 @@ def test_seenmask_step_learns_and_is_reproducible():
     print("seen-mask loss over 25 steps: %.4f -> %.4f" % (outs[0][0][0], outs[0][0][-1]))
     assert outs[0][0][-1] < outs[0][0][0] and outs[0][0][-1] < 0.98 * max(outs[0][0][:3])
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_seenmask_predict_equals_the_materialised_path():
+    """validation path of phase 2 (trainer_seenmask.py:104-166): models.FCN32s.seenmask_predict (no (n,2,h,w) score) against
+    forward(mode='seenmask') + cross_entropy2d + channel_argmax"""
+    E, K, H, W, B = 20, 33, 70, 101, 2
+    unseen = [0, 12]
+    seen = [k for k in range(K) if k not in unseen]
+    m = models.FCN32s(E).load_synthetic(1337).cuda().eval()
+    x = cu(synth.make_images(B, H, W, seed=60))
+    t = synth.make_labels(B, H, W, K, seed=61, block=8)
+    loss, pred = m.seenmask_predict(x, cu(t), K, unseen)
+    with torch.no_grad():
+        score = m(x, mode="seenmask")
+    want = utils.cross_entropy2d(score, cu(np.isin(t, seen).astype(np.int64)), size_average=True)
+    assert abs(loss.item() - want.item()) < 1e-6 * max(1.0, abs(want.item()))
+    assert torch.equal(pred, utils.channel_argmax(score))

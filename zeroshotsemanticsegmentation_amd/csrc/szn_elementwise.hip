@@ -468,10 +468,12 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
 int szn_conv1_1_wgrad_fused_try(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
                                 void* workspace, size_t workspace_bytes, szn_stream_t stream);
 
+static constexpr size_t kC11SlabBytes = (size_t)32 << 20;
 extern "C" size_t szn_conv1_1_wgrad_workspace_bytes(int dtype, int B, int H, int W, int pad) {
     if (B <= 0 || H <= 0 || W <= 0 || pad < 0) return 0;
     const size_t Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
-    return (size_t)B * Ho * Wo * 32 * szn_esize(dtype) + 64 * 32 * sizeof(float);
+    // im2col image + the [64][32] fp32 result + room for the fixed-order pixel-split slabs of the GEMM behind it (8 KiB per split)
+    return (size_t)B * Ho * Wo * 32 * szn_esize(dtype) + 64 * 32 * sizeof(float) + kC11SlabBytes;
 }
 
 extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw,
@@ -509,6 +511,11 @@ extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const 
     SZN_CHECK_LAUNCH("im2col_c3_kernel");
     // 1x1 "conv" over M rows: in = xcol [M][32], dout [M][64] -> dw32 [64][1][1][32]
     szn_conv_desc_t d = {dtype, 1, 1, (int)M, 32, 1, (int)M, 64, 1, 1, 0, 32, 64, 0, 0, 0};
+    {   // slabs of the pixel splits (deterministic reduction) behind the im2col image, 256-B aligned
+        const size_t off = ((size_t)64 * 32 * sizeof(float) + (size_t)M * 32 * es + 255) & ~(size_t)255;
+        d.workspace = (char*)workspace + off;
+        d.workspace_bytes = kC11SlabBytes - 256;
+    }
     int rc = szn_conv2d_wgrad(&d, xcol, dout, dw32, 0, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(unpack_dw32_kernel, dim3((64 * 27 + 255) / 256), dim3(256), 0, st, (const float*)dw32, dw, accumulate);

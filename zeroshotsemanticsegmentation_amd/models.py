@@ -813,6 +813,33 @@ class FCN32s(nn.Module):
                    L.ptr(tgt), L.ptr(loss), L.ptr(stats), L.ptr(pred), L.SZN_F32, None, L.ptr(ws), L.stream_ptr())
         return (loss.reshape(()) if loss is not None else None), pred
 
+    def seenmask_predict(self, x, target, n_class, unseen):
+        """forward pass + seen-mask loss and prediction WITHOUT the (B,2,H,W) score: szn_seenmask_head evaluates the learned
+        stride-32 deconv + crop (models.py:150-151), the binary target `label is a seen class` (trainer_seenmask.py:53-56), the
+        2-class cross entropy (size_average) and the channel argmax per 32x32 pixel cell of the 1/32 map.  target: (B,H,W)
+        int64 class labels.  -> (loss 0-dim tensor, pred (B,H,W) int64 device tensor).
+        Same numbers as forward(mode='seenmask') + utils.cross_entropy2d / channel_argmax (bit-identical score arithmetic).
+        Used by trainer_seenmask.Trainer.validate."""
+        if n_class > 64:
+            raise L.SznError("seenmask_predict: at most 64 classes (64-bit seen mask), got %d" % n_class)
+        eng = self._engine
+        with torch.no_grad():
+            ctx = eng.forward(x.detach(), train=False, keep=False)
+            dev = ctx.coarse.device
+            B, H, W = ctx.B, ctx.H, ctx.W
+            tgt = target.to(device=dev, dtype=torch.int64).contiguous()
+            seen_bits = 0
+            for k in range(n_class):
+                if k not in set(unseen):
+                    seen_bits |= 1 << k
+            pred = torch.empty(B, H, W, dtype=torch.int64, device=dev)
+            loss = torch.empty(1, device=dev)
+            ws = torch.empty(L.load().szn_seenmask_head_workspace_bytes(B, ctx.h, ctx.w, H, W, CROP), dtype=torch.uint8, device=dev)
+            L.call("szn_seenmask_head", B, ctx.h, ctx.w, self.head_width, self.n_class, H, W, CROP, L.ptr(ctx.coarse),
+                   L.ptr(eng._images["up.w"]), L.ptr(tgt), n_class, seen_bits, L.ptr(loss), None, None, L.ptr(pred), None, None,
+                   L.ptr(ws), L.stream_ptr())
+        return loss.reshape(()), pred
+
     def copy_params_from_vgg16(self, vgg16):
         """reference models.py:162-193: zip vgg16.features with our conv list; fc6/fc7 from classifier[0], [3]"""
         features = []

@@ -168,7 +168,15 @@ class Trainer(object):
                 # a loader that is not already sharded per rank (train.py shards it: each rank decodes only its own images)
                 if world > 1 and not getattr(self.val_loader, 'szn_sharded', False) and batch_idx % world != self.rank:
                     continue
-                score, loss, pred, tgt = self._forward_device(data, target)
+                if self._fused_step and self.n_class <= 64:
+                    # loss + prediction straight from the 1/32 map (models.FCN32s.seenmask_predict): no (n,2,h,w) score
+                    if isinstance(target, (tuple, list)):
+                        target = target[0]
+                    data = utils.image_to_device(data, self.device) if data.dtype == torch.uint8 else data.to(self.device, non_blocking=True)
+                    loss, pred = self.model.seenmask_predict(data, target.to(self.device), self.n_class, self.unseen)
+                    tgt = self.binary_target(target)
+                else:
+                    score, loss, pred, tgt = self._forward_device(data, target)
                 acc[0] += loss.double()
                 acc[1] += 1
                 utils.confusion_hist_device(tgt, pred, self.n_class, None, hist)
