@@ -261,7 +261,7 @@ def test_proj_fp8_backward_kernels_match_oracle_restatement(dt):
     L.call("szn_proj_fp8_wgrad", code, code, M, K, N, ldg, K, L.ptr(gd), L.ptr(xd), L.ptr(dw), L.ptr(wsb), L.stream_ptr())
     wantw = O.proj_fp8_wgrad(gs, xs)
     gotw = dw.cpu().numpy()
-    assert np.abs(gotw - wantw).max() < 1e-4 * np.abs(wantw).max()
+    assert np.abs(gotw - wantw).max() < 5e-4 * np.abs(wantw).max()       # 1,253-term fp32 sums of mixed-sign products vs float64
     refw = gs.astype(np.float64).T @ xs.astype(np.float64)
     e_w = np.abs(gotw - refw).max() / np.abs(refw).max()
     print("fp8 backward vs fp32 products (%s operands): dgrad %.3e, wgrad %.3e of the output scale" % (dt, e_d, e_w))
