@@ -28,6 +28,7 @@ struct WideArgs {
     float* ws;                 // split-K: fp32 slabs [nsplit][M][Co] (plain stores, no epilogue); nullptr = single pass
     int nsplit, chunks_per_split;
     int stagger;               // 1: wave pairs take turns issuing the LDS-DMA loads of a chunk (SZN_WIDE_STAGGER=0: all at once)
+    int gate_prefetch;         // 1: the epilogue fetches the ReLU-gate rows one pass ahead (SZN_WIDE_GATEPF=0: inside the store loop)
 };
 
 constexpr unsigned kOOBx = 0x80000000u;
@@ -59,7 +60,25 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
     float bv[8], cs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bv[e] = (a.bias && n + e < a.Co) ? a.bias[n + e] : 0.f; cs[e] = 0.f; }
+    // ReLU-gate rows (dgrad: 16 B of the forward activation per 8 outputs) are fetched ONE PASS AHEAD: issued in front of the two
+    // barriers and the LDS staging of the pass before, so their latency is no longer paid NIT times per pass in the store loop
+    // (dgrad ran ~10 % behind the forward pass of the same layer).  16-bit gates with 16-B rows only; SZN_WIDE_GATEPF=0: off.
+    // (the 320-wide tile keeps 160 accumulator registers and is never gated: no prefetch registers there)
+    constexpr int NG = (ES == 2 && WNF <= 8) ? NIT : 1;
+    const bool gpf = ES == 2 && WNF <= 8 && fast_g && full && a.gate_prefetch && !a.ws;
+    u32x4_t gcur[NG], gnext[NG];
+    auto load_gates = [&](int pass, u32x4_t (&dst)[NG]) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int row = row0 + k * RG;
+            const int m = m0 + pass * 64 + row;
+            const bool ok = row0 < RG && row < 64 && m < a.M;
+            dst[k] = ok ? *(const u32x4_t*)(gate + (long)m * a.ldg + n) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    };
+    if (gpf) load_gates(0, gcur);
     for (int pass = 0; pass < 4; ++pass) {
+        if (gpf && pass + 1 < 4) load_gates(pass + 1, gnext);
         __syncthreads();
         if (wm == pass) {
 #pragma unroll
@@ -102,7 +121,11 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
                     *(f32x4_t*)&v[0] = *(const f32x4_t*)tp;
                     *(f32x4_t*)&v[4] = *(const f32x4_t*)(tp + 4);
                     float gv[8];
-                    if (gate) {
+                    if (gpf) {
+                        const T* qe = (const T*)&gcur[k < NG ? k : 0];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gv[e] = elem<T>::ld(qe + e);
+                    } else if (gate) {
                         const T* gp = gate + (long)m * a.ldg + n;
                         if (full && fast_g) {
                             if constexpr (ES == 2) {
@@ -154,6 +177,10 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
                     }
                 }
             }
+        }
+        if (gpf) {
+#pragma unroll
+            for (int k = 0; k < NG; ++k) gcur[k] = gnext[k];
         }
     }
     if (a.colsum && !a.ws) {
@@ -639,6 +666,7 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     WideArgs a;
     a.ws = nsplit > 1 ? ws : nullptr; a.nsplit = nsplit > 1 ? nsplit : 1;
     { static int stg = -1; if (stg < 0) { const char* e = getenv("SZN_WIDE_STAGGER"); stg = e ? atoi(e) : 1; } a.stagger = stg; }
+    { static int gp = -1; if (gp < 0) { const char* e = getenv("SZN_WIDE_GATEPF"); gp = e ? atoi(e) : 1; } a.gate_prefetch = gp; }
     a.chunks_per_split = nsplit > 1 ? chunks_per_split : (1 << 30);
     a.M = d->B * d->Ho * d->Wo;
     // cout tile 256, or 320 (bf16) when that wastes fewer columns: the 300-d projection is one 320-wide tile
@@ -704,7 +732,7 @@ int szn_proj_stream_try(const szn_conv_desc_t* d, const void* in, const void* w,
     a.M = d->B * d->Ho * d->Wo;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = 1; a.nmajor = 0;
     if (a.mtiles < min_tiles) return 1;
-    a.ws = nullptr; a.nsplit = 1; a.chunks_per_split = 1 << 30; a.stagger = 0;
+    a.ws = nullptr; a.nsplit = 1; a.chunks_per_split = 1 << 30; a.stagger = 0; a.gate_prefetch = 0;
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = nullptr; a.cscale = nullptr;
     a.out = (char*)out; a.colsum = nullptr; a.cslab = nullptr;
     a.in_bytes = 0; a.w_bytes = (unsigned)((size_t)d->Co * d->Ci * 2);

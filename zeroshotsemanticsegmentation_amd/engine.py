@@ -418,7 +418,14 @@ class TrainStep(object):
         pred = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
         stats = torch.empty(B, 2, device=self.dev)
         scaled = self.dynamic or self._loss_scale0 != 1.0
-        dcoarse = torch.zeros(B, ctx.h, ctx.w, CP, device=self.dev, dtype=torch.float32 if scaled else eng.dtype)
+        # d(loss)/d(coarse): the fused head writes channels [0, E) and the padding channels stay zero, so the buffer of the previous
+        # step is reused without a fill (everything that read it was queued on this stream -- or joined -- before this step)
+        key = (B, ctx.h, ctx.w, CP, torch.float32 if scaled else eng.dtype)
+        if self.fused_head and getattr(self, "_dcoarse_key", None) == key:
+            dcoarse = self._dcoarse
+        else:
+            dcoarse = torch.zeros(B, ctx.h, ctx.w, CP, device=self.dev, dtype=key[4])
+            self._dcoarse, self._dcoarse_key = (dcoarse, key) if self.fused_head else (None, None)
         code = L.dtype_code(dcoarse.dtype)
         if self.fused_head:
             nbytes = L.load().szn_fused_head_workspace_bytes(B, ctx.h, ctx.w, E, K)
