@@ -29,6 +29,9 @@ struct WideArgs {
     int nsplit, chunks_per_split;
     int stagger;               // 1: wave pairs take turns issuing the LDS-DMA loads of a chunk (SZN_WIDE_STAGGER=0: all at once)
     int gate_prefetch;         // 1: the epilogue fetches the ReLU-gate rows one pass ahead (SZN_WIDE_GATEPF=0: inside the store loop)
+    int direct_ep;             // 1: epilogue straight from the accumulator registers (wide_epilogue_direct)
+    int abl_ep;                // ablation builds only (SZN_WIDE_EPABL): 1 = epilogue without global stores / gate loads, 2 = no epilogue
+    int proj_abl;              // ablation builds only (SZN_PROJ_ABLATE): 1 = every block of proj_gemm_stream streams the rows of block 0
 };
 
 constexpr unsigned kOOBx = 0x80000000u;
@@ -49,7 +52,8 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
     constexpr int RG = 512 / CPR;                      // row groups (16 / 12; threads >= RG * CPR idle in the epilogue)
     constexpr int NIT = (64 + RG - 1) / RG;
     float* tile = (float*)smem;
-    const T* __restrict__ gate = (const T*)a.gate;
+    if (a.abl_ep == 2) return;
+    const T* __restrict__ gate = a.abl_ep ? nullptr : (const T*)a.gate;
     const bool out32 = a.out_f32 || sizeof(T) == 4;
     const int oes = out32 ? 4 : 2;
     const bool fast_o = (((long)a.ldo * oes) & 15) == 0;
@@ -152,7 +156,8 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
                         v[e] = x;
                         cs[e] += x;
                     }
-                    if (out32) {
+                    if (a.abl_ep) { if (v[0] == 1.2345e-33f) ((float*)a.out)[0] = v[1]; }
+                    else if (out32) {
                         float* o = (float*)a.out + (long)m * a.ldo + n;
                         if (full && fast_o) {
                             *(f32x4_t*)o = *(const f32x4_t*)&v[0];
@@ -198,6 +203,215 @@ __device__ __forceinline__ void wide_epilogue(const WideArgs& a, f32x4_t (&acc)[
             else if (t != 0.f) atomicAdd(a.colsum + n0 + tid, t);
         }
     }
+}
+
+
+__device__ __forceinline__ float row16_sum_w(float x) {                    // sum over the 16 lanes of a DPP row
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x140, 0xF, 0xF, true));   // row_mirror
+    return x;
+}
+
+// ---- epilogue straight from the accumulator registers (16-bit operands, Co a multiple of 8, 16-B aligned rows) ----------------
+// The LDS-staged epilogue above costs 10-13 us per 256 x 256 tile (SZN_WIDE_EPABL accounting, profiles/r03_ablations.txt section 4:
+// conv3_2 forward 0.305 ms, 0.299 without its global stores, 0.255 without the epilogue): four passes in which two of the eight
+// waves write 64 KiB into LDS while six wait at the barrier, then a branchy read-back loop.  Here nothing is staged: a lane of the
+// MFMA result holds 4 consecutive couts of one pixel for each cout fragment; v_permlane16_swap on a PAIR of fragments (the DPP rows
+// g and g ^ 1 exchange one fragment each) leaves 8 consecutive couts of one pixel in every lane -- column 16 (g & 1) + 8 (g >> 1) of
+// the 32-cout pair -- so bias / ReLU / gate / Dropout2d factor / column sums run on whole 16-B pieces and every lane stores one
+// 16-B piece (two for fp32 rows) per (pair, pixel fragment).  Gate pieces (dgrad: the forward activation) are loaded in the same
+// layout, the four of a pair up front.  No barrier unless column sums are wanted (bias gradient of the producer layer: DPP row sums ->
+// LDS -> thread c adds the four pixel groups in ascending order: fixed order, bit-reproducible).  Same arithmetic per element as the
+// staged epilogue: outputs are bit-identical; the column sums add the same terms in another order.
+template <typename T, int WNF, bool GATE, bool SCALE>
+__device__ __forceinline__ void wide_epilogue_direct(const WideArgs& a, f32x4_t (&acc)[WNF][4], char* smem, int tid, int wm, int wn,
+                                                     int g, int r16, int m0, int n0) {
+    static_assert(sizeof(T) == 2 && (WNF % 2) == 0, "16-bit storage, fragment pairs");
+    constexpr int BN = 32 * WNF, NP = WNF / 2;
+    const T* __restrict__ gate = (const T*)a.gate;
+    const bool out32 = a.out_f32 != 0;
+    const bool do_cs = a.colsum != nullptr;
+    const float lo = a.relu ? 0.f : -__builtin_inff();        // ReLU as max(x, lo): max(x, -inf) == x
+    const int cl = 16 * (g & 1) + 8 * (g >> 1);
+    const int nw = n0 + wn * (BN / 2) + cl;                    // column of this lane's piece in pair 0
+    int mrow[4];
+    bool okm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mrow[j] = m0 + wm * 64 + 16 * j + r16;
+        okm[j] = mrow[j] < a.M;
+    }
+    float* const pw = (float*)smem;                            // [8 waves][4 g][NP][8] row sums (column sums only)
+    if (do_cs) __syncthreads();                                // every wave has left the operand ring
+    // gfx950 counts loads AND stores in vmcnt, in issue order: a load issued behind the stores of the previous pair would make its
+    // s_waitcnt sit out those stores' round trip (16 times per tile).  Bias and gate pieces of pair p + 1 are therefore issued in
+    // front of the stores of pair p, and the wait in front of their first use is vmcnt(stores of p).
+    float bvn[8];
+    auto fetch = [&](int p) {
+        const int n = nw + 32 * p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bvn[e] = 0.f;
+        if (a.bias && n < a.Co) {                              // Co % 8 == 0: the whole piece is inside or outside
+            *(f32x4_t*)&bvn[0] = *(const f32x4_t*)(a.bias + n);
+            *(f32x4_t*)&bvn[4] = *(const f32x4_t*)(a.bias + n + 4);
+        }
+    };
+    // gate pieces (dgrad: 16 B of the forward activation per piece): a ring of two pairs, pair p + 2 is requested when pair p is done
+    // (all NP pairs up front need 16 NP registers beside the accumulators: spills)
+    u32x4_t gq[GATE ? 2 : 1][4];
+    auto fetch_gate = [&](int p, int slot) {
+        const int n = nw + 32 * p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            gq[slot][j] = (okm[j] && n < a.Co) ? *(const u32x4_t*)(gate + (long)mrow[j] * a.ldg + n) : u32x4_t{0u, 0u, 0u, 0u};
+    };
+    if constexpr (GATE) {
+        fetch_gate(0, 0);
+        if (NP > 1) fetch_gate(1, 1);
+    }
+    fetch(0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int n = nw + 32 * p;
+        const bool okn = n < a.Co;
+        float bv[8], cs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bv[e] = bvn[e]; cs[e] = 0.f; }
+        float sc[SCALE ? 4 : 1][8];
+        if constexpr (SCALE) {                                 // Dropout2d factor of (image, channel): fc7 only (few tiles)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sc[j][e] = 1.f;
+                if (okm[j] && okn) {
+                    const float* sp = a.cscale + (long)(mrow[j] / a.HoWo) * a.Co + n;
+                    *(f32x4_t*)&sc[j][0] = *(const f32x4_t*)sp;
+                    *(f32x4_t*)&sc[j][4] = *(const f32x4_t*)(sp + 4);
+                }
+            }
+        }
+        if (p + 1 < NP) fetch(p + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][j][c]), __float_as_uint(acc[2 * p + 1][j][c]),
+                                                                false, false);
+                v[c] = __uint_as_float(r[0]);
+                v[4 + c] = __uint_as_float(r[1]);
+            }
+            const bool ok = okm[j] && okn;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = fmaxf(v[e] + bv[e], lo);
+                if constexpr (GATE) {
+                    const uint32_t gw = gq[p & 1][j][e >> 1];
+                    const float gv = from_bits16<T>((uint16_t)((e & 1) ? (gw >> 16) : (gw & 0xffffu)));
+                    x = (gv > 0.f) ? x : 0.f;
+                }
+                if constexpr (SCALE) x *= sc[j][e];
+                v[e] = x;
+            }
+            if (do_cs) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[e] += ok ? v[e] : 0.f;
+            }
+            if (ok && !a.abl_ep) {
+                if (out32) {
+                    float* o = (float*)a.out + (long)mrow[j] * a.ldo + n;
+                    *(f32x4_t*)o = *(const f32x4_t*)&v[0];
+                    *(f32x4_t*)(o + 4) = *(const f32x4_t*)&v[4];
+                } else {
+                    u32x4_t pk;
+                    pk.x = pack2<T>(v[0], v[1]);
+                    pk.y = pack2<T>(v[2], v[3]);
+                    pk.z = pack2<T>(v[4], v[5]);
+                    pk.w = pack2<T>(v[6], v[7]);
+                    *(u32x4_t*)((uint16_t*)a.out + (long)mrow[j] * a.ldo + n) = pk;
+                }
+            }
+        }
+        if constexpr (GATE) {
+            if (p + 2 < NP) fetch_gate(p + 2, p & 1);
+        }
+        if (do_cs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = row16_sum_w(cs[e]);
+                if (r16 == 0) pw[((((wm * 2 + wn) * 4 + g) * NP) + p) * 8 + e] = x;
+            }
+        }
+    }
+    if (do_cs) {
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Co) {
+            const int wnc = tid / (BN / 2), rem = tid % (BN / 2);
+            const int pc = rem >> 5, r2 = rem & 31;
+            const int gc = (r2 >> 4) | (((r2 >> 3) & 1) << 1), ec = r2 & 7;        // inverse of cl = 16 (g & 1) + 8 (g >> 1)
+            float t = 0.f;
+#pragma unroll
+            for (int wmc = 0; wmc < 4; ++wmc) t += pw[((((wmc * 2 + wnc) * 4 + gc) * NP) + pc) * 8 + ec];
+            if (a.cslab) a.cslab[(long)(m0 >> 8) * a.Co + n0 + tid] = t;
+            else if (t != 0.f) atomicAdd(a.colsum + n0 + tid, t);
+        }
+    }
+}
+
+// split-K slab: the raw fp32 partial sums of this split, whole 32-B pieces per lane
+template <int WNF>
+__device__ __forceinline__ void wide_epilogue_raw(const WideArgs& a, f32x4_t (&acc)[WNF][4], int wm, int wn, int g, int r16, int m0,
+                                                  int n0, int split) {
+    constexpr int BN = 32 * WNF, NP = WNF / 2;
+    float* const slab = a.ws + (size_t)split * a.M * a.Co;
+    const int nw = n0 + wn * (BN / 2) + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int n = nw + 32 * p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + 16 * j + r16;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][j][c]), __float_as_uint(acc[2 * p + 1][j][c]),
+                                                                false, false);
+                v[c] = __uint_as_float(r[0]);
+                v[4 + c] = __uint_as_float(r[1]);
+            }
+            if (m < a.M && n < a.Co && !a.abl_ep) {
+                float* o = slab + (size_t)m * a.Co + n;
+                *(f32x4_t*)o = *(const f32x4_t*)&v[0];
+                *(f32x4_t*)(o + 4) = *(const f32x4_t*)&v[4];
+            }
+        }
+    }
+}
+
+template <typename T, int WNF>
+__device__ __forceinline__ void wide_finish(const WideArgs& a, f32x4_t (&acc)[WNF][4], char* smem, int tid, int wm, int wn,
+                                            int g, int r16, int m0, int n0, int split) {
+    if constexpr (sizeof(T) == 2) {
+        if (a.direct_ep) {
+            if constexpr (WNF == 10) {             // the 320-wide projection tile (160 accumulator registers): ungated rows only
+                if (!a.ws && !a.gate && !a.cscale) {
+                    wide_epilogue_direct<T, WNF, false, false>(a, acc, smem, tid, wm, wn, g, r16, m0, n0);
+                    return;
+                }
+            } else if (a.ws) wide_epilogue_raw<WNF>(a, acc, wm, wn, g, r16, m0, n0, split);
+            else if (a.gate) {
+                if (a.cscale) wide_epilogue_direct<T, WNF, true, true>(a, acc, smem, tid, wm, wn, g, r16, m0, n0);
+                else wide_epilogue_direct<T, WNF, true, false>(a, acc, smem, tid, wm, wn, g, r16, m0, n0);
+            } else {
+                if (a.cscale) wide_epilogue_direct<T, WNF, false, true>(a, acc, smem, tid, wm, wn, g, r16, m0, n0);
+                else wide_epilogue_direct<T, WNF, false, false>(a, acc, smem, tid, wm, wn, g, r16, m0, n0);
+            }
+            if constexpr (WNF != 10) return;
+        }
+    }
+    wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, split);
 }
 
 // ABL (debug, SZN_WIDE_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no fragment reads / MFMA
@@ -328,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wide(WideArgs a) {
         stage ^= 1;
     }
 
-    wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, split);
+    wide_finish<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, split);
 #endif
 }
 
@@ -483,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_rows(WideArgs a) {
         if (++ckw == 3) { ckw = 0; ++cgrp; if (++cic == cpt) { cic = 0; ctap_base += 3; } }
     }
 
-    wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, 0);
+    wide_finish<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, n0, 0);
 #endif
 }
 
@@ -524,7 +738,8 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_stream(WideArgs a) {
 
     // the activation resource covers this block's rows only (base = row m0): no 2 GB limit on the matrix, rows >= M fall outside
     const int rows = min(BM, a.M - m0);
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)m0 * a.ldi * 2), 0, (int)((size_t)rows * a.ldi * 2), 0x00020000);
+    const size_t abase = a.proj_abl == 1 ? 0 : (size_t)m0 * a.ldi * 2;     // ablation 1: every block streams the rows of block 0 (L2 hits)
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + abase), 0, (int)((size_t)rows * a.ldi * 2), 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
 
     // activations: wave w fills pixel rows 32 w .. 32 w + 31, one instruction = 8 rows x 128 B (lane -> row lane >> 3, 16-B chunk
@@ -595,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_stream(WideArgs a) {
             for (int j = 0; j < 4; ++j) acc[WNF - 1][j] = mfma16<T>(wf[WNF - 1], pf[j], acc[WNF - 1][j]);
         }
     }
-    wide_epilogue<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, 0, 0);
+    wide_finish<T, WNF>(a, acc, smem, tid, wm, wn, g, r16, m0, 0, 0);
 #endif
 }
 
@@ -664,6 +879,8 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
                       float* ws, int nsplit, int chunks_per_split, szn_stream_t stream) {
     if (d->Co < 256) return 1;
     WideArgs a;
+    a.proj_abl = 0;
+    { static int ea = -1; if (ea < 0) ea = szn_ablate_env("SZN_WIDE_EPABL"); a.abl_ep = ea; }
     a.ws = nsplit > 1 ? ws : nullptr; a.nsplit = nsplit > 1 ? nsplit : 1;
     { static int stg = -1; if (stg < 0) { const char* e = getenv("SZN_WIDE_STAGGER"); stg = e ? atoi(e) : 1; } a.stagger = stg; }
     { static int gp = -1; if (gp < 0) { const char* e = getenv("SZN_WIDE_GATEPF"); gp = e ? atoi(e) : 1; } a.gate_prefetch = gp; }
@@ -699,6 +916,15 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
     a.relu = d->relu; a.out_f32 = d->out_f32; a.HoWo = d->Ho * d->Wo;
     {
+        // epilogue from registers (wide_epilogue_direct): whole 16-B pieces of 8 couts, so rows and bases have to be 16-B aligned
+        static int de = -1;
+        if (de < 0) { const char* e = getenv("SZN_WIDE_DIRECT"); de = e ? atoi(e) : 1; }
+        const size_t oes = (d->out_f32 || a.ws) ? 4 : 2;
+        const uintptr_t al = (uintptr_t)out | (uintptr_t)gate | (uintptr_t)bias | (uintptr_t)chan_scale | (uintptr_t)a.ws;
+        a.direct_ep = de && szn_is16(d->dtype) && (d->Co % 8) == 0 && (((size_t)d->ldo * oes) & 15) == 0 && (al & 15) == 0 &&
+                      (!gate || (((size_t)d->ldg * 2) & 15) == 0);
+    }
+    {
         static int rows = -1;
         if (rows < 0) { const char* e = getenv("SZN_WIDE_ROWS"); rows = e ? atoi(e) : 1; }
         if (rows && bn == 256 && szn_is16(d->dtype) && a.nsplit == 1 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->Hi == d->Ho &&
@@ -733,6 +959,15 @@ int szn_proj_stream_try(const szn_conv_desc_t* d, const void* in, const void* w,
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = 1; a.nmajor = 0;
     if (a.mtiles < min_tiles) return 1;
     a.ws = nullptr; a.nsplit = 1; a.chunks_per_split = 1 << 30; a.stagger = 0; a.gate_prefetch = 0;
+    {
+        static int abl = -1;
+        if (abl < 0) abl = szn_ablate_env("SZN_PROJ_ABLATE");
+        a.proj_abl = abl; a.abl_ep = 0;
+        static int de = -1;
+        if (de < 0) { const char* e = getenv("SZN_WIDE_DIRECT"); de = e ? atoi(e) : 1; }
+        const size_t oes = d->out_f32 ? 4 : 2;
+        a.direct_ep = de && (d->Co % 8) == 0 && (((size_t)d->ldo * oes) & 15) == 0 && (((uintptr_t)out | (uintptr_t)bias) & 15) == 0;
+    }
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = nullptr; a.cscale = nullptr;
     a.out = (char*)out; a.colsum = nullptr; a.cslab = nullptr;
     a.in_bytes = 0; a.w_bytes = (unsigned)((size_t)d->Co * d->Ci * 2);
