@@ -19,6 +19,7 @@
 // The dispatcher tries the specialised kernels first (szn_conv_regw.hip: 64/128-channel 3x3 layers; szn_conv_wide.hip:
 // >= 256 couts) and falls back to the register-staged kernel of szn_conv.hip for tensors >= 2 GiB / odd strides.
 #include "szn_common.h"
+#include "szn_epilogue.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
@@ -67,6 +68,8 @@ struct Conv2Args {
     int M, HoWo, mtiles, ntiles, nsplit, chunks_per_split;
     int nmajor;                // tile order: 1 = pixel tile fastest (weights larger than activations)
     int stagger;               // 1: wave pairs take turns issuing a chunk's LDS-DMA loads (SZN_IGEMM_STAGGER=0: all at once)
+    int direct_ep;             // 1: epilogue straight from the accumulator registers (szn_epilogue.h)
+    int abl_ep;                // always 0 here (the accounting switch of the wide kernels)
 };
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
@@ -296,6 +299,19 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v2(Conv2Args a) {
         if (keep == 123.456f) ((float*)a.out)[0] = keep;
         return;
     }
+    // ---- epilogue from registers (16-bit operands, aligned rows: szn_epilogue.h); the staged one below is the general path ----
+    if constexpr (sizeof(T) == 2) {
+        if (a.direct_ep) {
+            if (a.gate) {
+                if (a.cscale) tile_epilogue_direct<T, WNF, true, true>(a, acc, smem, tid, wm, wn, g, r16, m0, n0);
+                else tile_epilogue_direct<T, WNF, true, false>(a, acc, smem, tid, wm, wn, g, r16, m0, n0);
+            } else {
+                if (a.cscale) tile_epilogue_direct<T, WNF, false, true>(a, acc, smem, tid, wm, wn, g, r16, m0, n0);
+                else tile_epilogue_direct<T, WNF, false, false>(a, acc, smem, tid, wm, wn, g, r16, m0, n0);
+            }
+            return;
+        }
+    }
     // ---- epilogue staged through LDS: the MFMA layout gives each lane 4 couts of 16 different pixels (8-B pieces at a
     // Co-row stride: measured 2x the kernel time on the 710^2 / 355^2 layers); instead the fp32 tile goes to LDS
     // (pitch BN+4 floats: conflict-free float4 writes) and is written out as whole rows, 8 couts (16 B bf16) per lane,
@@ -523,6 +539,16 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     a.relu = d->relu; a.out_f32 = d->out_f32;
     a.M = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo;
     { static int stg = -1; if (stg < 0) { const char* e = getenv("SZN_IGEMM_STAGGER"); stg = e ? atoi(e) : 1; } a.stagger = stg; }
+    {
+        // epilogue from registers (szn_epilogue.h): whole 16-B pieces of 8 couts, so rows and bases have to be 16-B aligned
+        static int de = -1;
+        if (de < 0) { const char* e = getenv("SZN_IGEMM_DIRECT"); de = e ? atoi(e) : 1; }
+        const size_t oes = d->out_f32 ? 4 : 2;
+        const uintptr_t al = (uintptr_t)out | (uintptr_t)gate | (uintptr_t)bias | (uintptr_t)chan_scale;
+        a.direct_ep = de && szn_is16(d->dtype) && (d->Co % 8) == 0 && (((size_t)d->ldo * oes) & 15) == 0 && (al & 15) == 0 &&
+                      (!gate || (((size_t)d->ldg * 2) & 15) == 0);
+        a.abl_ep = 0;
+    }
     { static int nm = -1; if (nm < 0) { const char* e = getenv("SZN_NMAJOR"); nm = e ? atoi(e) : 0; } a.nmajor = (nm && w_bytes > in_bytes) ? 1 : 0; }   // measured slower on fc6/fc7: off
     const bool narrow = d->Co <= 64;
     const int BN = narrow ? 64 : 128;
