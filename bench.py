@@ -239,15 +239,21 @@ def _workload(args, torch, rank=0):
 
 def _time_steps(torch, fn, steps, warmup):
     """ms per call of fn(): HIP events on the current stream around `steps` calls"""
+    import gc
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()                     # a generation-2 pass over the bench's event lists is a 10-20 ms host stall inside a 30 ms region
+    try:
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        gc.enable()
     return e0.elapsed_time(e1) / steps
 
 
@@ -531,6 +537,9 @@ def main():
         if tot:
             dom_k = max(tot, key=tot.get)
             dom_ord[0] = {k for (_, _, _, kern, _, _, k) in learn_events if kern == dom_k}
+    import gc
+    gc.collect()
+    gc.disable()                         # no collector pause inside the timed region (re-enabled right behind it)
     sync()
     mode[0] = "dominant"
     t0 = time.perf_counter()
@@ -540,6 +549,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     mode[0] = "off"
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
