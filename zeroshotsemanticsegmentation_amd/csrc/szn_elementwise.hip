@@ -163,6 +163,130 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
 #endif
 }
 
+// 16-bit variant (round 3): the fp32 MFMA above needs 28 x 32 = 896 matrix-pipe cycles per 16-pixel segment and ran the layer at
+// 0.19 ms for a 516 MB output that a plain fill writes in 0.08 ms (tools/probe_hbm.py: 6.8 TB/s).  Here the image values and the
+// filter bank are rounded to the storage type -- what every other layer of the 16-bit path does with its operands, and what the
+// fused conv1_1 wgrad already does with the image -- and K = 27 (padded to 32) is ONE v_mfma_f32_16x16x32 per cout fragment:
+// lane (r16, g) supplies taps 8 g .. 8 g + 7 of pixel r16.  Segments whose nine taps are all inside the image (wave-uniform test)
+// load without per-tap bounds checks; segments that only see padding store a constant computed once per wave.
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_1_fwd16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, T* __restrict__ out, int B,
+                                                            int H, int W, int pad, int Ho, int Wo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(T) == 2, "16-bit storage only");
+    const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
+    const long plane = (long)H * W;
+    u32x4_t wa[4];                                       // A fragments: couts 16 i + r16, taps 8 g .. 8 g + 7 (t >= 27: zero)
+    int toff[8], tdhw[8];                                // image offset of tap e relative to (ci 0, ih0, iw0); kh << 8 | kw, -1 = pad tap
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int t = 8 * g + e;                         // (kh*3+kw)*3+ci, the OHWI order of w
+        const int tt = t < 27 ? t : 0;
+        const int kh = tt / 9, kw = (tt / 3) % 3, ci = tt % 3;
+        toff[e] = (int)(ci * plane + (long)kh * W + kw);
+        tdhw[e] = t < 27 ? ((kh << 8) | kw) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = (8 * g + e < 27) ? w[(16 * i + r16) * 27 + 8 * g + e] : 0.f;
+        wa[i] = u32x4_t{pack2<T>(wv[0], wv[1]), pack2<T>(wv[2], wv[3]), pack2<T>(wv[4], wv[5]), pack2<T>(wv[6], wv[7])};
+    }
+    float bv[2][8];
+    int cst[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        cst[p] = 32 * p + (g & 1) * 16 + (g >> 1) * 8;   // first of the 8 consecutive couts this lane holds after the swap
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[p][e] = bias ? bias[cst[p] + e] : 0.f;
+    }
+    const bool lo = r16 < 8;
+    // pieces of a padding-only segment: relu(bias) in the store layout (lanes r16 < 8 hold couts cst[0] .. + 7, the others cst[1] .. + 7)
+    u32x4_t cpiece;
+    {
+        const int p = lo ? 0 : 1;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(lo ? bv[0][e] : bv[1][e], 0.f);
+        (void)p;
+        cpiece = u32x4_t{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+    }
+    // a wave takes runs of SEGS consecutive 16-pixel segments of one output row (2 KiB of output each): one division pair per run
+    // (the per-segment 64-bit index arithmetic of the fp32 kernel cost more than its MFMAs), contiguous stores
+    constexpr int SEGS = 8;
+    const int nsx = (Wo + 15) >> 4, nch = (nsx + SEGS - 1) / SEGS;
+    const int ntask = B * Ho * nch;
+    const int nwaves = (int)gridDim.x * 4;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    for (int task = wave0; task < ntask; task += nwaves) {
+      const int ch = task % nch, rowid = task / nch;
+      const int oh = rowid % Ho, b = rowid / Ho;
+      const int ih0 = oh - pad;
+      const int sx_end = min(nsx, (ch + 1) * SEGS);
+      const bool rowhit = (ih0 + 2 >= 0) && (ih0 < H);
+      const float* xrow = x + (long)b * 3 * plane + (long)ih0 * W + r16;
+      T* orow = out + (((long)b * Ho + oh) * Wo) * 64 + (lo ? cst[0] : cst[1]);
+      // (two segments per iteration and the next segments' loads issued ahead of the stores were both measured: no change)
+      for (int sx = ch * SEGS; sx < sx_end; ++sx) {
+        const int iw0 = sx * 16 - pad;
+        const int owa = sx * 16 + (r16 & 7);
+        T* op = orow + (long)owa * 64;
+        const bool touches = rowhit && (iw0 + 17 >= 0) && (iw0 < W);                            // wave-uniform
+        if (!touches) {
+            if (owa < Wo) *(u32x4_t*)op = cpiece;
+            if (owa + 8 < Wo) *(u32x4_t*)(op + 8 * 64) = cpiece;
+            continue;
+        }
+        const float* xb = xrow + iw0;
+        float xv[8];
+        const bool inner = ih0 >= 0 && ih0 + 2 < H && iw0 >= 0 && iw0 + 17 < W;                 // wave-uniform: every tap of every pixel inside
+        if (inner) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = xb[toff[e]];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ih = ih0 + (tdhw[e] >> 8), iw = iw0 + r16 + (tdhw[e] & 255);
+                const bool ok = tdhw[e] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                xv[e] = ok ? xb[toff[e]] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = tdhw[e] >= 0 ? xv[e] : 0.f;                         // lane-constant mask: taps 27 .. 31 are padding
+        const u32x4_t xf = u32x4_t{pack2<T>(xv[0], xv[1]), pack2<T>(xv[2], xv[3]), pack2<T>(xv[4], xv[5]), pack2<T>(xv[6], xv[7])};
+        f32x4_t acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = mfma16<T>(wa[i], xf, f32x4_t{0.f, 0.f, 0.f, 0.f});
+        // 16-bit rows are 128 B: lanes r16 < 8 and r16 >= 8 exchange one 16-B piece (row_ror:8), so that ONE store instruction
+        // writes the whole 128-B line of pixels 0..7 (the other one of pixels 8..15)
+        u32x4_t v2[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][c]), __float_as_uint(acc[2 * p + 1][c]), false, false);
+                v[c] = fmaxf(__uint_as_float(r[0]) + bv[p][c], 0.f);
+                v[4 + c] = fmaxf(__uint_as_float(r[1]) + bv[p][4 + c], 0.f);
+            }
+            v2[p] = u32x4_t{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+        }
+        const u32x4_t send = lo ? v2[1] : v2[0];
+        u32x4_t recv;
+        recv.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.x, 0x128, 0xf, 0xf, false);
+        recv.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.y, 0x128, 0xf, 0xf, false);
+        recv.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.z, 0x128, 0xf, 0xf, false);
+        recv.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.w, 0x128, 0xf, 0xf, false);
+        const u32x4_t va = lo ? v2[0] : recv, vb = lo ? recv : v2[1];
+        if (owa < Wo) *(u32x4_t*)op = va;
+        if (owa + 8 < Wo) *(u32x4_t*)(op + 8 * 64) = vb;
+      }
+    }
+#endif
+}
+
 // conv1_1 wgrad = a 1x1-conv wgrad on the im2col image: xcol[m][t] = x[b][ci][oh+kh-pad][ow+kw-pad], t = (kh*3+kw)*3+ci
 // (27 taps padded to 32 "channels"), so the MFMA wgrad kernel does the reduction over the B*Ho*Wo pixels.
 template <typename T>
@@ -450,7 +574,19 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
     const long nseg = (long)B * Ho * ((Wo + 15) / 16);     // 16-pixel segments, one wave each (grid-stride)
     long blocks = (nseg + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    if (dtype == SZN_BF16)
+    static int mm16 = -1;          // SZN_CONV1_1_F32MMA=1: the 16-bit paths keep fp32 image / filter operands (rounds 1-2 behaviour)
+    if (mm16 < 0) { const char* e = getenv("SZN_CONV1_1_F32MMA"); mm16 = (e && atoi(e)) ? 0 : 1; }
+    const long ntask = (long)B * Ho * (((Wo + 15) / 16 + 7) / 8);       // runs of 8 segments, one wave each (grid-stride)
+    long blocks16 = (ntask + 3) / 4;
+    if (blocks16 > 256 * 16) blocks16 = 256 * 16;
+    if (ntask >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd: output too large");
+    if (dtype == SZN_BF16 && mm16)
+        hipLaunchKernelGGL(conv1_1_fwd16_kernel<bf16_raw>, dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (bf16_raw*)out, B, H, W, pad, Ho, Wo);
+    else if (dtype == SZN_F16 && mm16)
+        hipLaunchKernelGGL(conv1_1_fwd16_kernel<f16_raw>, dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (f16_raw*)out, B, H, W, pad, Ho, Wo);
+    else if (dtype == SZN_BF16)
         hipLaunchKernelGGL(conv1_1_fwd_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                            (bf16_raw*)out, B, H, W, pad, Ho, Wo);
     else if (dtype == SZN_F16)
