@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Time line of ONE train step from a rocprofv3 (rocpd sqlite) kernel trace: every dispatch in start order with the idle gap in
 front of it, the busy / idle totals of the step and the kernels launched by torch itself (at::native / rocclr) with their neighbours.
-usage: tools/prof_timeline.py <results.db> <out.md> [anchor-kernel-substring = conv1_1_fwd_kernel]"""
+usage: tools/prof_timeline.py <results.db> <out.md> [anchor-kernel-substring = conv1_1_fwd]"""
 import re
 import sqlite3
 import sys
@@ -15,7 +15,7 @@ def short(n):
 
 def main():
     db, out = sys.argv[1:3]
-    anchor = sys.argv[3] if len(sys.argv) > 3 else "conv1_1_fwd_kernel"
+    anchor = sys.argv[3] if len(sys.argv) > 3 else "conv1_1_fwd"
     con = sqlite3.connect(db)
     cur = con.cursor()
     names = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
