@@ -44,13 +44,28 @@ __global__ __launch_bounds__(256) void fh_prep_kernel(const float* __restrict__ 
         const int k = i % KP, c = i / KP;
         embT[i] = (k < K) ? embed[(size_t)k * E + c] : 0.f;
     }
-    if (blockIdx.x == 0 && threadIdx.x < KP) {
-        const int k = threadIdx.x;
+    if (blockIdx.x == 0) {
+        // norms: thread k walks its row in ascending order (the order is part of the arithmetic contract with the oracle).  The
+        // rows are staged through LDS in slices first: as a chain of dependent global loads the 300 steps took ~25 us.
+        __shared__ float row[64][65];
         float s = 0.f;
-        if (k < K) for (int c = 0; c < E; ++c) s = fmaf(embed[(size_t)k * E + c], embed[(size_t)k * E + c], s);
-        const float n = sqrtf(s);
-        en[k] = (n == 0.f) ? 1.f : n;
-        ent[k] = n;
+        const int k = threadIdx.x;
+        for (int c0 = 0; c0 < E; c0 += 64) {
+            const int n = min(64, E - c0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+                const int kk = i >> 6, c = i & 63;
+                row[kk][c] = (kk < K && c < n) ? embed[(size_t)kk * E + c0 + c] : 0.f;
+            }
+            __syncthreads();
+            if (k < K)
+                for (int c = 0; c < n; ++c) s = fmaf(row[k][c], row[k][c], s);
+        }
+        if (k < KP) {
+            const float nrm = sqrtf(s);
+            en[k] = (nrm == 0.f) ? 1.f : nrm;
+            ent[k] = nrm;
+        }
     }
 }
 
@@ -89,7 +104,16 @@ __global__ __launch_bounds__(256) void fh_cell_kernel(FhArgs a) {
     if (lane < KP) {
         float g = 0.f;
         const float* ct = Ct + wave * a.E;
-        for (int c = 0; c < a.E; ++c) g = fmaf(ct[c], embT[(size_t)c * KP + lane], g);
+        // (the chain is sequential by contract; 20 independent L2 loads per batch keep it fed)
+        int c = 0;
+        for (; c + 20 <= a.E; c += 20) {
+            float ev[20];
+#pragma unroll
+            for (int u = 0; u < 20; ++u) ev[u] = embT[(size_t)(c + u) * KP + lane];
+#pragma unroll
+            for (int u = 0; u < 20; ++u) g = fmaf(ct[c + u], ev[u], g);
+        }
+        for (; c < a.E; ++c) g = fmaf(ct[c], embT[(size_t)c * KP + lane], g);
         G[wave * KP + lane] = g;
     }
     // Q[t][t']: wave t computes its row; lanes stride over c, fixed-order wave reduction
