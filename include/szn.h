@@ -145,7 +145,10 @@ int szn_gemm_proj_wgrad(int dtype, long M, int K, int N, int ldd, const void* x,
                         float* dw, int accumulate, szn_stream_t stream);
 
 /* ---- conv1_1: 3 -> 64 channels, 3x3, pad 100, reads the NCHW f32 image directly ----------------
- * models.py:43,116 (+ ReLU models.py:44).  w is OHWI f32 [64][3][3][3], out NHWC dtype.           */
+ * models.py:43,116 (+ ReLU models.py:44).  w is OHWI f32 [64][3][3][3], out NHWC dtype.
+ * dtype SZN_F32: exact fp32 products (v_mfma_f32_16x16x4_f32).  SZN_BF16 / SZN_F16: image values and filters are rounded to the
+ * storage type before the 16-bit MFMA, fp32 accumulation -- the arithmetic of every other layer on those paths (max error against
+ * fp32 on pixel-valued inputs 4e-3 / 6e-4 of the output range); SZN_CONV1_1_F32MMA=1 keeps fp32 operands there too.             */
 int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const float* x_nchw, const float* w,
                     const float* bias, void* out, szn_stream_t stream);
 /* dw[64][3][3][3], db[64] from dout (already ReLU-gated) -- no dgrad: the image needs no gradient.
