@@ -431,3 +431,62 @@ def test_proj_gemm_stream(dt, M, out32, N):
         got = outs[0][s:s + 65536, :N].float()
         worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
     assert worst < (2e-4 if out32 else 6e-3), worst
+
+
+_EPILOGUE_PROBE = r'''
+import ctypes as C, hashlib, sys, torch
+sys.path.insert(0, %r)
+from zeroshotsemanticsegmentation_amd import _lib as L
+torch.manual_seed(7)
+dt = L.dtype_code(torch.bfloat16)
+out_lines = []
+# (B, Hi, Ci, Co, K, pad): wide_rows (3x3, 256 couts), igemm_wide 192-tiles (1x1, few tiles), igemm_v2 (128 couts), ragged sizes
+for (B, Hi, Ci, Co, K, pad) in [(2, 47, 256, 256, 3, 1), (8, 89, 128, 256, 3, 1), (8, 17, 512, 4096, 1, 0), (2, 45, 512, 128, 3, 1),
+                                (1, 33, 64, 320, 1, 0)]:
+    Ho = Hi + 2 * pad - K + 1
+    x = torch.randn(B, Hi, Hi, Ci, device="cuda").bfloat16()
+    w = (torch.randn(Co, K, K, Ci, device="cuda") / (Ci * K * K) ** 0.5).bfloat16()
+    bias = torch.randn(Co, device="cuda")
+    gate = torch.relu(torch.randn(B, Hi, Hi, Ci, device="cuda")).bfloat16()
+    scale = (torch.rand(B, Co, device="cuda") > 0.5).float() * 2
+    out = torch.zeros(B, Ho, Ho, Co, device="cuda", dtype=torch.bfloat16)
+    d = L.ConvDesc(dt, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, pad, Ci, Co, Ci, 1, 0)
+    L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, L.ptr(scale) if K == 1 else None, L.ptr(out), L.stream_ptr())
+    k1 = L.last_kernel()
+    wT = torch.empty(Ci, K, K, Co, device="cuda", dtype=torch.bfloat16)
+    L.call("szn_pack_weight_dgrad", dt, Co, K, K, Ci, L.ptr(w), L.ptr(wT), L.stream_ptr())
+    dout = torch.randn(B, Ho, Ho, Co, device="cuda").bfloat16()
+    din = torch.zeros(B, Hi, Hi, Ci, device="cuda", dtype=torch.bfloat16)
+    cs = torch.zeros(Ci, device="cuda"); slab = torch.zeros(4096, Ci, device="cuda")
+    d2 = L.ConvDesc(dt, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, pad, Ci, Co, Ci, 0, 0)
+    d2.colsum, d2.colsum_slab, d2.colsum_slab_rows = cs.data_ptr(), slab.data_ptr(), 4096
+    L.call("szn_conv2d_dgrad", C.byref(d2), L.ptr(dout), L.ptr(wT), L.ptr(gate), None, L.ptr(din), L.stream_ptr())
+    k2 = L.last_kernel()
+    torch.cuda.synchronize()
+    h = hashlib.sha256(out.view(torch.int16).cpu().numpy().tobytes() + din.view(torch.int16).cpu().numpy().tobytes()).hexdigest()
+    out_lines.append("%%s %%s %%s %%.6e" %% (h, k1, k2, float(slab.sum())))
+print("\n".join(out_lines))
+'''
+
+
+def test_register_epilogue_equals_the_staged_epilogue_bit_for_bit():
+    """the epilogue from the accumulator registers (szn_epilogue.h) and the LDS-staged one it replaced write the same bits
+    (forward: bias + ReLU (+ Dropout2d factor); dgrad: gate + column sums, whose ORDER differs: compared to 1e-5)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for tag, env in (("direct", {}), ("staged", {"SZN_WIDE_DIRECT": "0", "SZN_IGEMM_DIRECT": "0"})):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _EPILOGUE_PROBE % root], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[tag] = [ln.split() for ln in r.stdout.strip().splitlines() if len(ln.split()) == 4]
+    assert len(runs["direct"]) == 5 and len(runs["staged"]) == 5, (runs,)
+    kernels = set()
+    for a, b in zip(runs["direct"], runs["staged"]):
+        assert a[0] == b[0], (a, b)                      # outputs + input gradients: same bits
+        assert a[1] == b[1] and a[2] == b[2], (a, b)     # same kernels picked
+        assert abs(float(a[3]) - float(b[3])) <= 1e-5 * max(1.0, abs(float(b[3]))), (a, b)
+        kernels.update((a[1], a[2]))
+    assert {"conv3x3_wide_rows", "conv_igemm_wide", "conv_igemm_v2"} <= kernels, kernels
