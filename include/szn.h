@@ -112,6 +112,15 @@ int szn_conv2d_dgrad(const szn_conv_desc_t* d, const void* dout, const void* wT,
 size_t szn_conv2d_dgrad_gemm_workspace_bytes(const szn_conv_desc_t* d);
 int szn_conv2d_dgrad_gemm(const szn_conv_desc_t* d, const void* dout, const void* wG, void* din,
                           szn_stream_t stream);
+/* The same dgrad on the filter bank in its FORWARD layout w [Co][KH][KW][Ci] (no transposed copy per optimizer step: for fc6 that copy
+ * is 205 MB in + 205 MB out): Y = dout x w runs on the two-K-major-operand kernel of the wide weight gradient with A = dout^T (only the
+ * small dout is transposed, into the workspace).  16-bit dtypes, dense dout (ldo == Co), B*Ho*Wo a multiple of 8 and >= 256, enough
+ * 256 x 256 tiles: szn_conv2d_dgrad_gemm_native_supported(d) says whether this shape qualifies (callers fall back to
+ * szn_conv2d_dgrad_gemm otherwise).  Workspace: szn_conv2d_dgrad_gemm_native_workspace_bytes(d) (Y fp32 | dout^T).             */
+int szn_conv2d_dgrad_gemm_native_supported(const szn_conv_desc_t* d);
+size_t szn_conv2d_dgrad_gemm_native_workspace_bytes(const szn_conv_desc_t* d);
+int szn_conv2d_dgrad_gemm_native(const szn_conv_desc_t* d, const void* dout, const void* w, void* din,
+                                 szn_stream_t stream);
 
 /* dw[co][kh][kw][ci] (+)= sum_pixels dout[p][co] * in[p shifted by (kh,kw)][ci]   (fp32, OHWI)
  * accumulate != 0 adds into dw (split-K partial sums are added with fp32 atomics; dw must then be

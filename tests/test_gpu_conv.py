@@ -490,3 +490,38 @@ def test_register_epilogue_equals_the_staged_epilogue_bit_for_bit():
         assert abs(float(a[3]) - float(b[3])) <= 1e-5 * max(1.0, abs(float(b[3]))), (a, b)
         kernels.update((a[1], a[2]))
     assert {"conv3x3_wide_rows", "conv_igemm_wide", "conv_igemm_v2"} <= kernels, kernels
+
+
+@pytest.mark.parametrize("geom", [(8, 23, 512, 1024, 7), (4, 28, 128, 128, 5)])
+def test_dgrad_gemm_on_the_forward_weight_layout(geom):
+    """szn_conv2d_dgrad_gemm_native (GEMM on the filter bank as the forward pass stores it, dout transposed instead) ==
+    szn_conv2d_dgrad_gemm on the packed transpose, to fp32 accumulation order, and both == torch"""
+    B, Hi, Ci, Co, K = geom
+    Ho = Hi - K + 1
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5).bfloat16().float()
+    dout = torch.randn(B, Co, Ho, Ho, generator=g).bfloat16().float()
+    ref = torch.nn.grad.conv2d_input((B, Ci, Hi, Hi), w, dout)
+    dt = L.dtype_code(torch.bfloat16)
+    wd, dd = nhwc(w).cuda().bfloat16(), nhwc(dout).cuda().bfloat16()
+    N = K * K * Ci
+    d = L.ConvDesc(dt, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, 0, Ci, Co, 0, 0, 0)
+    lib = L.load()
+    assert lib.szn_conv2d_dgrad_gemm_native_supported(C.byref(d)) == 1
+    ws = torch.empty(lib.szn_conv2d_dgrad_gemm_native_workspace_bytes(C.byref(d)), dtype=torch.uint8, device="cuda")
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    din = torch.empty(B, Hi, Hi, Ci, device="cuda", dtype=torch.bfloat16)
+    L.call("szn_conv2d_dgrad_gemm_native", C.byref(d), L.ptr(dd), L.ptr(wd), L.ptr(din), L.stream_ptr())
+    assert L.last_kernel() == "col2im_kernel" and L.prev_kernel() == "conv_wgrad_wide", (L.prev_kernel(), L.last_kernel())
+    torch.cuda.synchronize()
+    wG = torch.empty(N, Co, device="cuda", dtype=torch.bfloat16)
+    L.call("szn_pack_weight_dgrad", dt, Co, 1, 1, N, L.ptr(wd), L.ptr(wG), L.stream_ptr())
+    din2 = torch.empty_like(din)
+    L.call("szn_conv2d_dgrad_gemm", C.byref(d), L.ptr(dd), L.ptr(wG), L.ptr(din2), L.stream_ptr())
+    torch.cuda.synchronize()
+    a, b2 = din.float().cpu().permute(0, 3, 1, 2), din2.float().cpu().permute(0, 3, 1, 2)
+    assert relerr(a, ref) < 1e-2 and relerr(b2, ref) < 1e-2
+    assert relerr(a, b2) < 4e-3                       # both round the same fp32 sums (different order) to bf16
+    # a shape the two-K-major kernel does not take (too few pixels): the caller has to use the packed form
+    d3 = L.ConvDesc(dt, 1, 8, 8, 64, 2, 2, 256, 7, 7, 0, 64, 256, 0, 0, 0)
+    assert lib.szn_conv2d_dgrad_gemm_native_supported(C.byref(d3)) == 0

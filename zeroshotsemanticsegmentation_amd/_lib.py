@@ -47,6 +47,9 @@ SIGNATURES = {
     "szn_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "szn_conv2d_dgrad_gemm_workspace_bytes": (C.c_size_t, [_D]),
     "szn_conv2d_dgrad_gemm": (_I, [_D, _P, _P, _P, _P]),
+    "szn_conv2d_dgrad_gemm_native_supported": (_I, [_D]),
+    "szn_conv2d_dgrad_gemm_native_workspace_bytes": (C.c_size_t, [_D]),
+    "szn_conv2d_dgrad_gemm_native": (_I, [_D, _P, _P, _P, _P]),
     "szn_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "szn_bias_grad": (_I, [_I, _L, _I, _I, _P, _P, _I, _P]),
     "szn_bias_grad_slab": (_I, [_I, _L, _I, _I, _P, _P, _I, _P, _I, _P]),

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256) void pack_dgrad16_kernel(const uint16_t* __res
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int r = r0 + 32 * p;
-        const uint4 v = *(const uint4*)(w + ((long)((co0 + r) * KH + kh) * KW + kw) * Ci + ci0 + c8 * 8);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);                    // (rows past a ragged Co: Co is a multiple of 8 there, not of 64)
+        if (co0 + r < Co) v = *(const uint4*)(w + ((long)((co0 + r) * KH + kh) * KW + kw) * Ci + ci0 + c8 * 8);
         uint32_t* d32 = (uint32_t*)&tile[r][c8 * 8];             // row pitch 132 B: 4-B aligned
         d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
     }
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void pack_dgrad16_kernel(const uint16_t* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             o[e] = (uint32_t)tile[c8 * 8 + 2 * e][ci] | ((uint32_t)tile[c8 * 8 + 2 * e + 1][ci] << 16);
-        *(uint4*)(wT + ((long)(ci0 + ci) * KH * KW + tapT) * Co + co0 + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (co0 + c8 * 8 < Co) *(uint4*)(wT + ((long)(ci0 + ci) * KH * KW + tapT) * Co + co0 + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -566,8 +567,8 @@ extern "C" int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, 
                                      szn_stream_t stream) {
     if (!w || !wT || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) SZN_FAIL(SZN_ERR_ARG, "pack_weight_dgrad: bad argument");
     dim3 grid(szn_div_up(Ci, 32), szn_div_up(Co, 32), KH * KW);
-    if (szn_is16(dtype) && (Co & 63) == 0 && (Ci & 63) == 0 && !(((uintptr_t)w | (uintptr_t)wT) & 15)) {
-        hipLaunchKernelGGL(pack_dgrad16_kernel, dim3(Ci / 64, Co / 64, KH * KW), dim3(256), 0, (hipStream_t)stream,
+    if (szn_is16(dtype) && (Co & 7) == 0 && (Ci & 63) == 0 && !(((uintptr_t)w | (uintptr_t)wT) & 15)) {
+        hipLaunchKernelGGL(pack_dgrad16_kernel, dim3(Ci / 64, (Co + 63) / 64, KH * KW), dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t*)w, (uint16_t*)wT, Co, KH, KW, Ci);
         SZN_CHECK_LAUNCH("pack_dgrad16_kernel");
         return SZN_OK;
@@ -655,6 +656,10 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ Y
     }
 }
 
+static int launch_col2im(const szn_conv_desc_t* d, const float* Y, void* din, szn_stream_t stream);
+int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
+                            int min_tiles, szn_stream_t stream);
+
 extern "C" size_t szn_conv2d_dgrad_gemm_workspace_bytes(const szn_conv_desc_t* d) {
     if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->KH <= 0 || d->KW <= 0 || d->Ci <= 0) return 0;
     return (size_t)d->B * d->Ho * d->Wo * d->KH * d->KW * d->Ci * sizeof(float);
@@ -680,23 +685,73 @@ extern "C" int szn_conv2d_dgrad_gemm(const szn_conv_desc_t* d, const void* dout,
     g.workspace = nullptr; g.workspace_bytes = 0; g.colsum = nullptr;
     rc = szn_conv2d_fwd(&g, dout, wG, nullptr, nullptr, nullptr, d->workspace, stream);
     if (rc) return rc;
+    return launch_col2im(d, (const float*)d->workspace, din, stream);
+}
+
+static int launch_col2im(const szn_conv_desc_t* d, const float* Y, void* din, szn_stream_t stream) {
     const long total = (long)d->B * d->Hi * d->Wi * (d->Ci >> 2);
     long blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     if (d->dtype == SZN_BF16)
         hipLaunchKernelGGL(col2im_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)d->workspace, (bf16_raw*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
+                           Y, (bf16_raw*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
                            d->pad, d->ldi);
     else if (d->dtype == SZN_F16)
         hipLaunchKernelGGL(col2im_kernel<f16_raw>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)d->workspace, (f16_raw*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
+                           Y, (f16_raw*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
                            d->pad, d->ldi);
     else
         hipLaunchKernelGGL(col2im_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)d->workspace, (float*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
+                           Y, (float*)din, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->KH, d->KW,
                            d->pad, d->ldi);
     SZN_CHECK_LAUNCH("col2im_kernel");
     return SZN_OK;
+}
+
+// ---- the same dgrad on the filter bank in its FORWARD layout (round 3) -------------------------------------------------------------
+// szn_conv2d_dgrad_gemm needs wG = the plain transpose of the [Co][KH*KW*Ci] forward image: for fc6 a 205 MB read + 205 MB write per
+// step (85 of the 115 us of szn_pack_weight_dgrad_batch) just to make co the contiguous index.  conv_wgrad_wide multiplies two
+// K-MAJOR operands (D[a][b] = sum_k A[k][a] B[k][b], transposing LDS reads on both): with k = co, A = dout^T [Co][M] and B = the
+// forward image [Co][N] it yields Y[m][n] directly -- only the 19 MB dout is transposed.  Same workspace Y, same col2im.
+static bool dgrad_native_shape_ok(const szn_conv_desc_t* d) {
+    if (!d || !szn_is16(d->dtype) || d->KH != d->KW || d->ldo != d->Co || (d->Ci & 3)) return false;
+    const long M = (long)d->B * d->Ho * d->Wo, N = (long)d->KH * d->KW * d->Ci;
+    if ((M & 7) || M < 256 || N < 256 || (N & 7) || (d->Co & 63) || M >= (1L << 22) || N >= (1L << 31)) return false;
+    const long cot = (M + 255) / 256, cit = (N + 255) / 256;
+    if (cot * cit < 96 || cot * 256 * cit * 256 > M * N * 5 / 4) return false;          // conv_wgrad_wide's own admission rules
+    return (size_t)d->Co * N * 2 < 0xffff0000ul && (size_t)d->Co * M * 2 < 0xffff0000ul;
+}
+
+extern "C" int szn_conv2d_dgrad_gemm_native_supported(const szn_conv_desc_t* d) { return dgrad_native_shape_ok(d) ? 1 : 0; }
+
+extern "C" size_t szn_conv2d_dgrad_gemm_native_workspace_bytes(const szn_conv_desc_t* d) {
+    const size_t y = szn_conv2d_dgrad_gemm_workspace_bytes(d);
+    if (!y) return 0;
+    return (y + 255) / 256 * 256 + (size_t)d->Co * d->B * d->Ho * d->Wo * 2;            // Y | dout^T
+}
+
+extern "C" int szn_conv2d_dgrad_gemm_native(const szn_conv_desc_t* d, const void* dout, const void* w, void* din,
+                                            szn_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dout || !w || !din) SZN_FAIL(SZN_ERR_ARG, "conv2d_dgrad_gemm_native: null pointer");
+    if (!dgrad_native_shape_ok(d)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_dgrad_gemm_native: shape not supported (use szn_conv2d_dgrad_gemm)");
+    const size_t need = szn_conv2d_dgrad_gemm_native_workspace_bytes(d);
+    if (!d->workspace || d->workspace_bytes < need || ((uintptr_t)d->workspace & 15))
+        SZN_FAIL(SZN_ERR_ARG, "conv2d_dgrad_gemm_native: needs a 16-B aligned workspace of %zu bytes", need);
+    const int M = d->B * d->Ho * d->Wo;
+    const long N = (long)d->KH * d->KW * d->Ci;
+    float* Y = (float*)d->workspace;
+    void* doutT = (char*)d->workspace + (szn_conv2d_dgrad_gemm_workspace_bytes(d) + 255) / 256 * 256;
+    rc = szn_pack_weight_dgrad(d->dtype, M, 1, 1, d->Co, dout, doutT, stream);          // [M][Co] -> [Co][M]
+    if (rc) return rc;
+    szn_conv_desc_t g = {};
+    g.dtype = d->dtype; g.B = 1; g.Hi = 1; g.Wi = d->Co; g.Ci = (int)N; g.Ho = 1; g.Wo = d->Co; g.Co = M;
+    g.KH = 1; g.KW = 1; g.pad = 0; g.ldi = (int)N; g.ldo = M; g.ldg = 0;
+    rc = szn_conv_wgrad_wide_try(&g, w, doutT, Y, 0, 1, stream);
+    if (rc > 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_dgrad_gemm_native: conv_wgrad_wide refused the shape");
+    if (rc) return rc;
+    return launch_col2im(d, Y, din, stream);
 }
 
 // first-generation kernel (register-staged, 128x128 tile): fallback of szn_conv2d_wgrad (szn_conv_wgrad.hip)

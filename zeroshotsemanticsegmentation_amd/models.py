@@ -45,6 +45,7 @@ _BACKBONE = [("conv1_1", PAD1), ("conv1_2", 1), "P", ("conv2_1", 1), ("conv2_2",
              ("conv3_1", 1), ("conv3_2", 1), ("conv3_3", 1), "P", ("conv4_1", 1), ("conv4_2", 1), ("conv4_3", 1), "P",
              ("conv5_1", 1), ("conv5_2", 1), ("conv5_3", 1), "P"]
 _TRUNK = [n for n, _, _, _ in synth.CONV_LAYERS]          # conv1_1 .. fc7
+_FC6_NATIVE = os.environ.get("SZN_FC6_NATIVE", "1") != "0"      # 0: fc6's dgrad GEMM on the packed transpose (rounds 1-2)
 _OPT_LAYERS = _TRUNK + ["score_fr"]                        # the layers train.get_parameters yields (train.py:302-331)
 _OPT_LAYERS8 = _TRUNK + ["score_pool3", "score_pool4", "score_fr"]       # ... for FCN8s (score_fr stays last: engine.TrainStep)
 
@@ -157,10 +158,11 @@ class _Engine(object):
             else:
                 wc = w32.to(dt)
             img[name + ".w"] = wc
-            if k >= 5:      # fc6: dgrad runs as GEMM + col2im on the plain transpose [k*k*ci][co] (szn_conv2d_dgrad_gemm)
-                wg = torch.empty(k * k * ci, co, device=dev, dtype=dt)
-                jobs.append((wc, wg, co, 1, k * k * ci))
-                img[name + ".wG"] = wg
+            if k >= 5:      # fc6: dgrad runs as GEMM + col2im (szn_conv2d_dgrad_gemm*).  On the 16-bit paths the GEMM takes the
+                # forward image itself (szn_conv2d_dgrad_gemm_native: no transposed copy of the 205 MB filter bank per step); the plain
+                # transpose [k*k*ci][co] the other form needs is built on demand (_dgrad) and stamped with the weight version
+                img[name + ".wG"] = img.get(name + ".wG")           # (buffer kept; its content is stale now)
+                img[name + ".wG.stale"] = True
                 continue
             wt = torch.empty(ci, k, k, co, device=dev, dtype=dt)
             jobs.append((wc, wt, co, k, ci))
@@ -479,17 +481,30 @@ class _Engine(object):
         B, Hi, Wi, Ci = in_shape
         Ho, Wo, Co = dout.shape[1:]
         din = torch.empty(B, Hi, Wi, Ci, device=dout.device, dtype=self.dtype)
-        wG = self._images.get(name + ".wG") if wT is None else None
-        if wG is not None:      # large window (fc6): GEMM + col2im, no gate / dropout factor / column sums on this edge
+        if wT is None and (name + ".wG") in self._images:
+            # large window (fc6): GEMM + col2im, no gate / dropout factor / column sums on this edge
             if gate is not None or scale is not None or colsum is not None:
                 raise L.SznError("dgrad of %s: the GEMM form has no gate / scale / colsum epilogue" % name)
-            k = int(round((wG.shape[0] // Ci) ** 0.5))
-            d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, 0, 0, 0)
-            nb = L.load().szn_conv2d_dgrad_gemm_workspace_bytes(C.byref(d))
+            img = self._images
+            wf = img[name + ".w"]                                  # forward image [Co][k][k][Ci]
+            k = wf.shape[1]
+            code = L.dtype_code(self.dtype)
+            d = L.ConvDesc(code, B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, 0, 0, 0)
+            lib = L.load()
+            native = _FC6_NATIVE and dout.is_contiguous() and lib.szn_conv2d_dgrad_gemm_native_supported(C.byref(d)) == 1
+            nb = (lib.szn_conv2d_dgrad_gemm_native_workspace_bytes if native else lib.szn_conv2d_dgrad_gemm_workspace_bytes)(C.byref(d))
             if self._gemm_ws is None or self._gemm_ws.numel() < nb or self._gemm_ws.device != dout.device:
                 self._gemm_ws = torch.empty(nb, dtype=torch.uint8, device=dout.device)
             d.workspace, d.workspace_bytes = self._gemm_ws.data_ptr(), self._gemm_ws.numel()
-            L.call("szn_conv2d_dgrad_gemm", C.byref(d), L.ptr(dout), L.ptr(wG), L.ptr(din), L.stream_ptr())
+            if native:
+                L.call("szn_conv2d_dgrad_gemm_native", C.byref(d), L.ptr(dout), L.ptr(wf), L.ptr(din), L.stream_ptr())
+                return din
+            if img.get(name + ".wG.stale", True) or img[name + ".wG"] is None:
+                if img[name + ".wG"] is None:
+                    img[name + ".wG"] = torch.empty(k * k * Ci, Co, device=dout.device, dtype=self.dtype)
+                L.call("szn_pack_weight_dgrad", code, Co, 1, 1, k * k * Ci, L.ptr(wf), L.ptr(img[name + ".wG"]), L.stream_ptr())
+                img[name + ".wG.stale"] = False
+            L.call("szn_conv2d_dgrad_gemm", C.byref(d), L.ptr(dout), L.ptr(img[name + ".wG"]), L.ptr(din), L.stream_ptr())
             return din
         wT = self._images[name + ".wT"] if wT is None else wT
         k = wT.shape[1]
