@@ -79,7 +79,7 @@ def _conv_flops(d):
 
 def call_work(name, a):
     """-> (bound, work) with work in FLOP (mfma) or bytes (hbm); None for calls that are not accounted"""
-    if name in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm", "szn_conv2d_wgrad"):
+    if name in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm", "szn_conv2d_dgrad_gemm_native", "szn_conv2d_wgrad"):
         return "mfma", _conv_flops(a[0]._obj)
     if name == "szn_conv1_1_fwd":          # reads the f32 image once, writes B x (H+198)^2 x 64 activations
         code, B, H, W, pad = a[:5]
@@ -263,7 +263,7 @@ def _conv_family(torch, L, mods, fn):
     ev = []
 
     def timed(name, *a):
-        if name not in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm"):
+        if name not in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm", "szn_conv2d_dgrad_gemm_native"):
             return orig(name, *a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); orig(name, *a); e1.record()
@@ -479,7 +479,7 @@ def main():
     ts = (make_phase1_fcn8s() if (args.arch == "fcn8s" and args.unfused_head) else make_phase1()) if args.phase == "fcn" else make_phase2()
 
     # ---- HIP events on the launch stream around C-ABI calls (torch's current stream IS the stream handed to the C-ABI) ----
-    CONV_ENTRIES = ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm")
+    CONV_ENTRIES = ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm", "szn_conv2d_dgrad_gemm_native")
     events = []                      # (e0, e1, entry, kernel, bound, work)
     mode = ["off"]                   # off | dominant (timed region: conv fwd/dgrad calls only) | all (instrumented pass)
     orig_call = L.call
