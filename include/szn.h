@@ -76,6 +76,12 @@ typedef struct {
                          bit-reproducible bias gradients.  Without it the partials are added to colsum with fp32 atomics
                          (same value up to the order of the additions).                                            */
     int colsum_slab_rows; /* rows the slab can hold; an error is returned if the kernel needs more                  */
+    void* pool_code;    /* optional, with pool_out: one byte per pooled element [B][ceil(Ho/2)][ceil(Wo/2)][Co] = position 2 dy + dx
+                         of the FIRST maximum of its window (torch's scan order), or 4 when that maximum is not positive (the
+                         ReLU gate): everything szn_maxpool2x2_ceil_bwd_code needs.  8-B aligned.                            */
+    int pool_only;      /* with pool_out: the caller does not need the un-pooled tensor (in training it is read once, by the pool's
+                         backward pass, which takes pool_code instead: 516 + 258 MB per step that are neither written nor read back);
+                         `out` must still be valid memory, a kernel that fuses the pool MAY leave it unwritten             */
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
@@ -177,6 +183,13 @@ int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void*
                             const void* out, const void* dout, void* din, float* colsum /* [C] += sum of din, or NULL */,
                             float* colsum_slab /* optional, see szn_conv_desc_t.colsum_slab */, int colsum_slab_rows,
                             szn_stream_t stream);
+/* The pair that works from winner codes (one byte per pooled element: 0 .. 3 = position 2 dy + dx of the first maximum, 4 = maximum
+ * not positive) instead of the pool's input: the forward pass writes them (here, or fused into the producing conv through
+ * szn_conv_desc_t.pool_code), the backward pass reads d(pooled) + codes only.  Same gradients bit for bit.                     */
+int szn_maxpool2x2_ceil_fwd_code(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out, void* code /* or NULL */,
+                                 szn_stream_t stream);
+int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
+                                 float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream);
 
 /* ---- upscore: ConvTranspose2d(E,E,64,stride 32,bias=False) with the fixed bilinear kernel of
  * get_upsampling_weight (models.py:11-24,94,146) fused with the crop [19:19+H] (models.py:147).

@@ -525,3 +525,56 @@ def test_dgrad_gemm_on_the_forward_weight_layout(geom):
     # a shape the two-K-major kernel does not take (too few pixels): the caller has to use the packed form
     d3 = L.ConvDesc(dt, 1, 8, 8, 64, 2, 2, 256, 7, 7, 0, 64, 256, 0, 0, 0)
     assert lib.szn_conv2d_dgrad_gemm_native_supported(C.byref(d3)) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("geom", [(2, 37, 41, 64, 64), (1, 710, 64, 64, 64), (2, 45, 45, 512, 512)])
+def test_pool_winner_codes(dtype, geom):
+    """conv + fused / unfused MaxPool2d(2,2,ceil) with winner codes: codes == first maximum of the stored window (4 = not positive),
+    pool_only leaves the pooled tensor and the codes unchanged, and szn_maxpool2x2_ceil_bwd_code == szn_maxpool2x2_ceil_bwd bit for bit"""
+    B, Hi, Wi, Ci, Co = geom
+    if dtype == torch.float32 and Hi > 100:
+        pytest.skip("large fp32 case not needed")
+    g = torch.Generator().manual_seed(21)
+    x = torch.relu(torch.randn(B, Hi, Wi, Ci, generator=g)).cuda().to(dtype)
+    w = (torch.randn(Co, 3, 3, Ci, generator=g) / (Ci * 9) ** 0.5).cuda().to(dtype)
+    bias = torch.randn(Co, generator=g).cuda()
+    dt = L.dtype_code(dtype)
+    Hp, Wp = (Hi + 1) // 2, (Wi + 1) // 2
+    res = []
+    for pool_only in (0, 1):
+        out = torch.full((B, Hi, Wi, Co), 7.0, device="cuda", dtype=dtype)
+        pool = torch.empty(B, Hp, Wp, Co, device="cuda", dtype=dtype)
+        code = torch.full((B, Hp, Wp, Co), 9, device="cuda", dtype=torch.uint8)
+        d = L.ConvDesc(dt, B, Hi, Wi, Ci, Hi, Wi, Co, 3, 3, 1, Ci, Co, 0, 1, 0)
+        d.pool_out, d.pool_code, d.pool_only = pool.data_ptr(), code.data_ptr(), pool_only
+        L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, None, L.ptr(out), L.stream_ptr())
+        torch.cuda.synchronize()
+        res.append((out, pool, code))
+    out, pool, code = res[0]
+    assert torch.equal(res[1][1], pool) and torch.equal(res[1][2], code)
+    # reference codes from the stored un-pooled tensor
+    xo = out.float().permute(0, 3, 1, 2)
+    pad = torch.nn.functional.pad(xo, (0, 2 * Wp - Wi, 0, 2 * Hp - Hi), value=-1.0)          # out-of-range members never win
+    win = pad.unfold(2, 2, 2).unfold(3, 2, 2).reshape(B, Co, Hp, Wp, 4)
+    mx, arg = win.max(dim=-1)
+    first = (win == mx.unsqueeze(-1)).float().argmax(dim=-1)                                # first maximum in scan order
+    want = torch.where(mx > 0, first, torch.full_like(first, 4)).permute(0, 2, 3, 1).to(torch.uint8)
+    assert torch.equal(pool.float().permute(0, 3, 1, 2), mx)
+    assert torch.equal(code, want)
+    # backward: from the codes == from the tensor
+    dp = torch.randn(B, Hp, Wp, Co, generator=g).cuda().to(dtype)
+    outs = []
+    for use_code in (False, True):
+        din = torch.empty(B, Hi, Wi, Co, device="cuda", dtype=dtype)
+        cs = torch.zeros(Co, device="cuda"); slab = torch.zeros(512, Co, device="cuda")
+        if use_code:
+            L.call("szn_maxpool2x2_ceil_bwd_code", dt, B, Hi, Wi, Co, L.ptr(code), L.ptr(dp), L.ptr(din), L.ptr(cs), L.ptr(slab), 512,
+                   L.stream_ptr())
+        else:
+            L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Co, L.ptr(out), L.ptr(pool), L.ptr(dp), L.ptr(din), L.ptr(cs), L.ptr(slab), 512,
+                   L.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((din, slab.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].float().abs().sum()) > 0

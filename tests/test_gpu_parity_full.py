@@ -357,6 +357,7 @@ def test_cfg1_softmax_fcn_step_vs_oracle():
     opt = make_fcn_optimizer(m, cfg)
     assert [g["lr"] for g in opt.param_groups] == [1e-10, 2e-10] and [g["weight_decay"] for g in opt.param_groups] == [0.0005, 0]
     osgd = O.SGD(1e-10, 0.99)
+    m._engine.keep_prepool = True                    # adopt_forward below reads the un-pooled activations
     for it in range(2):
         score = m(cu(x), mode="fcn")
         of = om.forward(x, "fcn")

@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")] + [
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p),
-        ("colsum_slab", C.c_void_p), ("colsum_slab_rows", C.c_int)]
+        ("colsum_slab", C.c_void_p), ("colsum_slab_rows", C.c_int), ("pool_code", C.c_void_p), ("pool_only", C.c_int)]
 
 
 class DeviceInfo(C.Structure):
@@ -63,6 +63,8 @@ SIGNATURES = {
     "szn_conv1_1_wgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "szn_maxpool2x2_ceil_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
     "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "szn_maxpool2x2_ceil_fwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "szn_maxpool2x2_ceil_bwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "szn_bilinear_up32_crop_fwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_bilinear_up32_crop_bwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_bilinear_up_crop_fwd": (_I, [_I] * 10 + [_P, _P, _P]),

@@ -490,12 +490,14 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
     if (d->colsum_slab && ((uintptr_t)d->colsum_slab & 15)) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab must be 16-B aligned");
     if (d->pool_out && (!d->relu || d->ldo != d->Co || gate || chan_scale))
         SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: pool_out needs relu, ldo == Co and no gate / chan_scale");
+    if ((d->pool_code || d->pool_only) && !d->pool_out) SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: pool_code / pool_only need pool_out");
+    if (d->pool_code && (((uintptr_t)d->pool_code) & 7)) SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: pool_code must be 8-B aligned");
     int pooled = 0;
     const int rc = conv2d_fwd_dispatch(d, in, w, bias, gate, chan_scale, out, stream, &pooled);
     if (rc || !d->pool_out || pooled) return rc;
-    // the kernel that ran has no fused pooling: pool the tensor it wrote
-    return szn_maxpool2x2_ceil_fwd((d->out_f32 || d->dtype == SZN_F32) ? SZN_F32 : d->dtype, d->B, d->Ho, d->Wo, d->Co, out,
-                                   d->pool_out, stream);
+    // the kernel that ran has no fused pooling: pool the tensor it wrote (and write the winner codes when asked for)
+    return szn_maxpool2x2_ceil_fwd_code((d->out_f32 || d->dtype == SZN_F32) ? SZN_F32 : d->dtype, d->B, d->Ho, d->Wo, d->Co, out,
+                                        d->pool_out, d->pool_code, stream);
 }
 
 static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,

@@ -23,6 +23,7 @@
 #include "szn_common.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 typedef __attribute__((address_space(3))) void* ldsptr_t;
 
 namespace {
@@ -31,6 +32,8 @@ struct RwArgs {
     const char* in; const char* w; const float* bias; const char* gate; char* out; float* colsum;
     float* cslab;              // optional [grid][Co]: this block's column sums go to row blockIdx.x (fixed-order reduce later)
     char* pool;                        // optional: MaxPool2d(2,2,ceil) of the (ReLU'd) output, [B][Hp][Wp][Co] dense
+    unsigned char* pcode;              // optional (with pool): winner code per pooled element, szn_conv_desc_t.pool_code
+    int skip_x;                        // 1: the un-pooled output is not stored (szn_conv_desc_t.pool_only)
     unsigned in_bytes, gate_bytes;
     int Hp, Wp;
     int B, Hi, Wi, Ho, Wo, pad;
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             __builtin_amdgcn_s_barrier();
         }
         float pm[8];                                                       // pooling: the even row of the current row pair
+        u32x4_t pkm = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int e = 0; e < 8; ++e) pm[e] = 0.f;
 #pragma unroll
@@ -316,8 +320,45 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             pk.y = pack2<T>(v[2], v[3]);
             pk.z = pack2<T>(v[4], v[5]);
             pk.w = pack2<T>(v[6], v[7]);
-            if (ok && !RW_ABL(2)) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
+            if (ok && !RW_ABL(2) && !a.skip_x) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
             if constexpr (!GATED) {
+                if (a.pool && a.pcode) {
+                    // pooling on the packed 16-bit patterns (post-ReLU values are >= 0: they order like unsigned integers)
+                    const u32x4_t pz = ok ? pk : u32x4_t{0u, 0u, 0u, 0u};
+                    if ((j & 1) == 0) pkm = pz;
+                    else {
+                        u32x4_t Mo, Co4;
+                        auto pk_max = [](uint32_t x, uint32_t y) { uint32_t r; asm volatile("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+                        auto pk_min = [](uint32_t x, uint32_t y) { uint32_t r; asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+                        auto pk_sub = [](uint32_t x, uint32_t y) { uint32_t r; asm volatile("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+                        auto pk_mad = [](uint32_t x, uint32_t y, uint32_t z) { uint32_t r; asm volatile("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
+                        const uint32_t one = 0x00010001u, four = 0x00040004u;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t A = pkm[i], Cq = pz[i];
+                            const uint32_t Bq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A, 0xB1, 0xF, 0xF, true);
+                            const uint32_t Dq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Cq, 0xB1, 0xF, 0xF, true);
+                            const uint32_t M = pk_max(pk_max(A, Bq), pk_max(Cq, Dq));
+                            const uint32_t na = pk_min(pk_sub(M, A), one), nb = pk_min(pk_sub(M, Bq), one), nc = pk_min(pk_sub(M, Cq), one);
+                            // first maximum in scan order (a, b, c, d): na (1 + nb (1 + nc)); not positive: 4
+                            const uint32_t t = pk_mad(nb, pk_mad(nc, one, one), one);          // 1 + nb (1 + nc)
+                            uint32_t code = pk_mad(na, t, 0u);
+                            const uint32_t z = pk_min(M, one);
+                            code = pk_mad(pk_sub(code, four), z, four);
+                            Mo[i] = M;
+                            Co4[i] = code;
+                        }
+                        const int poh = (oh0 + j) >> 1, pw = ow >> 1;
+                        if ((r16 & 1) == 0 && okw && poh < a.Hp && !RW_ABL(2)) {
+                            const size_t pe = (size_t)((b * a.Hp + poh) * a.Wp + pw) * (32 * COG) + cstart;
+                            *(u32x4_t*)(a.pool + pe * 2) = Mo;
+                            u32x2_t cb;
+                            cb.x = __builtin_amdgcn_perm(Co4[1], Co4[0], 0x06040200u);
+                            cb.y = __builtin_amdgcn_perm(Co4[3], Co4[2], 0x06040200u);
+                            *(u32x2_t*)(a.pcode + pe) = cb;
+                        }
+                    }
+                } else
                 // fused MaxPool2d(2,2,ceil): rows (j, j + 1) pair up in this lane (oh0 is even), columns (ow, ow ^ 1) in
                 // neighbouring lanes; post-ReLU values are >= 0, so out-of-range window members count as 0
                 if (a.pool) {
@@ -417,6 +458,8 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.colsum = d->colsum;
     a.cslab = d->colsum ? d->colsum_slab : nullptr;
     a.pool = (char*)d->pool_out; a.Hp = (d->Ho + 1) / 2; a.Wp = (d->Wo + 1) / 2;
+    a.pcode = a.pool ? (unsigned char*)d->pool_code : nullptr;
+    a.skip_x = (a.pool && d->pool_only) ? 1 : 0;
     a.in_bytes = (unsigned)in_bytes; a.gate_bytes = (unsigned)gate_bytes;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.pad = d->pad;
     a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg; a.relu = d->relu;

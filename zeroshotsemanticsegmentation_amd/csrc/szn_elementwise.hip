@@ -330,7 +330,7 @@ __global__ void unpack_dw32_kernel(const float* __restrict__ dw32, float* __rest
 // ---- MaxPool2d(2,2,ceil_mode=True) on NHWC: thread = (output pixel, 16-B channel chunk) -----------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Hi,
-                                                          int Wi, int C, int Ho, int Wo) {
+                                                          int Wi, int C, int Ho, int Wo, uint8_t* __restrict__ code) {
     constexpr int CH = elem<T>::kPer16B;
     const int cpp = C / CH;
     const long total = (long)B * Ho * Wo * cpp;
@@ -341,8 +341,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         const long t = p / Wo;
         const int oh = (int)(t % Ho), b = (int)(t / Ho);
         float best[CH];
+        int win[CH];                                     // position (2 dy + dx) of the FIRST maximum (strict >, scan order)
 #pragma unroll
-        for (int e = 0; e < CH; ++e) best[e] = -INFINITY;
+        for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; win[e] = 0; }
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             const int ih = 2 * oh + dy;
@@ -354,7 +355,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 const u32x4_t v = *(const u32x4_t*)(in + (((long)b * Hi + ih) * Wi + iw) * C + cc * CH);
                 const T* ve = (const T*)&v;
 #pragma unroll
-                for (int e = 0; e < CH; ++e) best[e] = fmaxf(best[e], elem<T>::ld(ve + e));
+                for (int e = 0; e < CH; ++e) {
+                    const float x = elem<T>::ld(ve + e);
+                    if (x > best[e]) { best[e] = x; win[e] = 2 * dy + dx; }
+                }
             }
         }
         u32x4_t o;
@@ -362,6 +366,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int e = 0; e < CH; ++e) elem<T>::st(oe + e, best[e]);
         *(u32x4_t*)(out + p * C + cc * CH) = o;
+        if (code) {                                      // winner code per pooled element: 0 .. 3, or 4 = maximum not positive (ReLU gate)
+            uint8_t* cp = code + p * C + cc * CH;
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const uint32_t cd = best[e] > 0.f ? (uint32_t)win[e] : 4u;
+                if (e < 4) lo |= cd << (8 * e); else hi |= cd << (8 * (e - 4));
+            }
+            *(uint32_t*)cp = lo;
+            if (CH == 8) *(uint32_t*)(cp + 4) = hi;
+        }
     }
 }
 
@@ -435,6 +450,63 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
             float t = 0.f;
             for (int r = cc; r < 256; r += cpp) t += red[r * CH + e];
             if (cslab) cslab[(long)blockIdx.x * C + c] = t;      // one partial row per block, reduced in a fixed order later
+            else if (t != 0.f) atomicAdd(colsum + c, t);
+        }
+    }
+}
+
+// The same backward pass from the WINNER CODES the forward pass wrote (szn_conv_desc_t.pool_code / szn_maxpool2x2_ceil_fwd_code)
+// instead of the pool's input: code 0 .. 3 = position 2 dy + dx of the first maximum, 4 = maximum not positive (no gradient: the
+// ReLU gate).  2.75 B instead of 4.5 B of traffic per input element, and the forward pass no longer has to store the un-pooled
+// tensor for this kernel alone.  Same result bit for bit.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __restrict__ code, const T* __restrict__ dout,
+                                                               T* __restrict__ din, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                                               float* __restrict__ colsum, float* __restrict__ cslab) {
+    constexpr int CH = elem<T>::kPer16B;
+    __shared__ float red[256 * CH];
+    const int cpp = C / CH;
+    const long total = (long)B * Ho * Wo * cpp;
+    float cs[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) cs[e] = 0.f;
+    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+        const int cc = (int)(gid % cpp);
+        const long po = gid / cpp;
+        const int ow = (int)(po % Wo);
+        const long t = po / Wo;
+        const int oh = (int)(t % Ho), b = (int)(t / Ho);
+        const int ih = 2 * oh, iw = 2 * ow;
+        const bool okw = iw + 1 < Wi, okh = ih + 1 < Hi;
+        const long p00 = ((long)b * Hi + ih) * Wi + iw;
+        const u32x4_t vd = *(const u32x4_t*)(dout + po * C + cc * CH);
+        const T* de = (const T*)&vd;
+        const uint8_t* cp = code + po * C + cc * CH;
+        const uint32_t clo = *(const uint32_t*)cp, chi = CH == 8 ? *(const uint32_t*)(cp + 4) : 0u;
+        u32x4_t o[4];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const int win = (int)(((e < 4 ? clo : chi) >> (8 * (e & 3))) & 0xffu);
+            const float dv = elem<T>::ld(de + e);                  // a value of type T: storing it back is exact
+#pragma unroll
+            for (int k = 0; k < 4; ++k) elem<T>::st((T*)&o[k] + e, k == win ? dv : 0.f);
+            cs[e] += win < 4 ? dv : 0.f;                           // what was stored (one non-zero term)
+        }
+        T* op = din + p00 * C + cc * CH;
+        *(u32x4_t*)op = o[0];
+        if (okw) *(u32x4_t*)(op + C) = o[1];
+        if (okh) *(u32x4_t*)(op + (long)Wi * C) = o[2];
+        if (okh && okw) *(u32x4_t*)(op + (long)Wi * C + C) = o[3];
+    }
+    if (colsum) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = cs[e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const int cc = c / CH, e = c - cc * CH;
+            float t = 0.f;
+            for (int r = cc; r < 256; r += cpp) t += red[r * CH + e];
+            if (cslab) cslab[(long)blockIdx.x * C + c] = t;
             else if (t != 0.f) atomicAdd(colsum + c, t);
         }
     }
@@ -660,22 +732,30 @@ extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const 
     return SZN_OK;
 }
 
+extern "C" int szn_maxpool2x2_ceil_fwd_code(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out, void* code,
+                                            szn_stream_t stream);
 extern "C" int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out,
                                        szn_stream_t stream) {
+    return szn_maxpool2x2_ceil_fwd_code(dtype, B, Hi, Wi, C, in, out, nullptr, stream);
+}
+
+extern "C" int szn_maxpool2x2_ceil_fwd_code(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out, void* code,
+                                            szn_stream_t stream) {
     if (!in || !out || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_fwd: bad argument");
+    if (code && (((uintptr_t)code) & 3)) SZN_FAIL(SZN_ERR_ARG, "maxpool_fwd: code must be 4-B aligned");
     const int ch = szn_is16(dtype) ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_fwd: C must be a multiple of %d", ch);
     const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
     const long total = (long)B * Ho * Wo * (C / ch);
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_raw>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_raw*)in, (bf16_raw*)out, B, Hi, Wi, C, Ho, Wo);
+                           (const bf16_raw*)in, (bf16_raw*)out, B, Hi, Wi, C, Ho, Wo, (uint8_t*)code);
     else if (dtype == SZN_F16)
         hipLaunchKernelGGL(maxpool_fwd_kernel<f16_raw>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
-                           (const f16_raw*)in, (f16_raw*)out, B, Hi, Wi, C, Ho, Wo);
+                           (const f16_raw*)in, (f16_raw*)out, B, Hi, Wi, C, Ho, Wo, (uint8_t*)code);
     else if (dtype == SZN_F32)
         hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)in, (float*)out, B, Hi, Wi, C, Ho, Wo);
+                           (const float*)in, (float*)out, B, Hi, Wi, C, Ho, Wo, (uint8_t*)code);
     else
         SZN_FAIL(SZN_ERR_ARG, "maxpool_fwd: bad dtype %d", dtype);
     SZN_CHECK_LAUNCH("maxpool_fwd_kernel");
@@ -715,6 +795,37 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
     else
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad dtype %d", dtype);
     SZN_CHECK_LAUNCH("maxpool_bwd_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
+                                            float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream) {
+    if (!code || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: bad argument");
+    const int ch = szn_is16(dtype) ? 8 : 4;
+    if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_code: C must be a multiple of %d", ch);
+    if (((uintptr_t)code) & 3) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: code must be 4-B aligned");
+    const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
+    const long total = (long)B * Ho * Wo * (C / ch);
+    if (colsum && (256 % (C / ch)) != 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_code: colsum needs C/%d to divide 256", ch);
+    static int capx = -1;
+    if (capx < 0) { const char* e = getenv("SZN_POOLBWD_BLOCKS"); capx = e ? atoi(e) : 512; if (capx < 1) capx = 1; }
+    const int grid = grid_for(total, 256, colsum ? capx : 65536);
+    float* cslab = colsum ? colsum_slab : nullptr;
+    if (cslab && colsum_slab_rows < grid)
+        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: colsum_slab holds %d rows, %d needed", colsum_slab_rows, grid);
+    szn_note_colsum_rows(cslab ? grid : 0);
+    if (dtype == SZN_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_code_kernel<bf16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)code,
+                           (const bf16_raw*)dout, (bf16_raw*)din, B, Hi, Wi, C, Ho, Wo, colsum, cslab);
+    else if (dtype == SZN_F16)
+        hipLaunchKernelGGL(maxpool_bwd_code_kernel<f16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)code,
+                           (const f16_raw*)dout, (f16_raw*)din, B, Hi, Wi, C, Ho, Wo, colsum, cslab);
+    else if (dtype == SZN_F32)
+        hipLaunchKernelGGL(maxpool_bwd_code_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)code,
+                           (const float*)dout, (float*)din, B, Hi, Wi, C, Ho, Wo, colsum, cslab);
+    else
+        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: bad dtype %d", dtype);
+    SZN_CHECK_LAUNCH("maxpool_bwd_code_kernel");
     return SZN_OK;
 }
 

@@ -409,6 +409,7 @@ class TrainStep(object):
         m, eng = self.model, self.eng
         B, _, H, W = x.shape
         st = L.stream_ptr()
+        eng.keep_prepool = bool(self.keep_ctx)          # tests that read the forward state need the un-pooled tensors too
         ctx = eng.forward(x, train=m.training)
         self.last_ctx = ctx if self.keep_ctx else None
         if self.is8:

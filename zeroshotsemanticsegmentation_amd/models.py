@@ -75,6 +75,12 @@ class _Engine(object):
         self._gemm_ws = None          # fp32 Y of the GEMM + col2im dgrad (fc6)
         self._wg_ws = None            # slab workspace of the wgrad kernels (they run on their own stream)
         self._wg_stream = None        # torch.cuda.Stream, or False when disabled (SZN_WGRAD_STREAM=0)
+        # The un-pooled outputs of conv1_2 .. conv5_3 are read by nobody but the pool's backward pass: the forward pass writes a
+        # one-byte winner code per pooled element instead (szn_conv_desc_t.pool_code) and tells the conv kernel it may skip the
+        # un-pooled store (pool_only; conv3x3_regw does: 516 + 258 MB per step neither written nor read back).  keep_prepool = True
+        # (tests that inspect the forward state) keeps those tensors valid; SZN_POOL_CODES=0: the round-1/2 backward from the tensor.
+        self.keep_prepool = False
+        self.pool_codes = os.environ.get("SZN_POOL_CODES", "1") != "0"
         self.head_fp8 = False         # forward of the projection head on the fp8 matrix cores (set_head_precision)
         self.head_fp8_bwd = False     # ... and its dgrad / wgrad (e5m2 gradient x e4m3 operands)
         self._fp8_ws = None
@@ -255,7 +261,8 @@ class _Engine(object):
                IA(*[j[2] for j in jobs]), VP(*[j[3].data_ptr() for j in jobs]), L.stream_ptr())
 
     # ---- kernels ---------------------------------------------------------------------------------
-    def _conv(self, x, name, pad, relu=True, scale=None, out_f32=False, w=None, b=None, co=None, k=None, pool=False):
+    def _conv(self, x, name, pad, relu=True, scale=None, out_f32=False, w=None, b=None, co=None, k=None, pool=False, codes=False,
+              pool_only=False):
         """conv (+ bias, ReLU, dropout factor) through szn_conv2d_fwd; pool=True also returns MaxPool2d(2,2,ceil) of the
         output (the descriptor's pool_out: fused into the epilogue of the kernels that support it)"""
         B, Hi, Wi, Ci = x.shape
@@ -268,11 +275,17 @@ class _Engine(object):
         out = torch.empty(B, Ho, Wo, co, device=x.device, dtype=torch.float32 if out_f32 else self.dtype)
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, co, k, k, pad, Ci, co, 0, int(relu), int(out_f32))
         self._workspace(d, B * Ho * Wo * co * 4, x.device)
-        pooled = None
+        pooled = code = None
         if pool:
             pooled = torch.empty(B, (Ho + 1) // 2, (Wo + 1) // 2, co, device=x.device, dtype=out.dtype)
             d.pool_out = pooled.data_ptr()
+            if codes:
+                code = torch.empty(B, (Ho + 1) // 2, (Wo + 1) // 2, co, device=x.device, dtype=torch.uint8)
+                d.pool_code = code.data_ptr()
+            d.pool_only = int(pool_only)
         L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), None, L.ptr(scale), L.ptr(out), L.stream_ptr())
+        if pool and codes:
+            return out, pooled, code
         return (out, pooled) if pool else out
 
     def make_masks(self, B, F, device):
@@ -312,10 +325,15 @@ class _Engine(object):
                 continue                                  # pooled by the conv in front of it (pool_out)
             name, pad = item
             if i + 1 < len(items) and items[i + 1] == "P":
-                pin, a = self._conv(a, name, pad, pool=True)
-                if keep:
-                    acts[name] = pin
-                    pools.append((pin, a))
+                if keep and self.pool_codes:
+                    pin, a, code = self._conv(a, name, pad, pool=True, codes=True, pool_only=not self.keep_prepool)
+                    acts[name] = pin if self.keep_prepool else None       # (may be unwritten: the backward pass takes the codes)
+                    pools.append((acts[name], a, code, tuple(pin.shape)))
+                else:
+                    pin, a = self._conv(a, name, pad, pool=True, pool_only=not keep)
+                    if keep:
+                        acts[name] = pin
+                        pools.append((pin, a))
                 del pin
             else:
                 a = self._conv(a, name, pad)
@@ -573,14 +591,19 @@ class _Engine(object):
         for idx in range(len(items) - 1, -1, -1):
             item = items[idx]
             if item == "P":
-                pin, pout = ctx.pools[pi]
+                pin, pout = ctx.pools[pi][:2]
+                pcode = ctx.pools[pi][2] if len(ctx.pools[pi]) > 2 else None
                 pi -= 1
-                B, Hi, Wi, Cc = pin.shape
-                dn = torch.empty_like(pin)
                 producer = items[idx - 1][0]                   # the conv whose (ReLU'd) output this pool reads
+                B, Hi, Wi, Cc = ctx.pools[pi + 1][3] if pcode is not None else pin.shape
+                dn = torch.empty(B, Hi, Wi, Cc, device=d.device, dtype=pout.dtype)
                 slab, rows = self._cs_slab(B * Hi * Wi, Cc, d.device)
-                L.call("szn_maxpool2x2_ceil_bwd", code, B, Hi, Wi, Cc, L.ptr(pin), L.ptr(pout), L.ptr(d), L.ptr(dn),
-                       L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
+                if pcode is not None:
+                    L.call("szn_maxpool2x2_ceil_bwd_code", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), L.ptr(dn),
+                           L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
+                else:
+                    L.call("szn_maxpool2x2_ceil_bwd", code, B, Hi, Wi, Cc, L.ptr(pin), L.ptr(pout), L.ptr(d), L.ptr(dn),
+                           L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
                 self._cs_register(slab, Cc, grads[producer][1])
                 d = dn
                 continue
