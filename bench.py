@@ -93,6 +93,9 @@ def call_work(name, a):
     if name == "szn_maxpool2x2_ceil_bwd":  # pool input + pooled + d(pooled) in, d(input) out
         code, B, Hi, Wi, Cc = a[:5]
         return "hbm", B * Cc * _esize(code) * (2.0 * Hi * Wi + 2.0 * ((Hi + 1) // 2) * ((Wi + 1) // 2))
+    if name == "szn_maxpool2x2_ceil_bwd_code":   # d(pooled) + one code byte per pooled element in, d(input) out
+        code, B, Hi, Wi, Cc = a[:5]
+        return "hbm", B * Cc * (_esize(code) * (1.0 * Hi * Wi + ((Hi + 1) // 2) * ((Wi + 1) // 2)) + ((Hi + 1) // 2) * ((Wi + 1) // 2))
     if name == "szn_adam_step":            # p, g, m, v in; p, m, v out (+ the bf16 weight image when asked for)
         return "hbm", a[0] * (28.0 + (2.0 if a[12] is not None else 0.0))
     if name == "szn_sgd_momentum_step":
