@@ -32,12 +32,12 @@ def main():
             continue
         us = c['_us']
         util = c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * us * 2400.0)
-        clk = c.get('GRBM_GUI_ACTIVE', 0) / us / 1e3 if us else 0
+        clk = c.get('GRBM_GUI_ACTIVE', 0) / 8.0 / us / 1e3 if us else 0      # the counter is summed over the 8 XCDs
         tab.append((us, k, len(cnt[k]), util, clk, c.get('SQ_INSTS_MFMA', 0)))
     tab.sort(reverse=True)
     with open(out, 'w') as f:
         f.write("# MFMA utilisation per kernel (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE on the bench step)\n\n")
-        f.write("utilisation = MFMA-busy cycles / (1024 SIMDs x launch time x 2.4 GHz); clock = GRBM_GUI_ACTIVE / launch time (profiled passes run ~5 % below un-profiled ones)\n\n")
+        f.write("utilisation = MFMA-busy cycles / (1024 SIMDs x launch time x 2.4 GHz); clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / launch time (profiled passes run ~5 % below un-profiled ones)\n\n")
         f.write("| kernel | launches | total us | MFMA utilisation | clock GHz |\n|---|---|---|---|---|\n")
         for us, k, n, util, clk, _ in tab:
             f.write("| %s | %d | %.0f | %.3f | %.2f |\n" % (k, n, us, util, clk))
