@@ -506,6 +506,8 @@ def main():
         orig_call(name, *a)
         e1.record()
         kern = L.last_kernel()
+        if name == "szn_conv2d_fwd" and wk:                       # constant-border hint: only the executed tiles count as FLOPs
+            wk = (wk[0], wk[1] * L.last_work_fraction())
         helper = {"splitk_epilogue": "+splitk", "col2im_kernel": "+col2im", "maxpool_fwd_kernel": "+maxpool",
                   "wgrad_taps_reduce": "+reduce", "conv1_1_wgrad_reduce": "+reduce"}.get(kern)
         if helper:

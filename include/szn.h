@@ -82,6 +82,16 @@ typedef struct {
     int pool_only;      /* with pool_out: the caller does not need the un-pooled tensor (in training it is read once, by the pool's
                          backward pass, which takes pool_code instead: 516 + 258 MB per step that are neither written nor read back);
                          `out` must still be valid memory, a kernel that fuses the pool MAY leave it unwritten             */
+    int cb_on;          /* szn_conv2d_fwd only: constant-border hint.  models.py:43 pads conv1_1 by 100, so on the 710^2 / 355^2 maps most
+                         pixels outside the image's reach hold ONE value per channel (conv1_1 writes relu(bias) there) and stay that way
+                         through conv1_2 .. conv2_2 away from the tensor edge.  cb_rect = output rows [r0, r1) x columns [c0, c1) the image
+                         can influence; cb_const = output rows / columns [r0, r1) x [c0, c1) outside of which the zero padding of the
+                         layers so far is felt.  Output pixels inside cb_const and outside cb_rect are all equal: a kernel that takes the
+                         hint (conv3x3_regw) runs its tiles over cb_rect and the edge frame only, and broadcasts one computed pixel to the
+                         rest (out / pool_out / pool_code alike).  Same bits as the dense computation.  szn_last_work_fraction() = the
+                         fraction of the dense tiles the last call executed.                                                     */
+    int cb_rect[4];
+    int cb_const[4];
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
@@ -147,6 +157,7 @@ int szn_bias_grad_slab(int dtype, long M, int Co, int ldd, const void* dout, flo
  * szn_colsum_reduce_batch adds out[j][c] += sum_{r < rows[j]} slabs[j][r * C[j] + c] for n jobs in one launch, rows in
  * ascending order (host arrays of length n; every bias gradient of a backward pass in ONE launch).                  */
 int szn_last_colsum_rows(void);
+float szn_last_work_fraction(void);   /* 1.0, or the fraction of tiles the last szn_conv2d_fwd executed under cb_on */
 int szn_colsum_reduce_batch(int n, const float* const* slabs, const int* rows, const int* C, float* const* out,
                             szn_stream_t stream);
 

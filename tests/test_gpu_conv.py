@@ -578,3 +578,56 @@ def test_pool_winner_codes(dtype, geom):
         outs.append((din, slab.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert float(outs[0][0].float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("case", [("conv1_2", 2, 710, 64, 64, (97, 613, 1, 709)), ("conv2_1", 2, 355, 64, 128, (47, 308, 2, 353)),
+                                  ("conv2_2", 2, 355, 128, 128, (46, 309, 3, 352)), ("ragged", 1, 300, 64, 64, (60, 200, 1, 299))])
+def test_constant_border_hint_is_bit_exact(case):
+    """szn_conv_desc_t.cb_on: conv3x3_regw runs the tiles the image / the zero padding can reach and broadcasts one computed pixel to
+    the others -- out, pool_out and pool_code are the same bits as the dense run (input: constant outside the previous layer's rectangle)"""
+    name, B, Hi, Ci, Co, reg = case
+    g = torch.Generator().manual_seed(31)
+    dt = L.dtype_code(torch.bfloat16)
+    r0, r1, c0, c1 = reg                                  # this conv's OUTPUT regions (same on both axes)
+    # input: one value per channel outside [r0 + 1, r1 - 1) and at least c0 - 1 pixels from the edge, random elsewhere
+    x = torch.relu(torch.randn(B, Hi, Hi, Ci, generator=g))
+    const = torch.relu(torch.randn(Ci, generator=g)) + 0.1
+    inner = torch.zeros(Hi, Hi, dtype=torch.bool)
+    inner[r0 + 1:r1 - 1, r0 + 1:r1 - 1] = True
+    ring = torch.ones(Hi, Hi, dtype=torch.bool)
+    ring[c0 - 1:c1 + 1, c0 - 1:c1 + 1] = False
+    keep_random = inner | ring
+    x = torch.where(keep_random[None, :, :, None], x, const[None, None, None, :]).cuda().bfloat16()
+    w = (torch.randn(Co, 3, 3, Ci, generator=g) / (Ci * 9) ** 0.5).cuda().bfloat16()
+    bias = torch.randn(Co, generator=g).cuda()
+    Hp = (Hi + 1) // 2
+    lib = L.load()
+    res = []
+    for cb_on in (0, 1):
+        for pool_only in (0, 1):
+            out = torch.full((B, Hi, Hi, Co), 3.0, device="cuda", dtype=torch.bfloat16)
+            pool = torch.full((B, Hp, Hp, Co), 5.0, device="cuda", dtype=torch.bfloat16)
+            code = torch.full((B, Hp, Hp, Co), 9, device="cuda", dtype=torch.uint8)
+            ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+            d = L.ConvDesc(dt, B, Hi, Hi, Ci, Hi, Hi, Co, 3, 3, 1, Ci, Co, 0, 1, 0)
+            d.pool_out, d.pool_code, d.pool_only = pool.data_ptr(), code.data_ptr(), pool_only
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+            if cb_on:
+                d.cb_on = 1
+                for i, v in enumerate((r0, r1, r0, r1)):
+                    d.cb_rect[i] = v
+                for i, v in enumerate((c0, c1, c0, c1)):
+                    d.cb_const[i] = v
+            L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, None, L.ptr(out), L.stream_ptr())
+            assert L.last_kernel() == "conv3x3_regw", L.last_kernel()
+            frac = lib.szn_last_work_fraction()
+            torch.cuda.synchronize()
+            res.append((cb_on, pool_only, out, pool, code, frac))
+    dense = res[0]
+    assert dense[5] == 1.0
+    for cb_on, pool_only, out, pool, code, frac in res[1:]:
+        assert torch.equal(pool, dense[3]) and torch.equal(code, dense[4]), (cb_on, pool_only)
+        if not pool_only:
+            assert torch.equal(out, dense[2]), (cb_on, pool_only)
+        if cb_on:
+            assert 0.3 < frac < 0.9, frac                 # tiles were actually skipped

@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")] + [
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p),
-        ("colsum_slab", C.c_void_p), ("colsum_slab_rows", C.c_int), ("pool_code", C.c_void_p), ("pool_only", C.c_int)]
+        ("colsum_slab", C.c_void_p), ("colsum_slab_rows", C.c_int), ("pool_code", C.c_void_p), ("pool_only", C.c_int),
+        ("cb_on", C.c_int), ("cb_rect", C.c_int * 4), ("cb_const", C.c_int * 4)]
 
 
 class DeviceInfo(C.Structure):
@@ -54,6 +55,7 @@ SIGNATURES = {
     "szn_bias_grad": (_I, [_I, _L, _I, _I, _P, _P, _I, _P]),
     "szn_bias_grad_slab": (_I, [_I, _L, _I, _I, _P, _P, _I, _P, _I, _P]),
     "szn_last_colsum_rows": (_I, []),
+    "szn_last_work_fraction": (C.c_float, []),
     "szn_colsum_reduce_batch": (_I, [_I, _P, _P, _P, _P, _P]),
     "szn_gemm_proj_fwd": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "szn_gemm_proj_dgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -134,6 +136,11 @@ def check(rc, what):
 def last_kernel():
     """name of the kernel the library launched last on this thread (which specialised path the dispatcher took)"""
     return load().szn_last_kernel().decode()
+
+
+def last_work_fraction():
+    """fraction of the dense output tiles the last szn_conv2d_fwd on this thread executed (1.0 without the constant-border hint)"""
+    return float(load().szn_last_work_fraction())
 
 
 def prev_kernel():

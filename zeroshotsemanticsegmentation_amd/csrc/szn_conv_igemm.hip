@@ -487,6 +487,7 @@ extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const vo
                               const void* gate, const float* chan_scale, void* out, szn_stream_t stream) {
     if (!d) SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: null descriptor");
     szn_note_colsum_rows(0);
+    szn_note_work_fraction(1.f);
     if (d->colsum_slab && ((uintptr_t)d->colsum_slab & 15)) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab must be 16-B aligned");
     if (d->pool_out && (!d->relu || d->ldo != d->Co || gate || chan_scale))
         SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: pool_out needs relu, ldo == Co and no gate / chan_scale");

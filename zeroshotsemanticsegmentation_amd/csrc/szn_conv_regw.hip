@@ -21,6 +21,7 @@
 // Accumulation is fp32; per output the K terms are added tap-major inside 32-channel groups (a different order from
 // conv_igemm_v2, same tolerance against the oracle).
 #include "szn_common.h"
+#include <algorithm>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
@@ -28,12 +29,61 @@ typedef __attribute__((address_space(3))) void* ldsptr_t;
 
 namespace {
 
+// ---- constant-border hint (szn_conv_desc_t.cb_on): which tiles have to run ---------------------------------------------------------
+// A tile (TR rows x 16 columns of one image) can be skipped when it lies inside the rectangle in which the layers' zero padding is not
+// felt (tile rows [fy0, fy1) x tile columns [fx0, fx1)) and outside the window of tiles the image can influence ([wy0, wy1) x
+// [wx0, wx1), widened by one tile row: a tile of that extra row supplies the value every skipped pixel has).  The kept tiles of an
+// image are numbered in dense order; decode() inverts that numbering with a few integer divisions (no list in memory: a list entry
+// loaded per tile kept a scalar load outstanding across the MFMA phase and turned its counted LDS waits into full ones).
+struct CbGeom {
+    int on, tiles_y, tiles_x, fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1;
+    int nF, nW, n0, n1, n2, n3, per_image;      // kept tiles per frame row / window row; cumulative counts of the five row bands
+};
+
+__host__ __device__ inline bool cb_skippable(const CbGeom& c, int ty, int tx) {
+    if (ty < c.fy0 || ty >= c.fy1 || tx < c.fx0 || tx >= c.fx1) return false;
+    return !(ty >= c.wy0 && ty < c.wy1 && tx >= c.wx0 && tx < c.wx1);
+}
+__host__ inline void cb_finish(CbGeom& c) {
+    // window clipped to the padding-free rectangle (tiles outside it are kept anyway)
+    c.wy0 = c.wy0 > c.fy0 ? c.wy0 : c.fy0; c.wy1 = c.wy1 < c.fy1 ? c.wy1 : c.fy1;
+    c.wx0 = c.wx0 > c.fx0 ? c.wx0 : c.fx0; c.wx1 = c.wx1 < c.fx1 ? c.wx1 : c.fx1;
+    if (c.wy1 < c.wy0) c.wy1 = c.wy0;
+    if (c.wx1 < c.wx0) c.wx1 = c.wx0;
+    c.nF = c.tiles_x - (c.fx1 - c.fx0);
+    c.nW = c.nF + (c.wx1 - c.wx0);
+    c.n0 = c.fy0 * c.tiles_x;
+    c.n1 = c.n0 + (c.wy0 - c.fy0) * c.nF;
+    c.n2 = c.n1 + (c.wy1 - c.wy0) * c.nW;
+    c.n3 = c.n2 + (c.fy1 - c.wy1) * c.nF;
+    c.per_image = c.n3 + (c.tiles_y - c.fy1) * c.tiles_x;
+}
+// index of a kept tile within its image -> (ty, tx)
+__device__ __forceinline__ void cb_decode(const CbGeom& c, int v, int& ty, int& tx) {
+    if (v < c.n0) { ty = v / c.tiles_x; tx = v - ty * c.tiles_x; return; }
+    if (v >= c.n3) { const int u = v - c.n3; const int q = u / c.tiles_x; ty = c.fy1 + q; tx = u - q * c.tiles_x; return; }
+    int k;
+    if (v < c.n1) { const int u = v - c.n0; const int q = u / c.nF; ty = c.fy0 + q; k = u - q * c.nF; }
+    else if (v >= c.n2) { const int u = v - c.n2; const int q = u / c.nF; ty = c.wy1 + q; k = u - q * c.nF; }
+    else {
+        const int u = v - c.n1; const int q = u / c.nW; ty = c.wy0 + q; k = u - q * c.nW;
+        if (k < c.fx0) { tx = k; return; }
+        k -= c.fx0;
+        const int ow = c.wx1 - c.wx0;
+        if (k < ow) { tx = c.wx0 + k; return; }
+        tx = c.fx1 + (k - ow);
+        return;
+    }
+    tx = k < c.fx0 ? k : k + (c.fx1 - c.fx0);
+}
+
 struct RwArgs {
     const char* in; const char* w; const float* bias; const char* gate; char* out; float* colsum;
     float* cslab;              // optional [grid][Co]: this block's column sums go to row blockIdx.x (fixed-order reduce later)
     char* pool;                        // optional: MaxPool2d(2,2,ceil) of the (ReLU'd) output, [B][Hp][Wp][Co] dense
     unsigned char* pcode;              // optional (with pool): winner code per pooled element, szn_conv_desc_t.pool_code
     int skip_x;                        // 1: the un-pooled output is not stored (szn_conv_desc_t.pool_only)
+    CbGeom cb;                         // constant-border hint (cb.on): ntiles counts the kept tiles only
     unsigned in_bytes, gate_bytes;
     int Hp, Wp;
     int B, Hi, Wi, Ho, Wo, pad;
@@ -131,10 +181,19 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
     const int slot = lane % CPR, psub = lane / CPR;
     const unsigned chunkoff = (unsigned)((CPR == 8 ? (slot ^ psub) : (slot ^ ((4 * (w & 3) + psub) & 15))) << 4);
     const int q0 = RPP * w + psub;                                         // patch pixel of slot p: q0 + 8 RPP p
+    auto tile_of = [&](int t, int& b, int& ty, int& tx) {
+        if (a.cb.on) {
+            b = t / a.cb.per_image;
+            cb_decode(a.cb, t - b * a.cb.per_image, ty, tx);
+        } else {
+            int bb = t;
+            tx = bb % a.tiles_x; bb /= a.tiles_x;
+            ty = bb % a.tiles_y; b = bb / a.tiles_y;
+        }
+    };
     auto issue = [&](int t, int buf) {
-        int bb = t;
-        const int tx = bb % a.tiles_x; bb /= a.tiles_x;
-        const int ty = bb % a.tiles_y; const int b = bb / a.tiles_y;
+        int b, ty, tx;
+        tile_of(t, b, ty, tx);
         const int ih0 = ty * TR - a.pad, iw0 = tx * 16 - a.pad;
         char* base = smem + buf * PATCHB;
         int q0v = q0;
@@ -190,9 +249,8 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
     int buf = 0;
     for (int t = first; t < last; ++t) {
         const bool more = t + NBUF - 1 < last;
-        int bb = t;
-        const int tx = bb % a.tiles_x; bb /= a.tiles_x;
-        const int ty = bb % a.tiles_y; const int b = bb / a.tiles_y;
+        int b, ty, tx;
+        tile_of(t, b, ty, tx);
         const int ow = tx * 16 + r16;
         const int oh0 = ty * TR + pg * 4 + j0;                             // output row of this wave's first finished fragment
         const unsigned m0 = (unsigned)((b * a.Ho + oh0) * a.Wo + ow);       // < 2^31 pixels (checked by the caller)
@@ -419,6 +477,52 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
 #endif
 }
 
+// the skipped tiles: every pixel = the reference pixel (the un-pooled output unless pool_only, the pooled output and its winner codes).
+// One block per (image, tile row, group of CB_FILL_G tile columns): it walks the skippable tiles of its group (a block per tile
+// was 16 k blocks of a few KB each, a block per whole row too few blocks for the wide layers).
+constexpr int CB_FILL_G = 8;
+__global__ __launch_bounds__(256) void regw_const_fill_kernel(CbGeom c, int TR, int Co, int Ho, int Wo, int Hp, int Wp, uint16_t* __restrict__ out,
+                                                             int ldo, uint16_t* __restrict__ pool, unsigned char* __restrict__ pcode,
+                                                             int ref_oh, int ref_ow) {
+    const int ngrp = (c.tiles_x + CB_FILL_G - 1) / CB_FILL_G;
+    const int grp = blockIdx.x % ngrp, ty = (blockIdx.x / ngrp) % c.tiles_y, b = blockIdx.x / (ngrp * c.tiles_y);
+    if (ty < c.fy0 || ty >= c.fy1) return;
+    const int g0 = grp * CB_FILL_G, g1 = g0 + CB_FILL_G;
+    const int cpp = Co / 8;                                   // 16-B chunks per pixel
+    const bool inwin = ty >= c.wy0 && ty < c.wy1;
+    // skippable columns of this row: [fx0, fx1) minus the window columns -> pixel columns [x0, x1) in up to two runs
+    for (int run = 0; run < 2; ++run) {
+        int t0, t1;
+        if (!inwin) { if (run) break; t0 = c.fx0; t1 = c.fx1; }
+        else if (run == 0) { t0 = c.fx0; t1 = c.wx0; }
+        else { t0 = c.wx1; t1 = c.fx1; }
+        t0 = t0 > g0 ? t0 : g0; t1 = t1 < g1 ? t1 : g1;
+        if (t1 <= t0) continue;
+        const int x0 = t0 * 16, nx = (t1 - t0) * 16;
+        if (out) {
+            const uint4* ref = (const uint4*)(out + ((long)ref_oh * Wo + ref_ow) * ldo);
+            for (int i = threadIdx.x; i < TR * nx * cpp; i += 256) {
+                const int cc = i % cpp, px = i / cpp;
+                const int oh = ty * TR + px / nx, ow = x0 + px % nx;
+                *(uint4*)(out + ((long)(b * Ho + oh) * Wo + ow) * ldo + cc * 8) = ref[cc];
+            }
+        }
+        if (pool) {
+            const int rp = ref_oh >> 1, rq = ref_ow >> 1;
+            const uint4* pref = (const uint4*)(pool + ((long)rp * Wp + rq) * Co);
+            const uint2* cref = pcode ? (const uint2*)(pcode + ((long)rp * Wp + rq) * Co) : nullptr;
+            const int px0 = x0 >> 1, npx = nx >> 1;
+            for (int i = threadIdx.x; i < (TR / 2) * npx * cpp; i += 256) {
+                const int cc = i % cpp, px = i / cpp;
+                const int ph = ty * (TR / 2) + px / npx, pw = px0 + px % npx;
+                const long pe = ((long)(b * Hp + ph) * Wp + pw) * Co + cc * 8;
+                *(uint4*)(pool + pe) = pref[cc];
+                if (cref) *(uint2*)(pcode + pe) = cref[cc];
+            }
+        }
+    }
+}
+
 template <typename T, int COG, int CIG, bool GATED, bool COLSUM>
 int launch_regw(const RwArgs& a, int grid, hipStream_t st) {
     constexpr int lds = RwGeom<COG, CIG>::LDS;
@@ -467,6 +571,36 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     const long nt = (long)a.B * a.tiles_y * a.tiles_x;
     if (nt >= (1L << 30) || nt * tr * 16 < (long)min_tiles * 256) return 1;      // min_tiles counts 256-pixel tiles
     a.ntiles = (int)nt;
+    // constant-border hint: run the tiles the image or the zero padding can reach (+ one more tile row, which holds the reference
+    // pixel), broadcast the rest
+    CbGeom cb = {};
+    bool use_cb = false;
+    int ref_oh = 0, ref_ow = 0;
+    {
+        static int cbe = -1;
+        if (cbe < 0) { const char* e = getenv("SZN_CONST_BORDER"); cbe = e ? atoi(e) : 1; }
+        if (cbe && d->cb_on && !gate && !d->colsum) {
+            cb.tiles_y = a.tiles_y; cb.tiles_x = a.tiles_x;
+            cb.fy0 = (std::max(d->cb_const[0], 0) + tr - 1) / tr; cb.fy1 = std::min(d->cb_const[1], d->Ho) / tr;
+            cb.fx0 = (std::max(d->cb_const[2], 0) + 15) / 16;     cb.fx1 = std::min(d->cb_const[3], d->Wo) / 16;
+            cb.wy0 = std::max(d->cb_rect[0], 0) / tr;             cb.wy1 = (std::min(d->cb_rect[1], d->Ho) + tr - 1) / tr;
+            cb.wx0 = std::max(d->cb_rect[2], 0) / 16;             cb.wx1 = (std::min(d->cb_rect[3], d->Wo) + 15) / 16;
+            if (cb.fy1 > cb.fy0 && cb.fx1 > cb.fx0 && cb.wy0 - 1 >= cb.fy0 && cb.wy1 > cb.wy0 && cb.wx1 > cb.wx0 && cb.wx0 >= cb.fx0) {
+                const int ry = cb.wy0 - 1, rx = cb.wx0;          // a tile above the window, inside the padding-free rectangle
+                cb.wy0 -= 1;                                     // ... its whole row of window tiles is run (no special case in decode())
+                cb_finish(cb);
+                const long kept = (long)cb.per_image * a.B;
+                if (kept * 10 <= nt * 9 && cb.nF > 0 && cb.nW > 0) {                  // worth it from 10 % skipped tiles
+                    use_cb = true;
+                    cb.on = 1;
+                    a.ntiles = (int)kept;
+                    ref_oh = ry * tr; ref_ow = rx * 16;
+                    szn_note_work_fraction((float)((double)kept / (double)nt));
+                }
+            }
+        }
+    }
+    a.cb = cb;
     { static int abl = -1; if (abl < 0) abl = szn_ablate_env("SZN_REGW_ABLATE"); a.ablate = abl; }
     { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_REGW_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
     static int ncu = 0;
@@ -480,14 +614,19 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     hipStream_t st = (hipStream_t)stream;
     if (a.cslab && d->colsum_slab_rows < ncu) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab holds %d rows, %d needed", d->colsum_slab_rows, ncu);
     szn_note_colsum_rows(a.cslab ? ncu : 0);
+    int rc;
     if (d->dtype == SZN_F16) {
-        if (cog == 2 && cig == 1) return launch_regw_flags<f16_raw, 2, 1>(a, ncu, st);
-        if (cog == 4 && cig == 1) return launch_regw_flags<f16_raw, 4, 1>(a, ncu, st);
-        if (cog == 2 && cig == 2) return launch_regw_flags<f16_raw, 2, 2>(a, ncu, st);
-        return launch_regw_flags<f16_raw, 4, 2>(a, ncu, st);
-    }
-    if (cog == 2 && cig == 1) return launch_regw_flags<bf16_raw, 2, 1>(a, ncu, st);
-    if (cog == 4 && cig == 1) return launch_regw_flags<bf16_raw, 4, 1>(a, ncu, st);
-    if (cog == 2 && cig == 2) return launch_regw_flags<bf16_raw, 2, 2>(a, ncu, st);
-    return launch_regw_flags<bf16_raw, 4, 2>(a, ncu, st);
+        if (cog == 2 && cig == 1) rc = launch_regw_flags<f16_raw, 2, 1>(a, ncu, st);
+        else if (cog == 4 && cig == 1) rc = launch_regw_flags<f16_raw, 4, 1>(a, ncu, st);
+        else if (cog == 2 && cig == 2) rc = launch_regw_flags<f16_raw, 2, 2>(a, ncu, st);
+        else rc = launch_regw_flags<f16_raw, 4, 2>(a, ncu, st);
+    } else if (cog == 2 && cig == 1) rc = launch_regw_flags<bf16_raw, 2, 1>(a, ncu, st);
+    else if (cog == 4 && cig == 1) rc = launch_regw_flags<bf16_raw, 4, 1>(a, ncu, st);
+    else if (cog == 2 && cig == 2) rc = launch_regw_flags<bf16_raw, 2, 2>(a, ncu, st);
+    else rc = launch_regw_flags<bf16_raw, 4, 2>(a, ncu, st);
+    if (rc || !use_cb) return rc;
+    hipLaunchKernelGGL(regw_const_fill_kernel, dim3((unsigned)(a.B * a.tiles_y * ((a.tiles_x + CB_FILL_G - 1) / CB_FILL_G))), dim3(256), 0, st, cb, tr, d->Co, d->Ho, d->Wo, a.Hp, a.Wp,
+                       a.skip_x ? nullptr : (uint16_t*)a.out, d->ldo, (uint16_t*)a.pool, a.pcode, ref_oh, ref_ow);
+    SZN_CHECK_LAUNCH("conv3x3_regw");
+    return SZN_OK;
 }

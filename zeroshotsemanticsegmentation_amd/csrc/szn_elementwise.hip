@@ -28,6 +28,9 @@ extern "C" const char* szn_prev_kernel(void) { return g_prev_kernel; }
 static thread_local int g_colsum_rows = 0;
 void szn_note_colsum_rows(int rows) { g_colsum_rows = rows; }
 extern "C" int szn_last_colsum_rows(void) { return g_colsum_rows; }
+static thread_local float g_work_fraction = 1.f;
+void szn_note_work_fraction(float f) { g_work_fraction = f; }
+extern "C" float szn_last_work_fraction(void) { return g_work_fraction; }
 
 extern "C" int szn_version(void) { return 100; /* 0.1.0 */ }
 extern "C" int szn_device_info(int device, szn_device_info_t* out) {

@@ -45,6 +45,7 @@ _BACKBONE = [("conv1_1", PAD1), ("conv1_2", 1), "P", ("conv2_1", 1), ("conv2_2",
              ("conv3_1", 1), ("conv3_2", 1), ("conv3_3", 1), "P", ("conv4_1", 1), ("conv4_2", 1), ("conv4_3", 1), "P",
              ("conv5_1", 1), ("conv5_2", 1), ("conv5_3", 1), "P"]
 _TRUNK = [n for n, _, _, _ in synth.CONV_LAYERS]          # conv1_1 .. fc7
+_CONST_BORDER = os.environ.get("SZN_CONST_BORDER", "1") != "0"  # 0: no constant-border hint to the 710^2 / 355^2 forward convs
 _FC6_NATIVE = os.environ.get("SZN_FC6_NATIVE", "1") != "0"      # 0: fc6's dgrad GEMM on the packed transpose (rounds 1-2)
 _OPT_LAYERS = _TRUNK + ["score_fr"]                        # the layers train.get_parameters yields (train.py:302-331)
 _OPT_LAYERS8 = _TRUNK + ["score_pool3", "score_pool4", "score_fr"]       # ... for FCN8s (score_fr stays last: engine.TrainStep)
@@ -53,6 +54,26 @@ _OPT_LAYERS8 = _TRUNK + ["score_pool3", "score_pool4", "score_fr"]       # ... f
 def opt_layers(model):
     """names of the Conv2d layers the phase-1 optimizer updates, in the order of TrainStep's flat buffers"""
     return _OPT_LAYERS8 if hasattr(model, "score_pool3") else _OPT_LAYERS
+
+
+# ---- constant-border bookkeeping (szn_conv_desc_t.cb_on) -------------------------------------------------------------------------
+# conv1_1 pads by 100 (models.py:43): outside the rows / columns the image can reach, its output is relu(bias) everywhere, and the
+# layers behind it keep one value per channel there until their own zero padding is felt.  A region is, per axis, (r0, r1) = the
+# interval the image can influence and (c0, c1) = the interval the zero padding of the layers so far cannot influence.
+def _cb_conv1_1(n_in, pad):
+    n_out = n_in + 2 * pad - 2
+    return (max(pad - 2, 0), min(pad + n_in, n_out), 0, n_out)
+
+
+def _cb_conv3x3(reg, n):
+    r0, r1, c0, c1 = reg
+    return (max(r0 - 1, 0), min(r1 + 1, n), c0 + 1, c1 - 1)
+
+
+def _cb_pool(reg, n):
+    r0, r1, c0, c1 = reg
+    npool = (n + 1) // 2
+    return (r0 // 2, min((r1 + 1) // 2, npool), (c0 + 1) // 2, npool if c1 >= n else c1 // 2)
 
 
 class _Ctx(object):
@@ -262,7 +283,7 @@ class _Engine(object):
 
     # ---- kernels ---------------------------------------------------------------------------------
     def _conv(self, x, name, pad, relu=True, scale=None, out_f32=False, w=None, b=None, co=None, k=None, pool=False, codes=False,
-              pool_only=False):
+              pool_only=False, cb=None):
         """conv (+ bias, ReLU, dropout factor) through szn_conv2d_fwd; pool=True also returns MaxPool2d(2,2,ceil) of the
         output (the descriptor's pool_out: fused into the epilogue of the kernels that support it)"""
         B, Hi, Wi, Ci = x.shape
@@ -283,6 +304,11 @@ class _Engine(object):
                 code = torch.empty(B, (Ho + 1) // 2, (Wo + 1) // 2, co, device=x.device, dtype=torch.uint8)
                 d.pool_code = code.data_ptr()
             d.pool_only = int(pool_only)
+        if cb is not None and _CONST_BORDER and self.dtype != torch.float32:
+            (ry, rx) = cb                                       # per-axis regions of THIS conv's output
+            d.cb_on = 1
+            d.cb_rect[0], d.cb_rect[1], d.cb_rect[2], d.cb_rect[3] = ry[0], ry[1], rx[0], rx[1]
+            d.cb_const[0], d.cb_const[1], d.cb_const[2], d.cb_const[3] = ry[2], ry[3], rx[2], rx[3]
         L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), None, L.ptr(scale), L.ptr(out), L.stream_ptr())
         if pool and codes:
             return out, pooled, code
@@ -320,23 +346,28 @@ class _Engine(object):
                L.ptr(self._images["conv1_1.b"]), L.ptr(a), L.stream_ptr())
         acts, pools = ({"conv1_1": a} if keep else {}), []
         items = _BACKBONE[1:]
+        regy, regx = _cb_conv1_1(H, PAD1), _cb_conv1_1(W, PAD1)         # constant-border regions of the current tensor, per axis
         for i, item in enumerate(items):
             if item == "P":
+                regy, regx = _cb_pool(regy, a_hw[0]), _cb_pool(regx, a_hw[1])
                 continue                                  # pooled by the conv in front of it (pool_out)
             name, pad = item
+            a_hw = (a.shape[1], a.shape[2])               # 3x3 / pad 1: the conv's output size
+            regy, regx = _cb_conv3x3(regy, a_hw[0]), _cb_conv3x3(regx, a_hw[1])
+            cb = (regy, regx)
             if i + 1 < len(items) and items[i + 1] == "P":
                 if keep and self.pool_codes:
-                    pin, a, code = self._conv(a, name, pad, pool=True, codes=True, pool_only=not self.keep_prepool)
+                    pin, a, code = self._conv(a, name, pad, pool=True, codes=True, pool_only=not self.keep_prepool, cb=cb)
                     acts[name] = pin if self.keep_prepool else None       # (may be unwritten: the backward pass takes the codes)
                     pools.append((acts[name], a, code, tuple(pin.shape)))
                 else:
-                    pin, a = self._conv(a, name, pad, pool=True, pool_only=not keep)
+                    pin, a = self._conv(a, name, pad, pool=True, pool_only=not keep, cb=cb)
                     if keep:
                         acts[name] = pin
                         pools.append((pin, a))
                 del pin
             else:
-                a = self._conv(a, name, pad)
+                a = self._conv(a, name, pad, cb=cb)
                 if keep:
                     acts[name] = a
         if train and masks is None:
