@@ -431,6 +431,32 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__ ws, Conv2Args a) {
     const long total = (long)a.M * a.Co;
     const T* __restrict__ gate = (const T*)a.gate;
+    // four consecutive couts per thread (16-B slab loads) when the row pitches allow it; same additions in the same order
+    const bool v4 = !(a.Co & 3) && !(a.ldo & 3) && (!gate || !(a.ldg & 3));
+    if (v4) {
+        const int c4n = a.Co >> 2;
+        const long tot4 = total >> 2;
+        for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < tot4; i4 += (long)gridDim.x * 256) {
+            const int n = (int)(i4 % c4n) * 4;
+            const long m = i4 / c4n;
+            f32x4_t x = {0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < a.nsplit; ++sp) x += *(const f32x4_t*)(ws + (long)sp * total + i4 * 4);
+            if (a.bias) x += *(const f32x4_t*)(a.bias + n);
+            if (a.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+            if (gate) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = (elem<T>::ld(gate + m * a.ldg + n + e) > 0.f) ? x[e] : 0.f;
+            }
+            if (a.cscale) x *= *(const f32x4_t*)(a.cscale + (m / a.HoWo) * a.Co + n);
+            if (a.out_f32 || sizeof(T) == 4) *(f32x4_t*)((float*)a.out + m * a.ldo + n) = x;
+            else {
+                uint2 o;
+                o.x = pack2<T>(x[0], x[1]); o.y = pack2<T>(x[2], x[3]);
+                *(uint2*)((uint16_t*)a.out + m * a.ldo + n) = o;
+            }
+        }
+        return;
+    }
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int n = (int)(idx % a.Co);
         const long m = idx / a.Co;
@@ -619,8 +645,9 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
         if (rc) return rc;
     }
     if (a.nsplit > 1) {
-        long blocks = ((long)a.M * a.Co + 255) / 256;
+        long blocks = ((long)a.M * a.Co / 4 + 255) / 256;
         if (blocks > 8192) blocks = 8192;
+        if (blocks < 1) blocks = 1;
         if (d->dtype == SZN_BF16)
             hipLaunchKernelGGL(splitk_epilogue<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a.ws, a);
         else if (d->dtype == SZN_F16)

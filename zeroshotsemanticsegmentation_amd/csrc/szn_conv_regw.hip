@@ -191,9 +191,28 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             ty = bb % a.tiles_y; b = bb / a.tiles_y;
         }
     };
-    auto issue = [&](int t, int buf) {
-        int b, ty, tx;
-        tile_of(t, b, ty, tx);
+    // A block's tiles are consecutive in the (kept-)tile numbering: two cursors -- the tile being issued and the tile being computed --
+    // are decoded once and then stepped (scalar compares; the divisions of tile_of per tile and per cursor were ~10 % of a
+    // constant-border launch)
+    auto step = [&](int& b, int& ty, int& tx) {
+        ++tx;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (a.cb.on && ty >= a.cb.fy0 && ty < a.cb.fy1 && tx >= a.cb.fx0 && tx < a.cb.fx1) {       // inside the padding-free rectangle
+                if (ty < a.cb.wy0 || ty >= a.cb.wy1) tx = a.cb.fx1;
+                else if (tx < a.cb.wx0) tx = a.cb.wx0;
+                else if (tx >= a.cb.wx1) tx = a.cb.fx1;
+            }
+            if (tx < a.tiles_x) break;
+            tx = 0;                                        // next tile row (its column 0 may be skippable too: second pass)
+            if (++ty == a.tiles_y) { ty = 0; ++b; }
+        }
+    };
+    int ib, ity, itx;                                      // the next tile to issue
+    tile_of(first, ib, ity, itx);
+    int cb_b = ib, cb_ty = ity, cb_tx = itx;               // the tile being computed
+    auto issue = [&](int buf) {
+        const int b = ib, ty = ity, tx = itx;
+        step(ib, ity, itx);
         const int ih0 = ty * TR - a.pad, iw0 = tx * 16 - a.pad;
         char* base = smem + buf * PATCHB;
         int q0v = q0;
@@ -218,10 +237,10 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
     const int qb = (pg * 4) * PWr + r16;
     const int j0 = CIG == 2 ? 2 * cig : 0;                                 // first pixel fragment this wave finishes
 
-    issue(first, 0);
+    issue(0);
     if constexpr (NBUF == 3) {
         if (first + 1 < last) {
-            issue(first + 1, 1);
+            issue(1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SLOTS) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -249,8 +268,8 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
     int buf = 0;
     for (int t = first; t < last; ++t) {
         const bool more = t + NBUF - 1 < last;
-        int b, ty, tx;
-        tile_of(t, b, ty, tx);
+        const int b = cb_b, ty = cb_ty, tx = cb_tx;
+        step(cb_b, cb_ty, cb_tx);
         const int ow = tx * 16 + r16;
         const int oh0 = ty * TR + pg * 4 + j0;                             // output row of this wave's first finished fragment
         const unsigned m0 = (unsigned)((b * a.Ho + oh0) * a.Wo + ow);       // < 2^31 pixels (checked by the caller)
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (ldsptr_t)(smem + G_::OFF_GATE + (w * NJ + jj) * 1024), 16, v, 0, 0, 0);
             }
         }
-        if (more && !RW_ABL(4)) issue(t + NBUF - 1, (buf + NBUF - 1) % NBUF);
+        if (more && !RW_ABL(4)) issue((buf + NBUF - 1) % NBUF);
 
         f32x4_t acc[2][4];
 #pragma unroll
