@@ -82,14 +82,20 @@ typedef struct {
     int pool_only;      /* with pool_out: the caller does not need the un-pooled tensor (in training it is read once, by the pool's
                          backward pass, which takes pool_code instead: 516 + 258 MB per step that are neither written nor read back);
                          `out` must still be valid memory, a kernel that fuses the pool MAY leave it unwritten             */
-    int cb_on;          /* szn_conv2d_fwd only: constant-border hint.  models.py:43 pads conv1_1 by 100, so on the 710^2 / 355^2 maps most
-                         pixels outside the image's reach hold ONE value per channel (conv1_1 writes relu(bias) there) and stay that way
-                         through conv1_2 .. conv2_2 away from the tensor edge.  cb_rect = output rows [r0, r1) x columns [c0, c1) the image
-                         can influence; cb_const = output rows / columns [r0, r1) x [c0, c1) outside of which the zero padding of the
-                         layers so far is felt.  Output pixels inside cb_const and outside cb_rect are all equal: a kernel that takes the
-                         hint (conv3x3_regw) runs its tiles over cb_rect and the edge frame only, and broadcasts one computed pixel to the
-                         rest (out / pool_out / pool_code alike).  Same bits as the dense computation.  szn_last_work_fraction() = the
-                         fraction of the dense tiles the last call executed.                                                     */
+    int cb_on;          /* constant-border hint (optional; a kernel that does not take it computes everything).  models.py:43 pads conv1_1
+                         by 100, so on the 710^2 / 355^2 maps most pixels outside the image's reach hold ONE value per channel (conv1_1
+                         writes relu(bias) there) and stay that way through conv1_2 .. conv2_2 away from the tensor edge.
+                         szn_conv2d_fwd: cb_rect = output rows [r0, r1) x columns [c0, c1) the image can influence; cb_const = output
+                         rows / columns [r0, r1) x [c0, c1) outside of which the zero padding of the layers so far is felt.  The caller
+                         asserts that the INPUT is constant accordingly, so output pixels inside cb_const and outside cb_rect are all
+                         equal: a kernel that takes the hint (conv3x3_regw) runs its tiles over cb_rect and the edge frame only, and
+                         broadcasts one computed pixel to the rest (out / pool_out / pool_code alike).  Same bits as the dense
+                         computation.  szn_last_work_fraction() = the fraction of the dense tiles the last call executed.
+                         szn_conv2d_dgrad with a gate (coordinates of DIN): cb_rect = the rows x columns outside of which every pixel of
+                         the gate tensor equals gate pixel (row r0 - 1, column c0) of image 0 (needs r0 >= 1) -- the kernel may read that
+                         pixel instead; cb_const = the rows x columns of DIN the caller is going to read -- stores outside may be
+                         skipped (DIN is undefined there; colsum still covers every pixel).  conv1_2's dgrad: its output feeds only
+                         szn_conv1_1_wgrad, whose read set szn_conv1_1_wgrad_reads() reports.                                    */
     int cb_rect[4];
     int cb_const[4];
 } szn_conv_desc_t;
@@ -184,6 +190,11 @@ size_t szn_conv1_1_wgrad_workspace_bytes(int dtype, int B, int H, int W, int pad
 int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const float* x_nchw,
                       const void* dout, float* dw, float* db, int accumulate, void* workspace,
                       szn_stream_t stream);
+/* The part of dout a szn_conv1_1_wgrad call with db == NULL and these arguments reads: rect = rows [r0, r1) x columns [c0, c1) of
+ * the (H + 2 pad - 2) x (W + 2 pad - 2) map.  Returns 1 when that is a proper sub-rectangle (the fused 16-bit kernel skips the pixels
+ * whose windows hold padding only), 0 when the call reads everything (rect = the whole map).  What the producer of dout -- conv1_2's
+ * dgrad -- may leave unwritten: szn_conv_desc_t.cb_const.                                                                          */
+int szn_conv1_1_wgrad_reads(int dtype, int B, int H, int W, int pad, int rect[4]);
 
 /* ---- MaxPool2d(2, stride 2, ceil_mode=True): models.py:47,54,63,72,81 ---------------------------- */
 int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out,

@@ -631,3 +631,43 @@ def test_constant_border_hint_is_bit_exact(case):
             assert torch.equal(out, dense[2]), (cb_on, pool_only)
         if cb_on:
             assert 0.3 < frac < 0.9, frac                 # tiles were actually skipped
+
+
+@pytest.mark.parametrize("case", [(2, 710, 64, 64, (98, 612, 98, 612), (98, 612, 96, 640)), (1, 300, 64, 64, (50, 210, 40, 222), (50, 210, 32, 224))])
+def test_constant_border_hint_of_a_gated_dgrad(case):
+    """szn_conv_desc_t.cb_on on szn_conv2d_dgrad (conv1_2's dgrad): the gate is read from one reference pixel where the caller says it is
+    constant, stores outside the rectangle the consumer reads are skipped -- din inside that rectangle and the column sums (conv1_1's
+    bias gradient) are the same bits as the dense run, and the skipped region really is left alone"""
+    B, Hi, Ci, Co, grect, srect = case
+    g = torch.Generator().manual_seed(37)
+    dt = L.dtype_code(torch.bfloat16)
+    dout = torch.randn(B, Hi, Hi, Co, generator=g).cuda().bfloat16()
+    gate = torch.relu(torch.randn(B, Hi, Hi, Ci, generator=g))
+    const = torch.relu(torch.randn(Ci, generator=g))                    # zeros and positive values: channels gated off and on
+    inside = torch.zeros(Hi, Hi, dtype=torch.bool)
+    inside[grect[0]:grect[1], grect[2]:grect[3]] = True
+    gate = torch.where(inside[None, :, :, None], gate, const[None, None, None, :]).cuda().bfloat16()
+    wT = (torch.randn(Ci, 3, 3, Co, generator=g) / (Co * 9) ** 0.5).cuda().bfloat16()
+    res = []
+    for cb_on in (0, 1):
+        din = torch.full((B, Hi, Hi, Ci), 7.0, device="cuda", dtype=torch.bfloat16)
+        colsum = torch.zeros(Ci, device="cuda")
+        slab = torch.zeros(1024, Ci, device="cuda")
+        d = L.ConvDesc(dt, B, Hi, Hi, Ci, Hi, Hi, Co, 3, 3, 1, Ci, Co, Ci, 0, 0)
+        d.colsum, d.colsum_slab, d.colsum_slab_rows = colsum.data_ptr(), slab.data_ptr(), 1024
+        if cb_on:
+            d.cb_on = 1
+            for i in range(4):
+                d.cb_rect[i], d.cb_const[i] = grect[i], srect[i]
+        L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), None, L.ptr(din), L.stream_ptr())
+        assert L.last_kernel() == "conv3x3_regw", L.last_kernel()
+        rows = L.load().szn_last_colsum_rows()
+        torch.cuda.synchronize()
+        res.append((din, slab[:rows].clone()))
+    (dense, cs0), (hint, cs1) = res
+    r0, r1, c0, c1 = srect
+    assert torch.equal(hint[:, r0:r1, c0:c1], dense[:, r0:r1, c0:c1])
+    assert torch.equal(cs0, cs1)
+    assert not (dense == 7.0).all(dim=-1).any()
+    untouched = (hint == 7.0).all(dim=-1)                                # pixels the hinted run did not store
+    assert untouched.float().mean() > 0.2 and not untouched[:, r0:r1, c0:c1].any()

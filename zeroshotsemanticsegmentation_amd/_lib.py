@@ -63,6 +63,7 @@ SIGNATURES = {
     "szn_conv1_1_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "szn_conv1_1_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "szn_conv1_1_wgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "szn_conv1_1_wgrad_reads": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_int)]),
     "szn_maxpool2x2_ceil_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
     "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "szn_maxpool2x2_ceil_fwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),

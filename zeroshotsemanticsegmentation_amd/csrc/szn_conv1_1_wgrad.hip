@@ -188,24 +188,46 @@ __global__ __launch_bounds__(256) void conv1_1_wgrad_reduce(const float* __restr
 
 }  // namespace
 
+// the rows / 32-pixel column segments of dout whose 3x3 windows overlap the image; false: the fused kernel does not apply
+static bool c11_geometry(int dtype, int B, int H, int W, int pad, int& oh_lo, int& oh_hi, int& seg_lo, int& seg_hi) {
+    if (!szn_is16(dtype) || B <= 0 || H <= 0 || W <= 0 || pad < 0) return false;
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const size_t dout_bytes = (size_t)B * Ho * Wo * 128, x_bytes = (size_t)B * 3 * H * W * 4;
+    if (Ho <= 0 || Wo <= 0 || dout_bytes >= 0x7fff0000ul || x_bytes >= 0x7fff0000ul) return false;
+    // output pixel (oh, ow) sees the image iff oh - pad + kh in [0, H) for some kh in 0..2, same for columns
+    oh_lo = pad - 2; if (oh_lo < 0) oh_lo = 0;
+    oh_hi = pad + H; if (oh_hi > Ho) oh_hi = Ho;                      // exclusive
+    int ow_lo = pad - 2; if (ow_lo < 0) ow_lo = 0;
+    int ow_hi = pad + W; if (ow_hi > Wo) ow_hi = Wo;
+    if (oh_hi <= oh_lo || ow_hi <= ow_lo) return false;
+    seg_lo = ow_lo / 32; seg_hi = (ow_hi + 31) / 32;
+    return true;
+}
+
+// the part of dout szn_conv1_1_wgrad (db == NULL) reads: rect = rows [r0, r1) x columns [c0, c1); 1 = a proper sub-rectangle
+extern "C" int szn_conv1_1_wgrad_reads(int dtype, int B, int H, int W, int pad, int rect[4]) {
+    if (!rect) return 0;
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    rect[0] = 0; rect[1] = Ho; rect[2] = 0; rect[3] = Wo;
+    int oh_lo, oh_hi, seg_lo, seg_hi;
+    if (!c11_geometry(dtype, B, H, W, pad, oh_lo, oh_hi, seg_lo, seg_hi)) return 0;
+    rect[0] = oh_lo; rect[1] = oh_hi; rect[2] = seg_lo * 32; rect[3] = seg_hi * 32 < Wo ? seg_hi * 32 : Wo;
+    return 1;
+}
+
 // bf16 path of szn_conv1_1_wgrad (szn_elementwise.hip).  workspace: >= nblocks * 8 KiB.  Returns 1 if not applicable.
 int szn_conv1_1_wgrad_fused_try(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
                                 void* workspace, size_t workspace_bytes, szn_stream_t stream) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    int oh_lo, oh_hi, seg_lo, seg_hi;
+    if (!c11_geometry(dtype, B, H, W, pad, oh_lo, oh_hi, seg_lo, seg_hi)) return 1;
     const size_t dout_bytes = (size_t)B * Ho * Wo * 128, x_bytes = (size_t)B * 3 * H * W * 4;
-    if (dout_bytes >= 0x7fff0000ul || x_bytes >= 0x7fff0000ul) return 1;
     C11Args a;
     a.dout = (const char*)dout; a.x = x; a.ws = (float*)workspace;
     a.dout_bytes = (unsigned)dout_bytes; a.x_bytes = (unsigned)x_bytes;
     a.B = B; a.H = H; a.W = W; a.pad = pad; a.Ho = Ho; a.Wo = Wo;
-    // output pixel (oh, ow) sees the image iff oh - pad + kh in [0, H) for some kh in 0..2, same for columns
-    int oh_lo = pad - 2; if (oh_lo < 0) oh_lo = 0;
-    int oh_hi = pad + H; if (oh_hi > Ho) oh_hi = Ho;                  // exclusive
-    int ow_lo = pad - 2; if (ow_lo < 0) ow_lo = 0;
-    int ow_hi = pad + W; if (ow_hi > Wo) ow_hi = Wo;
-    if (oh_hi <= oh_lo || ow_hi <= ow_lo) return 1;
     a.oh_lo = oh_lo; a.nrows = oh_hi - oh_lo;
-    a.seg_lo = ow_lo / 32; a.nsegx = (ow_hi + 31) / 32 - a.seg_lo;
+    a.seg_lo = seg_lo; a.nsegx = seg_hi - seg_lo;
     a.nseg = (long)B * a.nrows * a.nsegx;
     long blocks = (a.nseg + 4 * 16 - 1) / (4 * 16);                   // >= 16 segments per wave
     if (blocks > 768) blocks = 768;

@@ -84,6 +84,10 @@ struct RwArgs {
     unsigned char* pcode;              // optional (with pool): winner code per pooled element, szn_conv_desc_t.pool_code
     int skip_x;                        // 1: the un-pooled output is not stored (szn_conv_desc_t.pool_only)
     CbGeom cb;                         // constant-border hint (cb.on): ntiles counts the kept tiles only
+    // constant-border hint of a GATED launch (dgrad): tiles wholly outside rows [gy0, gy1) x columns [gx0, gx1) read the gate of
+    // pixel `gref` (their own gate rows hold the same values), tiles wholly outside [sy0, sy1) x [sx0, sx1) store nothing
+    int dg_on, gy0, gy1, gx0, gx1, sy0, sy1, sx0, sx1;
+    unsigned gref;
     unsigned in_bytes, gate_bytes;
     int Hp, Wp;
     int B, Hi, Wi, Ho, Wo, pad;
@@ -274,12 +278,20 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
         const int oh0 = ty * TR + pg * 4 + j0;                             // output row of this wave's first finished fragment
         const unsigned m0 = (unsigned)((b * a.Ho + oh0) * a.Wo + ow);       // < 2^31 pixels (checked by the caller)
         const bool okw = ow < a.Wo;
+        bool gconst = false, nostore = false;
+        if constexpr (GATED) {
+            if (a.dg_on) {
+                const int y0 = ty * TR, x0 = tx * 16;
+                gconst = y0 + TR <= a.gy0 || y0 >= a.gy1 || x0 + 16 <= a.gx0 || x0 >= a.gx1;
+                nostore = y0 + TR <= a.sy0 || y0 >= a.sy1 || x0 + 16 <= a.sx0 || x0 >= a.sx1;
+            }
+        }
         if constexpr (GATED) {
             // each lane's 16 gate bytes per finished pixel row go to its own LDS slot: an asynchronous, register-free prefetch
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
                 const bool ok = okw && oh0 + jj < a.Ho;
-                const unsigned v = ok ? ((m0 + jj * a.Wo) * a.ldg + cstart) * 2u : kOOBr;
+                const unsigned v = ok ? ((gconst ? a.gref : m0 + jj * a.Wo) * a.ldg + cstart) * 2u : kOOBr;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (ldsptr_t)(smem + G_::OFF_GATE + (w * NJ + jj) * 1024), 16, v, 0, 0, 0);
             }
         }
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             pk.y = pack2<T>(v[2], v[3]);
             pk.z = pack2<T>(v[4], v[5]);
             pk.w = pack2<T>(v[6], v[7]);
-            if (ok && !RW_ABL(2) && !a.skip_x) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
+            if (ok && !RW_ABL(2) && !a.skip_x && !nostore) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
             if constexpr (!GATED) {
                 if (a.pool && a.pcode) {
                     // pooling on the packed 16-bit patterns (post-ReLU values are >= 0: they order like unsigned integers)
@@ -620,6 +632,18 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
         }
     }
     a.cb = cb;
+    a.dg_on = 0; a.gy0 = a.gy1 = a.gx0 = a.gx1 = a.sy0 = a.sy1 = a.sx0 = a.sx1 = 0; a.gref = 0;
+    {
+        static int cbe = -1;
+        if (cbe < 0) { const char* e = getenv("SZN_CONST_BORDER"); cbe = e ? atoi(e) : 1; }
+        // (dgrad form of the hint: see szn_conv_desc_t.cb_on)
+        if (cbe && d->cb_on && gate && d->cb_rect[0] >= 1 && d->cb_rect[0] <= d->Ho && d->cb_rect[2] >= 0 && d->cb_rect[2] < d->Wo) {
+            a.dg_on = 1;
+            a.gy0 = d->cb_rect[0]; a.gy1 = d->cb_rect[1]; a.gx0 = d->cb_rect[2]; a.gx1 = d->cb_rect[3];
+            a.sy0 = d->cb_const[0]; a.sy1 = d->cb_const[1]; a.sx0 = d->cb_const[2]; a.sx1 = d->cb_const[3];
+            a.gref = (unsigned)((d->cb_rect[0] - 1) * d->Wo + d->cb_rect[2]);
+        }
+    }
     { static int abl = -1; if (abl < 0) abl = szn_ablate_env("SZN_REGW_ABLATE"); a.ablate = abl; }
     { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_REGW_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
     static int ncu = 0;

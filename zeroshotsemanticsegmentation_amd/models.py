@@ -524,7 +524,7 @@ class _Engine(object):
             if after is not None:
                 after()
 
-    def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None, colsum=None, wT=None):
+    def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None, colsum=None, wT=None, cb=None):
         """din = conv(dout, flipped weights) with the ReLU gate / dropout factor of the producing layer fused; colsum
         (f32 [Ci], pre-zeroed) receives the column sums of din = that layer's bias gradient"""
         B, Hi, Wi, Ci = in_shape
@@ -566,6 +566,11 @@ class _Engine(object):
                 d.colsum_slab, d.colsum_slab_rows = slab.data_ptr(), rows
         else:
             self._workspace(d, B * Hi * Wi * Ci * 4, dout.device)
+        if cb is not None and gate is not None and _CONST_BORDER and self.dtype != torch.float32:
+            grect, srect = cb                                   # (r0, r1, c0, c1) each: where the gate varies / what the consumer reads
+            d.cb_on = 1
+            for i in range(4):
+                d.cb_rect[i], d.cb_const[i] = grect[i], srect[i]
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
         self._cs_register(slab, Ci, colsum)
         return din
@@ -660,7 +665,14 @@ class _Engine(object):
                 if side is not None:
                     d = d + side.to(d.dtype)
             else:
-                d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1])
+                cb = None
+                if prev[0] == "conv1_1":
+                    # conv1_1's output is constant outside the image's reach, and this gradient is read by szn_conv1_1_wgrad only
+                    ry, rx = _cb_conv1_1(ctx.H, PAD1), _cb_conv1_1(ctx.W, PAD1)
+                    reads = (C.c_int * 4)()
+                    L.load().szn_conv1_1_wgrad_reads(code, ctx.B, ctx.H, ctx.W, PAD1, reads)
+                    cb = ((ry[0], ry[1], rx[0], rx[1]), tuple(reads))
+                d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1], cb=cb)
         self._join_wgrad()
 
 
