@@ -8,9 +8,11 @@
 //   * a K step is a segment of 32 consecutive output pixels of one row; only segments whose 3x3 windows overlap the
 //     image are enumerated; a WAVE owns segments (no block barriers): its dout rows (32 x 128 B) stream into a private
 //     3-deep LDS ring by LDS-DMA, A fragments (dout^T) come out with ds_read_b64_tr_b16;
-//   * the B operand (xcol^T, 2 fragments of 16 taps) is gathered straight from the f32 NCHW image into registers with
-//     buffer loads (out-of-range offsets = the zero padding), rounded to bf16 like the im2col path did, one segment
-//     ahead of its use;
+//   * the B operand (xcol^T, 2 fragments of 16 taps): the 3 x 3 rows x 34 columns of the f32 NCHW image a segment's windows cover
+//     are fetched with 5 coalesced buffer loads per lane (out-of-range offsets = the zero padding) one segment ahead, parked in a
+//     wave-private LDS patch, and the 16 taps x pixels a lane supplies are read from there and rounded to bf16 like the im2col
+//     path did.  (Round 2 gathered them straight from memory: 16 four-byte loads per lane whose 64 lanes hit ~20 different
+//     cache lines -- the CU's address path, not HBM, bounded the kernel at 3 TB/s; STAGED = false keeps that form.);
 //   * 8 MFMA 16x16x32 per segment into 8 accumulator fragments per wave; at the end the 4 waves of a block add up in
 //     LDS and write one fp32 slab [64][32] per block; conv1_1_wgrad_reduce sums the slabs in a fixed order
 //     (deterministic) into dw[64][27].
@@ -33,11 +35,14 @@ struct C11Args {
 constexpr unsigned kOOB1 = 0x80000000u;
 constexpr int RING1 = 3;
 
-template <typename T>      // bf16_raw | f16_raw: rounding of the gathered image taps + the MFMA opcode
+constexpr int PS1 = 36;                      // floats per row of the image patch (34 used)
+constexpr int PATCH1 = 9 * PS1 * 4;          // bytes per wave: rows (ci, kh)
+
+template <typename T, bool STAGED>      // bf16_raw | f16_raw: rounding of the gathered image taps + the MFMA opcode
 __global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(C11Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
-    __shared__ __attribute__((aligned(16))) char smem[4 * RING1 * 4096];      // per wave: 3 stages of 32 px x 128 B
+    __shared__ __attribute__((aligned(16))) char smem[4 * RING1 * 4096 + 4 * PATCH1];      // per wave: 3 stages of 32 px x 128 B | patch
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, r16 = lane & 15;
@@ -105,6 +110,50 @@ __global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(C11Args a) {
         }
     };
 
+    // staged form: element idx = lane + 64 k of the patch is (row = idx / 34 = ci * 3 + kh, column c = idx % 34) <-> image pixel
+    // (oh + kh - pad, ow0 + c - pad) of channel ci
+    float* const patch = (float*)(smem + 4 * RING1 * 4096 + w * PATCH1);
+    auto stage_load = [&](long s, float (&xr)[5]) {
+        int b, oh, ow0;
+        seg_coords(s, b, oh, ow0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int idx = lane + 64 * k;
+            const int row = (idx * 1928) >> 16;                        // idx / 34 for idx < 320
+            const int c = idx - row * 34;
+            const int ci = (row * 11) >> 5, kh = row - ci * 3;         // row / 3 for row < 10
+            const int ih = oh + kh - a.pad, iw = ow0 + c - a.pad;
+            const bool ok = idx < 306 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const unsigned off = ok ? (((unsigned)(b * 3 + ci)) * plane + (unsigned)(ih * a.W + iw)) * 4u : kOOB1;
+            xr[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, off, 0, 0));
+        }
+    };
+    auto stage_store = [&](const float (&xr)[5]) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int idx = lane + 64 * k;
+            const int row = (idx * 1928) >> 16;
+            if (idx < 306) patch[row * PS1 + (idx - row * 34)] = xr[k];
+        }
+    };
+    int poff[2];                                                        // word offset of this lane's first tap pixel per fragment
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int t = r16 + 16 * f;
+        poff[f] = t < 27 ? ((int)tci[f] * 3 + t / 9) * PS1 + tkw[f] + 4 * g : -1;
+    }
+    auto patch_read = [&](float (&xv)[2][8]) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const float* pp = patch + (poff[f] < 0 ? 0 : poff[f]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = pp[e < 4 ? e : 16 + e - 4];
+                xv[f][e] = poff[f] < 0 ? 0.f : v;
+            }
+        }
+    };
+
     f32x4_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -113,6 +162,49 @@ __global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(C11Args a) {
 
     const long nwaves = (long)gridDim.x * 4;
     const long s0 = (long)blockIdx.x * 4 + w;
+    if constexpr (STAGED) {
+        float xr[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (s0 < a.nseg) { issue_dma(s0, 0); stage_load(s0, xr); }
+        if (s0 + nwaves < a.nseg) issue_dma(s0 + nwaves, 1);
+        int stage = 0;
+        for (long s = s0; s < a.nseg; s += nwaves) {
+            // park this segment's image values (forces the wait for their loads; the DMA issued behind them stays in flight)
+            stage_store(xr);
+            float xn[2][8];
+            patch_read(xn);
+            u32x4_t xf[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                xf[f].x = pack2<T>(xn[f][0], xn[f][1]);
+                xf[f].y = pack2<T>(xn[f][2], xn[f][3]);
+                xf[f].z = pack2<T>(xn[f][4], xn[f][5]);
+                xf[f].w = pack2<T>(xn[f][6], xn[f][7]);
+            }
+            const bool more1 = s + nwaves < a.nseg, more2 = s + 2 * nwaves < a.nseg;
+            if (more1) stage_load(s + nwaves, xr);
+            if (more2) issue_dma(s + 2 * nwaves, stage >= 1 ? stage - 1 : 2);
+            // dout rows of THIS segment: newer in flight = this iteration's image loads (5) + DMA (4) and last iteration's DMA (4)
+            if (more2) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            else if (more1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* sb = ring + stage * 4096;
+            u32x4_t df[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + offA[i]));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(sb + 2048 + offA[i]));
+                const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+                df[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+                    acc[i][f] = mfma16<T>(df[i], xf[f], acc[i][f]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // stage drained before it is refilled
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+    } else {
     // software pipeline per wave: DMA two segments ahead, gather one segment ahead
     float xn[2][8];
     if (s0 < a.nseg) { issue_dma(s0, 0); gather(s0, xn); }
@@ -153,6 +245,7 @@ __global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(C11Args a) {
                 acc[i][f] = mfma16<T>(df[i], xf[f], acc[i][f]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // stage drained before it is refilled
         stage = stage == 2 ? 0 : stage + 1;
+    }
     }
 
     // ---- block partial: D[co = 16 i + 4 g + e][t = 16 f + r16], waves added in a fixed order ----
@@ -234,8 +327,15 @@ int szn_conv1_1_wgrad_fused_try(int dtype, int B, int H, int W, int pad, const f
     if (blocks < 1) blocks = 1;
     if (workspace_bytes < (size_t)blocks * 2048 * sizeof(float)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SZN_F16) hipLaunchKernelGGL(conv1_1_wgrad_kernel<f16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(conv1_1_wgrad_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    static int gather = -1;                  // SZN_C11_WGRAD_GATHER=1: the round-2 form (taps gathered straight from memory)
+    if (gather < 0) { const char* e = getenv("SZN_C11_WGRAD_GATHER"); gather = e ? atoi(e) : 0; }
+    if (gather) {
+        if (dtype == SZN_F16) hipLaunchKernelGGL((conv1_1_wgrad_kernel<f16_raw, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv1_1_wgrad_kernel<bf16_raw, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else {
+        if (dtype == SZN_F16) hipLaunchKernelGGL((conv1_1_wgrad_kernel<f16_raw, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv1_1_wgrad_kernel<bf16_raw, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
     SZN_CHECK_LAUNCH("conv1_1_wgrad_kernel");
     hipLaunchKernelGGL(conv1_1_wgrad_reduce, dim3(64 * 27 / 8), dim3(256), 0, st, (const float*)workspace, dw,
                        (int)blocks, accumulate);
