@@ -290,6 +290,158 @@ __global__ __launch_bounds__(256) void conv1_1_fwd16_kernel(const float* __restr
 #endif
 }
 
+// Staged variant (end of round 3).  The kernel above gathers 8 taps per lane per 16-pixel segment straight from memory: every one of those
+// load instructions touches 4-8 cache lines, and they share the CU's address path with the stores that are the layer's real work
+// (0.153 ms against 0.08 ms for a plain fill of the 516 MB output).  Here a wave parks the 3 channels x 3 rows x 130 columns of the
+// image that its run of 8 segments can see in a wave-private LDS patch -- 19 coalesced loads per lane (zero = padding, by the buffer
+// bounds check), issued one run ahead -- and every segment reads its 8 taps from there.  Same values, same rounding, same MFMA: same bits.
+constexpr int PSF = 132;                                 // floats per patch row (130 used)
+constexpr int PATCHF = 9 * PSF;                          // floats per wave
+template <typename T, bool AHEAD>      // AHEAD: the next run's image loads are issued before this run's segments (19 more live VGPRs)
+__global__ __launch_bounds__(256) void conv1_1_fwd16s_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ out, int B,
+                                                             int H, int W, int pad, int Ho, int Wo, unsigned x_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(T) == 2, "16-bit storage only");
+    __shared__ float spatch[4 * PATCHF];
+    const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
+    float* const patch = spatch + (threadIdx.x >> 6) * PATCHF;
+    const unsigned plane = (unsigned)(H * W);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, 0x00020000);
+    u32x4_t wa[4];                                       // A fragments: couts 16 i + r16, taps 8 g .. 8 g + 7 (t >= 27: zero)
+    int tpo[8];                                          // patch word of tap e for segment 0, pixel 0; -1 = pad tap
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int t = 8 * g + e;                         // (kh*3+kw)*3+ci, the OHWI order of w
+        const int tt = t < 27 ? t : 0;
+        const int kh = tt / 9, kw = (tt / 3) % 3, ci = tt % 3;
+        tpo[e] = t < 27 ? (ci * 3 + kh) * PSF + kw + r16 : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = (8 * g + e < 27) ? w[(16 * i + r16) * 27 + 8 * g + e] : 0.f;
+        wa[i] = u32x4_t{pack2<T>(wv[0], wv[1]), pack2<T>(wv[2], wv[3]), pack2<T>(wv[4], wv[5]), pack2<T>(wv[6], wv[7])};
+    }
+    float bv[2][8];
+    int cst[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        cst[p] = 32 * p + (g & 1) * 16 + (g >> 1) * 8;   // first of the 8 consecutive couts this lane holds after the swap
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[p][e] = bias ? bias[cst[p] + e] : 0.f;
+    }
+    const bool lo = r16 < 8;
+    u32x4_t cpiece;                                      // a padding-only segment: relu(bias) in the store layout
+    {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(lo ? bv[0][e] : bv[1][e], 0.f);
+        cpiece = u32x4_t{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+    }
+    constexpr int SEGS = 8, NLD = 19;                    // 19 x 64 >= 9 x 130 patch elements
+    const int nsx = (Wo + 15) >> 4, nch = (nsx + SEGS - 1) / SEGS;
+    const int ntask = B * Ho * nch;
+    const int nwaves = (int)gridDim.x * 4;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    // does the run see the image at all (wave-uniform)?
+    auto run_touches = [&](int task) {
+        const int ch = task % nch, oh = (task / nch) % Ho;
+        const int ih0 = oh - pad, iwA = ch * (SEGS * 16) - pad;
+        return (ih0 + 2 >= 0) && (ih0 < H) && (iwA + SEGS * 16 + 1 >= 0) && (iwA < W);
+    };
+    float xr[NLD];
+    auto stage_load = [&](int task) {
+        const int ch = task % nch, rowid = task / nch;
+        const int oh = rowid % Ho, b = rowid / Ho;
+        const int ih0 = oh - pad, iwA = ch * (SEGS * 16) - pad;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = lane + 64 * k;
+            const int row = (idx * 2017) >> 18;                         // idx / 130 for idx < 1216
+            const int c = idx - row * 130;
+            const int ci = (row * 11) >> 5, kh = row - ci * 3;          // row / 3 for row < 10
+            const int ih = ih0 + kh, iw = iwA + c;
+            const bool ok = idx < 9 * 130 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            const unsigned off = ok ? (((unsigned)(b * 3 + ci)) * plane + (unsigned)(ih * W + iw)) * 4u : 0x80000000u;
+            xr[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, off, 0, 0));
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = lane + 64 * k;
+            const int row = (idx * 2017) >> 18;
+            if (idx < 9 * 130) patch[row * PSF + (idx - row * 130)] = xr[k];
+        }
+    };
+    bool have = false;                                   // xr holds the image values of the current task
+    if (AHEAD && wave0 < ntask && run_touches(wave0)) { stage_load(wave0); have = true; }
+    for (int task = wave0; task < ntask; task += nwaves) {
+      const int ch = task % nch, rowid = task / nch;
+      const int oh = rowid % Ho, b = rowid / Ho;
+      const int ih0 = oh - pad;
+      const int sx0 = ch * SEGS, sx_end = min(nsx, sx0 + SEGS);
+      const bool rowhit = (ih0 + 2 >= 0) && (ih0 < H);
+      T* orow = out + (((long)b * Ho + oh) * Wo) * 64 + (lo ? cst[0] : cst[1]);
+      if constexpr (!AHEAD) {
+          if (run_touches(task)) { stage_load(task); have = true; }
+      }
+      if (have) stage_store();                           // (waits for this run's loads; wave-private, LDS ops of a wave stay in order)
+      have = false;
+      if constexpr (AHEAD) {
+          const int nxt = task + nwaves;
+          if (nxt < ntask && run_touches(nxt)) { stage_load(nxt); have = true; }
+      }
+#pragma unroll 1
+      for (int sx = sx0; sx < sx_end; ++sx) {
+        const int iw0 = sx * 16 - pad;
+        const int owa = sx * 16 + (r16 & 7);
+        T* op = orow + (long)owa * 64;
+        const bool touches = rowhit && (iw0 + 17 >= 0) && (iw0 < W);                            // wave-uniform
+        if (!touches) {
+            if (owa < Wo) *(u32x4_t*)op = cpiece;
+            if (owa + 8 < Wo) *(u32x4_t*)(op + 8 * 64) = cpiece;
+            continue;
+        }
+        const float* pp = patch + (sx - sx0) * 16;
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = pp[tpo[e] < 0 ? 0 : tpo[e]];
+            xv[e] = tpo[e] < 0 ? 0.f : v;
+        }
+        const u32x4_t xf = u32x4_t{pack2<T>(xv[0], xv[1]), pack2<T>(xv[2], xv[3]), pack2<T>(xv[4], xv[5]), pack2<T>(xv[6], xv[7])};
+        f32x4_t acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = mfma16<T>(wa[i], xf, f32x4_t{0.f, 0.f, 0.f, 0.f});
+        u32x4_t v2[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][c]), __float_as_uint(acc[2 * p + 1][c]), false, false);
+                v[c] = fmaxf(__uint_as_float(r[0]) + bv[p][c], 0.f);
+                v[4 + c] = fmaxf(__uint_as_float(r[1]) + bv[p][4 + c], 0.f);
+            }
+            v2[p] = u32x4_t{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+        }
+        const u32x4_t send = lo ? v2[1] : v2[0];
+        u32x4_t recv;
+        recv.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.x, 0x128, 0xf, 0xf, false);
+        recv.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.y, 0x128, 0xf, 0xf, false);
+        recv.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.z, 0x128, 0xf, 0xf, false);
+        recv.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.w, 0x128, 0xf, 0xf, false);
+        const u32x4_t va = lo ? v2[0] : recv, vb = lo ? recv : v2[1];
+        if (owa < Wo) *(u32x4_t*)op = va;
+        if (owa + 8 < Wo) *(u32x4_t*)(op + 8 * 64) = vb;
+      }
+    }
+#endif
+}
+
 // conv1_1 wgrad = a 1x1-conv wgrad on the im2col image: xcol[m][t] = x[b][ci][oh+kh-pad][ow+kw-pad], t = (kh*3+kw)*3+ci
 // (27 taps padded to 32 "channels"), so the MFMA wgrad kernel does the reduction over the B*Ho*Wo pixels.
 template <typename T>
@@ -655,7 +807,29 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
     long blocks16 = (ntask + 3) / 4;
     if (blocks16 > 256 * 16) blocks16 = 256 * 16;
     if (ntask >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd: output too large");
-    if (dtype == SZN_BF16 && mm16)
+    static int c11g = -1;          // SZN_C11_FWD_GATHER=1: taps gathered straight from memory (the first 16-bit form)
+    if (c11g < 0) { const char* e = getenv("SZN_C11_FWD_GATHER"); c11g = e ? atoi(e) : 0; }
+    const size_t x_bytes = (size_t)B * 3 * H * W * 4;
+    const bool staged = !c11g && x_bytes < 0x7fff0000ul;
+    static int ahead = -1, sblocks = -1;
+    // (sweep on MI355X, bf16, B = 8: gather 165 us; staged 142 / 134 us with 4096 / 1024 blocks; + loads one run ahead 125 / 118 us:
+    //  a wave pays its filter / bias set-up once for ~8 runs instead of ~2)
+    if (ahead < 0) { const char* e = getenv("SZN_C11_FWD_AHEAD"); ahead = e ? atoi(e) : 1; }
+    if (sblocks < 0) { const char* e = getenv("SZN_C11_FWD_BLOCKS"); sblocks = e ? atoi(e) : 1024; }
+    if (staged && sblocks > 0 && blocks16 > sblocks) blocks16 = sblocks;
+    if (dtype == SZN_BF16 && mm16 && staged && ahead)
+        hipLaunchKernelGGL((conv1_1_fwd16s_kernel<bf16_raw, true>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (bf16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes);
+    else if (dtype == SZN_BF16 && mm16 && staged)
+        hipLaunchKernelGGL((conv1_1_fwd16s_kernel<bf16_raw, false>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (bf16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes);
+    else if (dtype == SZN_F16 && mm16 && staged && ahead)
+        hipLaunchKernelGGL((conv1_1_fwd16s_kernel<f16_raw, true>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (f16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes);
+    else if (dtype == SZN_F16 && mm16 && staged)
+        hipLaunchKernelGGL((conv1_1_fwd16s_kernel<f16_raw, false>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (f16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes);
+    else if (dtype == SZN_BF16 && mm16)
         hipLaunchKernelGGL(conv1_1_fwd16_kernel<bf16_raw>, dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                            (bf16_raw*)out, B, H, W, pad, Ho, Wo);
     else if (dtype == SZN_F16 && mm16)
