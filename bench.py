@@ -286,6 +286,28 @@ def _conv_family(torch, L, mods, fn):
     return fl / (ms * 1e-3) / 1e12, ms, len(ev)
 
 
+def _skipped_flops_one_step(L, mods, step_fn):
+    """FLOPs of one step that the constant-border hint replaces by a broadcast (szn_last_work_fraction of every szn_conv2d_fwd call)"""
+    tot = [0.0]
+    orig = L.call
+
+    def hooked(name, *a):
+        r = orig(name, *a)
+        if name == "szn_conv2d_fwd":
+            tot[0] += _conv_flops(a[0]._obj) * (1.0 - L.last_work_fraction())
+        return r
+    for mod in mods:
+        mod.L.call = hooked
+    L.call = hooked
+    try:
+        step_fn()
+    finally:
+        L.call = orig
+        for mod in mods:
+            mod.L.call = orig
+    return tot[0]
+
+
 def sub_record(args):
     """child process: `fp32` = the headline workload at the reference's arithmetic; `b1` = at the reference's batch size
     (train.py:82-84), eager and replayed from a captured hipGraph (host pacing out).  Prints one JSON object."""
@@ -309,12 +331,12 @@ def sub_record(args):
         t = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337, classes=seen)).to(dev)
         return m, ts, x, t
 
-    def record(B, dtype, ms, extra=None):
+    def record(B, dtype, ms, extra=None, skipped=0.0):
         peak = PEAK_F32 if dtype == torch.float32 else PEAK_BF16
         r = {"per_gpu_batch": B, "dtype": "f32" if dtype == torch.float32 else "bf16", "ms_per_step": round(ms, 3),
              "value": round(B * H * H / (ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s", "peak_TF": peak}
-        if mflop_px:
-            r["step_mfma_frac"] = round(mflop_px * 1e6 * B * H * H / (ms * 1e-3) / 1e12 / peak, 4)
+        if mflop_px:      # executed FLOPs (the constant-border hint skips tiles on the 16-bit path)
+            r["step_mfma_frac"] = round((mflop_px * 1e6 * B * H * H - skipped) / (ms * 1e-3) / 1e12 / peak, 4)
         r.update(extra or {})
         return r
 
@@ -337,7 +359,8 @@ def sub_record(args):
             m, ts, x, t = build(1, dtype)
             steps = 20 if dtype == torch.bfloat16 else 8
             ms = _time_steps(torch, lambda: ts.step(x, t), steps, 3)
-            rec = record(1, dtype, ms)
+            skipped = _skipped_flops_one_step(L, (models, engine), lambda: ts.step(x, t))
+            rec = record(1, dtype, ms, skipped=skipped)
             rec["eager_ms_per_step"] = rec.pop("ms_per_step")
             rec["eager_value"] = rec.pop("value")
             eager_frac = rec.pop("step_mfma_frac", None)
@@ -352,7 +375,7 @@ def sub_record(args):
                 with torch.cuda.graph(g):
                     ts.step(x, t)
                 gms = _time_steps(torch, g.replay, steps, 3)
-                grec = record(1, dtype, gms)
+                grec = record(1, dtype, gms, skipped=skipped)
                 rec.update({"graph": True, "ms_per_step": grec["ms_per_step"], "value": grec["value"]})
                 if "step_mfma_frac" in grec:
                     rec["step_mfma_frac"] = grec["step_mfma_frac"]
@@ -490,6 +513,7 @@ def main():
     # Every event pair costs GPU time (instrumenting all ~35 conv launches of a step measured 2.5-5 % of `value`), so the timed
     # region instruments the launches of the DOMINANT kernel only: the last warmup step times every conv forward / dgrad call
     # ("learn"), the kernel with the largest total is the dominant one, and the ordinals of its calls within a step are kept.
+    skipped = [0.0]                  # FLOPs per step the constant-border hint does not execute
     ordn = [0]                       # ordinal of the next conv forward / dgrad call within the current step
     dom_ord = [None]                 # ordinals of the dominant kernel's calls (None: instrument every conv call)
 
@@ -526,6 +550,8 @@ def main():
         torch.cuda.synchronize()
 
     learn_events = []
+    if args.phase == "fcn":          # one untimed step that adds up what the hint skips (every szn_conv2d_fwd call reports its fraction)
+        skipped[0] = _skipped_flops_one_step(L, (models, engine), lambda: ts.step(x, target))
     for i in range(args.warmup):
         if i == args.warmup - 1 and not args.no_kernel_events:
             torch.cuda.synchronize()
@@ -621,7 +647,11 @@ def main():
                                "events": "HIP events around every launch of the dominant kernel inside the timed region "
                                          "(%d per step)" % (n // args.steps)}
             if H in STEP_MFLOP_PER_PX and E == 300 and args.phase == "fcn" and args.arch == "fcn32s":
-                out["roofline"]["step_mfma_frac"] = round(STEP_MFLOP_PER_PX[H] * 1e6 * B * H * H * args.steps / dt / 1e12 / peak, 4)
+                # executed FLOPs: the dense algorithmic count minus the tiles the constant-border hint replaced by a broadcast
+                step_fl = STEP_MFLOP_PER_PX[H] * 1e6 * B * H * H - skipped[0]
+                out["roofline"]["step_mfma_frac"] = round(step_fl * args.steps / dt / 1e12 / peak, 4)
+                out["roofline"]["step_gflop_executed"] = round(step_fl / 1e9, 1)
+                out["roofline"]["step_gflop_skipped_constant_border"] = round(skipped[0] / 1e9, 1)
 
     # ---- instrumented pass: every C-ABI call of 3 more steps (same state, not part of `value`) ----
     if not args.no_kernel_events and not args.no_extras and world == 1:
