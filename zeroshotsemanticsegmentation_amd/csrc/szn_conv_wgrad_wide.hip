@@ -36,6 +36,7 @@ struct WgwArgs {
     int ablate;                // debug (env SZN_WGW_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no reads / MFMA
     int use_tab;               // 1: pixel -> input-offset table of this block's tap in LDS behind the ring (M <= kTabMax)
     int shift;                 // 1: phase-shifted wave groups (SZN_WGW_SHIFT=0: lockstep)
+    int xcd_order;             // 1: an XCD takes a contiguous share of the tiles, cout tile fastest (the B operand is the large one)
 };
 
 constexpr unsigned kOOBg = 0x80000000u;
@@ -56,8 +57,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
     const int g = lane >> 4, r16 = lane & 15;
 
     int bid = blockIdx.x;
-    const int cit = bid % a.citiles; bid /= a.citiles;
-    const int cot = bid % a.cotiles; const int tap = bid / a.cotiles;
+    int cit, cot, tap;
+    if (a.xcd_order) {
+        // Blocks go to the 8 XCDs round-robin.  When B (the "input": for fc6's dgrad on the forward layout the 205 MB filter bank) is far
+        // larger than A, the cout tiles that share one B slice should run on ONE XCD at the same time, so that the slice crosses the
+        // fabric once instead of once per cout tile: XCD x takes the contiguous range of tiles, cout tile fastest
+        const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        cot = lid % a.cotiles; lid /= a.cotiles;
+        cit = lid % a.citiles; tap = lid / a.citiles;
+    } else {
+        cit = bid % a.citiles; bid /= a.citiles;
+        cot = bid % a.cotiles; tap = bid / a.cotiles;
+    }
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
     const int co0 = cot * 256, ci0 = cit * 256;
 
@@ -288,6 +300,8 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGW_ABLATE"); } a.ablate = abl; }
     { static int tab = -1; if (tab < 0) { const char* e = getenv("SZN_WGW_TAB"); tab = e ? atoi(e) : 1; } a.use_tab = (tab && a.M <= kTabMax) ? 1 : 0; }
     { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_WGW_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
+    { static int xo = -1; if (xo < 0) { const char* e = getenv("SZN_WGW_XCD"); xo = e ? atoi(e) : 1; }
+      a.xcd_order = (xo && (size_t)a.in_bytes > 4 * (size_t)a.dout_bytes) ? 1 : 0; }
     const int lds = LDS_WGW + (a.use_tab ? kTabMax * 4 : 0);
     static bool attr_done = false;
     if (!attr_done) {

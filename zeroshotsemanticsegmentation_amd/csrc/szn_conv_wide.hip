@@ -707,7 +707,9 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     const int waste256 = szn_div_up(d->Co, 256) * 256 - d->Co, waste320 = szn_div_up(d->Co, 320) * 320 - d->Co;
     int bn = (szn_is16(d->dtype) && waste320 < waste256) ? 320 : 256;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(d->Co, bn);
-    a.nmajor = 0;
+    // tile order within an XCD's share of the grid: pixel tile fastest when the filter bank is the larger operand (fc6: 205 MB against a
+    // 4 MB map), so that the blocks of one XCD share cout tiles and the bank crosses the fabric once, not once per XCD
+    { static int nm = -1; if (nm < 0) { const char* e = getenv("SZN_WIDE_NMAJOR"); nm = e ? atoi(e) : 1; } a.nmajor = (nm && w_bytes > in_bytes) ? 1 : 0; }
     if ((long)a.mtiles * a.ntiles * a.nsplit < min_tiles) {         // too few blocks to fill the chip: keep 256 x 128 ...
         // ... unless 256 x 192 tiles fit ONE round of the chip where the 256 x 128 tiles need two (fc7 at B = 8, 512 x 512:
         // 2,312 x 4096 is 10 x 32 = 320 narrow tiles = 1.25 rounds, but 10 x 22 = 220 tiles of 192 couts: 0.117 -> ~0.09 ms)
