@@ -640,15 +640,23 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ Y
         const int iw = (int)(p % Wi);
         const long t = p / Wi;
         const int ih = (int)(t % Hi), b = (int)(t / Hi);
+        // taps whose output pixel exists: kh in [kh0, kh1], kw in [kw0, kw1] (ranges instead of per-tap tests: the loads of a row of taps
+        // are independent and issue back to back); two running sums per kernel row, added in a fixed order
+        const int kh0 = max(0, ih + pad - (Ho - 1)), kh1 = min(KH - 1, ih + pad);
+        const int kw0 = max(0, iw + pad - (Wo - 1)), kw1 = min(KW - 1, iw + pad);
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        for (int kh = 0; kh < KH; ++kh) {
+        for (int kh = kh0; kh <= kh1; ++kh) {
             const int oh = ih + pad - kh;
-            if ((unsigned)oh >= (unsigned)Ho) continue;
-            for (int kw = 0; kw < KW; ++kw) {
-                const int ow = iw + pad - kw;
-                if ((unsigned)ow >= (unsigned)Wo) continue;
-                acc += *(const f32x4_t*)(Y + (((long)b * Ho + oh) * Wo + ow) * N + (long)(kh * KW + kw) * Ci + c4 * 4);
+            const float* yrow = Y + (((long)b * Ho + oh) * Wo + (iw + pad)) * N + (long)kh * KW * Ci + c4 * 4;
+            f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            int kw = kw0;
+#pragma unroll 4
+            for (; kw + 1 <= kw1; kw += 2) {
+                a0 += *(const f32x4_t*)(yrow - (long)kw * N + (long)kw * Ci);
+                a1 += *(const f32x4_t*)(yrow - (long)(kw + 1) * N + (long)(kw + 1) * Ci);
             }
+            if (kw <= kw1) a0 += *(const f32x4_t*)(yrow - (long)kw * N + (long)kw * Ci);
+            acc += a0 + a1;
         }
         T* o = din + p * ldi + c4 * 4;
 #pragma unroll

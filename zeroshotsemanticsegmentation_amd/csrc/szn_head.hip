@@ -554,13 +554,28 @@ __global__ __launch_bounds__(256) void hist_kernel(const int64_t* __restrict__ l
     const int nh = unseen_bits ? 3 : 1;
     for (int i = threadIdx.x; i < nh * K * K; i += 256) hl[i] = 0;
     __syncthreads();
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const long t = lt[i], p = lp[i];
-        if (t >= 0 && t < K && p >= 0 && p < K) {
-            const int idx = (int)(t * K + p);
-            atomicAdd(&hl[idx], 1u);
-            if (unseen_bits) atomicAdd(&hl[(((unseen_bits >> t) & 1ull) ? 2 : 1) * K * K + idx], 1u);
+    // a thread takes 8 consecutive pixels and merges runs of equal (true, predicted) pairs into one LDS atomic: label maps are
+    // piecewise constant, and one atomic per pixel on a handful of hot counters serialised the block
+    auto flush = [&](int idx, unsigned cnt, long t) {
+        if (idx < 0 || !cnt) return;
+        atomicAdd(&hl[idx], cnt);
+        if (unseen_bits) atomicAdd(&hl[(((unseen_bits >> t) & 1ull) ? 2 : 1) * K * K + idx], cnt);
+    };
+    for (long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i0 < n; i0 += (long)gridDim.x * 256 * 8) {
+        int cur = -1; unsigned cnt = 0; long curt = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long i = i0 + e;
+            int idx = -1; long t = 0;
+            if (i < n) {
+                t = lt[i];
+                const long p = lp[i];
+                if (t >= 0 && t < K && p >= 0 && p < K) idx = (int)(t * K + p);
+            }
+            if (idx == cur) ++cnt;
+            else { flush(cur, cnt, curt); cur = idx; cnt = 1; curt = t; }
         }
+        flush(cur, cnt, curt);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nh * K * K; i += 256)
@@ -829,7 +844,7 @@ extern "C" int szn_confusion_hist(long npix, int K, const int64_t* label_true, c
     const int nh = unseen_bits ? 3 : 1;
     const size_t lds = (size_t)nh * K * K * sizeof(unsigned int);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(hist_kernel, dim3(grid_for(npix, 1024)), dim3(256), lds, (hipStream_t)stream, label_true, label_pred,
+    hipLaunchKernelGGL(hist_kernel, dim3(grid_for((npix + 7) / 8, 256)), dim3(256), lds, (hipStream_t)stream, label_true, label_pred,
                        npix, K, unseen_bits, (unsigned long long*)hist);
     SZN_CHECK_LAUNCH("hist_kernel");
     return SZN_OK;
