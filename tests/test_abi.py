@@ -52,3 +52,20 @@ def test_product_path_has_no_cpu_fallback():
     for fn in os.listdir(pkg):
         if fn.endswith(".py"):
             assert "oracle" not in open(os.path.join(pkg, fn)).read().replace("the oracle", "").replace("CPU oracle", ""), fn
+
+
+def test_conv1_1_wgrad_read_set_is_host_logic():
+    """szn_conv1_1_wgrad_reads (what conv1_2's dgrad may leave unwritten under the constant-border hint) is plain host arithmetic:
+    the fused 16-bit kernel reads the rows whose 3x3 windows meet the image and whole 32-pixel column segments around them; fp32 and
+    shapes the fused kernel does not take read everything"""
+    from zeroshotsemanticsegmentation_amd import _lib
+    lib = _lib.load()
+    rect = (ctypes.c_int * 4)()
+    assert lib.szn_conv1_1_wgrad_reads(_lib.SZN_BF16, 8, 512, 512, 100, rect) == 1
+    assert tuple(rect) == (98, 612, 96, 640)
+    assert lib.szn_conv1_1_wgrad_reads(_lib.SZN_F16, 2, 300, 500, 100, rect) == 1
+    assert tuple(rect) == (98, 400, 96, 608)                       # map 498 x 698; columns [98, 600) -> segments [96, 608)
+    assert lib.szn_conv1_1_wgrad_reads(_lib.SZN_F32, 8, 512, 512, 100, rect) == 0
+    assert tuple(rect) == (0, 710, 0, 710)
+    assert lib.szn_conv1_1_wgrad_reads(_lib.SZN_BF16, 1, 64, 64, 1, rect) == 0
+    assert tuple(rect) == (0, 64, 0, 64)                            # pad 1: the map is 64 x 64, every window meets the image

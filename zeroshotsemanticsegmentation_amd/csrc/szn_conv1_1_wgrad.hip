@@ -305,7 +305,7 @@ extern "C" int szn_conv1_1_wgrad_reads(int dtype, int B, int H, int W, int pad, 
     int oh_lo, oh_hi, seg_lo, seg_hi;
     if (!c11_geometry(dtype, B, H, W, pad, oh_lo, oh_hi, seg_lo, seg_hi)) return 0;
     rect[0] = oh_lo; rect[1] = oh_hi; rect[2] = seg_lo * 32; rect[3] = seg_hi * 32 < Wo ? seg_hi * 32 : Wo;
-    return 1;
+    return (rect[0] > 0 || rect[1] < Ho || rect[2] > 0 || rect[3] < Wo) ? 1 : 0;
 }
 
 // bf16 path of szn_conv1_1_wgrad (szn_elementwise.hip).  workspace: >= nblocks * 8 KiB.  Returns 1 if not applicable.
