@@ -21,6 +21,9 @@ Prints ONE JSON line: metric train_Mpixels_per_sec (whole job) plus
   projection    the three labelled MFMA numbers SURVEY 8-d asks for (true shape, step aggregate, nominal shape)
   phase2        BASELINE configs[2]: the seen-mask step (engine.SeenmaskStep: frozen backbone forward, fused-from-coarse
                 2-class head, head-only backward + Adam), three repeats, its own roofline record
+  comm          BASELINE configs[3]'s gradient exchange forced through a one-rank RCCL communicator on this GPU (child process):
+                step time with the real buckets going through librccl on its own stream vs without, fp32 / bf16 wire, and with CUs
+                reserved for RCCL by the persistent kernels
   fp32, b1      measured in a child process after the headline (a crash there cannot lose the line): the same step at the
                 reference's arithmetic (fp32, B = 8, against the 157.3 TF fp32 MFMA peak) and at the reference's batch size
                 (B = 1, bf16 and fp32, eager and replayed from a captured hipGraph)
@@ -63,7 +66,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the kernels / projection / phase2 / fp32 / b1 sub-records")
-    ap.add_argument("--sub-record", choices=["fp32", "b1"], default=None,
+    ap.add_argument("--sub-record", choices=["fp32", "b1", "comm"], default=None,
                     help="(internal) measure one sub-record and print it as JSON; run by the main process as a child")
     return ap.parse_args()
 
@@ -341,6 +344,51 @@ def sub_record(args):
         return r
 
     out = {}
+    if args.sub_record == "comm":
+        # BASELINE configs[3]'s exchange on ONE GPU: a one-rank RCCL communicator (RCCL refuses two ranks per device), the step's
+        # real gradient buckets forced through librccl on ProcessGroupNCCL's stream (engine.GradBuckets(force=True): pre-multiplied
+        # sum, factor 1.0 -> librccl's one-rank reduce kernel reads + writes every bucket while dgrad / wgrad continue).  What a ring
+        # all-reduce adds on top of this at N > 1 is the xGMI transfer itself; the stream plumbing, the bucket order, the waits in
+        # front of the optimizer and the competition for CUs / HBM with the backward kernels are the same code.
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        B = args.batch
+        variants = [("comm_off", dict(force_comm=False)),
+                    ("fp32_wire", dict(force_comm=True, grad_comm_dtype=torch.float32, reserved_cus=0)),
+                    ("bf16_wire", dict(force_comm=True, grad_comm_dtype=torch.bfloat16, reserved_cus=0)),
+                    ("fp32_wire_reserved_16cu", dict(force_comm=True, grad_comm_dtype=torch.float32, reserved_cus=16)),
+                    ("fp32_wire_reserved_32cu", dict(force_comm=True, grad_comm_dtype=torch.float32, reserved_cus=32))]
+        x = torch.from_numpy(synth.make_images(B, H, H, seed=1337)).to(dev)
+        t = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337, classes=seen)).to(dev)
+        steps = {}
+        for name, kw in variants:
+            torch.manual_seed(1337)
+            m = models.FCN32s(n_class=E)
+            m.load_synthetic(1337, device=dev)
+            m.train()
+            steps[name] = engine.TrainStep(m, emb_np, optimizer="adam", lr=1e-5, precision=torch.bfloat16, fused_head=True, **kw)
+        n = max(args.steps, 10)
+        times = {name: [] for name, _ in variants}
+        for rnd in range(3):                                   # interleaved rounds: box drift hits every variant alike
+            for name, _ in variants:
+                ts = steps[name]
+                times[name].append(_time_steps(torch, lambda: ts.step(x, t), n, 2))
+        bk = steps["fp32_wire"].buckets
+        out = {"workload": "configs[3] per-rank step (bf16, B=%d, %dx%d, E=%d, K=%d) with its gradient buckets exchanged through a "
+                           "one-rank RCCL communicator on this GPU (forced; see DESIGN.md section 5)" % (B, H, H, E, K),
+               "backend": dist.get_backend(), "world": 1, "steps_per_round": n, "rounds": 3,
+               "bucket_mib": [round((e - o) * 4 / 2 ** 20, 1) for o, e, _ in bk.buckets],
+               "allreduce_calls_per_step": len(bk.buckets) + 1,
+               "rccl_kernel": "one-rank reduce (pre-multiplied sum x 1.0) over every bucket on RCCL's stream",
+               "ms_per_step": {k: round(sorted(v)[1], 3) for k, v in times.items()},
+               "rounds_ms": {k: [round(a, 3) for a in v] for k, v in times.items()}}
+        off = out["ms_per_step"]["comm_off"]
+        out["overlap_cost_frac"] = {k: round(v / off - 1.0, 4) for k, v in out["ms_per_step"].items() if k != "comm_off"}
+        dist.destroy_process_group()
+        print("SUBRECORD " + json.dumps(out))
+        return
     if args.sub_record == "fp32":
         B = args.batch
         m, ts, x, t = build(B, torch.float32)
@@ -749,6 +797,8 @@ def main():
         if args.phase == "fcn" and args.arch == "fcn32s" and not args.unfused_head:
             out["fp32"] = run_sub_record("fp32", args)
             out["b1"] = run_sub_record("b1", args)
+            if dtype == torch.bfloat16:
+                out["comm"] = run_sub_record("comm", args)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

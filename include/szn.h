@@ -98,6 +98,10 @@ typedef struct {
                          szn_conv1_1_wgrad, whose read set szn_conv1_1_wgrad_reads() reports.                                    */
     int cb_rect[4];
     int cb_const[4];
+    int reserved_cus;   /* optional (0 = none): compute units the persistent one-block-per-CU kernels (conv3x3_regw, conv_wgrad_taps)
+                         leave idle for another queue -- under data parallelism the RCCL all-reduce of the gradient buckets runs on
+                         its own stream while dgrad / wgrad continue (engine.GradBuckets; train.py has no counterpart: the reference
+                         is single-GPU).  Tiled kernels ignore it (their blocks come and go; the hardware interleaves the queues).  */
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
@@ -253,7 +257,9 @@ int szn_deconv64s32_wgrad(int B, int h, int w, int C, int ldc, int c0, int H, in
  * (models.py:150-151, utils.py:19-48) without the (B,2,H,W) score or its gradient in HBM.  coarse: NHWC f32
  * [B][h][w] with pixel stride ldc, the two seen-mask channels at [c0, c0+2); weight: seenmask_upscore.weight
  * (2,2,64,64) f32.  Binary target of a pixel: n_class > 0: (0 <= label < n_class and bit `label` of seen_bits) ? 1 : 0
- * -- unlabelled pixels (-1) become 0 and COUNT, like the reference; n_class == 0: `target` already holds {0,1}
+ * -- unlabelled pixels (-1) become 0 and COUNT, like the reference; labels below -1 mark batch padding (datasets.pad_collate
+ * writes -2 where a smaller image of a ragged batch was extended: no counterpart in the reference, which trains at batch size 1)
+ * and are ignored like cross_entropy2d ignores negative targets; n_class == 0: `target` already holds {0,1}
  * (anything else is ignored, cross_entropy2d's mask).  Outputs: loss[1]; stats[2] = {sum of terms, valid pixels}
  * (may be NULL); conf[4] int64 += confusion counts [target][prediction] (may be NULL; the running train metrics,
  * trainer_seenmask.py:87); pred int64 (B,H,W) (may be NULL); dscore2 f32 [B*h*w][2] = d loss / d coarse (compact) and

@@ -105,7 +105,7 @@ def test_presence_cache_is_versioned(tiny, monkeypatch):
 
 
 def test_pad_collate_ragged_batch():
-    """PASCAL images differ in size (context_dataset.py:143-150): batches > 1 are padded with mean-colour pixels labelled -1"""
+    """PASCAL images differ in size (context_dataset.py:143-150): batches > 1 are padded with mean-colour pixels labelled datasets.PAD_LABEL = -2 (ignored by both phases; -1 = "unlabelled" COUNTS in phase 2)"""
     rs = np.random.RandomState(0)
     sizes = [(10, 12), (7, 15), (13, 5)]
     batch = [(torch.from_numpy(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)),
@@ -118,7 +118,7 @@ def test_pad_collate_ragged_batch():
         assert int((lbl[k] >= 0).sum()) == h * w                      # every padded pixel is ignored
         pad = torch.ones(13, 15, dtype=torch.bool)
         pad[:h, :w] = False
-        assert (lbl[k][pad] == -1).all()
+        assert datasets.PAD_LABEL < -1 and (lbl[k][pad] == datasets.PAD_LABEL).all()
         assert (img[k][pad] == torch.tensor(datasets.MEAN_RGB_U8, dtype=torch.uint8)).all()
     # the padding colour is the mean: at most half a grey level away from zero after the transform
     bgr = np.array(datasets.MEAN_RGB_U8[::-1], np.float64) - datasets.MEAN_BGR

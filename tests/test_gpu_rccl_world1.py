@@ -1,0 +1,115 @@
+"""The gradient exchange of BASELINE configs[3] through librccl itself, on the one GPU a test box has.
+
+RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the only communicator a 1-GPU box can build is a
+one-rank one: `init_process_group("nccl", world_size=1)`.  `engine.GradBuckets(force=True)` then issues the step's real buckets
+(68.7 | 392 | 27 | 27 | 2.1 MiB + the bias vector at E = 300) as asynchronous all-reduces on ProcessGroupNCCL's stream from the real
+`layer_done` hooks while dgrad / wgrad continue on the compute stream; with one rank it uses the pre-multiplied sum (factor 1.0),
+for which librccl launches its one-rank reduce kernel over each bucket instead of returning early.  The configs[3] per-rank step
+(bf16, B = 8, 512 x 512, E = 300, K = 59) must come out bit-equal to the step without any exchange -- fp32 wire exactly, bf16 wire
+exactly equal to the gradient rounded through bf16 -- which pins the stream ordering (bucket issued after its last wgrad, optimizer
+after the waits) that the 8-GPU run depends on.  Runs in a child process: the communicator must not leak into other tests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+E3, K3, H3, B3 = 300, 59, 512, 8
+
+
+def _worker(port, size, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from zeroshotsemanticsegmentation_amd import engine, models, synth
+        B, H = (B3, H3) if size == "configs3" else (2, 64)
+        x = torch.from_numpy(synth.make_images(B, H, H, seed=81)).to(dev)
+        t = torch.from_numpy(synth.make_labels(B, H, H, K3, seed=82, classes=list(range(49)))).to(dev)
+        emb = synth.make_embeddings(K3, E3)
+
+        def run(force, comm):
+            m = models.FCN32s(E3)
+            m.load_synthetic(1337, device=dev)
+            m.eval()
+            ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=torch.bfloat16, fused_head=True, bucket_mb=25,
+                                  grad_comm_dtype=comm, force_comm=force)
+            losses = []
+            gw1 = None
+            for it in range(2):                                  # two steps: the second one starts from exchanged state
+                loss, _p = ts.step(x, t)
+                losses.append(float(loss))
+                if it == 0:
+                    gw1 = ts.flat_gw.clone()
+            torch.cuda.synchronize()
+            ts.gw1 = gw1
+            return ts, losses
+
+        ref, ref_loss = run(False, torch.float32)
+        assert not ref.buckets.active and ref.buckets.issued == 0
+        out = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+        with open("/proc/self/maps") as f:
+            out["librccl_mapped"] = any("librccl" in ln for ln in f)
+        for name, comm in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            ts, losses = run(True, comm)
+            bk = ts.buckets
+            out[name] = {
+                "active": bk.active, "issued": bk.issued, "premul": "PREMUL" in repr(bk.op).upper() or bk.op != dist.ReduceOp.SUM,
+                "bucket_mib": [(e - o) * 4 / 2 ** 20 for o, e, _ in bk.buckets],
+                "loss_equal": losses == ref_loss,
+                # fp32 wire: the gradients of both steps; bf16 wire: the first step's gradient == the reference's rounded through
+                # bf16 (the second step then starts from slightly different weights)
+                "gw_equal": bool(torch.equal(ts.gw1, ref.gw1) and torch.equal(ts.flat_gw, ref.flat_gw)) if comm == torch.float32
+                else bool(torch.equal(ts.gw1, ref.gw1.to(torch.bfloat16).float())),
+                "gb_equal": bool(torch.equal(ts.flat_gb, ref.flat_gb)),
+                "w_equal": bool(torch.equal(ts.flat_w, ref.flat_w)),
+                "w_maxdiff": float((ts.flat_w - ref.flat_w).abs().max()),
+                "b_equal": bool(torch.equal(ts.flat_b, ref.flat_b)),
+            }
+            del ts
+            torch.cuda.empty_cache()
+        q.put(out)
+        dist.destroy_process_group()
+    except Exception as ex:
+        import traceback
+        q.put({"error": "%r\n%s" % (ex, traceback.format_exc())})
+
+
+@pytest.mark.parametrize("size", ["small", "configs3"])
+def test_forced_rccl_exchange_world1_is_bit_equal_to_no_exchange(size):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(33700 + os.getpid() % 2000, size, q))
+    p.start()
+    o = q.get(timeout=900)
+    p.join(120)
+    assert "error" not in o, o.get("error")
+    assert o["backend"] == "nccl" and o["world"] == 1 and o["librccl_mapped"]
+    for wire in ("fp32", "bf16"):
+        r = o[wire]
+        assert r["active"] and r["premul"], r
+        # two steps x (5 weight buckets + the flat bias gradient)
+        assert r["issued"] == 2 * (len(r["bucket_mib"]) + 1), r
+        if size == "configs3":
+            mb = r["bucket_mib"]
+            assert len(mb) >= 4 and max(mb) > 390 and min(mb) < 25, mb      # fc6 alone is 392 MiB; the tail bucket is the 2.2 MB rest
+        assert r["gw_equal"], r
+        if wire == "fp32":
+            assert r["gb_equal"], r
+            # identical gradients -> identical Adam updates, identical second step
+            assert r["loss_equal"] and r["w_equal"] and r["b_equal"], r
+        else:
+            # bf16 wire rounds the weight gradient (2^-9 relative): Adam moves each weight by at most ~lr per step either way
+            assert r["w_maxdiff"] <= 4.1e-5, r
+    print("forced one-rank RCCL exchange (%s): %d + 1 buckets/step %s MiB, fp32 wire bit-equal, bf16 wire == bf16(grad)"
+          % (size, len(o["fp32"]["bucket_mib"]), [round(v, 1) for v in o["fp32"]["bucket_mib"]]))

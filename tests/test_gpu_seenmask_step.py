@@ -89,6 +89,49 @@ def test_seenmask_head_vs_oracle_sequence(case):
     assert again[0].item() == loss.item() and torch.equal(again[4], dsc) and torch.equal(again[5], dw)
 
 
+def test_seenmask_head_ignores_batch_padding():
+    """datasets.pad_collate extends the smaller images of a ragged batch with label PAD_LABEL = -2: those pixels are not part of any
+    image, so phase 2 must not count them -- while -1 ("unlabelled") still becomes target 0 and counts (trainer_seenmask.py:55-56).
+    Checked against the oracle sequence with the padding removed from the binary target (cross_entropy2d ignores negatives), and
+    through Trainer.binary_target (the autograd path)."""
+    from zeroshotsemanticsegmentation_amd import datasets
+    B, h, w, H, W = 2, 3, 4, 70, 101
+    K, unseen = 33, [3, 16, 18, 30]
+    seen = [k for k in range(K) if k not in unseen]
+    coarse = np.zeros((B, h, w, 4), np.float32)
+    coarse[..., 2:4] = synth.uniform(911, (B, h, w, 2), -2, 2)
+    wt = (synth.uniform(912, (2, 2, 64, 64), -1, 1) * 0.05).astype(np.float32)
+    target = synth.make_labels(B, H, W, K, seed=913, block=8)
+    assert (target == -1).any()
+    target[1, 50:, :] = datasets.PAD_LABEL                 # image 1 is 50 x 80, padded to 70 x 101
+    target[1, :, 80:] = datasets.PAD_LABEL
+    npad = int((target == datasets.PAD_LABEL).sum())
+    loss, st, conf, pred, dsc, dw = run_head(cu(coarse), cu(wt), cu(target), K, synth.unseen_bits(seen), H, W, c0=2)
+    cs = np.ascontiguousarray(coarse[..., 2:4].transpose(0, 3, 1, 2))
+    s = O.deconv_fwd(cs, wt, H, W)
+    bin_t = np.isin(target, seen).astype(np.int64)         # -1 -> 0 (counted)
+    bin_t[target == datasets.PAD_LABEL] = -1               # padding: ignored
+    oloss, ods, opred = O.cross_entropy2d(s, bin_t, size_average=True)
+    assert st[1].item() == B * H * W - npad
+    assert abs(loss.item() - float(oloss)) < 1e-5 * max(1.0, abs(float(oloss)))
+    ok = bin_t >= 0
+    assert np.array_equal(conf.cpu().numpy(), np.bincount((2 * bin_t + opred)[ok].ravel(), minlength=4))
+    assert rel(dsc.view(B, h, w, 2).permute(0, 3, 1, 2), O.deconv_dgrad(ods, wt, (B, 2, h, w))) < 1e-4
+    assert rel(dw, O.deconv_wgrad(cs, ods)) < 1e-4
+    # the autograd path's target construction
+    from zeroshotsemanticsegmentation_amd import trainer_seenmask
+
+    class _T(object):
+        pass
+    tr = _T()
+    tr.device, tr.n_class = torch.device("cuda"), K
+    lut = torch.zeros(K + 1, dtype=torch.int64, device="cuda")
+    lut[torch.tensor(seen, device="cuda")] = 1
+    tr._seen_lut = lut
+    bt = trainer_seenmask.Trainer.binary_target(tr, torch.from_numpy(target))
+    assert np.array_equal(bt.cpu().numpy(), bin_t)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_seenmask_score_wgrad(dtype):
     M, F = 2312, 4096

@@ -352,10 +352,12 @@ def g8_seenmask_step():
 def g9_embeddings():
     import hashlib
     for ds, K in (("pascal", 21), ("context", 33)):
-        for E in (20, 300) + ((21,) if ds == "pascal" else ()):
+        # every width the reference CLI accepts (train.py:31: -e {2,5,10,20,21,50,100,200,300})
+        for E in (2, 5, 10, 20, 21, 50, 100, 200, 300):
             emb = load_embed(ds, E)
             assert emb.shape == (K, E) and emb.dtype == np.float32
             np.save(os.path.join(OUT, "embeddings_%s_%d.npy" % (ds, E)), emb)
+            np.save(os.path.join(ROOT, "zeroshotsemanticsegmentation_amd", "data", "embeddings_%s_%d.npy" % (ds, E)), emb)
             print("embeddings_%s_%d sha256[:16]=%s" % (ds, E, hashlib.sha256(emb.tobytes()).hexdigest()[:16]))
 
 

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
         "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")] + [
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p),
         ("colsum_slab", C.c_void_p), ("colsum_slab_rows", C.c_int), ("pool_code", C.c_void_p), ("pool_only", C.c_int),
-        ("cb_on", C.c_int), ("cb_rect", C.c_int * 4), ("cb_const", C.c_int * 4)]
+        ("cb_on", C.c_int), ("cb_rect", C.c_int * 4), ("cb_const", C.c_int * 4), ("reserved_cus", C.c_int)]
 
 
 class DeviceInfo(C.Structure):

@@ -432,7 +432,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__
     const long total = (long)a.M * a.Co;
     const T* __restrict__ gate = (const T*)a.gate;
     // four consecutive couts per thread (16-B slab loads) when the row pitches allow it; same additions in the same order
-    const bool v4 = !(a.Co & 3) && !(a.ldo & 3) && (!gate || !(a.ldg & 3));
+    // (... and the base pointers: bias / chan_scale / an fp32 out are accessed 16 B at a time, a 16-bit out 8 B at a time; a view at
+    // an odd offset is legal per szn.h and takes the scalar loop)
+    const bool out32 = a.out_f32 || sizeof(T) == 4;
+    const bool v4 = !(a.Co & 3) && !(a.ldo & 3) && (!gate || !(a.ldg & 3)) && !((uintptr_t)ws & 15) &&
+                    !((uintptr_t)a.bias & 15) && !((uintptr_t)a.cscale & 15) && !((uintptr_t)a.out & (out32 ? 15 : 7));
     if (v4) {
         const int c4n = a.Co >> 2;
         const long tot4 = total >> 2;

@@ -616,7 +616,9 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
             cb.fx0 = (std::max(d->cb_const[2], 0) + 15) / 16;     cb.fx1 = std::min(d->cb_const[3], d->Wo) / 16;
             cb.wy0 = std::max(d->cb_rect[0], 0) / tr;             cb.wy1 = (std::min(d->cb_rect[1], d->Ho) + tr - 1) / tr;
             cb.wx0 = std::max(d->cb_rect[2], 0) / 16;             cb.wx1 = (std::min(d->cb_rect[3], d->Wo) + 15) / 16;
-            if (cb.fy1 > cb.fy0 && cb.fx1 > cb.fx0 && cb.wy0 - 1 >= cb.fy0 && cb.wy1 > cb.wy0 && cb.wx1 > cb.wx0 && cb.wx0 >= cb.fx0) {
+            if (cb.fy1 > cb.fy0 && cb.fx1 > cb.fx0 && cb.wy0 - 1 >= cb.fy0 && cb.wy0 - 1 < cb.fy1 && cb.wy1 > cb.wy0 && cb.wx1 > cb.wx0 && cb.wx0 >= cb.fx0 && cb.wx0 < cb.fx1) {
+                // (the reference tile (wy0 - 1, wx0) has to lie INSIDE the padding-free rectangle: a hint whose window starts at or
+                // beyond it would broadcast a pixel that sees the zero padding -- such a hint runs dense)
                 const int ry = cb.wy0 - 1, rx = cb.wx0;          // a tile above the window, inside the padding-free rectangle
                 cb.wy0 -= 1;                                     // ... its whole row of window tiles is run (no special case in decode())
                 cb_finish(cb);
@@ -654,19 +656,25 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
         ncu &= ~7;                                   // whole XCD groups
         if (ncu < 8) ncu = 8;
     }
+    // reserved_cus: leave that many CUs (whole XCD groups of 8 blocks) to another queue -- the RCCL all-reduce that runs under the
+    // backward pass; a persistent block per CU cannot share its CU's LDS with an RCCL workgroup, which would otherwise wait for a
+    // whole kernel (or make one block of this kernel wait for a whole collective)
+    const int ncu_all = ncu;
+    int grid_cus = ncu_all;
+    if (d->reserved_cus > 0) { grid_cus = (ncu_all - d->reserved_cus) & ~7; if (grid_cus < 8) grid_cus = 8; }
     hipStream_t st = (hipStream_t)stream;
-    if (a.cslab && d->colsum_slab_rows < ncu) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab holds %d rows, %d needed", d->colsum_slab_rows, ncu);
-    szn_note_colsum_rows(a.cslab ? ncu : 0);
+    if (a.cslab && d->colsum_slab_rows < grid_cus) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab holds %d rows, %d needed", d->colsum_slab_rows, grid_cus);
+    szn_note_colsum_rows(a.cslab ? grid_cus : 0);
     int rc;
     if (d->dtype == SZN_F16) {
-        if (cog == 2 && cig == 1) rc = launch_regw_flags<f16_raw, 2, 1>(a, ncu, st);
-        else if (cog == 4 && cig == 1) rc = launch_regw_flags<f16_raw, 4, 1>(a, ncu, st);
-        else if (cog == 2 && cig == 2) rc = launch_regw_flags<f16_raw, 2, 2>(a, ncu, st);
-        else rc = launch_regw_flags<f16_raw, 4, 2>(a, ncu, st);
-    } else if (cog == 2 && cig == 1) rc = launch_regw_flags<bf16_raw, 2, 1>(a, ncu, st);
-    else if (cog == 4 && cig == 1) rc = launch_regw_flags<bf16_raw, 4, 1>(a, ncu, st);
-    else if (cog == 2 && cig == 2) rc = launch_regw_flags<bf16_raw, 2, 2>(a, ncu, st);
-    else rc = launch_regw_flags<bf16_raw, 4, 2>(a, ncu, st);
+        if (cog == 2 && cig == 1) rc = launch_regw_flags<f16_raw, 2, 1>(a, grid_cus, st);
+        else if (cog == 4 && cig == 1) rc = launch_regw_flags<f16_raw, 4, 1>(a, grid_cus, st);
+        else if (cog == 2 && cig == 2) rc = launch_regw_flags<f16_raw, 2, 2>(a, grid_cus, st);
+        else rc = launch_regw_flags<f16_raw, 4, 2>(a, grid_cus, st);
+    } else if (cog == 2 && cig == 1) rc = launch_regw_flags<bf16_raw, 2, 1>(a, grid_cus, st);
+    else if (cog == 4 && cig == 1) rc = launch_regw_flags<bf16_raw, 4, 1>(a, grid_cus, st);
+    else if (cog == 2 && cig == 2) rc = launch_regw_flags<bf16_raw, 2, 2>(a, grid_cus, st);
+    else rc = launch_regw_flags<bf16_raw, 4, 2>(a, grid_cus, st);
     if (rc || !use_cb) return rc;
     hipLaunchKernelGGL(regw_const_fill_kernel, dim3((unsigned)(a.B * a.tiles_y * ((a.tiles_x + CB_FILL_G - 1) / CB_FILL_G))), dim3(256), 0, st, cb, tr, d->Co, d->Ho, d->Wo, a.Hp, a.Wp,
                        a.skip_x ? nullptr : (uint16_t*)a.out, d->ldo, (uint16_t*)a.pool, a.pcode, ref_oh, ref_ow);

@@ -332,7 +332,9 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     // ms/step under contention, 11.7 vs 11.9 without -- no net gain, so nothing sets it by default.
     static int oversub = 0;
     if (!oversub) { const char* e = getenv("SZN_WGT_OVERSUB"); oversub = e ? atoi(e) : 1; if (oversub < 1) oversub = 1; }
-    long ns = (long)ncu * oversub / ncombo;
+    // reserved_cus: CUs left to another queue (the RCCL all-reduce under the backward pass), see szn_conv_desc_t
+    const int cus = (d->reserved_cus > 0 && ncu - d->reserved_cus >= ncombo) ? ncu - d->reserved_cus : ncu;
+    long ns = (long)cus * oversub / ncombo;
     if (min_tiles_per_block < 1) min_tiles_per_block = 1;
     if (ns > nt / min_tiles_per_block) ns = nt / min_tiles_per_block;
     const size_t slab_bytes = (size_t)ncombo * SLAB * sizeof(float);

@@ -876,6 +876,13 @@ extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const 
                                                    szn_conv1_1_wgrad_workspace_bytes(dtype, B, H, W, pad), stream);
         if (rc < 0) return rc;
         if (rc == 0) return db ? szn_bias_grad(dtype, M, 64, 64, dout, db, accumulate, stream) : SZN_OK;
+        // The im2col path below reads ALL of dout.  szn_conv1_1_wgrad_reads() lets the producer of dout (conv1_2's dgrad under the
+        // constant-border hint) leave everything outside the reported rectangle unwritten: if it promised a sub-rectangle for these
+        // arguments, falling back here would sum uninitialised memory into dw -- fail instead of returning a silent wrong gradient.
+        int rect[4];
+        if (szn_conv1_1_wgrad_reads(dtype, B, H, W, pad, rect) == 1)
+            SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_wgrad: the fused kernel declined a shape for which szn_conv1_1_wgrad_reads() "
+                     "reports the sub-rectangle [%d,%d) x [%d,%d): dout may be undefined outside it", rect[0], rect[1], rect[2], rect[3]);
     }
     float* dw32 = (float*)workspace;                              // [64][32]
     char* xcol = (char*)workspace + 64 * 32 * sizeof(float);      // [M][32] of dtype

@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void smh_cell_kernel(const float* __restrict__
             const long lbl = target[pix];
             int tb;
             bool valid = true;
-            if (n_class > 0) tb = (lbl >= 0 && lbl < n_class && ((seen_bits >> lbl) & 1ull)) ? 1 : 0;
+            // labels below -1 are batch PADDING (datasets.pad_collate writes -2): not a pixel of any image, so it is neither a
+            // target nor counted -- unlike -1 ("unlabelled"), which the reference turns into target 0 (trainer_seenmask.py:55-56)
+            if (n_class > 0) { valid = lbl >= -1; tb = (lbl >= 0 && lbl < n_class && ((seen_bits >> lbl) & 1ull)) ? 1 : 0; }
             else { valid = lbl >= 0 && lbl < 2; tb = (int)lbl; }
             if (!valid) continue;
             const float mx = am ? s1 : s0;

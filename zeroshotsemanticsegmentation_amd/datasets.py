@@ -233,13 +233,18 @@ class PascalVOC(_SegmentationDataset):
 MEAN_RGB_U8 = tuple(int(round(v)) for v in utils.MEAN_BGR[::-1])       # the uint8 colour closest to the mean: ~0 after the transform
 
 
+PAD_LABEL = -2     # label of the pixels pad_collate adds: ignored by every loss / metric kernel, in BOTH phases (see pad_collate)
+
+
 def pad_collate(batch):
     """collate_fn for NATIVE samples (uint8 (H,W,3) RGB image, int64 (H,W) label) of different sizes -- PASCAL images differ in
     size (context_dataset.py:143-150 never resizes; the reference therefore trains at batch size 1, train.py:82-84).  Every
     sample is padded at the bottom / right to the largest height / width of the batch: image pixels with the mean colour (zero
-    after the BGR - mean transform, i.e. what conv1_1's own zero padding continues with), labels with -1, which every loss,
-    class-assignment and histogram kernel of this path already ignores (utils.py:33,60,84: `target >= 0`).  Per-image losses
-    keep their own valid-pixel counts, so a padded batch is the mean of its images' losses.  -> ((B,Hm,Wm,3) uint8, (B,Hm,Wm)
+    after the BGR - mean transform, i.e. what conv1_1's own zero padding continues with), labels with PAD_LABEL = -2.  Phase 1:
+    every loss, class-assignment and histogram kernel ignores negative labels (utils.py:33,60,84: `target >= 0`); per-image losses
+    keep their own valid-pixel counts, so a padded batch is the mean of its images' losses.  Phase 2 (trainer_seenmask.py:55-56)
+    turns the UNLABELLED value -1 into target 0 = "unseen" and counts it -- padding must not be counted, hence its own value:
+    szn_seenmask_head and Trainer.binary_target leave labels below -1 out of the loss, the gradients and the confusion counts.  -> ((B,Hm,Wm,3) uint8, (B,Hm,Wm)
     int64).  Samples that carry the reference's (label, label_embedding) tuple keep the label only (the embedding is gathered
     on the GPU)."""
     imgs, lbls = [], []
@@ -254,7 +259,7 @@ def pad_collate(batch):
     Hm, Wm = max(i.shape[0] for i in imgs), max(i.shape[1] for i in imgs)
     out_i = torch.empty(len(imgs), Hm, Wm, 3, dtype=torch.uint8)
     out_i[:] = torch.tensor(MEAN_RGB_U8, dtype=torch.uint8)
-    out_l = torch.full((len(imgs), Hm, Wm), -1, dtype=torch.int64)
+    out_l = torch.full((len(imgs), Hm, Wm), PAD_LABEL, dtype=torch.int64)
     for k, (img, lbl) in enumerate(zip(imgs, lbls)):
         h, w = img.shape[:2]
         out_i[k, :h, :w] = img

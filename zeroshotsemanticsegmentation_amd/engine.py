@@ -33,9 +33,21 @@ class GradBuckets(object):
     bucket is rounded to bf16 into a staging buffer, summed there by the all-reduce and widened back into `flat` by
     `finish` (gradient noise of 2^-9 relative per rank; the fp32 default is exact)."""
 
-    def __init__(self, flat, layers, bucket_elems, extra=(), group=None, comm_dtype=torch.float32):
+    def __init__(self, flat, layers, bucket_elems, extra=(), group=None, comm_dtype=torch.float32, force=None):
+        """force (default: SZN_FORCE_COMM=1): issue the bucket all-reduces even in a process group of ONE rank -- the whole
+        exchange path (bucket slicing, RCCL's stream, the waits in front of the optimizer, the bf16 staging) then runs on a
+        single GPU.  RCCL returns from an in-place sum over one rank without touching the device, so on the `nccl` backend the
+        forced single-rank exchange uses the pre-multiplied sum (factor 1.0): librccl's one-rank reduce kernel reads and writes
+        every bucket on RCCL's stream while dgrad / wgrad keep running on the compute stream (same bits as no exchange)."""
         self.flat, self.extra, self.group = flat, list(extra), group
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
+        if force is None:
+            force = os.environ.get("SZN_FORCE_COMM", "0") == "1"
+        self.active = ready and (self.world > 1 or bool(force))
+        self.op = dist.ReduceOp.SUM
+        if self.active and self.world == 1 and dist.get_backend(group) == "nccl" and hasattr(dist, "_make_nccl_premul_sum"):
+            self.op = dist._make_nccl_premul_sum(1.0)
         self.buckets = []            # (start, end, name of the layer whose completion closes the bucket)
         end = None
         for name, off, cnt in reversed(layers):
@@ -46,24 +58,29 @@ class GradBuckets(object):
                 end = None
         self.ready_after = {name: (o, e) for o, e, name in self.buckets}
         self.works = []
+        self.issued = 0              # all-reduce calls handed to the backend so far (tests / bench)
         self.comm_dtype = comm_dtype
         self.stage = None
-        if self.world > 1 and comm_dtype != torch.float32:
+        if self.active and comm_dtype != torch.float32:
             self.stage = torch.empty(flat.numel(), dtype=comm_dtype, device=flat.device)
 
+    def _reduce(self, t):
+        self.issued += 1
+        return dist.all_reduce(t, op=self.op, group=self.group, async_op=True)
+
     def layer_done(self, name):
-        if self.world > 1 and name in self.ready_after:
+        if self.active and name in self.ready_after:
             o, e = self.ready_after[name]
             if self.stage is None:
-                self.works.append((dist.all_reduce(self.flat[o:e], group=self.group, async_op=True), None))
+                self.works.append((self._reduce(self.flat[o:e]), None))
             else:
                 self.stage[o:e].copy_(self.flat[o:e])
-                self.works.append((dist.all_reduce(self.stage[o:e], group=self.group, async_op=True), (o, e)))
+                self.works.append((self._reduce(self.stage[o:e]), (o, e)))
 
     def finish(self):
-        if self.world > 1:
+        if self.active:
             for t in self.extra:
-                self.works.append((dist.all_reduce(t, group=self.group, async_op=True), None))
+                self.works.append((self._reduce(t), None))
             for wk, span in self.works:
                 wk.wait()
                 if span is not None:
@@ -237,7 +254,7 @@ class TrainStep(object):
                  precision=torch.bfloat16, fused_head=True, loss="cos", process_group=None, bucket_mb=25,
                  train_metrics=True, betas=(0.9, 0.999), eps=1e-8, bias_lr=None, bias_weight_decay=0.0,
                  adam_weight_decay=0.0, grad_comm_dtype=None, loss_scale=None, dynamic_loss_scale=None,
-                 scale_growth=2.0, scale_backoff=0.5, scale_growth_interval=2000):
+                 scale_growth=2.0, scale_backoff=0.5, scale_growth_interval=2000, force_comm=None, reserved_cus=None):
         if loss not in ("cos", "mse") or (fused_head and loss != "cos"):
             raise L.SznError("TrainStep: fused head supports the cosine loss; use fused_head=False for mse")
         self.model = model
@@ -279,10 +296,16 @@ class TrainStep(object):
         self.scale_state = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.force_comm = force_comm
         self.train_metrics = train_metrics
         self.nstep = 0
         self._flatten()
         self._buckets(bucket_mb)
+        # CUs the persistent one-block-per-CU backward kernels (conv3x3_regw dgrad, conv_wgrad_taps) leave to RCCL's workgroups
+        # while an exchange is in flight (default SZN_RESERVED_CUS, 0 = none; only when buckets are actually exchanged)
+        if reserved_cus is None:
+            reserved_cus = int(os.environ.get("SZN_RESERVED_CUS", "0"))
+        self.eng.reserved_cus = int(reserved_cus) if self.buckets.active else 0
         if self.dynamic:
             self.scale_state = torch.tensor([self._loss_scale0, 0.0, 0.0, 0.0], device=self.dev)
         self.hist = torch.zeros(3, self.K, self.K, dtype=torch.int64, device=self.dev)
@@ -400,7 +423,7 @@ class TrainStep(object):
     def _buckets(self, bucket_mb):
         layers = [(n,) + self.woff[n] for n in self.layers]
         self.buckets = GradBuckets(self.flat_gw, layers, bucket_mb * (1 << 20) // 4, extra=[self.flat_gb], group=self.pg,
-                                   comm_dtype=self.grad_comm_dtype)
+                                   comm_dtype=self.grad_comm_dtype, force=self.force_comm)
 
     # ---- one training step -----------------------------------------------------------------------------
     def step(self, x, target):

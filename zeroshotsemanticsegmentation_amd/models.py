@@ -101,6 +101,7 @@ class _Engine(object):
         # un-pooled store (pool_only; conv3x3_regw does: 516 + 258 MB per step neither written nor read back).  keep_prepool = True
         # (tests that inspect the forward state) keeps those tensors valid; SZN_POOL_CODES=0: the round-1/2 backward from the tensor.
         self.keep_prepool = False
+        self.reserved_cus = 0         # CUs the persistent backward kernels leave to the RCCL queue (szn_conv_desc_t.reserved_cus; TrainStep)
         self.pool_codes = os.environ.get("SZN_POOL_CODES", "1") != "0"
         self.head_fp8 = False         # forward of the projection head on the fp8 matrix cores (set_head_precision)
         self.head_fp8_bwd = False     # ... and its dgrad / wgrad (e5m2 gradient x e4m3 operands)
@@ -507,6 +508,7 @@ class _Engine(object):
         ldo = dout.shape[3] if ldo is None else ldo
         code = L.dtype_code(self.dtype)
         d = L.ConvDesc(code, B, Hi, Wi, ci, Ho, Wo, co, k, k, pad, ci, ldo, 0, 0, 0)
+        d.reserved_cus = self.reserved_cus
         # slab workspace of the weight-gradient kernels: the all-taps kernel (szn_conv_wgrad_taps.hip: <= 256 blocks x 64*9*64
         # fp32, room for SZN_WGT_OVERSUB=2) and the pixel splits of conv_wgrad_v2 (head / skip layers, every f32 layer: fixed-order
         # slabs instead of fp32 atomics -- it takes as many splits as fit)
@@ -558,6 +560,7 @@ class _Engine(object):
         wT = self._images[name + ".wT"] if wT is None else wT
         k = wT.shape[1]
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, Ci, 0, 0)
+        d.reserved_cus = self.reserved_cus
         slab = None
         if colsum is not None:
             d.colsum = colsum.data_ptr()
@@ -669,8 +672,13 @@ class _Engine(object):
                 if prev[0] == "conv1_1":
                     # conv1_1's output is constant outside the image's reach, and this gradient is read by szn_conv1_1_wgrad only
                     ry, rx = _cb_conv1_1(ctx.H, PAD1), _cb_conv1_1(ctx.W, PAD1)
+                    # (returns 1 and a proper sub-rectangle only when szn_conv1_1_wgrad takes its fused kernel for these
+                    # arguments -- otherwise `reads` is the whole map and nothing may be skipped; the library refuses to fall
+                    # back to a kernel that reads more than it reported)
                     reads = (C.c_int * 4)()
-                    L.load().szn_conv1_1_wgrad_reads(code, ctx.B, ctx.H, ctx.W, PAD1, reads)
+                    sub = L.load().szn_conv1_1_wgrad_reads(code, ctx.B, ctx.H, ctx.W, PAD1, reads)
+                    if sub not in (0, 1):
+                        raise L.SznError("szn_conv1_1_wgrad_reads failed (%d)" % sub)
                     cb = ((ry[0], ry[1], rx[0], rx[1]), tuple(reads))
                 d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1], cb=cb)
         self._join_wgrad()

@@ -66,10 +66,13 @@ class Trainer(object):
                         f.write(','.join(hdr) + '\n')
 
     def binary_target(self, target):
-        """np.in1d(target, seen) on the device: labels outside [0, n_class) (incl. -1) map to 0"""
+        """np.in1d(target, seen) on the device: labels outside [0, n_class) (incl. -1) map to 0 (trainer_seenmask.py:55-56);
+        batch padding (datasets.PAD_LABEL = -2, written by pad_collate around the smaller images of a ragged batch) stays
+        negative, so cross_entropy2d's `target >= 0` mask and the metrics leave it out"""
         t = target.to(self.device)
         idx = torch.where((t >= 0) & (t < self.n_class), t, torch.full_like(t, self.n_class))
-        return self._seen_lut[idx]
+        b = self._seen_lut[idx]
+        return torch.where(t < -1, torch.full_like(b, -1), b)
 
     def _forward_device(self, data, target):
         """-> (score, loss, pred (n,h,w) int64 device tensor, binary target device tensor)"""
@@ -129,6 +132,10 @@ class Trainer(object):
                     target = target[0]
                 data = utils.image_to_device(data, self.device) if data.dtype == torch.uint8 else data.to(self.device, non_blocking=True)
                 step.conf.zero_()
+                # hyperparameters are the optimizer object's, read every step (an LR schedule or a manual decay on
+                # optim.param_groups keeps working on the fused path)
+                g = self.optim.param_groups[0]
+                step.lr, step.betas, step.eps, step.wd = g['lr'], tuple(g['betas']), g['eps'], g.get('weight_decay', 0.0)
                 loss, pred = step.step(data, target.to(self.device, non_blocking=True).long().contiguous())
                 # one D2H per iteration: the loss and the 2 x 2 confusion counts the step accumulated on the device
                 packed = torch.cat([loss.reshape(1).double(), step.conf.double()]).cpu().numpy()
@@ -154,6 +161,12 @@ class Trainer(object):
                 for name, v in zip(['loss', 'pxl_acc', 'class_acc', 'mean_iu', 'fwavacc'], [lossv] + list(metrics)):
                     self.tb_writer.add_scalar('seenmask/train/' + name, v, self.iteration)
             self.iteration += 1
+        if step is not None:
+            # the fused step owns the Adam moments (flat buffers): expose them as per-parameter state of the optimizer object
+            # (views, torch.optim.Adam layout), so that checkpointing / inspecting `optim` after phase 2 sees what autograd +
+            # optim.step() would have left there.  The three head Parameters stay views of the step's flat master buffer (the
+            # update is written in place; seenmask_score.weight is a permuted, non-contiguous (2,F,1,1) view of its (2,F) rows).
+            step.export_optimizer_state(self.optim)
 
     def validate(self):
         """reference :104-166; histogram and loss sum accumulated on the GPU, one read-back per epoch; validation images are
