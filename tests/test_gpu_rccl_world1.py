@@ -64,7 +64,7 @@ def _worker(port, size, q):
             ts, losses = run(True, comm)
             bk = ts.buckets
             out[name] = {
-                "active": bk.active, "issued": bk.issued, "premul": "PREMUL" in repr(bk.op).upper() or bk.op != dist.ReduceOp.SUM,
+                "active": bk.active, "issued": bk.issued, "premul": bk.op != dist.ReduceOp.SUM,
                 "bucket_mib": [(e - o) * 4 / 2 ** 20 for o, e, _ in bk.buckets],
                 "loss_equal": losses == ref_loss,
                 # fp32 wire: the gradients of both steps; bf16 wire: the first step's gradient == the reference's rounded through

@@ -1,0 +1,21 @@
+# round 4: tools/r04_profile.sh <tag>  ->  gpurun_out/r4prof_<tag>/: kernel stats + time line of the headline step and of a B = 1 step,
+# the stall-breakdown PMC pass, MFMA utilisation, and the forced one-rank RCCL exchange time line (1b)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; T=${1:-a}
+O=$R/gpurun_out/r4prof_$T
+mkdir -p $O
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-kernel-events"
+rocprofv3 --kernel-trace --stats -d $O/p1 -o p1 -- python $R/bench.py $ARGS > $O/p1.log 2>&1
+DB=$(find $O/p1 -name "*_results.db" | head -1)
+python $R/tools/prof_summary.py $DB $O/r04_${T}_bf16_b8_k59_kernel_stats.md "round 4 state $T: python bench.py $ARGS (bf16, B=8, K=59; 7 steps traced)"
+python $R/tools/prof_timeline.py $DB $O/r04_${T}_timeline.md > /dev/null
+rm -rf $O/p1
+rocprofv3 --kernel-trace --stats -d $O/p2 -o p2 -- python $R/bench.py --batch 1 $ARGS > $O/p2.log 2>&1
+DB=$(find $O/p2 -name "*_results.db" | head -1)
+python $R/tools/prof_summary.py $DB $O/r04_${T}_bf16_b1_kernel_stats.md "round 4 state $T, B = 1 (the reference's batch size): python bench.py --batch 1 $ARGS (7 steps traced)"
+python $R/tools/prof_timeline.py $DB $O/r04_${T}_b1_timeline.md > /dev/null
+rm -rf $O/p2
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d $O/raw -o pmc --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-events > $O/pmc.log 2>&1
+python $R/tools/pmc_stalls.py $O/raw $O/r04_${T}_stalls.md "round 4 state $T: stall breakdown per kernel of the bench step (bf16, B=8, K=59; 3 steps)" > /dev/null
+rm -rf $O/raw
+head -14 $O/r04_${T}_bf16_b8_k59_kernel_stats.md; head -24 $O/r04_${T}_bf16_b1_kernel_stats.md; head -20 $O/r04_${T}_stalls.md

@@ -37,8 +37,9 @@ class GradBuckets(object):
         """force (default: SZN_FORCE_COMM=1): issue the bucket all-reduces even in a process group of ONE rank -- the whole
         exchange path (bucket slicing, RCCL's stream, the waits in front of the optimizer, the bf16 staging) then runs on a
         single GPU.  RCCL returns from an in-place sum over one rank without touching the device, so on the `nccl` backend the
-        forced single-rank exchange uses the pre-multiplied sum (factor 1.0): librccl's one-rank reduce kernel reads and writes
-        every bucket on RCCL's stream while dgrad / wgrad keep running on the compute stream (same bits as no exchange)."""
+        forced single-rank exchange uses the pre-multiplied sum (factor 1.0; AVG for 16-bit wire buffers): librccl's one-rank
+        reduce kernel reads and writes every bucket on RCCL's stream while dgrad / wgrad keep running on the compute stream (same
+        bits as no exchange)."""
         self.flat, self.extra, self.group = flat, list(extra), group
         ready = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if ready else 1
@@ -46,8 +47,15 @@ class GradBuckets(object):
             force = os.environ.get("SZN_FORCE_COMM", "0") == "1"
         self.active = ready and (self.world > 1 or bool(force))
         self.op = dist.ReduceOp.SUM
-        if self.active and self.world == 1 and dist.get_backend(group) == "nccl" and hasattr(dist, "_make_nccl_premul_sum"):
-            self.op = dist._make_nccl_premul_sum(1.0)
+        if self.active and self.world == 1 and dist.get_backend(group) == "nccl":
+            # one rank: sum == average == x * 1.0.  RCCL skips an in-place SUM entirely; the pre-multiplied sum (fp32 buckets) and
+            # AVG (16-bit staging buffers: torch 2.10 hands RCCL a zero factor for a bf16 pre-multiplied sum) make it launch its
+            # one-rank reduce kernel.  SZN_FORCE_COMM_OP = premul | avg | sum overrides.
+            which = os.environ.get("SZN_FORCE_COMM_OP", "premul" if comm_dtype == torch.float32 else "avg")
+            if which == "premul" and hasattr(dist, "_make_nccl_premul_sum"):
+                self.op = dist._make_nccl_premul_sum(1.0)
+            elif which == "avg":
+                self.op = dist.ReduceOp.AVG
         self.buckets = []            # (start, end, name of the layer whose completion closes the bucket)
         end = None
         for name, off, cnt in reversed(layers):
