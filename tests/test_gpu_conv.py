@@ -62,10 +62,10 @@ EXPECT_BF16 = {
     (1, 260, 260, 64, 300, 1, 0): ("conv_igemm_wide", None, None),
     (5, 32, 32, 64, 2000, 1, 0): ("conv_igemm_wide", None, None),
     (8, 17, 17, 4096, 4096, 1, 0): ("conv_igemm_wide", "conv_igemm_wide", "conv_wgrad_wide"),
-    (3, 150, 151, 64, 256, 3, 1): ("conv3x3_wide_rows", None, None),
-    (1, 260, 258, 256, 256, 3, 1): ("conv3x3_wide_rows", "conv3x3_wide_rows", None),
-    (37, 43, 42, 64, 256, 3, 1): ("conv3x3_wide_rows", None, None),
-    (1, 3, 25000, 64, 256, 3, 1): ("conv3x3_wide_rows", None, None),
+    (3, 150, 151, 64, 256, 3, 1): ("conv_igemm_8ph", None, None),
+    (1, 260, 258, 256, 256, 3, 1): ("conv_igemm_8ph", "conv_igemm_8ph", None),
+    (37, 43, 42, 64, 256, 3, 1): ("conv_igemm_8ph", None, None),
+    (1, 3, 25000, 64, 256, 3, 1): ("conv_igemm_8ph", None, None),
     (1, 9, 9, 256, 512, 7, 0): (None, None, "conv_wgrad_wide"),
     (2, 7, 6, 448, 512, 5, 1): (None, None, "conv_wgrad_wide"),
     (2, 8, 8, 512, 128, 7, 0): ("splitk_epilogue", None, None),
@@ -433,6 +433,9 @@ def test_proj_gemm_stream(dt, M, out32, N):
     assert worst < (2e-4 if out32 else 6e-3), worst
 
 
+_PROBE_SHAPES = [(2, 47, 256, 256, 3, 1), (8, 89, 128, 256, 3, 1), (8, 17, 512, 4096, 1, 0), (2, 45, 512, 128, 3, 1), (1, 33, 64, 320, 1, 0)]
+# 256-wide tile shapes with >= 240 tiles: 3x3 forward + dgrad (gate, column sums), a 1x1 with a Dropout2d factor, ragged pixel tiles
+_PROBE_SHAPES_8PH = [(8, 89, 256, 256, 3, 1), (3, 150, 64, 256, 3, 1), (4, 131, 256, 512, 1, 0), (2, 181, 256, 256, 5, 2), (1, 260, 128, 256, 3, 1)]
 _EPILOGUE_PROBE = r'''
 import ctypes as C, hashlib, sys, torch
 sys.path.insert(0, %r)
@@ -441,8 +444,7 @@ torch.manual_seed(7)
 dt = L.dtype_code(torch.bfloat16)
 out_lines = []
 # (B, Hi, Ci, Co, K, pad): wide_rows (3x3, 256 couts), igemm_wide 192-tiles (1x1, few tiles), igemm_v2 (128 couts), ragged sizes
-for (B, Hi, Ci, Co, K, pad) in [(2, 47, 256, 256, 3, 1), (8, 89, 128, 256, 3, 1), (8, 17, 512, 4096, 1, 0), (2, 45, 512, 128, 3, 1),
-                                (1, 33, 64, 320, 1, 0)]:
+for (B, Hi, Ci, Co, K, pad) in %s:
     Ho = Hi + 2 * pad - K + 1
     x = torch.randn(B, Hi, Hi, Ci, device="cuda").bfloat16()
     w = (torch.randn(Co, K, K, Ci, device="cuda") / (Ci * K * K) ** 0.5).bfloat16()
@@ -477,9 +479,11 @@ def test_register_epilogue_equals_the_staged_epilogue_bit_for_bit():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = {}
-    for tag, env in (("direct", {}), ("staged", {"SZN_WIDE_DIRECT": "0", "SZN_IGEMM_DIRECT": "0"})):
+    # (SZN_WIDE_8PH=0: the round 1-3 tile kernels, which have both epilogues; conv_igemm_8ph has the register epilogue only and is
+    # compared with them in test_8phase_kernel_equals_conv_igemm_wide_bit_for_bit)
+    for tag, env in (("direct", {"SZN_WIDE_8PH": "0"}), ("staged", {"SZN_WIDE_8PH": "0", "SZN_WIDE_DIRECT": "0", "SZN_IGEMM_DIRECT": "0"})):
         e = dict(os.environ); e.update(env)
-        r = subprocess.run([sys.executable, "-c", _EPILOGUE_PROBE % root], env=e, capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", _EPILOGUE_PROBE % (root, _PROBE_SHAPES)], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         runs[tag] = [ln.split() for ln in r.stdout.strip().splitlines() if len(ln.split()) == 4]
     assert len(runs["direct"]) == 5 and len(runs["staged"]) == 5, (runs,)
@@ -490,6 +494,34 @@ def test_register_epilogue_equals_the_staged_epilogue_bit_for_bit():
         assert abs(float(a[3]) - float(b[3])) <= 1e-5 * max(1.0, abs(float(b[3]))), (a, b)
         kernels.update((a[1], a[2]))
     assert {"conv3x3_wide_rows", "conv_igemm_wide", "conv_igemm_v2"} <= kernels, kernels
+
+
+def test_8phase_kernel_equals_conv_igemm_wide_bit_for_bit():
+    """conv_igemm_8ph (round 4: the 8-phase schedule) accumulates every output element over the same K order (tap, cin chunk, two
+    K halves) as conv_igemm_wide, so the two kernels must write the same bits -- forward (bias, ReLU, Dropout2d factor) and dgrad
+    (gate; column sums to rounding: another grouping).  The probe runs each kernel set in its own process (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for tag, env in (("8ph", {}), ("wide", {"SZN_WIDE_8PH": "0", "SZN_WIDE_ROWS": "0"})):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _EPILOGUE_PROBE % (root, _PROBE_SHAPES_8PH)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[tag] = [ln.split() for ln in r.stdout.strip().splitlines() if len(ln.split()) == 4]
+    assert len(runs["8ph"]) == 5 and len(runs["wide"]) == 5, (runs,)
+    seen = 0
+    for a, b in zip(runs["8ph"], runs["wide"]):
+        assert a[0] == b[0], (a, b)                      # outputs + input gradients: same bits
+        assert abs(float(a[3]) - float(b[3])) <= 1e-5 * max(1.0, abs(float(b[3]))), (a, b)
+        for ka, kb in ((a[1], b[1]), (a[2], b[2])):
+            if ka == "conv_igemm_8ph":
+                seen += 1
+                assert kb == "conv_igemm_wide", (a, b)
+            else:
+                assert ka == kb, (a, b)
+    assert seen >= 7, runs
 
 
 @pytest.mark.parametrize("geom", [(8, 23, 512, 1024, 7), (4, 28, 128, 128, 5)])

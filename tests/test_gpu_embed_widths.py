@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import szn_oracle as O  # noqa: E402
 from zeroshotsemanticsegmentation_amd import engine, models, synth  # noqa: E402
+from helpers_parity import adopt_forward  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
 WIDTHS = [2, 5, 10, 20, 21, 50, 100, 200, 300]
@@ -69,7 +70,6 @@ def test_trainstep_every_cli_embedding_width_vs_oracle(E, fused):
     of = om.forward(x, "fcn", keep=True)
     oloss, odf, _ = O.cosine_loss(of, t, embed=emb)
     opred = O.infer_lbl(of, emb)
-    og = om.backward(df=odf)
     m = models.FCN32s(E)
     sd = m.state_dict()
     for k, v in params.items():
@@ -77,6 +77,7 @@ def test_trainstep_every_cli_embedding_width_vs_oracle(E, fused):
     m._engine.mark_dirty()
     m = m.cuda().eval()
     ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=torch.float32, fused_head=fused)
+    ts.keep_ctx = True
     before = m.score_fr.weight.detach().clone()
     loss, pred = ts.step(cu(x), cu(t))
     torch.cuda.synchronize()
@@ -84,12 +85,22 @@ def test_trainstep_every_cli_embedding_width_vs_oracle(E, fused):
     clear = margins(of, emb)[None] > 1e-5
     assert clear.mean() > 0.9                     # (E = 2: many near-ties on a 2-d circle; still the bulk of the pixels)
     assert np.array_equal(pred.cpu().numpy()[clear], opred[clear])
+    # backward: every element of the probed gradients against the oracle's backward pass run on the HIP pass's forward state (ReLU
+    # gates, pooling winners: two correct fp32 forwards differ in a few of them, and each flip moves a whole gradient element --
+    # tests/helpers_parity.py); the forward state itself was compared by value above (loss, class assignment)
+    om2 = O.FCN32sOracle(params, E)
+    assert adopt_forward(om2, ts.last_ctx, x, None, E) == 0.0
+    assert np.abs(om2.saved["coarse_f"] - om.saved["coarse_f"]).max() < 1e-3 * np.abs(om.saved["coarse_f"]).max()
+    f_hip = O.deconv_fwd(om2.saved["coarse_f"], np.broadcast_to(O.get_upsampling_weight(1, 1, 64)[0, 0], (E, 64, 64)), H, W, diag=True)
+    _, odf_hip, _ = O.cosine_loss(f_hip, t, embed=emb)
+    og = om2.backward(df=odf_hip)
+    ts.last_ctx = None
     named = dict(m.named_parameters())
     for k in KEYS:
         g = named[k].grad.detach().cpu().numpy().astype(np.float64)
         r = og[k].astype(np.float64)
         err = np.abs(g - r).max() / (np.abs(r).max() + 1e-30)
-        assert err < (2e-3 if k.endswith(".bias") else 1e-3), (E, k, err)       # north star: 1e-3 relative fp32
+        assert err < (1e-3 if k.endswith(".bias") else 1e-4), (E, k, err)       # north star: 1e-3 relative fp32
     # Adam's first step from zero moments moves every score_fr weight with a clear gradient by lr * sign(g)
     g = named["score_fr.weight"].grad
     d = (m.score_fr.weight.detach() - before)

@@ -66,8 +66,8 @@ def test_fullsize_fp32_forward_matches_oracle():
 # name: (Hi, Ci, Co, K, pad) at 512x512 input (the bench's layers), expected forward kernel in bf16
 LAYERS = {   # (shape), batch, expected forward kernel (None: a split-K epilogue kernel runs last at this batch)
     "conv1_2": ((710, 64, 64, 3, 1), 2, "conv3x3_regw"), "conv2_1": ((355, 64, 128, 3, 1), 2, "conv3x3_regw"),
-    "conv2_2": ((355, 128, 128, 3, 1), 2, "conv3x3_regw"), "conv3_2": ((178, 256, 256, 3, 1), 4, "conv3x3_wide_rows"),
-    "conv4_2": ((89, 512, 512, 3, 1), 8, "conv3x3_wide_rows"), "conv5_1": ((45, 512, 512, 3, 1), 8, "conv_igemm_v2"),
+    "conv2_2": ((355, 128, 128, 3, 1), 2, "conv3x3_regw"), "conv3_2": ((178, 256, 256, 3, 1), 4, "conv_igemm_8ph"),
+    "conv4_2": ((89, 512, 512, 3, 1), 8, "conv_igemm_8ph"), "conv5_1": ((45, 512, 512, 3, 1), 8, "conv_igemm_v2"),
     "fc6": ((23, 512, 4096, 7, 0), 8, None), "fc7": ((17, 4096, 4096, 1, 0), 8, "conv_igemm_wide"),      # 256 x 192 tiles: one round of 220
 }
 WGRAD_KERNEL = {"conv1_2": "wgrad_taps_reduce", "conv2_1": "wgrad_taps_reduce", "conv2_2": "wgrad_taps_reduce",
@@ -148,7 +148,7 @@ def test_fullsize_fc6_forward_parity_split_k():
     d = L.ConvDesc(code, B, Hi, Hi, Ci, Ho, Ho, Co, K, K, 0, Ci, Co, 0, 1, 0)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     L.call("szn_conv2d_fwd", C.byref(d), L.ptr(xd), L.ptr(wd), L.ptr(bd), None, None, L.ptr(out), L.stream_ptr())
-    assert L.last_kernel() == "splitk_epilogue" and L.prev_kernel() == "conv_igemm_wide", (L.prev_kernel(), L.last_kernel())
+    assert L.last_kernel() == "splitk_epilogue" and L.prev_kernel() == "conv_igemm_8ph", (L.prev_kernel(), L.last_kernel())
     torch.cuda.synchronize()
     got = out.float().cpu().permute(0, 3, 1, 2)
     err = float((got - ref).abs().max() / ref.abs().max())

@@ -7,8 +7,9 @@ on THIS repo's GEMM shapes, same box, same operands, interleaved rounds (VERDICT
 shapes: conv3_2 forward as a GEMM (M = 8 x 178^2 = 253,472, N = 256, K = 9 x 256 = 2,304) and conv4_2 (M = 8 x 89^2 = 63,368, N = 512,
 K = 4,608), plus 4096^3 / 8192^3 (the guide's own shapes).  Contenders per shape:
   gemm8[...]         the template (variants: xor8 / st16x32 / linear swizzle; no-setprio; lockstep groups)
-  conv_igemm_wide    libszn_hip's 256 x 256 tile kernel on the same plain GEMM (a 1x1 convolution with Ci = K)
-  conv3x3_wide_rows  the kernel the training step actually runs for that layer (3x3 convolution, same FLOPs)
+  libszn 1x1 conv    libszn_hip's kernel for the same plain GEMM (a 1x1 convolution with Ci = K); the kernel name is recorded
+  libszn 3x3 conv    the kernel the training step actually runs for that layer (3x3 convolution, same FLOPs); SZN_WIDE_8PH=0
+                     selects the round 1-3 kernels (conv_igemm_wide / conv3x3_wide_rows), the default is conv_igemm_8ph
 operands: randn, relu(randn) (what the layers see), uniform(-1,1), zeros (DVFS upper bound; never quoted as a result)."""
 import argparse
 import ctypes as C
@@ -35,11 +36,13 @@ def gemm8(A, B, Cm, variant=0, flags=0):
     assert rc == 0, rc
 
 
-def wide_gemm(A, B, Cm):
-    """the same GEMM through szn_conv2d_fwd: a 1x1 convolution over an (1, 1, M, K) map"""
+def wide_gemm(A, B, Cm, bhw=None):
+    """the same GEMM through szn_conv2d_fwd: a 1x1 convolution over a (b, h, w, K) map with b h w = M (map sides stay below 32768)"""
     M, K = A.shape
     N = B.shape[0]
-    d = L.ConvDesc(L.SZN_BF16, 1, 1, M, K, 1, M, N, 1, 1, 0, K, Cm.shape[1], 0, 0, 0)
+    b, h, w_ = bhw if bhw else (1, M // 64, 64)
+    assert b * h * w_ == M
+    d = L.ConvDesc(L.SZN_BF16, b, h, w_, K, h, w_, N, 1, 1, 0, K, Cm.shape[1], 0, 0, 0)
     L.call("szn_conv2d_fwd", C.byref(d), L.ptr(A), L.ptr(B), None, None, None, L.ptr(Cm), L.stream_ptr())
 
 
@@ -113,13 +116,13 @@ def main():
                     "gemm8[xor8,lockstep]": lambda: gemm8(A, B, out, 0, 2), "gemm8[xor8,lockstep,no-setprio]": lambda: gemm8(A, B, out, 0, 3)}
             kernels = {}
             if N % 256 == 0 and (M * K * 2) < 0x7fff0000:
-                cont["conv_igemm_wide (same GEMM)"] = lambda: wide_gemm(A, B, out)
+                cont["libszn 1x1 conv (same GEMM)"] = lambda: wide_gemm(A, B, out, conv[:3] if conv else None)
             if conv is not None:
                 Bc, Hc, Wc, Ci = conv
                 x = fill((Bc, Hc, Wc, Ci), kind)
                 w = fill((N, 3, 3, Ci), "zeros" if kind == "zeros" else "randn", (9 * Ci) ** -0.5)
                 oc = torch.empty(Bc, Hc, Wc, N, device="cuda", dtype=torch.bfloat16)
-                cont["conv3x3_wide_rows (the layer itself)"] = lambda: conv3x3(x, w, oc)
+                cont["libszn 3x3 conv (the layer itself)"] = lambda: conv3x3(x, w, oc)
             for k, fn in cont.items():               # warm-up + which kernel the dispatcher took
                 fn()
                 if not k.startswith("gemm8"):

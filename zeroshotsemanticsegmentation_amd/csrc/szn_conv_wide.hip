@@ -11,36 +11,13 @@
 //     OOB offsets for padding, bias / ReLU / gate / dropout / column-sum epilogue on whole output rows.
 #include "szn_common.h"
 #include "szn_epilogue.h"
+#include "szn_wide_args.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((address_space(3))) void* ldsptr_t;
 
 namespace {
-
-struct WideArgs {
-    const char* in; const char* w; const float* bias; const char* gate; const float* cscale; char* out;
-    float* colsum;
-    float* cslab;              // optional [mtiles][Co]: the column sums of a pixel tile go to its row instead of fp32 atomics on colsum
-    unsigned in_bytes, w_bytes;
-    int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
-    int ldi, ldo, ldg, relu, out_f32;
-    int M, HoWo, mtiles, ntiles, nmajor;
-    float* ws;                 // split-K: fp32 slabs [nsplit][M][Co] (plain stores, no epilogue); nullptr = single pass
-    int nsplit, chunks_per_split;
-    int stagger;               // 1: wave pairs take turns issuing the LDS-DMA loads of a chunk (SZN_WIDE_STAGGER=0: all at once)
-    int gate_prefetch;         // 1: the epilogue fetches the ReLU-gate rows one pass ahead (SZN_WIDE_GATEPF=0: inside the store loop)
-    int direct_ep;             // 1: epilogue straight from the accumulator registers (wide_epilogue_direct)
-    int abl_ep;                // ablation builds only (SZN_WIDE_EPABL): 1 = epilogue without global stores / gate loads, 2 = no epilogue
-    int proj_abl;              // ablation builds only (SZN_PROJ_ABLATE): 1 = every block of proj_gemm_stream streams the rows of block 0
-};
-
-constexpr unsigned kOOBx = 0x80000000u;
-
-__device__ __forceinline__ int xcd_remap_w(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 // ---- epilogue staged through LDS in four 64-pixel passes ----
 template <typename T, int WNF>
@@ -690,6 +667,8 @@ int launch_wide(const WideArgs& a, hipStream_t st) {
 
 }  // namespace
 
+int szn_conv_8ph_launch(const void* args, int dtype, szn_stream_t stream);      // szn_conv_8ph.hip (args = WideArgs)
+
 // Called by szn_conv2d_fwd (which has validated the descriptor).  Returns 1 when the shape is not a good fit.
 int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, unsigned in_bytes, unsigned w_bytes, int min_tiles,
@@ -742,6 +721,15 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
         const uintptr_t al = (uintptr_t)out | (uintptr_t)gate | (uintptr_t)bias | (uintptr_t)chan_scale | (uintptr_t)a.ws;
         a.direct_ep = de && szn_is16(d->dtype) && (d->Co % 8) == 0 && (((size_t)d->ldo * oes) & 15) == 0 && (al & 15) == 0 &&
                       (!gate || (((size_t)d->ldg * 2) & 15) == 0);
+    }
+    if (bn == 256 && szn_is16(d->dtype)) {
+        // the 8-phase schedule (szn_conv_8ph.hip): every 256-wide 16-bit shape, split-K included; SZN_WIDE_8PH=0: the round 1-3 kernels
+        static int ph8 = -1;
+        if (ph8 < 0) { const char* e = getenv("SZN_WIDE_8PH"); ph8 = e ? atoi(e) : 1; }
+        if (ph8) {
+            const int rc = szn_conv_8ph_launch(&a, d->dtype, stream);
+            if (rc <= 0) return rc;
+        }
     }
     {
         static int rows = -1;

@@ -29,26 +29,25 @@ __device__ __forceinline__ float row16_sum_w(float x) {                    // su
 // layout, the four of a pair up front.  No barrier unless column sums are wanted (bias gradient of the producer layer: DPP row sums ->
 // LDS -> thread c adds the four pixel groups in ascending order: fixed order, bit-reproducible).  Same arithmetic per element as the
 // staged epilogue: outputs are bit-identical; the column sums add the same terms in another order.
+// One wave block: 64 pixels (rows mb + 16 j + r16) x 32 NP couts (columns nb ..) held as acc[WNF][4].  pws = where this block's row
+// sums go ([4 g][NP][8] floats in LDS; nullptr: no column sums).  No barrier inside.
 template <typename T, int WNF, bool GATE, bool SCALE, typename Args>
-__device__ __forceinline__ void tile_epilogue_direct(const Args& a, f32x4_t (&acc)[WNF][4], char* smem, int tid, int wm, int wn,
-                                                     int g, int r16, int m0, int n0) {
+__device__ __forceinline__ void tile_epilogue_block(const Args& a, f32x4_t (&acc)[WNF][4], int g, int r16, int mb, int nb, float* pws) {
     static_assert(sizeof(T) == 2 && (WNF % 2) == 0, "16-bit storage, fragment pairs");
-    constexpr int BN = 32 * WNF, NP = WNF / 2;
+    constexpr int NP = WNF / 2;
     const T* __restrict__ gate = (const T*)a.gate;
     const bool out32 = a.out_f32 != 0;
-    const bool do_cs = a.colsum != nullptr;
+    const bool do_cs = pws != nullptr;
     const float lo = a.relu ? 0.f : -__builtin_inff();        // ReLU as max(x, lo): max(x, -inf) == x
     const int cl = 16 * (g & 1) + 8 * (g >> 1);
-    const int nw = n0 + wn * (BN / 2) + cl;                    // column of this lane's piece in pair 0
+    const int nw = nb + cl;                                    // column of this lane's piece in pair 0
     int mrow[4];
     bool okm[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        mrow[j] = m0 + wm * 64 + 16 * j + r16;
+        mrow[j] = mb + 16 * j + r16;
         okm[j] = mrow[j] < a.M;
     }
-    float* const pw = (float*)smem;                            // [8 waves][4 g][NP][8] row sums (column sums only)
-    if (do_cs) __syncthreads();                                // every wave has left the operand ring
     // gfx950 counts loads AND stores in vmcnt, in issue order: a load issued behind the stores of the previous pair would make its
     // s_waitcnt sit out those stores' round trip (16 times per tile).  Bias and gate pieces of pair p + 1 are therefore issued in
     // front of the stores of pair p, and the wait in front of their first use is vmcnt(stores of p).
@@ -145,10 +144,23 @@ __device__ __forceinline__ void tile_epilogue_direct(const Args& a, f32x4_t (&ac
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float x = row16_sum_w(cs[e]);
-                if (r16 == 0) pw[((((wm * 2 + wn) * 4 + g) * NP) + p) * 8 + e] = x;
+                if (r16 == 0) pws[((g * NP) + p) * 8 + e] = x;
             }
         }
     }
+}
+
+// the 4 x 2 wave layout of conv_igemm_v2 / conv_igemm_wide / conv3x3_wide_rows / proj_gemm_stream: wave (wm, wn) owns the block at
+// (m0 + 64 wm, n0 + (BN / 2) wn); column sums: the four pixel groups of a column are added in ascending order by one thread
+template <typename T, int WNF, bool GATE, bool SCALE, typename Args>
+__device__ __forceinline__ void tile_epilogue_direct(const Args& a, f32x4_t (&acc)[WNF][4], char* smem, int tid, int wm, int wn,
+                                                     int g, int r16, int m0, int n0) {
+    constexpr int BN = 32 * WNF, NP = WNF / 2;
+    const bool do_cs = a.colsum != nullptr;
+    float* const pw = (float*)smem;                            // [8 waves][4 g][NP][8] row sums (column sums only)
+    if (do_cs) __syncthreads();                                // every wave has left the operand ring
+    tile_epilogue_block<T, WNF, GATE, SCALE>(a, acc, g, r16, m0 + wm * 64, n0 + wn * (BN / 2),
+                                             do_cs ? pw + ((wm * 2 + wn) * 4) * NP * 8 : nullptr);
     if (do_cs) {
         __syncthreads();
         if (tid < BN && n0 + tid < a.Co) {

@@ -46,6 +46,7 @@ _BACKBONE = [("conv1_1", PAD1), ("conv1_2", 1), "P", ("conv2_1", 1), ("conv2_2",
              ("conv5_1", 1), ("conv5_2", 1), ("conv5_3", 1), "P"]
 _TRUNK = [n for n, _, _, _ in synth.CONV_LAYERS]          # conv1_1 .. fc7
 _CONST_BORDER = os.environ.get("SZN_CONST_BORDER", "1") != "0"  # 0: no constant-border hint to the 710^2 / 355^2 forward convs
+_DGRAD_SPLIT = os.environ.get("SZN_DGRAD_SPLIT", "1") != "0"      # 0: few-tile dgrads keep their fused column sums (no split-K)
 _FC6_NATIVE = os.environ.get("SZN_FC6_NATIVE", "1") != "0"      # 0: fc6's dgrad GEMM on the packed transpose (rounds 1-2)
 _OPT_LAYERS = _TRUNK + ["score_fr"]                        # the layers train.get_parameters yields (train.py:302-331)
 _OPT_LAYERS8 = _TRUNK + ["score_pool3", "score_pool4", "score_fr"]       # ... for FCN8s (score_fr stays last: engine.TrainStep)
@@ -562,19 +563,29 @@ class _Engine(object):
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, Ci, 0, 0)
         d.reserved_cus = self.reserved_cus
         slab = None
-        if colsum is not None:
+        # Few output tiles and a long reduction (conv4_x / conv5_x at the reference's batch size of one image: 32 .. 124 tiles of
+        # 256 x 128 on 256 CUs): the library's deterministic split-K needs the epilogue to itself, so the column sums (= the producer
+        # layer's bias gradient) come from a pass over the small din instead of the dgrad epilogue
+        M = B * Hi * Wi
+        split_cs = (colsum is not None and cb is None and self.dtype != torch.float32 and
+                    ((M + 255) // 256) * ((Ci + 127) // 128) < 128 and k * k * Co >= 64 * 64 and _DGRAD_SPLIT)
+        if colsum is not None and not split_cs:
             d.colsum = colsum.data_ptr()
-            slab, rows = self._cs_slab(B * Hi * Wi, Ci, dout.device)
+            slab, rows = self._cs_slab(M, Ci, dout.device)
             if slab is not None:
                 d.colsum_slab, d.colsum_slab_rows = slab.data_ptr(), rows
         else:
-            self._workspace(d, B * Hi * Wi * Ci * 4, dout.device)
+            self._workspace(d, M * Ci * 4, dout.device)
         if cb is not None and gate is not None and _CONST_BORDER and self.dtype != torch.float32:
             grect, srect = cb                                   # (r0, r1, c0, c1) each: where the gate varies / what the consumer reads
             d.cb_on = 1
             for i in range(4):
                 d.cb_rect[i], d.cb_const[i] = grect[i], srect[i]
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
+        if split_cs:
+            slab, rows = self._cs_slab(M, Ci, dout.device)
+            L.call("szn_bias_grad_slab", L.dtype_code(self.dtype), M, Ci, Ci, L.ptr(din), L.ptr(colsum), 1, L.ptr(slab), rows,
+                   L.stream_ptr())
         self._cs_register(slab, Ci, colsum)
         return din
 
