@@ -191,6 +191,33 @@ def test_train_step_is_bit_reproducible(precision, size, B):
     assert float(a[3].abs().max()) > 0                          # the bias gradients are really there
 
 
+@pytest.mark.parametrize("optname", ["adam", "sgd"])
+def test_early_optimizer_pass_is_bit_identical(monkeypatch, optname):
+    """small steps update fc6 / fc7 / score_fr on a second stream under the rest of the backward pass (TrainStep._layer_done_hook):
+    three steps with it forced on == three steps with it off, bit for bit (weights, biases, moments, 16-bit weight image)"""
+    E, K, H = 300, 59, 128
+    emb = synth.make_embeddings(K, E)
+    x = cu(synth.make_images(1, H, H, seed=95))
+    t = cu(synth.make_labels(1, H, H, K, seed=96, block=16))
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SZN_EARLY_ADAM", mode)
+        m = models.FCN32s(E)
+        m.load_synthetic(1337, device=torch.device("cuda"))
+        m.train()
+        ts = engine.TrainStep(m, emb, optimizer=optname, lr=1e-5, precision=torch.bfloat16, fused_head=True)
+        used = []
+        for _ in range(3):
+            loss, _p = ts.step(x, t)
+            used.append(getattr(ts, "_side", None) is not None)
+        torch.cuda.synchronize()
+        assert used[-1] == (mode == "1")
+        runs.append((float(loss), ts.flat_w.clone(), ts.flat_b.clone(), ts.flat_w_lp.clone(), [s_.clone() for s_ in ts.state["w"]]))
+    a, b = runs
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert all(torch.equal(u, v) for u, v in zip(a[4], b[4]))
+
+
 def test_deterministic_bias_gradients_equal_the_atomic_ones(monkeypatch):
     """SZN_DETERMINISTIC=0 (fp32 atomics, the round-2 behaviour) and the slab form agree to rounding"""
     E, K, H = 20, 33, 96

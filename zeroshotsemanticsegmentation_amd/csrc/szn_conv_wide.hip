@@ -667,7 +667,7 @@ int launch_wide(const WideArgs& a, hipStream_t st) {
 
 }  // namespace
 
-int szn_conv_8ph_launch(const void* args, int dtype, szn_stream_t stream);      // szn_conv_8ph.hip (args = WideArgs)
+int szn_conv_8ph_launch(const void* args, int dtype, int bn, szn_stream_t stream);      // szn_conv_8ph.hip (args = WideArgs)
 
 // Called by szn_conv2d_fwd (which has validated the descriptor).  Returns 1 when the shape is not a good fit.
 int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
@@ -727,7 +727,7 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
         static int ph8 = -1;
         if (ph8 < 0) { const char* e = getenv("SZN_WIDE_8PH"); ph8 = e ? atoi(e) : 1; }
         if (ph8) {
-            const int rc = szn_conv_8ph_launch(&a, d->dtype, stream);
+            const int rc = szn_conv_8ph_launch(&a, d->dtype, 256, stream);
             if (rc <= 0) return rc;
         }
     }

@@ -30,8 +30,9 @@ __device__ __forceinline__ float row16_sum_w(float x) {                    // su
 // LDS -> thread c adds the four pixel groups in ascending order: fixed order, bit-reproducible).  Same arithmetic per element as the
 // staged epilogue: outputs are bit-identical; the column sums add the same terms in another order.
 // One wave block: 64 pixels (rows mb + 16 j + r16) x 32 NP couts (columns nb ..) held as acc[WNF][4].  pws = where this block's row
-// sums go ([4 g][NP][8] floats in LDS; nullptr: no column sums).  No barrier inside.
-template <typename T, int WNF, bool GATE, bool SCALE, typename Args>
+// sums go ([4 g][NP][8] floats in LDS; nullptr: no column sums).  No barrier inside.  RAGGED: Co may be a multiple of 4 only (the last
+// 8-cout piece is then written element by element); otherwise Co % 8 == 0 is the caller's contract.
+template <typename T, int WNF, bool GATE, bool SCALE, bool RAGGED = false, typename Args>
 __device__ __forceinline__ void tile_epilogue_block(const Args& a, f32x4_t (&acc)[WNF][4], int g, int r16, int mb, int nb, float* pws) {
     static_assert(sizeof(T) == 2 && (WNF % 2) == 0, "16-bit storage, fragment pairs");
     constexpr int NP = WNF / 2;
@@ -56,9 +57,12 @@ __device__ __forceinline__ void tile_epilogue_block(const Args& a, f32x4_t (&acc
         const int n = nw + 32 * p;
 #pragma unroll
         for (int e = 0; e < 8; ++e) bvn[e] = 0.f;
-        if (a.bias && n < a.Co) {                              // Co % 8 == 0: the whole piece is inside or outside
+        if (a.bias && n + 8 <= a.Co) {                         // Co % 8 == 0: the whole piece is inside or outside ...
             *(f32x4_t*)&bvn[0] = *(const f32x4_t*)(a.bias + n);
             *(f32x4_t*)&bvn[4] = *(const f32x4_t*)(a.bias + n + 4);
+        } else if (RAGGED && a.bias && n < a.Co) {             // ... a ragged Co (the 300-d projection, RAGGED callers only): its last piece
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bvn[e] = n + e < a.Co ? a.bias[n + e] : 0.f;
         }
     };
     // gate pieces (dgrad: 16 B of the forward activation per piece): a ring of two pairs, pair p + 2 is requested when pair p is done
@@ -122,7 +126,15 @@ __device__ __forceinline__ void tile_epilogue_block(const Args& a, f32x4_t (&acc
 #pragma unroll
                 for (int e = 0; e < 8; ++e) cs[e] += ok ? v[e] : 0.f;
             }
-            if (ok && !a.abl_ep) {
+            if (RAGGED && ok && !a.abl_ep && n + 8 > a.Co) {   // ragged last piece: element by element
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e < a.Co) {
+                        if (out32) ((float*)a.out)[(long)mrow[j] * a.ldo + n + e] = v[e];
+                        else ((uint16_t*)a.out)[(long)mrow[j] * a.ldo + n + e] = to_bits16<T>(v[e]);
+                    }
+                }
+            } else if (ok && !a.abl_ep) {
                 if (out32) {
                     float* o = (float*)a.out + (long)mrow[j] * a.ldo + n;
                     *(f32x4_t*)o = *(const f32x4_t*)&v[0];

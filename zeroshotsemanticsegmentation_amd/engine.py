@@ -480,7 +480,7 @@ class TrainStep(object):
         if scaled:
             dcoarse = self._scale(dcoarse)
         self.stats = stats
-        self._backward(ctx, dcoarse, self.buckets.layer_done)
+        self._backward(ctx, dcoarse, self._layer_done_hook(B * H * W))
         self.buckets.finish()
         self._optimizer_step()
         if self.train_metrics:
@@ -588,35 +588,81 @@ class TrainStep(object):
         # phase 1): nothing to copy, the first bucket can go as soon as the head wgrad has been queued
         return lambda: layer_done("score_fr")
 
+    # ---- optimizer --------------------------------------------------------------------------------------
+    def _layer_done_hook(self, pixels):
+        """layer_done callback of one backward pass.  Small steps (the reference's batch size of one image: train.py:82-84) leave most
+        of the chip idle during conv5_3 .. conv1_1's backward kernels (32 .. 124 tiles on 256 CUs) while the HBM-bound optimizer pass
+        over fc6 / fc7 / score_fr -- 90 % of the parameters, final as soon as fc6's dgrad has been queued -- waits for the end of the
+        step: on one rank without dynamic loss scaling that slice is updated on a second stream from layer_done("conv5_3") on (fc6's
+        dgrad, the last reader of fc6's weight image, is queued before it).  Same kernels, same values.  At B = 8 the MFMA-bound backward
+        kernels slow down by what the overlapped pass takes (profiles/r03_ablations.txt section 17), and at B = 1 the 16-bit step does not gain
+        either (3.09 -> 3.12 ms: the pass takes CUs from the few-tile kernels it was meant to hide behind), but the fp32 step does (15.41
+        -> 14.90 ms, profiles/r04_ablations.txt section 7): SZN_EARLY_ADAM = 0 / 1 forces it off / on, default = fp32 steps of at most
+        2 x 512 x 512 pixels."""
+        self._early = False
+        base = self.buckets.layer_done
+        mode = os.environ.get("SZN_EARLY_ADAM", "auto")
+        on = mode == "1" or (mode == "auto" and pixels <= 2 * 512 * 512 and self.eng.dtype == torch.float32)
+        if not on or self.buckets.active or self.dynamic or self.is8 or "fc6" not in self.woff:
+            return base
+
+        def done(name):
+            base(name)
+            if name == "conv5_3":
+                if getattr(self, "_side", None) is None:
+                    self._side = torch.cuda.Stream(device=self.dev)
+                cur = torch.cuda.current_stream()
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    self._opt_launch("w", self.woff["fc6"][0], self.flat_w.numel(), self.nstep + 1)
+                self._early = True
+        return done
+
+    def _opt_launch(self, key, lo, hi, nstep):
+        """one optimizer launch over elements [lo, hi) of the flat weight ("w") or bias ("b") buffers, on the current stream"""
+        if hi <= lo:
+            return
+        st = L.stream_ptr()
+        dyn = self.scale_state
+        gs = 1.0 / self.world if self.dynamic else 1.0 / (self.world * self._loss_scale0)
+        flat, grad = (self.flat_w, self.flat_gw) if key == "w" else (self.flat_b, self.flat_gb)
+        lr, wd = (self.lr, self.wd) if key == "w" else (self.bias_lr, self.bias_wd)
+        lp_on = key == "w" and self.flat_w_lp is not None
+        lp_code = L.dtype_code(self.flat_w_lp.dtype) if self.flat_w_lp is not None else 0
+        lp = L.ptr(self.flat_w_lp[lo:hi]) if lp_on else None
+        n = hi - lo
+        if self.opt == "adam":           # train.py:130-133 (Adam has no weight decay in the reference wiring)
+            m1, m2 = self.state[key]
+            awd = float(self.bias_wd if key == "b" else self.adam_wd)
+            if self.dynamic:
+                L.call("szn_adam_step_scaled", n, L.ptr(flat[lo:hi]), L.ptr(grad[lo:hi]), L.ptr(m1[lo:hi]), L.ptr(m2[lo:hi]), float(lr),
+                       float(self.betas[0]), float(self.betas[1]), float(self.eps), awd, L.ptr(dyn), gs, lp, lp_code, st)
+            else:
+                L.call("szn_adam_step", n, L.ptr(flat[lo:hi]), L.ptr(grad[lo:hi]), L.ptr(m1[lo:hi]), L.ptr(m2[lo:hi]), float(lr),
+                       float(self.betas[0]), float(self.betas[1]), float(self.eps), awd, nstep, gs, lp, lp_code, st)
+        else:                            # train.py:126-129
+            (buf,) = self.state[key]
+            if self.dynamic:
+                L.call("szn_sgd_momentum_step_scaled", n, L.ptr(flat[lo:hi]), L.ptr(grad[lo:hi]), L.ptr(buf[lo:hi]), float(lr),
+                       float(self.momentum), float(wd), L.ptr(dyn), gs, lp, lp_code, st)
+            else:
+                L.call("szn_sgd_momentum_step", n, L.ptr(flat[lo:hi]), L.ptr(grad[lo:hi]), L.ptr(buf[lo:hi]), float(lr),
+                       float(self.momentum), float(wd), int(nstep == 1), gs, lp, lp_code, st)
+
     def _optimizer_step(self):
         self.nstep += 1
         st = L.stream_ptr()
         dyn = self.scale_state
-        gs = 1.0 / self.world if self.dynamic else 1.0 / (self.world * self._loss_scale0)
-        lp_code = L.dtype_code(self.flat_w_lp.dtype) if self.flat_w_lp is not None else 0
         if self.dynamic:                 # raise the overflow flag from the (already all-reduced) gradients
             L.call("szn_grad_check_finite", self.flat_gw.numel(), L.ptr(self.flat_gw), L.ptr(dyn), st)
             L.call("szn_grad_check_finite", self.flat_gb.numel(), L.ptr(self.flat_gb), L.ptr(dyn), st)
-        for key, flat, grad, lr, wd in (("w", self.flat_w, self.flat_gw, self.lr, self.wd),
-                                        ("b", self.flat_b, self.flat_gb, self.bias_lr, self.bias_wd)):
-            lp = L.ptr(self.flat_w_lp) if (key == "w" and self.flat_w_lp is not None) else None
-            if self.opt == "adam":       # train.py:130-133 (Adam has no weight decay in the reference wiring)
-                m1, m2 = self.state[key]
-                awd = float(self.bias_wd if key == "b" else self.adam_wd)
-                if self.dynamic:
-                    L.call("szn_adam_step_scaled", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr),
-                           float(self.betas[0]), float(self.betas[1]), float(self.eps), awd, L.ptr(dyn), gs, lp, lp_code, st)
-                else:
-                    L.call("szn_adam_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(m1), L.ptr(m2), float(lr),
-                           float(self.betas[0]), float(self.betas[1]), float(self.eps), awd, self.nstep, gs, lp, lp_code, st)
-            else:                        # train.py:126-129
-                (buf,) = self.state[key]
-                if self.dynamic:
-                    L.call("szn_sgd_momentum_step_scaled", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(buf), float(lr),
-                           float(self.momentum), float(wd), L.ptr(dyn), gs, lp, lp_code, st)
-                else:
-                    L.call("szn_sgd_momentum_step", flat.numel(), L.ptr(flat), L.ptr(grad), L.ptr(buf), float(lr),
-                           float(self.momentum), float(wd), int(self.nstep == 1), gs, lp, lp_code, st)
+        whi = self.flat_w.numel()
+        if getattr(self, "_early", False):           # fc6 .. score_fr were updated under the backward pass (_layer_done_hook)
+            torch.cuda.current_stream().wait_stream(self._side)
+            whi = self.woff["fc6"][0]
+            self._early = False
+        self._opt_launch("w", 0, whi, self.nstep)
+        self._opt_launch("b", 0, self.flat_b.numel(), self.nstep)
         if self.dynamic:
             g, b, iv, lo, hi = self.scale_cfg
             L.call("szn_loss_scale_update", L.ptr(dyn), g, b, iv, lo, hi, st)
