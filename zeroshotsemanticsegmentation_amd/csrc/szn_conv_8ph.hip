@@ -14,7 +14,8 @@
 //     weights, so lane (g, r16) holds couts 16 i + 4 g .. + 3 of pixel 16 j + r16 (register epilogue of szn_epilogue.h);
 //   * LDS 128 KiB = 2 buffers x {P0, P1, W0, W1}: half-tiles of 128 rows x 128 B (K = 64).  P0 / P1 = the lower / upper 64 pixels of
 //     each pixel group, W0 / W1 = the lower / upper 32 couts of each cout group -- every wave reads a half-tile in ONE phase;
-//   * K tile t = (tap, cin chunk); phases (P0,W0) (P0,W1) (P1,W1) (P1,W0) read 12 / 4 / 8 / 0 ds_read_b128;
+//   * [MODE 0, the template's form; the shipped default is MODE 2, see the kernel's comment: two phases of 32 MFMA per K tile]
+//     K tile t = (tap, cin chunk); phases (P0,W0) (P0,W1) (P1,W1) (P1,W0) read 12 / 4 / 8 / 0 ds_read_b128;
 //     phase P1 stages W1 of t + 1, P2: P1 of t + 1, P3: P0 of t + 2, P4: W0 of t + 2; the half-tile issued in phase p is waited for
 //     in phase p + 4 and read from p + 5 on; a slot is re-staged >= 2 phases after its last read;
 //   * pixel rows are gathered per tap: per-lane offsets of the 4 rows a lane stages, re-validated when a stream enters a new tap
@@ -72,8 +73,13 @@ __device__ __forceinline__ void tile_epilogue_single(const Args& a, f32x4_t (&ac
 // SPLIT: the second LDS-DMA instruction of a phase's half-tile is issued from the MIDDLE of the phase's MFMA block instead of the read
 // segment (an LDS-DMA instruction costs its wave 100-185 cycles beside fragment reads, ~60 among MFMAs, and the read segments are the
 // longer ones: profiles/r04_ablations.txt section 6)
-template <typename T, int NF0, int NF1, bool SPLIT>
+// MODE 2 (LONG): two phases of 32 MFMA per K tile instead of four of 16 -- half the barriers.  Phase A = (P0,W0) + (P0,W1): 16 fragment
+// reads, phase B = (P1,W1) + (P1,W0): 8; four LDS-DMA loads per phase.  The fragment reads are retired (s_waitcnt lgkmcnt(0)) BEFORE the
+// phase's first barrier, so a slot may be re-staged in the next phase: A stages W1, P1 of tile t + 1, B stages P0, W0 of t + 2; a unit
+// issued in phase p is waited for in p + 1 (vmcnt(4)) and read in p + 2.
+template <typename T, int NF0, int NF1, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
+    constexpr bool SPLIT = MODE == 1, LONG = MODE == 2;
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(sizeof(T) == 2, "16-bit storage only");
     static_assert(NF0 >= NF1 && NF1 == 2 && NF0 <= 3, "W0 = 2 or 3 fragments per wave, W1 = 2");
@@ -222,7 +228,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
 
     // ---- prologue: P0 W0 W1 P1 of the first tile, P0 W0 of the second (what phases -6 .. -1 of the steady state would have issued)
     stageA(0, 0, 2); stageB(0, 0, kbeg, 2); stageB(1, 0, kbeg, 2); stageA(1, 0, 2); stageA(0, 1, 2); stageB(0, 1, kbeg + 1, 2);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");    // P0, W0 of the first tile landed (this wave's pieces)
+    // short phases: P0, W0 of the first tile landed (this wave's pieces); long phases: the whole first tile
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LONG ? 4 : VMC) : "memory");
     __builtin_amdgcn_s_barrier();                                 // ... everyone's
     if (wr == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier behind group 0
 
@@ -278,13 +285,53 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
         C8_READ_A(1, BUFI) stageA(0, BUFI, P0_); C8_SYNC_AND_MMA(acc11, fb1, NF1, stageA(0, BUFI, 1))                \
         stageB(0, BUFI, (t) + 2, P0_); C8_SYNC_AND_MMA(acc10, fb0, NF0, stageB(0, BUFI, (t) + 2, 1))                 \
     }
+#define C8_MMA32(ACCX, FBX, ACCY, FBY)                                                                               \
+    {                                                                                                                \
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)"                                                                 \
+                     : "+v"(fa[0][0]), "+v"(fa[1][0]), "+v"(fa[2][0]), "+v"(fa[3][0]), "+v"(fa[0][1]), "+v"(fa[1][1]), \
+                       "+v"(fa[2][1]), "+v"(fa[3][1])                                                                \
+                     :: "memory");                                                                                   \
+        tie_frags<NF0>(fb0);                                                                                         \
+        tie_frags<NF1>(fb1);                                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                    ACCX[i][j] = mfma16<T>(FBX[i][s], fa[j][s], ACCX[i][j]);                                         \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                    ACCY[i][j] = mfma16<T>(FBY[i][s], fa[j][s], ACCY[i][j]);                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                \
+    }
+#define C8_TILE_LONG(BUFI, t)                                                                                        \
+    {                                                                                                                \
+        C8_READ_B0(BUFI) C8_READ_B1(BUFI) C8_READ_A(0, BUFI)                                                         \
+        stageB(1, (BUFI) ^ 1, (t) + 1, 2); stageA(1, (BUFI) ^ 1, 2);                                                 \
+        C8_MMA32(acc00, fb0, acc01, fb1)                                                                             \
+        C8_READ_A(1, BUFI)                                                                                           \
+        stageA(0, BUFI, 2); stageB(0, BUFI, (t) + 2, 2);                                                             \
+        C8_MMA32(acc11, fb1, acc10, fb0)                                                                             \
+    }
     constexpr int P0_ = SPLIT ? 0 : 2;                            // what the read segment issues: the first load / both
     int t = kbeg;
-    for (; t + 1 < kend; t += 2) {
-        C8_TILE(0, t)
-        C8_TILE(1, t + 1)
+    if constexpr (LONG) {
+        for (; t + 1 < kend; t += 2) {
+            C8_TILE_LONG(0, t)
+            C8_TILE_LONG(1, t + 1)
+        }
+        if (t < kend) C8_TILE_LONG(0, t)
+    } else {
+        for (; t + 1 < kend; t += 2) {
+            C8_TILE(0, t)
+            C8_TILE(1, t + 1)
+        }
+        if (t < kend) C8_TILE(0, t)
     }
-    if (t < kend) C8_TILE(0, t)
+#undef C8_TILE_LONG
+#undef C8_MMA32
 #undef C8_TILE
 #undef C8_SYNC_AND_MMA
 #undef C8_READ_A
@@ -344,24 +391,28 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
 #endif
 }
 
-template <typename T, int NF0, int NF1, bool SPLIT>
+template <typename T, int NF0, int NF1, int MODE>
 int launch_8ph_v(const WideArgs& a, hipStream_t st) {
     constexpr int lds = 2 * (2 * SLOT + 64 * (NF0 + NF1) * 128);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_8ph<T, NF0, NF1, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_8ph<T, NF0, NF1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_8ph<T, NF0, NF1, SPLIT>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_8ph<T, NF0, NF1, MODE>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
     SZN_CHECK_LAUNCH("conv_igemm_8ph");
     return SZN_OK;
 }
 
 template <typename T, int NF0, int NF1>
 int launch_8ph(const WideArgs& a, hipStream_t st) {
-    static int split = -1;
-    if (split < 0) { const char* e = getenv("SZN_8PH_SPLIT"); split = e ? atoi(e) : 0; }
-    return split ? launch_8ph_v<T, NF0, NF1, true>(a, st) : launch_8ph_v<T, NF0, NF1, false>(a, st);
+    // SZN_8PH_MODE: 2 (default) = two phases of 32 MFMA per K tile; 0 = four phases of 16 (the template's form: 2-4 % slower per kernel,
+    // profiles/r04_ablations.txt section 8); 1 = four phases with the second LDS-DMA load issued among the MFMAs (6-8 % slower, section 6)
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SZN_8PH_MODE"); mode = e ? atoi(e) : 2; }
+    if (mode == 1) return launch_8ph_v<T, NF0, NF1, 1>(a, st);
+    if (mode == 2) return launch_8ph_v<T, NF0, NF1, 2>(a, st);
+    return launch_8ph_v<T, NF0, NF1, 0>(a, st);
 }
 
 }  // namespace
