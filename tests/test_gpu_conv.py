@@ -481,7 +481,8 @@ def test_register_epilogue_equals_the_staged_epilogue_bit_for_bit():
     runs = {}
     # (SZN_WIDE_8PH=0: the round 1-3 tile kernels, which have both epilogues; conv_igemm_8ph has the register epilogue only and is
     # compared with them in test_8phase_kernel_equals_conv_igemm_wide_bit_for_bit)
-    for tag, env in (("direct", {"SZN_WIDE_8PH": "0"}), ("staged", {"SZN_WIDE_8PH": "0", "SZN_WIDE_DIRECT": "0", "SZN_IGEMM_DIRECT": "0"})):
+    for tag, env in (("direct", {"SZN_WIDE_8PH": "0", "SZN_IGEMM_8PH": "0"}),
+                     ("staged", {"SZN_WIDE_8PH": "0", "SZN_IGEMM_8PH": "0", "SZN_WIDE_DIRECT": "0", "SZN_IGEMM_DIRECT": "0"})):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", _EPILOGUE_PROBE % (root, _PROBE_SHAPES)], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -497,15 +498,15 @@ def test_register_epilogue_equals_the_staged_epilogue_bit_for_bit():
 
 
 def test_8phase_kernel_equals_conv_igemm_wide_bit_for_bit():
-    """conv_igemm_8ph (round 4: the 8-phase schedule) accumulates every output element over the same K order (tap, cin chunk, two
-    K halves) as conv_igemm_wide, so the two kernels must write the same bits -- forward (bias, ReLU, Dropout2d factor) and dgrad
+    """conv_igemm_8ph (round 4: the 8-phase schedule; 256- and 128-cout tiles) accumulates every output element over the same K order
+    (tap, cin chunk, two K halves) as conv_igemm_wide / conv_igemm_v2, so the kernels must write the same bits -- forward (bias, ReLU, Dropout2d factor) and dgrad
     (gate; column sums to rounding: another grouping).  The probe runs each kernel set in its own process (the switch is read once)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = {}
-    for tag, env in (("8ph", {}), ("wide", {"SZN_WIDE_8PH": "0", "SZN_WIDE_ROWS": "0"})):
+    for tag, env in (("8ph", {"SZN_IGEMM_8PH": "1"}), ("wide", {"SZN_WIDE_8PH": "0", "SZN_IGEMM_8PH": "0", "SZN_WIDE_ROWS": "0"})):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", _EPILOGUE_PROBE % (root, _PROBE_SHAPES_8PH)], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -516,9 +517,9 @@ def test_8phase_kernel_equals_conv_igemm_wide_bit_for_bit():
         assert a[0] == b[0], (a, b)                      # outputs + input gradients: same bits
         assert abs(float(a[3]) - float(b[3])) <= 1e-5 * max(1.0, abs(float(b[3]))), (a, b)
         for ka, kb in ((a[1], b[1]), (a[2], b[2])):
-            if ka == "conv_igemm_8ph":
+            if ka.startswith("conv_igemm_8ph"):
                 seen += 1
-                assert kb == "conv_igemm_wide", (a, b)
+                assert kb in ("conv_igemm_wide", "conv_igemm_v2"), (a, b)     # 256- / 128-cout tiles
             else:
                 assert ka == kb, (a, b)
     assert seen >= 7, runs

@@ -22,7 +22,7 @@
 //     (padding = out-of-range offset = zeros); weights: one scalar offset per K tile;
 //   * fragment reads are inline asm (a compiler-visible LDS read behind an LDS-DMA load gets s_waitcnt vmcnt(0));
 //   * split-K ranges (fp32 slabs), bias / ReLU / gate / Dropout2d factor / column-sum epilogue as the other tile kernels;
-//   * <NF0, NF1> = 16-cout fragments of a wave's W0 / W1 sub-tile: <2, 2> is the 256-cout tile (the only one instantiated);
+//   * <NF0, NF1> = 16-cout fragments of a wave's W0 / W1 sub-tile: <2, 2> is the 256-cout tile, <1, 1> a 128-cout tile (conv5_x; one-image steps);
 //   * 1x1 / pad 0 maps are addressed flat, the pixel resource rebased per block (no 2 GiB operand limit).
 #include "szn_common.h"
 #include "szn_epilogue.h"
@@ -41,8 +41,9 @@ template <int OFF> __device__ __forceinline__ void dsr(u32x4_t& v, unsigned addr
 }
 
 template <int N> __device__ __forceinline__ void tie_frags(u32x4_t (&f)[N][2]) {      // uses of f stay behind this point
-    static_assert(N >= 2 && N <= 4, "2 .. 4 fragments");
-    asm volatile("" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]));
+    static_assert(N >= 1 && N <= 4, "1 .. 4 fragments");
+    asm volatile("" : "+v"(f[0][0]), "+v"(f[0][1]));
+    if constexpr (N >= 2) asm volatile("" : "+v"(f[1][0]), "+v"(f[1][1]));
     if constexpr (N >= 3) asm volatile("" : "+v"(f[2][0]), "+v"(f[2][1]));
     if constexpr (N >= 4) asm volatile("" : "+v"(f[3][0]), "+v"(f[3][1]));
 }
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
     constexpr bool SPLIT = MODE == 1, LONG = MODE == 2;
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(sizeof(T) == 2, "16-bit storage only");
-    static_assert(NF0 >= NF1 && NF1 == 2 && NF0 <= 3, "W0 = 2 or 3 fragments per wave, W1 = 2");
+    static_assert(NF0 >= NF1 && NF1 >= 1 && NF1 <= 2 && NF0 <= 3, "W0 = 1 .. 3 fragments per wave, W1 = 1 or 2");
     constexpr int NFA = NF0 + NF1, BN = 64 * NFA;                 // couts per wave = 16 NFA, per tile 256 / 320
     constexpr int W0ROWS = 64 * NF0, W1ROWS = 64 * NF1;           // half-tile image rows (4 cout groups x 16 NF)
     constexpr int OFF_W0 = 2 * SLOT, OFF_W1 = OFF_W0 + W0ROWS * 128, BUF = OFF_W1 + W1ROWS * 128;     // 64 / 72 KiB per buffer
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
     // ---- prologue: P0 W0 W1 P1 of the first tile, P0 W0 of the second (what phases -6 .. -1 of the steady state would have issued)
     stageA(0, 0, 2); stageB(0, 0, kbeg, 2); stageB(1, 0, kbeg, 2); stageA(1, 0, 2); stageA(0, 1, 2); stageB(0, 1, kbeg + 1, 2);
     // short phases: P0, W0 of the first tile landed (this wave's pieces); long phases: the whole first tile
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LONG ? 4 : VMC) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LONG ? 2 + NF0 : VMC) : "memory");
     __builtin_amdgcn_s_barrier();                                 // ... everyone's
     if (wr == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier behind group 0
 
@@ -243,15 +244,19 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
     }
 #define C8_READ_B0(BUFI)                                                                                             \
     {                                                                                                                \
-        dsr<0>(fb0[0][0], adB0[BUFI][0]); dsr<2048>(fb0[1][0], adB0[BUFI][0]);                                       \
+        dsr<0>(fb0[0][0], adB0[BUFI][0]);                                                                            \
+        if constexpr (NF0 >= 2) dsr<2048>(fb0[NF0 >= 2 ? 1 : 0][0], adB0[BUFI][0]);                                  \
         if constexpr (NF0 == 3) dsr<4096>(fb0[NF0 - 1][0], adB0[BUFI][0]);                                           \
-        dsr<0>(fb0[0][1], adB0[BUFI][1]); dsr<2048>(fb0[1][1], adB0[BUFI][1]);                                       \
+        dsr<0>(fb0[0][1], adB0[BUFI][1]);                                                                            \
+        if constexpr (NF0 >= 2) dsr<2048>(fb0[NF0 >= 2 ? 1 : 0][1], adB0[BUFI][1]);                                  \
         if constexpr (NF0 == 3) dsr<4096>(fb0[NF0 - 1][1], adB0[BUFI][1]);                                           \
     }
 #define C8_READ_B1(BUFI)                                                                                             \
     {                                                                                                                \
-        dsr<0>(fb1[0][0], adB1[BUFI][0]); dsr<2048>(fb1[1][0], adB1[BUFI][0]);                                       \
-        dsr<0>(fb1[0][1], adB1[BUFI][1]); dsr<2048>(fb1[1][1], adB1[BUFI][1]);                                       \
+        dsr<0>(fb1[0][0], adB1[BUFI][0]);                                                                            \
+        if constexpr (NF1 >= 2) dsr<2048>(fb1[NF1 >= 2 ? 1 : 0][0], adB1[BUFI][0]);                                  \
+        dsr<0>(fb1[0][1], adB1[BUFI][1]);                                                                            \
+        if constexpr (NF1 >= 2) dsr<2048>(fb1[NF1 >= 2 ? 1 : 0][1], adB1[BUFI][1]);                                  \
     }
 #define C8_SYNC_AND_MMA(ACC, FB, NFB, MID)                                                                           \
     {                                                                                                                \
@@ -285,22 +290,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
         C8_READ_A(1, BUFI) stageA(0, BUFI, P0_); C8_SYNC_AND_MMA(acc11, fb1, NF1, stageA(0, BUFI, 1))                \
         stageB(0, BUFI, (t) + 2, P0_); C8_SYNC_AND_MMA(acc10, fb0, NF0, stageB(0, BUFI, (t) + 2, 1))                 \
     }
-#define C8_MMA32(ACCX, FBX, ACCY, FBY)                                                                               \
+#define C8_MMA32(ACCX, FBX, NFX, ACCY, FBY, NFY)                                                                     \
     {                                                                                                                \
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)"                                                                 \
+        asm volatile("s_waitcnt vmcnt(%[vm]) lgkmcnt(0)"                                                                 \
                      : "+v"(fa[0][0]), "+v"(fa[1][0]), "+v"(fa[2][0]), "+v"(fa[3][0]), "+v"(fa[0][1]), "+v"(fa[1][1]), \
                        "+v"(fa[2][1]), "+v"(fa[3][1])                                                                \
-                     :: "memory");                                                                                   \
+                     : [vm] "n"(2 + NF0) : "memory");                                                                     \
         tie_frags<NF0>(fb0);                                                                                         \
         tie_frags<NF1>(fb1);                                                                                         \
         __builtin_amdgcn_s_barrier();                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            _Pragma("unroll") for (int i = 0; i < NFX; ++i)                                                          \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
                     ACCX[i][j] = mfma16<T>(FBX[i][s], fa[j][s], ACCX[i][j]);                                         \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            _Pragma("unroll") for (int i = 0; i < NFY; ++i)                                                          \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
                     ACCY[i][j] = mfma16<T>(FBY[i][s], fa[j][s], ACCY[i][j]);                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -310,10 +315,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
     {                                                                                                                \
         C8_READ_B0(BUFI) C8_READ_B1(BUFI) C8_READ_A(0, BUFI)                                                         \
         stageB(1, (BUFI) ^ 1, (t) + 1, 2); stageA(1, (BUFI) ^ 1, 2);                                                 \
-        C8_MMA32(acc00, fb0, acc01, fb1)                                                                             \
+        C8_MMA32(acc00, fb0, NF0, acc01, fb1, NF1)                                                                             \
         C8_READ_A(1, BUFI)                                                                                           \
         stageA(0, BUFI, 2); stageB(0, BUFI, (t) + 2, 2);                                                             \
-        C8_MMA32(acc11, fb1, acc10, fb0)                                                                             \
+        C8_MMA32(acc11, fb1, NF1, acc10, fb0, NF0)                                                                             \
     }
     constexpr int P0_ = SPLIT ? 0 : 2;                            // what the read segment issues: the first load / both
     int t = kbeg;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
     // ---- epilogue: the wave's 128 x 16 NFA block as two pixel halves (P0, P1) of NFA cout fragments: W0's then W1's; fragments go
     // through the register epilogue in pairs (v_permlane16_swap), the fifth of a 320-wide tile alone
     const bool do_cs = a.colsum != nullptr && !a.ws;
-    float* const pw = (float*)smem;                               // [4 pixel blocks (wr, mh)][4 wc][2 pairs][4 g][8] (BN = 256 only)
+    float* const pw = (float*)smem;                               // [4 pixel blocks (wr, mh)][4 wc][NFA / 2 pairs][4 g][8]
     if (do_cs) __syncthreads();                                   // every wave's LDS-DMA has landed before the ring is reused
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
@@ -355,16 +360,19 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
             f32x4_t pr[2][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (NF0 == 2) {
+                if constexpr (NF0 == 1) {                         // one pair: W0[0] W1[0]
+                    pr[0][j] = aw0[0][j];
+                    pr[1][j] = aw1[0][j];
+                } else if constexpr (NF0 == 2) {
                     pr[0][j] = p == 0 ? aw0[0][j] : aw1[0][j];
-                    pr[1][j] = p == 0 ? aw0[1][j] : aw1[1][j];
+                    pr[1][j] = p == 0 ? aw0[NF0 - 1][j] : aw1[NF1 - 1][j];
                 } else {                                          // fragments: W0[0] W0[1] | W0[2] W1[0] | W1[1]
                     pr[0][j] = p == 0 ? aw0[0][j] : aw0[NF0 - 1][j];
                     pr[1][j] = p == 0 ? aw0[1][j] : aw1[0][j];
                 }
             }
             const int nb = nbw + 32 * p;
-            float* pws = do_cs ? pw + ((((wr * 2 + mh) * 4 + wc) * 2 + p) * 4) * 8 : nullptr;
+            float* pws = do_cs ? pw + ((((wr * 2 + mh) * 4 + wc) * (NFA / 2) + p) * 4) * 8 : nullptr;
             if (a.ws) tile_epilogue_raw<2>(a, pr, 0, 0, g, r16, mb, nb, (int)blockIdx.y);
             else if (a.gate) {
                 if (a.cscale) tile_epilogue_block<T, 2, true, true>(a, pr, g, r16, mb, nb, pws);
@@ -378,12 +386,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
     }
     if (do_cs) {
         __syncthreads();
-        if (tid < 256 && n0 + tid < a.Co) {
-            const int cb = tid >> 5, r2 = tid & 31;               // (wc, pair), column within the pair
+        if (tid < BN && n0 + tid < a.Co) {
+            const int cb = tid >> 5, r2 = tid & 31;               // (wc, pair) = wc NFA / 2 + pair, column within the pair
             const int gc = (r2 >> 4) | (((r2 >> 3) & 1) << 1), ec = r2 & 7;        // inverse of cl = 16 (g & 1) + 8 (g >> 1)
             float s = 0.f;
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) s += pw[((pb * 8 + cb) * 4 + gc) * 8 + ec];      // fixed order: bit-reproducible
+            for (int pb = 0; pb < 4; ++pb) s += pw[((pb * (2 * NFA) + cb) * 4 + gc) * 8 + ec];      // fixed order: bit-reproducible
             if (a.cslab) a.cslab[(long)(m0 >> 8) * a.Co + n0 + tid] = s;
             else if (s != 0.f) atomicAdd(a.colsum + n0 + tid, s);
         }
@@ -400,7 +408,7 @@ int launch_8ph_v(const WideArgs& a, hipStream_t st) {
         attr_done = true;
     }
     hipLaunchKernelGGL((conv_igemm_8ph<T, NF0, NF1, MODE>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
-    SZN_CHECK_LAUNCH("conv_igemm_8ph");
+    SZN_CHECK_LAUNCH(NF0 + NF1 == 2 ? "conv_igemm_8ph_n128" : "conv_igemm_8ph");
     return SZN_OK;
 }
 
@@ -427,6 +435,8 @@ int szn_conv_8ph_launch(const void* args, int dtype, int bn, szn_stream_t stream
     // (a 320-cout tile -- the 300-d projection as one cout tile -- does not fit this form: 160 accumulator + 72 fragment registers
     // spill, <3, 2> is not instantiated; a form with the whole weight operand resident and the pixel operand in quarters fits but
     // concentrates the LDS-DMA issue in two phases and measured 12-25 % slower: profiles/r04_ablations.txt)
+    if (bn == 128)                     // 256 pixels x 128 couts (conv5_x at B = 8; every 3x3 layer of a one-image step): <1, 1>
+        return dtype == SZN_F16 ? launch_8ph<f16_raw, 1, 1>(a, (hipStream_t)stream) : launch_8ph<bf16_raw, 1, 1>(a, (hipStream_t)stream);
     if (bn != 256) return 1;
     return dtype == SZN_F16 ? launch_8ph<f16_raw, 2, 2>(a, (hipStream_t)stream) : launch_8ph<bf16_raw, 2, 2>(a, (hipStream_t)stream);
 }

@@ -20,6 +20,7 @@
 // >= 256 couts) and falls back to the register-staged kernel of szn_conv.hip for tensors >= 2 GiB / odd strides.
 #include "szn_common.h"
 #include "szn_epilogue.h"
+#include "szn_wide_args.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
@@ -29,6 +30,7 @@ int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, c
                       const float* chan_scale, void* out, szn_stream_t stream);
 int szn_proj_stream_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                         const float* chan_scale, void* out, int min_tiles, szn_stream_t stream);
+int szn_conv_8ph_launch(const void* args, int dtype, int bn, szn_stream_t stream);      // szn_conv_8ph.hip (args = WideArgs)
 int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                       const float* chan_scale, void* out, unsigned in_bytes, unsigned w_bytes, int min_tiles,
                       float* ws, int nsplit, int chunks_per_split, szn_stream_t stream);
@@ -642,7 +644,29 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
                                a.nsplit, a.chunks_per_split, stream);
         if (rc < 0 || (rc == 0 && a.nsplit == 1)) return rc;
     }
-    if (rc != 0) {                                    // (rc == 0: the wide kernel wrote the slabs)
+    if (rc != 0 && !narrow && szn_is16(d->dtype)) {
+        // round 4: the 256 x 128 tile on the 8-phase schedule (szn_conv_8ph.hip <1, 1>: staggered wave groups, counted vmcnt).  Alone on
+        // the device conv5_1 runs 9-18 % faster than on conv_igemm_v2 (1,120 against 1,000-1,030 TF/s), inside the train step the six conv5_x
+        // launches take the same 0.54 ms and the step came out 0.13 ms SLOWER in two alternating pairs (profiles/r04_ablations.txt section
+        // 10): off by default, SZN_IGEMM_8PH=1 turns it on
+        static int p8 = -1;
+        if (p8 < 0) { const char* e = getenv("SZN_IGEMM_8PH"); p8 = e ? atoi(e) : 0; }
+        // one round of >= 200 full-length tiles: with few tiles per launch or short split-K ranges (a one-image step) the longer
+        // pipeline fill of the 8-phase kernel costs more than its loop returns (B = 1: 3.00 -> 3.09-3.16 ms, profiles/r04_ablations.txt 10)
+        if (p8 && a.nsplit == 1 && (long)a.mtiles * a.ntiles >= 200) {
+            WideArgs wa = {};
+            wa.in = a.in; wa.w = a.w; wa.bias = a.bias; wa.gate = a.gate; wa.cscale = a.cscale; wa.out = a.out;
+            wa.colsum = a.colsum; wa.cslab = a.cslab; wa.in_bytes = a.in_bytes; wa.w_bytes = a.w_bytes;
+            wa.B = a.B; wa.Hi = a.Hi; wa.Wi = a.Wi; wa.Ci = a.Ci; wa.Ho = a.Ho; wa.Wo = a.Wo; wa.Co = a.Co; wa.KH = a.KH; wa.KW = a.KW;
+            wa.pad = a.pad; wa.ldi = a.ldi; wa.ldo = a.ldo; wa.ldg = a.ldg; wa.relu = a.relu; wa.out_f32 = a.out_f32;
+            wa.M = a.M; wa.HoWo = a.HoWo; wa.mtiles = a.mtiles; wa.ntiles = a.ntiles; wa.nmajor = a.nmajor;
+            wa.ws = a.ws; wa.nsplit = a.nsplit; wa.chunks_per_split = a.chunks_per_split; wa.direct_ep = a.direct_ep;
+            const int r8 = szn_conv_8ph_launch(&wa, d->dtype, 128, stream);
+            if (r8 < 0) return r8;
+            if (r8 == 0) rc = 0;
+        }
+    }
+    if (rc != 0) {                                    // (rc == 0: the wide / 8-phase kernel ran, or wrote the slabs)
         if (d->dtype == SZN_BF16) rc = narrow ? launch_v2<bf16_raw, 2>(a, st) : launch_v2<bf16_raw, 4>(a, st);
         else if (d->dtype == SZN_F16) rc = narrow ? launch_v2<f16_raw, 2>(a, st) : launch_v2<f16_raw, 4>(a, st);
         else rc = narrow ? launch_v2<float, 2>(a, st) : launch_v2<float, 4>(a, st);
