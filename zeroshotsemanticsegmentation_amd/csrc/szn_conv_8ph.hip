@@ -290,12 +290,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
         C8_READ_A(1, BUFI) stageA(0, BUFI, P0_); C8_SYNC_AND_MMA(acc11, fb1, NF1, stageA(0, BUFI, 1))                \
         stageB(0, BUFI, (t) + 2, P0_); C8_SYNC_AND_MMA(acc10, fb0, NF0, stageB(0, BUFI, (t) + 2, 1))                 \
     }
-#define C8_MMA32(ACCX, FBX, NFX, ACCY, FBY, NFY)                                                                     \
+#define C8_MMA32(ACCX, FBX, NFX, ACCY, FBY, NFY, NLOADS)                                                                     \
     {                                                                                                                \
         asm volatile("s_waitcnt vmcnt(%[vm]) lgkmcnt(0)"                                                                 \
                      : "+v"(fa[0][0]), "+v"(fa[1][0]), "+v"(fa[2][0]), "+v"(fa[3][0]), "+v"(fa[0][1]), "+v"(fa[1][1]), \
                        "+v"(fa[2][1]), "+v"(fa[3][1])                                                                \
-                     : [vm] "n"(2 + NF0) : "memory");                                                                     \
+                     : [vm] "n"(NLOADS) : "memory");                                                                     \
         tie_frags<NF0>(fb0);                                                                                         \
         tie_frags<NF1>(fb1);                                                                                         \
         __builtin_amdgcn_s_barrier();                                                                                \
@@ -315,10 +315,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
     {                                                                                                                \
         C8_READ_B0(BUFI) C8_READ_B1(BUFI) C8_READ_A(0, BUFI)                                                         \
         stageB(1, (BUFI) ^ 1, (t) + 1, 2); stageA(1, (BUFI) ^ 1, 2);                                                 \
-        C8_MMA32(acc00, fb0, NF0, acc01, fb1, NF1)                                                                             \
+        C8_MMA32(acc00, fb0, NF0, acc01, fb1, NF1, 2 + NF1)      /* this phase issued W1 + P1: everything older has landed */                                                                             \
         C8_READ_A(1, BUFI)                                                                                           \
         stageA(0, BUFI, 2); stageB(0, BUFI, (t) + 2, 2);                                                             \
-        C8_MMA32(acc11, fb1, NF1, acc10, fb0, NF0)                                                                             \
+        C8_MMA32(acc11, fb1, NF1, acc10, fb0, NF0, 2 + NF0)      /* this phase issued P0 + W0 */                                                                             \
     }
     constexpr int P0_ = SPLIT ? 0 : 2;                            // what the read segment issues: the first load / both
     int t = kbeg;
