@@ -11,6 +11,6 @@ rocprofv3 --kernel-trace --stats -d $O/stats -o proj --output-format csv -- pyth
 i=0
 for pass in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $pass -d $O/pmc_$i -o pmc --output-format csv -- python $R/tools/bench_proj.py --nominal-only --iters 3 > $O/pmc_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $pass -d $O/pmc_$i -o pmc --output-format csv -- python $R/tools/bench_proj.py --nominal-only --iters 5 > $O/pmc_$i.log 2>&1
 done
-python $R/tools/pmc_proj.py $O $R/gpurun_out/r02_proj.json
+python $R/tools/pmc_proj.py $O $R/gpurun_out/${1:-r04}_proj.json

@@ -512,7 +512,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_rows(WideArgs a) {
 // Co <= 304 (the 300-d projection): the 20th 16-cout fragment is pure padding.  Its filter rows are not loaded and the waves of the
 // upper cout half run 9 fragments; waves w and w + 4 share a SIMD, so (wm, wn) = (w & 3, w >> 2) gives every SIMD 40 + 36 MFMA per half
 // step instead of 80.
-template <typename T, bool NT, bool NF19>
+// STAG (round 4, SZN_PROJ_STAG): the two wave groups (wn = 0 / 1: waves w and w + 4 share a SIMD) run one barrier apart, every half step
+// becomes {fragment reads (inline asm) + this half step's LDS-DMA issue + counted vmcnt + lgkmcnt(0); barrier; 40 MFMA; barrier}: one wave of
+// every SIMD multiplies while its partner reads and issues (the schedule of szn_conv_8ph.hip).  Reads are retired before the barrier, so a
+// slot is re-staged in the half step after its last read (the 3-unit rings stay); a unit issued in half step p is waited for in p + 1 (filters:
+// read in p + 2) -- the activation units keep three half steps of flight instead of four.
+template <typename T, bool NT, bool NF19, bool STAG>
 __global__ __launch_bounds__(512, 2) void proj_gemm_stream(WideArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(sizeof(T) == 2, "16-bit storage only");
@@ -581,6 +586,51 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_stream(WideArgs a) {
     if (nU > 1) issueA(1);
     if (H > 1) issueW(1);
     const int offw = ((g ^ ((r16 >> 1) & 3)) << 4);
+    if constexpr (STAG) {
+        const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        auto rd = [&](int addr) -> u32x4_t {
+            u32x4_t v;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+            return v;
+        };
+        // everything the un-staggered prologue issued stays; its first wait happens in half step 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (A0, W0, A1, W1 of this wave landed: a one-off)
+        __builtin_amdgcn_s_barrier();
+        if (wn == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0
+        for (int h = 0; h < H; ++h) {
+            const int base = smem_lds + (int)(sA - smem);
+            const int ap = base + ((h >> 1) % 3) * AUNIT + (wm * 64 + r16) * 128 + (((4 * (h & 1) + g) ^ (r16 & 7)) << 4);
+            const int wp = smem_lds + (int)(sW - smem) + (h % 3) * WUNIT + (wn * 160 + r16) * 64 + offw;
+            u32x4_t pf[4], wf[WNF];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pf[j] = rd(ap + j * 16 * 128);
+#pragma unroll
+            for (int i = 0; i < WNF; ++i) wf[i] = rd(wp + i * 16 * 64);
+            if (h + 2 < H) issueW(h + 2);                     // into the slot of W[h - 1] (its reads were retired before the last barrier)
+            if (!(h & 1) && (h >> 1) + 2 < nU) issueA((h >> 1) + 2);
+            // W[h + 1] (issued in half step h - 1) has to have landed: behind it in issue order there are at most one activation unit and
+            // this half step's filter unit
+            if (h + 4 >= H) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the activation issue stops four half steps before the end)
+            else if (w < W3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]),
+                           "+v"(wf[4]), "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7]), "+v"(wf[8]), "+v"(wf[9]));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < WNF - 1; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(wf[i], pf[j], acc[i][j]);
+            if (!NF19 || wn == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[WNF - 1][j] = mfma16<T>(wf[WNF - 1], pf[j], acc[WNF - 1][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wn == 0) __builtin_amdgcn_s_barrier();            // group 0 waits for group 1's last half step
+    } else
     for (int h = 0; h < H; ++h) {
         if (h + 4 >= H) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (w < W3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
@@ -610,8 +660,15 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_stream(WideArgs a) {
 
 template <typename T, bool NT, bool NF19>
 void launch_proj_variant(const WideArgs& a, size_t lds, hipStream_t st) {
-    (void)hipFuncSetAttribute((const void*)proj_gemm_stream<T, NT, NF19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((proj_gemm_stream<T, NT, NF19>), dim3(a.mtiles), dim3(512), lds, st, a);
+    static int stag = -1;
+    if (stag < 0) { const char* e = getenv("SZN_PROJ_STAG"); stag = e ? atoi(e) : 1; }
+    if (stag) {
+        (void)hipFuncSetAttribute((const void*)proj_gemm_stream<T, NT, NF19, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((proj_gemm_stream<T, NT, NF19, true>), dim3(a.mtiles), dim3(512), lds, st, a);
+        return;
+    }
+    (void)hipFuncSetAttribute((const void*)proj_gemm_stream<T, NT, NF19, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((proj_gemm_stream<T, NT, NF19, false>), dim3(a.mtiles), dim3(512), lds, st, a);
 }
 
 template <typename T>
