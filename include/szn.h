@@ -19,6 +19,7 @@
  */
 #ifndef SZN_H_
 #define SZN_H_
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -28,6 +29,13 @@ typedef void* szn_stream_t; /* hipStream_t */
 
 enum { SZN_OK = 0, SZN_ERR_ARG = -1, SZN_ERR_LAUNCH = -2, SZN_ERR_UNSUPPORTED = -3 };
 enum { SZN_F32 = 0, SZN_BF16 = 1, SZN_F16 = 2 };   /* SZN_F16: IEEE half activations / weight images (BASELINE configs[4]) */
+
+/* a set of class indices below SZN_MAX_CLASSES: bit (k % 64) of w[k / 64] = class k.  Passed by HOST pointer, read during the
+ * call (NULL = the empty set); used by the *_k entry points (more than 64 classes).                                                                                        */
+#define SZN_MAX_CLASSES 256
+typedef struct szn_class_set {
+    uint64_t w[4];
+} szn_class_set;
 
 /* ---- library -------------------------------------------------------------------------------- */
 const char* szn_last_error(void);
@@ -270,6 +278,11 @@ int szn_seenmask_head(int B, int h, int w, int ldc, int c0, int H, int W, int cr
                       const float* weight, const int64_t* target, int n_class, uint64_t seen_bits, float* loss,
                       float* stats, int64_t* conf, int64_t* pred, float* dscore2, float* dweight, void* workspace,
                       szn_stream_t stream);
+/* the same with n_class <= SZN_MAX_CLASSES and the seen classes as a szn_class_set */
+int szn_seenmask_head_k(int B, int h, int w, int ldc, int c0, int H, int W, int crop, const float* coarse,
+                        const float* weight, const int64_t* target, int n_class, const szn_class_set* seen, float* loss,
+                        float* stats, int64_t* conf, int64_t* pred, float* dscore2, float* dweight, void* workspace,
+                        szn_stream_t stream);
 /* seenmask_score = Conv2d(4096, 2, 1) (models.py:97,149) backward from the compact gradient above:
  * dw[c][k] = sum_m dscore2[m][c] * feat[m][k], db[c] = sum_m dscore2[m][c]; feat [M][ldf] of `dtype` (relu7 after
  * Dropout2d), F a multiple of 8.  Fixed-order slabs in `workspace` (szn_seenmask_score_wgrad_workspace_bytes).     */
@@ -311,7 +324,9 @@ int szn_ce2d_bwd(int B, int C, int H, int W, const float* score, const int64_t* 
 
 /* ---- nearest-class-embedding inference (utils.py:159-205) --------------------------------------
  * sim[k] = (score_px . embed[k]) / (||score_px|| * (||embed[k]|| == 0 ? 1 : ||embed[k]||)),
- * pred = first argmax_k.  embed[K][E] f32, K <= 64.
+ * pred = first argmax_k.  embed[K][E] f32.  K <= 64 through the uint64_t entry points below, K <= SZN_MAX_CLASSES (256)
+ * through the _k forms, which take class sets as szn_class_set (the reference's unseen lists are plain Python lists of any
+ * length, trainer_fcn.py:56-64; 64 classes cover its two datasets -- 21 and 33/59 classes -- but not a 150-class label set).
  * mode 0 (infer_lbl):    all K rows of embed compete.
  * mode 1 (stich_seen_unseen_with_mask / infer_lbl_szn / infer_lbl_forced_unseen):
  *        rows with bit k of unseen_bits set form the "unseen-only" matrix, the others the
@@ -324,12 +339,18 @@ int szn_ce2d_bwd(int B, int C, int H, int W, const float* score, const int64_t* 
 int szn_embed_argmax(int B, int E, int H, int W, int K, const float* score, const float* embed,
                      int mode, uint64_t unseen_bits, const float* seenmask, const int64_t* target,
                      int64_t* pred, szn_stream_t stream);
+int szn_embed_argmax_k(int B, int E, int H, int W, int K, const float* score, const float* embed,
+                       int mode, const szn_class_set* unseen, const float* seenmask, const int64_t* target,
+                       int64_t* pred, szn_stream_t stream);
 
 /* ---- confusion histogram (utils.py:104-154) ------------------------------------------------------
  * hist[3][K][K] int64 += bincount(K*gt+pred) over pixels with 0 <= gt < K, for {all, gt in seen,
  * gt in unseen}; unseen_bits == 0 fills only hist[0].                                              */
 int szn_confusion_hist(long npix, int K, const int64_t* label_true, const int64_t* label_pred,
                        uint64_t unseen_bits, int64_t* hist, szn_stream_t stream);
+/* K <= SZN_MAX_CLASSES; an empty or NULL set fills only hist[0] */
+int szn_confusion_hist_k(long npix, int K, const int64_t* label_true, const int64_t* label_pred,
+                         const szn_class_set* unseen, int64_t* hist, szn_stream_t stream);
 
 /* ---- fused head: coarse -> (loss, prediction, dcoarse) without materialising (B,E,H,W) ----------
  * Equivalent to szn_bilinear_up32_crop_fwd -> szn_cosine_loss_fwd -> szn_embed_argmax ->

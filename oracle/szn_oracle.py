@@ -315,12 +315,22 @@ def bits(unseen):
     return b
 
 
+def words(unseen, K):
+    """class set -> (K + 63) // 64 uint64 words (bit k % 64 of word k // 64), or None for the empty set"""
+    b = bits(unseen or [])
+    if not b:
+        return None
+    assert b >> K == 0, "class index >= K"
+    n = (K + 63) // 64
+    return (C.c_uint64 * n)(*[(b >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)])
+
+
 def infer_lbl(score, embed):
     """utils.py:159-185 -> int64 (B,H,W)"""
     score, embed = _c(score), _c(embed)
     B, E, H, W = score.shape
     pred = np.empty((B, H, W), np.int64)
-    lib().szo_embed_argmax(B, E, H * W, embed.shape[0], _p(score), _p(embed), 0, C.c_uint64(0), None, None, _p(pred))
+    lib().szo_embed_argmax(B, E, H * W, embed.shape[0], _p(score), _p(embed), 0, None, None, None, _p(pred))
     return pred
 
 
@@ -329,7 +339,7 @@ def infer_lbl_szn(score, seenmask_score, embed, unseen):
     score, embed, sm = _c(score), _c(embed), _c(seenmask_score)
     B, E, H, W = score.shape
     pred = np.empty((B, H, W), np.int64)
-    lib().szo_embed_argmax(B, E, H * W, embed.shape[0], _p(score), _p(embed), 1, C.c_uint64(bits(unseen)), _p(sm), None, _p(pred))
+    lib().szo_embed_argmax(B, E, H * W, embed.shape[0], _p(score), _p(embed), 1, words(unseen, embed.shape[0]), _p(sm), None, _p(pred))
     return pred
 
 
@@ -338,7 +348,7 @@ def infer_lbl_forced_unseen(score, target, embed, unseen):
     score, embed, t = _c(score), _c(embed), _c(target, np.int64)
     B, E, H, W = score.shape
     pred = np.empty((B, H, W), np.int64)
-    lib().szo_embed_argmax(B, E, H * W, embed.shape[0], _p(score), _p(embed), 1, C.c_uint64(bits(unseen)), None, _p(t), _p(pred))
+    lib().szo_embed_argmax(B, E, H * W, embed.shape[0], _p(score), _p(embed), 1, words(unseen, embed.shape[0]), None, _p(t), _p(pred))
     return pred
 
 
@@ -432,7 +442,7 @@ def confusion_hist(label_trues, label_preds, n_class, unseen=None):
     lt = _c(np.asarray(label_trues).reshape(-1), np.int64)
     lp = _c(np.asarray(label_preds).reshape(-1), np.int64)
     hist = np.zeros((3, n_class, n_class), np.int64)
-    lib().szo_confusion_hist(C.c_long(lt.size), n_class, _p(lt), _p(lp), C.c_uint64(bits(unseen or [])), _p(hist))
+    lib().szo_confusion_hist(C.c_long(lt.size), n_class, _p(lt), _p(lp), words(unseen, n_class), _p(hist))
     return hist
 
 

@@ -141,8 +141,20 @@ double szo_ce2d(int B, int C, int HW, const float* score, const int64_t* target,
 /* infer_lbl family.  mode 0: all rows compete.  mode 1: seen-only / unseen-only matrices (other group's rows
  * zeroed -> similarity exactly 0, still competing), stitched by the seen-mask argmax (seenmask != NULL,
  * utils.py:197-198) or by the ground-truth label being unseen (utils.py:190-191).  First index wins ties.   */
+/* class sets are word arrays: bit (k % 64) of word (k / 64) = class k, (K + 63) / 64 words, NULL = the empty set */
+#define SZO_MAX_CLASSES 256
+static int szo_in_set(const uint64_t* words, int K, int64_t k) {
+    return words && k >= 0 && k < K && ((words[k >> 6] >> (k & 63)) & 1ull);
+}
+static int szo_set_nonempty(const uint64_t* words, int K) {
+    if (!words) return 0;
+    for (int i = 0; i < (K + 63) / 64; ++i) if (words[i]) return 1;
+    return 0;
+}
+
 void szo_embed_argmax(int B, int E, int HW, int K, const float* score, const float* embed, int mode,
-                      uint64_t unseen_bits, const float* seenmask, const int64_t* target, int64_t* pred) {
+                      const uint64_t* unseen_words, const float* seenmask, const int64_t* target, int64_t* pred) {
+    if (K > SZO_MAX_CLASSES) abort();
     float* en = (float*)malloc((size_t)K * sizeof(float));
     for (int k = 0; k < K; ++k) {
         float s = 0.f;
@@ -154,7 +166,7 @@ void szo_embed_argmax(int B, int E, int HW, int K, const float* score, const flo
     for (int b = 0; b < B; ++b)
         for (int p = 0; p < HW; ++p) {
             const float* sp = score + (size_t)b * E * HW + p;
-            float acc[64];
+            float acc[SZO_MAX_CLASSES];
             float ss = 0.f;
             for (int k = 0; k < K; ++k) acc[k] = 0.f;
             for (int c = 0; c < E; ++c) {
@@ -176,7 +188,7 @@ void szo_embed_argmax(int B, int E, int HW, int K, const float* score, const flo
                 int is = 0, iu = 0;
                 for (int k = 0; k < K; ++k) {
                     const float sim = acc[k] / (sn * en[k]);
-                    const int un = (int)((unseen_bits >> k) & 1ull);
+                    const int un = szo_in_set(unseen_words, K, k);
                     const float vs = un ? zero_sim : sim, vu = un ? sim : zero_sim;
                     if (k == 0 || vs > bs) { bs = vs; is = k; }
                     if (k == 0 || vu > bu) { bu = vu; iu = k; }
@@ -187,7 +199,7 @@ void szo_embed_argmax(int B, int E, int HW, int K, const float* score, const flo
                     take_unseen = !(s1 > s0);
                 } else {
                     const int64_t t = target[(size_t)b * HW + p];
-                    take_unseen = (t >= 0 && t < 64) && ((unseen_bits >> t) & 1ull);
+                    take_unseen = szo_in_set(unseen_words, K, t);
                 }
                 best = take_unseen ? iu : is;
             }
@@ -196,13 +208,14 @@ void szo_embed_argmax(int B, int E, int HW, int K, const float* score, const flo
     free(en);
 }
 
-/* hist[h][K][K], h = 0 all, 1 gt in seen, 2 gt in unseen (only h = 0 when unseen_bits == 0) */
-void szo_confusion_hist(long n, int K, const int64_t* lt, const int64_t* lp, uint64_t unseen_bits, int64_t* hist) {
+/* hist[h][K][K], h = 0 all, 1 gt in seen, 2 gt in unseen (only h = 0 when the unseen set is empty) */
+void szo_confusion_hist(long n, int K, const int64_t* lt, const int64_t* lp, const uint64_t* unseen_words, int64_t* hist) {
+    const int split = szo_set_nonempty(unseen_words, K);
     for (long i = 0; i < n; ++i) {
         const int64_t t = lt[i], p = lp[i];
         if (t < 0 || t >= K || p < 0 || p >= K) continue;
         hist[t * K + p] += 1;
-        if (unseen_bits) hist[(size_t)(((unseen_bits >> t) & 1ull) ? 2 : 1) * K * K + t * K + p] += 1;
+        if (split) hist[(size_t)(szo_in_set(unseen_words, K, t) ? 2 : 1) * K * K + t * K + p] += 1;
     }
 }
 
@@ -237,6 +250,7 @@ static double fh_bil1d(int t, int S) { return 1.0 - fabs((double)t - ((double)S 
  * head (crop 31) -- same arithmetic over S x S cells.                                                                    */
 double szo_fused_head_s(int S, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K, const float* coarse,
                         const float* embed, const int64_t* target, float* stats, int64_t* pred, float* dcoarse) {
+    if (K > SZO_MAX_CLASSES) abort();
     float* en = (float*)malloc((size_t)K * sizeof(float));
     float* ent = (float*)malloc((size_t)K * sizeof(float));
     for (int k = 0; k < K; ++k) {
@@ -253,7 +267,7 @@ double szo_fused_head_s(int S, int B, int h, int w, int E, int ldc, int c0, int 
         for (int cell = 0; cell < cells; ++cell) {
             const int I = cell / cells_w, J = cell % cells_w;
             float* Ct = (float*)calloc((size_t)4 * E, sizeof(float));
-            float G[4][64], Q[16];
+            float G[4][SZO_MAX_CLASSES], Q[16];
             for (int t = 0; t < 4; ++t) {
                 const int ci = I - 1 + (t >> 1), cj = J - 1 + (t & 1);
                 if (ci >= 0 && ci < h && cj >= 0 && cj < w)

@@ -118,6 +118,52 @@ def test_synth_is_deterministic_and_shaped():
     assert synth.unseen_bits([0, 12, 63]) == (1 | (1 << 12) | (1 << 63))
 
 
+def test_class_sets_beyond_64_classes():
+    """szn_class_set packing (bit k % 64 of word k // 64) and the oracle's word-array class sets at K = 150 against a float64
+    numpy restatement of utils.py:159-205 / 104-154 (the oracle is what the -m gpu tests of the *_k entry points compare with)"""
+    from oracle import szn_oracle as O
+    from zeroshotsemanticsegmentation_amd import _lib as L
+    cs = L.class_set([0, 63, 64, 130, 255])._obj
+    assert list(cs.w) == [1 | (1 << 63), 1, 1 << 2, 1 << 63]
+    assert L.class_set([]) is None and L.class_set(None) is None
+    with pytest.raises(L.SznError):
+        L.class_set([256])
+    K, E, H, W = 150, 20, 16, 16
+    unseen = [3, 63, 64, 70, 127, 128, 149]
+    emb = synth.make_embeddings(K, E, seed=3)
+    score = synth.uniform(77, (2, E, H, W), -1, 1)
+    sm = synth.uniform(78, (2, 2, H, W), -1, 1)
+    target = synth.make_labels(2, H, W, K, seed=79, block=2)
+    s = score.transpose(0, 2, 3, 1).reshape(-1, E).astype(np.float64)
+    e = emb.astype(np.float64)
+    sim = (s @ e.T) / (np.linalg.norm(s, axis=1, keepdims=True) * np.linalg.norm(e, axis=1)[None])
+    top = np.sort(sim, axis=1)
+    clear = ((top[:, -1] - top[:, -2]) > 1e-5).reshape(2, H, W)
+    assert np.array_equal(O.infer_lbl(score, emb)[clear], sim.argmax(1).reshape(2, H, W)[clear])
+    un = np.zeros(K, bool)
+    un[unseen] = True
+    ps = np.where(un[None], 0.0, sim).argmax(1).reshape(2, H, W)       # seen-only matrix: unseen rows zeroed, still competing
+    pu = np.where(un[None], sim, 0.0).argmax(1).reshape(2, H, W)
+    # (top-2 margins of the two masked problems are not the full problem's: compare where both variants are far from ties)
+    def far(m):
+        t = np.sort(m, axis=1)
+        return ((t[:, -1] - t[:, -2]) > 1e-5).reshape(2, H, W)
+    ok = far(np.where(un[None], 0.0, sim)) & far(np.where(un[None], sim, 0.0))
+    want = np.where(sm[:, 1] > sm[:, 0], ps, pu)                       # utils.py:197-198: mask argmax 0 -> unseen
+    assert np.array_equal(O.infer_lbl_szn(score, sm, emb, unseen)[ok], want[ok])
+    want = np.where(np.isin(target, unseen), pu, ps)                   # utils.py:190-191
+    assert np.array_equal(O.infer_lbl_forced_unseen(score, target, emb, unseen)[ok], want[ok])
+    lp = synth.make_labels(2, H, W, K, seed=80, block=1, ignore_frac=0.0)
+    hist = O.confusion_hist(target, lp, K, unseen=unseen)
+    v = target >= 0
+    full = np.bincount(K * target[v] + lp[v], minlength=K * K).reshape(K, K)
+    vu = v & np.isin(target, unseen)
+    assert np.array_equal(hist[0], full)
+    assert np.array_equal(hist[2], np.bincount(K * target[vu] + lp[vu], minlength=K * K).reshape(K, K))
+    assert np.array_equal(hist[1], full - hist[2])
+    assert np.isin(target[v], [k for k in unseen if k >= 64]).any()
+
+
 def test_seenmask_binary_target_rule():
     from zeroshotsemanticsegmentation_amd import trainer_seenmask
     g = np.load(os.path.join(G, "g8_seenmask_step.npz"))

@@ -32,8 +32,30 @@ class DeviceInfo(C.Structure):
                 ("clock_mhz", C.c_int)]
 
 
+MAX_CLASSES = 256           # SZN_MAX_CLASSES
+
+
+class ClassSet(C.Structure):
+    """szn_class_set (include/szn.h): bit k % 64 of w[k // 64] = class k"""
+    _fields_ = [("w", C.c_uint64 * 4)]
+
+
+def class_set(classes):
+    """iterable of class indices -> a byref(ClassSet) argument for the *_k entry points (None = the empty set)"""
+    cs = ClassSet()
+    any_ = False
+    for k in classes or []:
+        k = int(k)
+        if not 0 <= k < MAX_CLASSES:
+            raise SznError("class index %d outside [0, %d)" % (k, MAX_CLASSES))
+        cs.w[k >> 6] |= 1 << (k & 63)
+        any_ = True
+    return C.byref(cs) if any_ else None
+
+
 _P, _I, _L, _F, _U64, _SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_size_t
 _D = C.POINTER(ConvDesc)
+_CS = C.POINTER(ClassSet)
 
 # name -> (restype, argtypes); must list every symbol of include/szn.h (tests/test_abi.py checks that)
 SIGNATURES = {
@@ -79,6 +101,7 @@ SIGNATURES = {
     "szn_deconv64s32_wgrad": (_I, [_I] * 9 + [_P, _P, _P, _I, _P]),
     "szn_seenmask_head_workspace_bytes": (_SZ, [_I] * 6),
     "szn_seenmask_head": (_I, [_I] * 8 + [_P, _P, _P, _I, _U64] + [_P] * 8),
+    "szn_seenmask_head_k": (_I, [_I] * 8 + [_P, _P, _P, _I, _CS] + [_P] * 8),
     "szn_seenmask_score_wgrad_workspace_bytes": (_SZ, [_L, _I]),
     "szn_seenmask_score_wgrad": (_I, [_I, _L, _I, _I, _P, _P, _P, _P, _P, _P]),
     "szn_loss_workspace_bytes": (_SZ, [_I, _I, _I]),
@@ -89,7 +112,9 @@ SIGNATURES = {
     "szn_ce2d_fwd": (_I, [_I] * 4 + [_P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "szn_ce2d_bwd": (_I, [_I] * 4 + [_P, _P, _P, _I, _P, _P, _P, _P]),
     "szn_embed_argmax": (_I, [_I] * 5 + [_P, _P, _I, _U64, _P, _P, _P, _P]),
+    "szn_embed_argmax_k": (_I, [_I] * 5 + [_P, _P, _I, _CS, _P, _P, _P, _P]),
     "szn_confusion_hist": (_I, [_L, _I, _P, _P, _U64, _P, _P]),
+    "szn_confusion_hist_k": (_I, [_L, _I, _P, _P, _CS, _P, _P]),
     "szn_fused_head_workspace_bytes": (_SZ, [_I] * 5),
     "szn_fused_head": (_I, [_I] * 10 + [_P] * 6 + [_I, _P, _P, _P]),
     "szn_fused_head_strided": (_I, [_I] * 11 + [_P] * 6 + [_I, _P, _P, _P]),

@@ -24,6 +24,35 @@ void szn_note_work_fraction(float f);            /* thread-local: fraction of th
 #define SZN_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); szn_note_kernel(name); \
     if (e__ != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); } while (0)
 
+// ---- class sets ---------------------------------------------------------------------------
+// class sets travel as kernel arguments (4 words = SZN_MAX_CLASSES bits).  Words are picked by selects, not by a dynamic index
+// into the by-value struct (which would put it in scratch).
+struct ClassBits {
+    uint64_t w[4];
+};
+__device__ __forceinline__ uint64_t class_word(const ClassBits& s, int i) {
+    return i == 0 ? s.w[0] : (i == 1 ? s.w[1] : (i == 2 ? s.w[2] : s.w[3]));
+}
+__device__ __forceinline__ bool in_set(const ClassBits& s, long k) {
+    return k >= 0 && k < SZN_MAX_CLASSES && ((class_word(s, (int)(k >> 6)) >> (k & 63)) & 1ull);
+}
+inline ClassBits class_bits(const szn_class_set* s) {
+    ClassBits b{};
+    if (s) for (int i = 0; i < 4; ++i) b.w[i] = s->w[i];
+    return b;
+}
+inline ClassBits class_bits64(uint64_t w0) {
+    ClassBits b{};
+    b.w[0] = w0;
+    return b;
+}
+inline bool class_bits_any(const ClassBits& b) { return (b.w[0] | b.w[1] | b.w[2] | b.w[3]) != 0; }
+inline bool class_bits_fit(const ClassBits& b, int K) {          // no member >= K
+    for (int k = K < 0 ? 0 : K; k < SZN_MAX_CLASSES; ++k)
+        if ((b.w[k >> 6] >> (k & 63)) & 1ull) return false;
+    return true;
+}
+
 // ---- element type traits --------------------------------------------------------------------
 struct bf16_raw { uint16_t v; };
 

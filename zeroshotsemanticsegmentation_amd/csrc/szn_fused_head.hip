@@ -49,18 +49,19 @@ __global__ __launch_bounds__(256) void fh_prep_kernel(const float* __restrict__ 
         // rows are staged through LDS in slices first: as a chain of dependent global loads the 300 steps took ~25 us.
         __shared__ float row[64][65];
         float s = 0.f;
-        const int k = threadIdx.x;
-        for (int c0 = 0; c0 < E; c0 += 64) {
-            const int n = min(64, E - c0);
-            __syncthreads();
-            for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-                const int kk = i >> 6, c = i & 63;
-                row[kk][c] = (kk < K && c < n) ? embed[(size_t)kk * E + c0 + c] : 0.f;
+        const int k = threadIdx.x;                 // class k (K <= 256 = the block)
+        for (int g0 = 0; g0 < K; g0 += 64)         // 64 classes at a time through the LDS tile
+            for (int c0 = 0; c0 < E; c0 += 64) {
+                const int n = min(64, E - c0);
+                __syncthreads();
+                for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+                    const int kk = i >> 6, c = i & 63;
+                    row[kk][c] = (g0 + kk < K && c < n) ? embed[(size_t)(g0 + kk) * E + c0 + c] : 0.f;
+                }
+                __syncthreads();
+                if (k < K && (k >> 6) == (g0 >> 6))
+                    for (int c = 0; c < n; ++c) s = fmaf(row[k & 63][c], row[k & 63][c], s);
             }
-            __syncthreads();
-            if (k < K)
-                for (int c = 0; c < n; ++c) s = fmaf(row[k][c], row[k][c], s);
-        }
         if (k < KP) {
             const float nrm = sqrtf(s);
             en[k] = (nrm == 0.f) ? 1.f : nrm;
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(256) void fh_cell_kernel(FhArgs a) {
     }
     for (int i = tid; i < 16 * KP; i += 256) Aw[i] = 0.f;
     __syncthreads();
-    // G[t][k]: wave t, lane k (KP <= 64)
-    if (lane < KP) {
+    // G[t][k]: wave t, lane k (+ 64, + 128, + 192 when KP > 64)
+    for (int k = lane; k < KP; k += 64) {
         float g = 0.f;
         const float* ct = Ct + wave * a.E;
         // (the chain is sequential by contract; 20 independent L2 loads per batch keep it fed)
@@ -109,12 +110,12 @@ __global__ __launch_bounds__(256) void fh_cell_kernel(FhArgs a) {
         for (; c + 20 <= a.E; c += 20) {
             float ev[20];
 #pragma unroll
-            for (int u = 0; u < 20; ++u) ev[u] = embT[(size_t)(c + u) * KP + lane];
+            for (int u = 0; u < 20; ++u) ev[u] = embT[(size_t)(c + u) * KP + k];
 #pragma unroll
             for (int u = 0; u < 20; ++u) g = fmaf(ct[c + u], ev[u], g);
         }
-        for (; c < a.E; ++c) g = fmaf(ct[c], embT[(size_t)c * KP + lane], g);
-        G[wave * KP + lane] = g;
+        for (; c < a.E; ++c) g = fmaf(ct[c], embT[(size_t)c * KP + k], g);
+        G[wave * KP + k] = g;
     }
     // Q[t][t']: wave t computes its row; lanes stride over c, fixed-order wave reduction
     {
@@ -239,10 +240,10 @@ __global__ __launch_bounds__(256) void fh_tables_kernel(FhArgs a, float* __restr
     for (int c = lane; c < a.E; c += 64) Cs[c] = cv[c];
     __syncthreads();
     const float* embT = a.ws_f;
-    if (ok && lane < KP) {
+    for (int k = lane; ok && k < KP; k += 64) {
         float g = 0.f;
-        for (int c = 0; c < a.E; ++c) g = fmaf(Cs[c], embT[(size_t)c * KP + lane], g);
-        D[(size_t)pos * KP + lane] = g;
+        for (int c = 0; c < a.E; ++c) g = fmaf(Cs[c], embT[(size_t)c * KP + k], g);
+        D[(size_t)pos * KP + k] = g;
     }
     const int di[5] = {0, 0, 1, 1, 1}, dj[5] = {0, 1, 0, 1, -1};
 #pragma unroll
@@ -285,11 +286,11 @@ __global__ __launch_bounds__(256) void fh_cell_tab_kernel(FhArgs a, const float*
         const int ci = I - 1 + (t >> 1), cj = J - 1 + (t & 1);
         tp[t] = (ci >= 0 && ci < a.h && cj >= 0 && cj < a.w) ? ((long)b * a.h + ci) * a.w + cj : -1;
     }
-    if (lane < KP) {
+    for (int k = lane; k < KP; k += 64) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            G[t * KP + lane] = (tp[t] >= 0) ? D[(size_t)tp[t] * KP + lane] : 0.f;
-            myA[t * KP + lane] = 0.f;
+            G[t * KP + k] = (tp[t] >= 0) ? D[(size_t)tp[t] * KP + k] : 0.f;
+            myA[t * KP + k] = 0.f;
         }
     }
     if (lane < 16) {
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256) void fh_gather_kernel(const float* __restrict_
                                                         const float* __restrict__ ws, const float* __restrict__ stats,
                                                         T* __restrict__ dcoarse, int B, int h, int w, int E, int ldc,
                                                         int c0, int K, int KP) {
-    __shared__ float Al[4][64];      // A of the 4 cells, row = the tap index this position has in that cell
+    __shared__ float Al[4][256];     // A of the 4 cells (KP <= 256), row = the tap index this position has in that cell
     __shared__ float Bl[4][4];       // matching rows of Bm
     const int pos = blockIdx.x;
     const int b = pos / (h * w), r = pos % (h * w);
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void fh_gather_kernel(const float* __restrict_
     }
     __syncthreads();
     // the class term is linear in A: sum the four cells' rows first, one pass over the K embeddings instead of four
-    if (threadIdx.x < 64) Al[0][threadIdx.x] = (threadIdx.x < KP) ? (Al[0][threadIdx.x] + Al[1][threadIdx.x]) + (Al[2][threadIdx.x] + Al[3][threadIdx.x]) : 0.f;
+    Al[0][threadIdx.x] = (threadIdx.x < KP) ? (Al[0][threadIdx.x] + Al[1][threadIdx.x]) + (Al[2][threadIdx.x] + Al[3][threadIdx.x]) : 0.f;
     __syncthreads();
     const float scale = 1.f / ((float)B * stats[2 * b + 1]);
     for (int c = threadIdx.x; c < E; c += 256) {
@@ -459,12 +460,12 @@ __global__ __launch_bounds__(256) void fh_gather_kernel(const float* __restrict_
     }
 }
 
-inline int kp_of(int K) { return K <= 24 ? 24 : (K <= 40 ? 40 : 64); }
+inline int kp_of(int K) { return K <= 24 ? 24 : (K <= 40 ? 40 : (K <= 64 ? 64 : (K + 63) / 64 * 64)); }      // K <= 256
 
 }  // namespace
 
 extern "C" size_t szn_fused_head_workspace_bytes(int B, int h, int w, int E, int K) {
-    if (B <= 0 || h <= 0 || w <= 0 || E <= 0 || K <= 0 || K > 64) return 0;
+    if (B <= 0 || h <= 0 || w <= 0 || E <= 0 || K <= 0 || K > 256) return 0;
     const int KP = kp_of(K);
     const size_t cells = (size_t)B * (h + 1) * (w + 1);
     size_t fl = ws_cell_off(E, KP) + cells * ws_cell_stride(KP);
@@ -481,7 +482,7 @@ extern "C" int szn_fused_head_strided(int stride, int B, int h, int w, int E, in
     if (!coarse || !embed || !workspace || B <= 0 || h <= 0 || w <= 0 || E <= 0 || c0 < 0 || ldc < c0 + E || H <= 0 ||
         W <= 0 || crop < 0 || K <= 0)
         SZN_FAIL(SZN_ERR_ARG, "fused_head: bad argument");
-    if (K > 64) SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head: K=%d > 64", K);
+    if (K > 256) SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head: K=%d > 256", K);
     if (H + crop > stride * h + stride || W + crop > stride * w + stride)
         SZN_FAIL(SZN_ERR_ARG, "fused_head: crop window exceeds the deconv output");
     if ((target == nullptr) != (loss == nullptr) || (loss && !stats)) SZN_FAIL(SZN_ERR_ARG, "fused_head: target/loss/stats go together");
@@ -522,7 +523,10 @@ extern "C" int szn_fused_head_strided(int stride, int B, int h, int w, int E, in
     } while (0)
     if (KP == 24) SZN_FH_LAUNCH(24);
     else if (KP == 40) SZN_FH_LAUNCH(40);
-    else SZN_FH_LAUNCH(64);
+    else if (KP == 64) SZN_FH_LAUNCH(64);
+    else if (KP == 128) SZN_FH_LAUNCH(128);
+    else if (KP == 192) SZN_FH_LAUNCH(192);
+    else SZN_FH_LAUNCH(256);
 #undef SZN_FH_LAUNCH
     SZN_CHECK_LAUNCH("fh_cell_kernel");
     if (loss) {

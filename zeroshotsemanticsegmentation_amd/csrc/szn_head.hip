@@ -450,116 +450,142 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ s
 // staged once per block, not once per 256 pixels.  Arithmetic per (pixel, class) is unchanged: one fmaf chain over ascending
 // channels, sqrtf, IEEE division -- bit-identical to szo_embed_argmax.  At K = 59 the work is 2*E*K = 35.4 kFLOP per 1.2 KB pixel
 // (29.5 FLOP/B): above the fp32-vector ridge of the chip (157 TF / 8 TB/s = 19.6), i.e. VALU-bound; at K = 21 it is HBM-bound.
+// running first-index argmax over class chunks: (bs, is) over the seen-only similarities (all classes in mode 0), (bu, iu) over the
+// unseen-only ones.  One pass over all K similarities gives both: a zeroed row scores (0 / (sn * 1)) and still competes, exactly like
+// utils.py:173-179.  Classes are visited in ascending order and only a strictly larger value replaces the best: first index wins.
+struct Best {
+    float bs, bu;
+    int is, iu;
+};
 template <int KP>
-__device__ __forceinline__ int argmax_finish(const float (&acc)[KP], float ss, const float* __restrict__ en, int K, int mode,
-                                             uint64_t unseen_bits, const float* __restrict__ seenmask,
-                                             const int64_t* __restrict__ target, int b, long p, int HW) {
-    const float sn = sqrtf(ss);
-    int best = 0;
-    if (mode == 0) {
-        float bv = 0.f;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            if (k < K) {
-                const float sim = acc[k] / (sn * en[k]);
-                if (k == 0 || sim > bv) { bv = sim; best = k; }
-            }
-        }
-        return best;
-    }
-    // one pass over all K similarities gives both the seen-only and the unseen-only prediction:
-    // a zeroed row scores (0 / (sn * 1)) and still competes, exactly like utils.py:173-179
+__device__ __forceinline__ void argmax_update(Best& r, const float (&acc)[KP], float sn, const float* __restrict__ en, int k0, int K,
+                                              int mode, uint64_t word) {
     const float zero_sim = 0.f / (sn * 1.f);
-    float bs = 0.f, bu = 0.f;
-    int is = 0, iu = 0;
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-        if (k < K) {
+        if (k0 + k < K) {
             const float sim = acc[k] / (sn * en[k]);
-            const bool un = (unseen_bits >> k) & 1ull;
-            const float vs = un ? zero_sim : sim, vu = un ? sim : zero_sim;
-            if (k == 0 || vs > bs) { bs = vs; is = k; }
-            if (k == 0 || vu > bu) { bu = vu; iu = k; }
+            if (mode == 0) {
+                if (k0 + k == 0 || sim > r.bs) { r.bs = sim; r.is = k0 + k; }
+            } else {
+                const bool un = (word >> (k & 63)) & 1ull;
+                const float vs = un ? zero_sim : sim, vu = un ? sim : zero_sim;
+                if (k0 + k == 0 || vs > r.bs) { r.bs = vs; r.is = k0 + k; }
+                if (k0 + k == 0 || vu > r.bu) { r.bu = vu; r.iu = k0 + k; }
+            }
         }
     }
+}
+__device__ __forceinline__ int argmax_pick(const Best& r, int mode, const ClassBits& unseen, const float* __restrict__ seenmask,
+                                           const int64_t* __restrict__ target, int b, long p, int HW) {
+    if (mode == 0) return r.is;
     bool take_unseen;
     if (seenmask) {
         const float s0 = seenmask[((long)b * 2 + 0) * HW + p], s1 = seenmask[((long)b * 2 + 1) * HW + p];
         take_unseen = !(s1 > s0);          // argmax over 2 channels == 0  (utils.py:197-198)
     } else {
-        const long t = target[(long)b * HW + p];
-        take_unseen = (t >= 0 && t < 64) && ((unseen_bits >> t) & 1ull);   // np.in1d(target, unseen)
+        take_unseen = in_set(unseen, target[(long)b * HW + p]);   // np.in1d(target, unseen)
     }
-    return take_unseen ? iu : is;
+    return take_unseen ? r.iu : r.is;
 }
 
-template <int KP>
+// CHUNKS == false: K <= KP, the table is staged once and a block walks several 512-pixel tiles.  CHUNKS == true (K > 64, KP = 64):
+// one tile per block, the class matrix goes through LDS in chunks of 64 rows and the two pixels of a thread keep their running best
+// across chunks (the score vector of a pixel is re-read per chunk: L2 hits, 1.2 KB per pixel).
+template <int KP, bool CHUNKS>
 __global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restrict__ score, const float* __restrict__ embed,
                                                            const float* __restrict__ seenmask,
                                                            const int64_t* __restrict__ target, int64_t* __restrict__ pred,
-                                                           int E, int HW, int K, int mode, uint64_t unseen_bits) {
+                                                           int E, int HW, int K, int mode, ClassBits unseen) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // embT [E][KP] | en [KP]
     float* embT = sm;
     float* en = sm + (long)E * KP;
-    for (int i = threadIdx.x; i < E * KP; i += 256) {
-        const int k = i % KP, c = i / KP;                        // conflict-free LDS writes; the 70 KB matrix is L2-resident
-        embT[i] = (k < K) ? embed[(long)k * E + c] : 0.f;
-    }
-    __syncthreads();
-    if (threadIdx.x < KP) {
-        float s = 0.f;
-        for (int c = 0; c < E; ++c) { const float v = embT[c * KP + threadIdx.x]; s = fmaf(v, v, s); }
-        const float n = sqrtf(s);
-        en[threadIdx.x] = (n == 0.f) ? 1.f : n;     // utils.py:175
-    }
-    __syncthreads();
     const int b = blockIdx.y;
     const float* sb = score + (long)b * E * HW;
-    for (long p0 = (long)blockIdx.x * 512 + threadIdx.x; p0 < HW; p0 += (long)gridDim.x * 512) {
-        const long p1 = p0 + 256;
-        const bool ok1 = p1 < HW;
-        const float* sp0 = sb + p0;
-        const float* sp1 = sb + (ok1 ? p1 : p0);
-        float acc0[KP], acc1[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
-        float ss0 = 0.f, ss1 = 0.f;
-        for (int c = 0; c < E; ++c) {
-            const float s0 = sp0[(long)c * HW], s1 = sp1[(long)c * HW];
-            ss0 = fmaf(s0, s0, ss0);
-            ss1 = fmaf(s1, s1, ss1);
-            const float4* er = (const float4*)(embT + c * KP);
-#pragma unroll
-            for (int k4 = 0; k4 < KP / 4; ++k4) {
-                const float4 e = er[k4];
-                acc0[4 * k4 + 0] = fmaf(s0, e.x, acc0[4 * k4 + 0]);
-                acc0[4 * k4 + 1] = fmaf(s0, e.y, acc0[4 * k4 + 1]);
-                acc0[4 * k4 + 2] = fmaf(s0, e.z, acc0[4 * k4 + 2]);
-                acc0[4 * k4 + 3] = fmaf(s0, e.w, acc0[4 * k4 + 3]);
-                acc1[4 * k4 + 0] = fmaf(s1, e.x, acc1[4 * k4 + 0]);
-                acc1[4 * k4 + 1] = fmaf(s1, e.y, acc1[4 * k4 + 1]);
-                acc1[4 * k4 + 2] = fmaf(s1, e.z, acc1[4 * k4 + 2]);
-                acc1[4 * k4 + 3] = fmaf(s1, e.w, acc1[4 * k4 + 3]);
-            }
+    auto stage = [&](int k0) {
+        for (int i = threadIdx.x; i < E * KP; i += 256) {
+            const int k = i % KP, c = i / KP;                    // conflict-free LDS writes; the 70 KB matrix is L2-resident
+            embT[i] = (k0 + k < K) ? embed[(long)(k0 + k) * E + c] : 0.f;
         }
-        pred[(long)b * HW + p0] = argmax_finish<KP>(acc0, ss0, en, K, mode, unseen_bits, seenmask, target, b, p0, HW);
-        if (ok1) pred[(long)b * HW + p1] = argmax_finish<KP>(acc1, ss1, en, K, mode, unseen_bits, seenmask, target, b, p1, HW);
+        __syncthreads();
+        if (threadIdx.x < KP) {
+            float s = 0.f;
+            for (int c = 0; c < E; ++c) { const float v = embT[c * KP + threadIdx.x]; s = fmaf(v, v, s); }
+            const float n = sqrtf(s);
+            en[threadIdx.x] = (n == 0.f) ? 1.f : n;     // utils.py:175
+        }
+        __syncthreads();
+    };
+    if (!CHUNKS) stage(0);
+    for (long p0 = (long)blockIdx.x * 512 + threadIdx.x; CHUNKS ? (p0 < (long)blockIdx.x * 512 + 256) : (p0 < HW);
+         p0 += (long)gridDim.x * 512) {
+        const long p1 = p0 + 256;
+        const bool ok0 = p0 < HW, ok1 = p1 < HW;
+        const float* sp0 = sb + (ok0 ? p0 : 0);
+        const float* sp1 = sb + (ok1 ? p1 : (ok0 ? p0 : 0));
+        Best r0{0.f, 0.f, 0, 0}, r1{0.f, 0.f, 0, 0};
+        float sn0 = 0.f, sn1 = 0.f;
+        for (int k0 = 0; k0 < (CHUNKS ? K : 1); k0 += KP) {
+            if (CHUNKS) {
+                __syncthreads();                                 // the previous chunk's readers are done with the table
+                stage(k0);
+            }
+            float acc0[KP], acc1[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
+            float ss0 = 0.f, ss1 = 0.f;
+            for (int c = 0; c < E; ++c) {
+                const float s0 = sp0[(long)c * HW], s1 = sp1[(long)c * HW];
+                ss0 = fmaf(s0, s0, ss0);
+                ss1 = fmaf(s1, s1, ss1);
+                const float4* er = (const float4*)(embT + c * KP);
+#pragma unroll
+                for (int k4 = 0; k4 < KP / 4; ++k4) {
+                    const float4 e = er[k4];
+                    acc0[4 * k4 + 0] = fmaf(s0, e.x, acc0[4 * k4 + 0]);
+                    acc0[4 * k4 + 1] = fmaf(s0, e.y, acc0[4 * k4 + 1]);
+                    acc0[4 * k4 + 2] = fmaf(s0, e.z, acc0[4 * k4 + 2]);
+                    acc0[4 * k4 + 3] = fmaf(s0, e.w, acc0[4 * k4 + 3]);
+                    acc1[4 * k4 + 0] = fmaf(s1, e.x, acc1[4 * k4 + 0]);
+                    acc1[4 * k4 + 1] = fmaf(s1, e.y, acc1[4 * k4 + 1]);
+                    acc1[4 * k4 + 2] = fmaf(s1, e.z, acc1[4 * k4 + 2]);
+                    acc1[4 * k4 + 3] = fmaf(s1, e.w, acc1[4 * k4 + 3]);
+                }
+            }
+            sn0 = sqrtf(ss0);
+            sn1 = sqrtf(ss1);
+            const uint64_t word = class_word(unseen, k0 >> 6);
+            argmax_update<KP>(r0, acc0, sn0, en, k0, K, mode, word);
+            argmax_update<KP>(r1, acc1, sn1, en, k0, K, mode, word);
+        }
+        if (ok0) pred[(long)b * HW + p0] = argmax_pick(r0, mode, unseen, seenmask, target, b, p0, HW);
+        if (ok1) pred[(long)b * HW + p1] = argmax_pick(r1, mode, unseen, seenmask, target, b, p1, HW);
     }
 }
 
 // ---- confusion histogram -------------------------------------------------------------------------------
+// LDS == true: per-block counters in LDS (nh K^2 x 4 B: K <= 64), merged into the int64 histogram at the end; LDS == false (more
+// classes than that): the merged runs go to the global counters directly
+template <bool LDS>
 __global__ __launch_bounds__(256) void hist_kernel(const int64_t* __restrict__ lt, const int64_t* __restrict__ lp, long n,
-                                                   int K, uint64_t unseen_bits, unsigned long long* __restrict__ hist) {
+                                                   int K, int nh, ClassBits unseen, unsigned long long* __restrict__ hist) {
     extern __shared__ unsigned int hl[];   // [nh][K*K]
-    const int nh = unseen_bits ? 3 : 1;
-    for (int i = threadIdx.x; i < nh * K * K; i += 256) hl[i] = 0;
-    __syncthreads();
-    // a thread takes 8 consecutive pixels and merges runs of equal (true, predicted) pairs into one LDS atomic: label maps are
+    if (LDS) {
+        for (int i = threadIdx.x; i < nh * K * K; i += 256) hl[i] = 0;
+        __syncthreads();
+    }
+    // a thread takes 8 consecutive pixels and merges runs of equal (true, predicted) pairs into one atomic: label maps are
     // piecewise constant, and one atomic per pixel on a handful of hot counters serialised the block
     auto flush = [&](int idx, unsigned cnt, long t) {
         if (idx < 0 || !cnt) return;
-        atomicAdd(&hl[idx], cnt);
-        if (unseen_bits) atomicAdd(&hl[(((unseen_bits >> t) & 1ull) ? 2 : 1) * K * K + idx], cnt);
+        const int idx2 = (in_set(unseen, t) ? 2 : 1) * K * K + idx;
+        if (LDS) {
+            atomicAdd(&hl[idx], cnt);
+            if (nh > 1) atomicAdd(&hl[idx2], cnt);
+        } else {
+            atomicAdd(&hist[idx], (unsigned long long)cnt);
+            if (nh > 1) atomicAdd(&hist[idx2], (unsigned long long)cnt);
+        }
     };
     for (long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i0 < n; i0 += (long)gridDim.x * 256 * 8) {
         int cur = -1; unsigned cnt = 0; long curt = 0;
@@ -577,9 +603,11 @@ __global__ __launch_bounds__(256) void hist_kernel(const int64_t* __restrict__ l
         }
         flush(cur, cnt, curt);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nh * K * K; i += 256)
-        if (hl[i]) atomicAdd(&hist[i], (unsigned long long)hl[i]);
+    if (LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nh * K * K; i += 256)
+            if (hl[i]) atomicAdd(&hist[i], (unsigned long long)hl[i]);
+    }
 }
 
 inline int grid_for(long n, int cap) {
@@ -804,48 +832,85 @@ extern "C" int szn_ce2d_bwd(int B, int C, int H, int W, const float* score, cons
     return SZN_OK;
 }
 
-extern "C" int szn_embed_argmax(int B, int E, int H, int W, int K, const float* score, const float* embed, int mode,
-                                uint64_t unseen_bits, const float* seenmask, const int64_t* target, int64_t* pred,
-                                szn_stream_t stream) {
+namespace {
+int embed_argmax_impl(int B, int E, int H, int W, int K, const float* score, const float* embed, int mode, const ClassBits& unseen,
+                      const float* seenmask, const int64_t* target, int64_t* pred, szn_stream_t stream) {
     if (!score || !embed || !pred || B <= 0 || E <= 0 || H <= 0 || W <= 0 || K <= 0)
         SZN_FAIL(SZN_ERR_ARG, "embed_argmax: bad argument");
-    if (K > 64) SZN_FAIL(SZN_ERR_UNSUPPORTED, "embed_argmax: K=%d > 64", K);
+    if (K > SZN_MAX_CLASSES) SZN_FAIL(SZN_ERR_UNSUPPORTED, "embed_argmax: K=%d > %d", K, SZN_MAX_CLASSES);
     if (mode != 0 && mode != 1) SZN_FAIL(SZN_ERR_ARG, "embed_argmax: bad mode %d", mode);
     if (mode == 1 && !seenmask && !target) SZN_FAIL(SZN_ERR_ARG, "embed_argmax: mode 1 needs seenmask or target");
+    if (!class_bits_fit(unseen, K)) SZN_FAIL(SZN_ERR_ARG, "embed_argmax: the unseen set names a class >= K = %d", K);
     const int HW = H * W;
-    // 512-pixel tiles, ~2 blocks per CU in total (the LDS table allows two resident blocks): a block stages the table once
+    // 512-pixel tiles, ~2 blocks per CU in total (the LDS table allows two resident blocks): a block stages the table once.
+    // K > 64: one tile per block (the table is re-staged per 64-class chunk, the running best stays in registers)
+    const bool chunks = K > 64;
     int nblk = (HW + 511) / 512;
     const int cap = (512 + B - 1) / B;
-    if (nblk > cap) nblk = cap;
+    if (!chunks && nblk > cap) nblk = cap;
     const int KP = K <= 24 ? 24 : (K <= 40 ? 40 : 64);
     const size_t lds = ((size_t)E * KP + KP) * sizeof(float);
     if (lds > kMaxDynLds) SZN_FAIL(SZN_ERR_UNSUPPORTED, "embed_argmax: E*KP*4 = %zu B exceeds the LDS budget", lds);
     hipStream_t st = (hipStream_t)stream;
-#define SZN_LAUNCH_AM(KPV)                                                                                             \
+#define SZN_LAUNCH_AM(KPV, CH)                                                                                         \
     do {                                                                                                               \
-        auto kern = embed_argmax_kernel<KPV>;                                                                          \
+        auto kern = embed_argmax_kernel<KPV, CH>;                                                                      \
         if (lds > 48 * 1024)                                                                                           \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         hipLaunchKernelGGL(kern, dim3(nblk, B), dim3(256), lds, st, score, embed, seenmask, target, pred, E, HW, K,    \
-                           mode, unseen_bits);                                                                         \
+                           mode, unseen);                                                                              \
     } while (0)
-    if (KP == 24) SZN_LAUNCH_AM(24);
-    else if (KP == 40) SZN_LAUNCH_AM(40);
-    else SZN_LAUNCH_AM(64);
+    if (chunks) SZN_LAUNCH_AM(64, true);
+    else if (KP == 24) SZN_LAUNCH_AM(24, false);
+    else if (KP == 40) SZN_LAUNCH_AM(40, false);
+    else SZN_LAUNCH_AM(64, false);
 #undef SZN_LAUNCH_AM
-    SZN_CHECK_LAUNCH("embed_argmax_kernel");
+    SZN_CHECK_LAUNCH(chunks ? "embed_argmax_kernel_chunks" : "embed_argmax_kernel");
     return SZN_OK;
+}
+
+int confusion_hist_impl(long npix, int K, const int64_t* label_true, const int64_t* label_pred, const ClassBits& unseen,
+                        int64_t* hist, szn_stream_t stream) {
+    if (!label_true || !label_pred || !hist || npix <= 0 || K <= 0 || K > SZN_MAX_CLASSES)
+        SZN_FAIL(SZN_ERR_ARG, "confusion_hist: bad argument");
+    if (!class_bits_fit(unseen, K)) SZN_FAIL(SZN_ERR_ARG, "confusion_hist: the unseen set names a class >= K = %d", K);
+    const int nh = class_bits_any(unseen) ? 3 : 1;
+    const dim3 grid(grid_for((npix + 7) / 8, 256));
+    if (K <= 64) {
+        const size_t lds = (size_t)nh * K * K * sizeof(unsigned int);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)hist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(hist_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, label_true, label_pred, npix, K, nh, unseen,
+                           (unsigned long long*)hist);
+        SZN_CHECK_LAUNCH("hist_kernel");
+    } else {
+        hipLaunchKernelGGL(hist_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, label_true, label_pred, npix, K, nh, unseen,
+                           (unsigned long long*)hist);
+        SZN_CHECK_LAUNCH("hist_kernel_global");
+    }
+    return SZN_OK;
+}
+}  // namespace
+
+extern "C" int szn_embed_argmax(int B, int E, int H, int W, int K, const float* score, const float* embed, int mode,
+                                uint64_t unseen_bits, const float* seenmask, const int64_t* target, int64_t* pred,
+                                szn_stream_t stream) {
+    if (K > 64) SZN_FAIL(SZN_ERR_UNSUPPORTED, "embed_argmax: K=%d > 64 needs szn_embed_argmax_k (szn_class_set)", K);
+    return embed_argmax_impl(B, E, H, W, K, score, embed, mode, class_bits64(unseen_bits), seenmask, target, pred, stream);
+}
+
+extern "C" int szn_embed_argmax_k(int B, int E, int H, int W, int K, const float* score, const float* embed, int mode,
+                                  const szn_class_set* unseen, const float* seenmask, const int64_t* target, int64_t* pred,
+                                  szn_stream_t stream) {
+    return embed_argmax_impl(B, E, H, W, K, score, embed, mode, class_bits(unseen), seenmask, target, pred, stream);
 }
 
 extern "C" int szn_confusion_hist(long npix, int K, const int64_t* label_true, const int64_t* label_pred,
                                   uint64_t unseen_bits, int64_t* hist, szn_stream_t stream) {
-    if (!label_true || !label_pred || !hist || npix <= 0 || K <= 0 || K > 64)
-        SZN_FAIL(SZN_ERR_ARG, "confusion_hist: bad argument");
-    const int nh = unseen_bits ? 3 : 1;
-    const size_t lds = (size_t)nh * K * K * sizeof(unsigned int);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(hist_kernel, dim3(grid_for((npix + 7) / 8, 256)), dim3(256), lds, (hipStream_t)stream, label_true, label_pred,
-                       npix, K, unseen_bits, (unsigned long long*)hist);
-    SZN_CHECK_LAUNCH("hist_kernel");
-    return SZN_OK;
+    if (K > 64) SZN_FAIL(SZN_ERR_ARG, "confusion_hist: K=%d > 64 needs szn_confusion_hist_k (szn_class_set)", K);
+    return confusion_hist_impl(npix, K, label_true, label_pred, class_bits64(unseen_bits), hist, stream);
+}
+
+extern "C" int szn_confusion_hist_k(long npix, int K, const int64_t* label_true, const int64_t* label_pred,
+                                    const szn_class_set* unseen, int64_t* hist, szn_stream_t stream) {
+    return confusion_hist_impl(npix, K, label_true, label_pred, class_bits(unseen), hist, stream);
 }

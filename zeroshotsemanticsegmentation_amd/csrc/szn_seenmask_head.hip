@@ -46,7 +46,7 @@ __device__ __forceinline__ void block_sum8(float (&v)[8], float (*red)[8], float
 // part[blk] = {sum of loss terms, valid pixels, conf[0..3]} (doubles); cellpart[cell][di][dj][ci]; slab[blk][kTaps]
 template <bool GRAD>
 __global__ __launch_bounds__(256) void smh_cell_kernel(const float* __restrict__ coarse, const float* __restrict__ wt,
-                                                       const int64_t* __restrict__ target, int n_class, uint64_t seen_bits,
+                                                       const int64_t* __restrict__ target, int n_class, ClassBits seen,
                                                        int64_t* __restrict__ pred, double* __restrict__ part,
                                                        float* __restrict__ cellpart, float* __restrict__ slab, SmhGeom g) {
     __shared__ float red[4][8];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void smh_cell_kernel(const float* __restrict__
             bool valid = true;
             // labels below -1 are batch PADDING (datasets.pad_collate writes -2): not a pixel of any image, so it is neither a
             // target nor counted -- unlike -1 ("unlabelled"), which the reference turns into target 0 (trainer_seenmask.py:55-56)
-            if (n_class > 0) { valid = lbl >= -1; tb = (lbl >= 0 && lbl < n_class && ((seen_bits >> lbl) & 1ull)) ? 1 : 0; }
+            if (n_class > 0) { valid = lbl >= -1; tb = (lbl < n_class && in_set(seen, lbl)) ? 1 : 0; }
             else { valid = lbl >= 0 && lbl < 2; tb = (int)lbl; }
             if (!valid) continue;
             const float mx = am ? s1 : s0;
@@ -317,13 +317,13 @@ extern "C" size_t szn_seenmask_head_workspace_bytes(int B, int h, int w, int H, 
     return align256(256 * 6 * sizeof(double)) + align256((size_t)ncell * 8 * sizeof(float)) + (size_t)256 * kTaps * sizeof(float);
 }
 
-extern "C" int szn_seenmask_head(int B, int h, int w, int ldc, int c0, int H, int W, int crop, const float* coarse,
-                                 const float* weight, const int64_t* target, int n_class, uint64_t seen_bits, float* loss,
-                                 float* stats, int64_t* conf, int64_t* pred, float* dscore2, float* dweight, void* workspace,
-                                 szn_stream_t stream) {
+namespace {
+int seenmask_head_impl(int B, int h, int w, int ldc, int c0, int H, int W, int crop, const float* coarse, const float* weight,
+                       const int64_t* target, int n_class, const ClassBits& seen_bits, float* loss, float* stats, int64_t* conf,
+                       int64_t* pred, float* dscore2, float* dweight, void* workspace, szn_stream_t stream) {
     if (B < 1 || h < 1 || w < 1 || H < 1 || W < 1 || crop < 0) SZN_FAIL(SZN_ERR_ARG, "szn_seenmask_head: bad geometry");
     if (!coarse || !weight || !target || !loss || !workspace) SZN_FAIL(SZN_ERR_ARG, "szn_seenmask_head: null pointer");
-    if (n_class < 0 || n_class > 64) SZN_FAIL(SZN_ERR_UNSUPPORTED, "szn_seenmask_head: n_class %d > 64 (seen_bits is 64 bits)", n_class);
+    if (n_class < 0 || n_class > SZN_MAX_CLASSES) SZN_FAIL(SZN_ERR_UNSUPPORTED, "szn_seenmask_head: n_class %d > %d", n_class, SZN_MAX_CLASSES);
     if ((dscore2 == nullptr) != (dweight == nullptr)) SZN_FAIL(SZN_ERR_ARG, "szn_seenmask_head: dscore2 and dweight go together");
     // every tap of a pixel must exist or be outside the map on the low side only when crop says so: (Y>>5) <= h
     if (((crop + H - 1) >> 5) > h || ((crop + W - 1) >> 5) > w)
@@ -345,6 +345,24 @@ extern "C" int szn_seenmask_head(int B, int h, int w, int ldc, int c0, int H, in
                                                                grad ? dweight : nullptr, g);
     SZN_CHECK_LAUNCH("smh_finalize_kernel");
     return SZN_OK;
+}
+}  // namespace
+
+extern "C" int szn_seenmask_head(int B, int h, int w, int ldc, int c0, int H, int W, int crop, const float* coarse,
+                                 const float* weight, const int64_t* target, int n_class, uint64_t seen_bits, float* loss,
+                                 float* stats, int64_t* conf, int64_t* pred, float* dscore2, float* dweight, void* workspace,
+                                 szn_stream_t stream) {
+    if (n_class > 64) SZN_FAIL(SZN_ERR_UNSUPPORTED, "szn_seenmask_head: n_class %d > 64 needs szn_seenmask_head_k (szn_class_set)", n_class);
+    return seenmask_head_impl(B, h, w, ldc, c0, H, W, crop, coarse, weight, target, n_class, class_bits64(seen_bits), loss, stats, conf,
+                              pred, dscore2, dweight, workspace, stream);
+}
+
+extern "C" int szn_seenmask_head_k(int B, int h, int w, int ldc, int c0, int H, int W, int crop, const float* coarse,
+                                   const float* weight, const int64_t* target, int n_class, const szn_class_set* seen, float* loss,
+                                   float* stats, int64_t* conf, int64_t* pred, float* dscore2, float* dweight, void* workspace,
+                                   szn_stream_t stream) {
+    return seenmask_head_impl(B, h, w, ldc, c0, H, W, crop, coarse, weight, target, n_class, class_bits(seen), loss, stats, conf, pred,
+                              dscore2, dweight, workspace, stream);
 }
 
 extern "C" size_t szn_seenmask_score_wgrad_workspace_bytes(long M, int F) {

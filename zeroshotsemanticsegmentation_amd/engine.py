@@ -17,7 +17,6 @@ import torch.distributed as dist
 from . import _lib as L
 from . import synth
 from .models import CROP, CROP_POOL3, CROP_POOL4, CROP_UP8, opt_layers
-from .synth import unseen_bits
 
 
 class GradBuckets(object):
@@ -135,8 +134,8 @@ class SeenmaskStep(object):
                  process_group=None):
         """n_class / unseen: the binary target of a pixel is "its label is one of the n_class classes and not in `unseen`"
         (trainer_seenmask.py:53-56); n_class = 0: step() is handed {0,1} targets already (other values are ignored)"""
-        if n_class > 64:
-            raise L.SznError("SeenmaskStep: at most 64 classes (seen_bits is a 64-bit mask), got %d" % n_class)
+        if n_class > L.MAX_CLASSES:
+            raise L.SznError("SeenmaskStep: at most %d classes (szn_class_set), got %d" % (L.MAX_CLASSES, n_class))
         self.model, self.eng = model, model._engine
         if precision is not None:
             model.set_precision(precision)
@@ -144,10 +143,7 @@ class SeenmaskStep(object):
         if self.dev.type != "cuda":
             raise L.SznError("SeenmaskStep needs the model on the GPU")
         self.n_class = int(n_class)
-        self.seen_bits = 0
-        for k in range(self.n_class):
-            if k not in set(unseen):
-                self.seen_bits |= 1 << k
+        self.seen = L.class_set(k for k in range(self.n_class) if k not in set(unseen))
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -207,8 +203,8 @@ class SeenmaskStep(object):
         pred = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
         (ow, nw), (ou, nu), (ob, nbias) = self.seg["score_w"], self.seg["up_w"], self.seg["score_b"]
         g = self.flat_g
-        L.call("szn_seenmask_head", B, ctx.h, ctx.w, CP, E, H, W, CROP, L.ptr(ctx.coarse), L.ptr(self.flat_p[ou:ou + nu]),
-               L.ptr(target), self.n_class, self.seen_bits, L.ptr(self.loss), L.ptr(self.stats), L.ptr(self.conf), L.ptr(pred),
+        L.call("szn_seenmask_head_k", B, ctx.h, ctx.w, CP, E, H, W, CROP, L.ptr(ctx.coarse), L.ptr(self.flat_p[ou:ou + nu]),
+               L.ptr(target), self.n_class, self.seen, L.ptr(self.loss), L.ptr(self.stats), L.ptr(self.conf), L.ptr(pred),
                L.ptr(dsc), L.ptr(g[ou:ou + nu]), L.ptr(self._ws), st)
         feat = ctx.relu7
         L.call("szn_seenmask_score_wgrad", L.dtype_code(feat.dtype), M, F, F, L.ptr(feat), L.ptr(dsc), L.ptr(g[ow:ow + nw]),
@@ -472,7 +468,7 @@ class TrainStep(object):
             bwd = "szn_cosine_loss_bwd" if self.loss_kind == "cos" else "szn_mse_loss_bwd"
             L.call(fwd, B, E, H, W, K, L.ptr(f), L.ptr(target), L.ptr(self.emb), None, L.ptr(self.loss), L.ptr(stats),
                    L.ptr(ws), st)
-            L.call("szn_embed_argmax", B, E, H, W, K, L.ptr(f), L.ptr(self.emb), 0, 0, None, None, L.ptr(pred), st)
+            L.call("szn_embed_argmax_k", B, E, H, W, K, L.ptr(f), L.ptr(self.emb), 0, None, None, None, L.ptr(pred), st)
             df = torch.empty_like(f)
             L.call(bwd, B, E, H, W, K, L.ptr(f), L.ptr(target), L.ptr(self.emb), None, L.ptr(stats), None, L.ptr(df), st)
             dc32, _ = eng.head_backward(ctx, df=df)
@@ -484,7 +480,7 @@ class TrainStep(object):
         self.buckets.finish()
         self._optimizer_step()
         if self.train_metrics:
-            L.call("szn_confusion_hist", target.numel(), K, L.ptr(target), L.ptr(pred), 0, L.ptr(self.hist), st)
+            L.call("szn_confusion_hist_k", target.numel(), K, L.ptr(target), L.ptr(pred), None, L.ptr(self.hist), st)
         return self.loss.reshape(()), pred
 
     # ---- FCN8s head chain (forward and backward by hand: no autograd objects on the step path) ----------------------------
@@ -576,7 +572,7 @@ class TrainStep(object):
         self.buckets.finish()
         self._optimizer_step()
         if self.train_metrics:
-            L.call("szn_confusion_hist", target.numel(), K, L.ptr(target), L.ptr(pred), 0, L.ptr(self.hist), st)
+            L.call("szn_confusion_hist_k", target.numel(), K, L.ptr(target), L.ptr(pred), None, L.ptr(self.hist), st)
         return self.loss.reshape(()), pred
 
     def _backward(self, ctx, dcoarse, layer_done):

@@ -920,23 +920,20 @@ class FCN32s(nn.Module):
         int64 class labels.  -> (loss 0-dim tensor, pred (B,H,W) int64 device tensor).
         Same numbers as forward(mode='seenmask') + utils.cross_entropy2d / channel_argmax (bit-identical score arithmetic).
         Used by trainer_seenmask.Trainer.validate."""
-        if n_class > 64:
-            raise L.SznError("seenmask_predict: at most 64 classes (64-bit seen mask), got %d" % n_class)
+        if n_class > L.MAX_CLASSES:
+            raise L.SznError("seenmask_predict: at most %d classes (szn_class_set), got %d" % (L.MAX_CLASSES, n_class))
         eng = self._engine
         with torch.no_grad():
             ctx = eng.forward(x.detach(), train=False, keep=False)
             dev = ctx.coarse.device
             B, H, W = ctx.B, ctx.H, ctx.W
             tgt = target.to(device=dev, dtype=torch.int64).contiguous()
-            seen_bits = 0
-            for k in range(n_class):
-                if k not in set(unseen):
-                    seen_bits |= 1 << k
+            seen = L.class_set(k for k in range(n_class) if k not in set(unseen))
             pred = torch.empty(B, H, W, dtype=torch.int64, device=dev)
             loss = torch.empty(1, device=dev)
             ws = torch.empty(L.load().szn_seenmask_head_workspace_bytes(B, ctx.h, ctx.w, H, W, CROP), dtype=torch.uint8, device=dev)
-            L.call("szn_seenmask_head", B, ctx.h, ctx.w, self.head_width, self.n_class, H, W, CROP, L.ptr(ctx.coarse),
-                   L.ptr(eng._images["up.w"]), L.ptr(tgt), n_class, seen_bits, L.ptr(loss), None, None, L.ptr(pred), None, None,
+            L.call("szn_seenmask_head_k", B, ctx.h, ctx.w, self.head_width, self.n_class, H, W, CROP, L.ptr(ctx.coarse),
+                   L.ptr(eng._images["up.w"]), L.ptr(tgt), n_class, seen, L.ptr(loss), None, None, L.ptr(pred), None, None,
                    L.ptr(ws), L.stream_ptr())
         return loss.reshape(()), pred
 
@@ -1161,8 +1158,8 @@ class FCN8s(FCN32s):
         emb = torch.as_tensor(embeddings).to(dev, torch.float32).contiguous()
         if emb.shape[1] != self.n_class:
             raise L.SznError("embedding dimension %d != model n_class %d" % (emb.shape[1], self.n_class))
-        if emb.shape[0] > 64:
-            raise L.SznError("the fused head holds at most 64 classes, got %d: use forward() + utils" % emb.shape[0])
+        if emb.shape[0] > L.MAX_CLASSES:
+            raise L.SznError("the fused head holds at most %d classes, got %d: use forward() + utils" % (L.MAX_CLASSES, emb.shape[0]))
         return emb
 
     def embed_loss(self, x, embeddings, target, dropout_masks=None):

@@ -217,7 +217,7 @@ class Trainer(object):
                 gsum = float('nan')                  # not read back on this path (a host sync per iteration for a debug print)
                 ssum = float('nan')                  # the (B,E,H,W) score is never materialised on this path
             elif (hasattr(self.model, 'embed_loss') and self._fused_step and self.pixel_embeddings and self.loss_func == "cos"
-                  and not self.forced_unseen and self.embeddings.shape[0] <= 64):
+                  and not self.forced_unseen and self.embeddings.shape[0] <= 256):
                 # FCN8s: autograd chain with the fused-from-1/8-map head (no (n,E,h,w) score), per-tensor fused optimizer
                 data, target, _ = self._unpack(data, target)
                 loss, pred = self.model.embed_loss(data, self.embeddings, target)
@@ -258,7 +258,7 @@ class Trainer(object):
         """forward + loss + class assignment with everything left on the GPU -> (score, loss 0-dim, pred (n,h,w), target)"""
         data, target, target_embed = self._unpack(data, target)
         if (self.pixel_embeddings and self.loss_func == "cos" and not szn and not self.forced_unseen and target_embed is None
-                and not self.verbose_val and self.embeddings.shape[0] <= 64):
+                and not self.verbose_val and self.embeddings.shape[0] <= 256):
             # plain embedding inference: loss + class assignment straight from the 1/32 map (no (n,E,h,w) score in HBM)
             loss, pred = self.model.embed_predict(data, self.embeddings, target)
             return None, loss, pred, target

@@ -181,7 +181,7 @@ class Trainer(object):
                 # a loader that is not already sharded per rank (train.py shards it: each rank decodes only its own images)
                 if world > 1 and not getattr(self.val_loader, 'szn_sharded', False) and batch_idx % world != self.rank:
                     continue
-                if self._fused_step and self.n_class <= 64:
+                if self._fused_step and self.n_class <= 256:
                     # loss + prediction straight from the 1/32 map (models.FCN32s.seenmask_predict): no (n,2,h,w) score
                     if isinstance(target, (tuple, list)):
                         target = target[0]

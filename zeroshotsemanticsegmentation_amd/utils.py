@@ -20,7 +20,6 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .synth import unseen_bits
 
 
 def load_obj(name):
@@ -195,8 +194,8 @@ def infer_lbl_device(score, embed_arr, mode=0, unseen=None, seenmask=None, targe
     pred = torch.empty(B, H, W, dtype=torch.int64, device=score.device)
     sm = None if seenmask is None else _data(seenmask).to(score.device).contiguous().float()
     tg = None if target is None else _data(target).to(device=score.device, dtype=torch.int64).contiguous()
-    L.call("szn_embed_argmax", B, E, H, W, emb.shape[0], L.ptr(score), L.ptr(emb), mode,
-           unseen_bits(unseen or []), L.ptr(sm), L.ptr(tg), L.ptr(pred), L.stream_ptr())
+    L.call("szn_embed_argmax_k", B, E, H, W, emb.shape[0], L.ptr(score), L.ptr(emb), mode,
+           L.class_set(unseen), L.ptr(sm), L.ptr(tg), L.ptr(pred), L.stream_ptr())
     return pred
 
 
@@ -244,7 +243,7 @@ def confusion_hist_device(label_true, label_pred, n_class, unseen=None, hist=Non
     lp = _data(label_pred).to(device=lt.device, dtype=torch.int64).contiguous()
     if hist is None:
         hist = torch.zeros(3, n_class, n_class, dtype=torch.int64, device=lt.device)
-    L.call("szn_confusion_hist", lt.numel(), n_class, L.ptr(lt), L.ptr(lp), unseen_bits(unseen or []), L.ptr(hist),
+    L.call("szn_confusion_hist_k", lt.numel(), n_class, L.ptr(lt), L.ptr(lp), L.class_set(unseen), L.ptr(hist),
            L.stream_ptr())
     return hist
 
