@@ -341,7 +341,7 @@ def sub_record(args):
         m = models.FCN32s(n_class=E)
         m.load_synthetic(1337, device=dev)
         m.train()
-        ts = engine.TrainStep(m, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=True)
+        ts = engine.TrainStep(m, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=True, keep_grads=False)
         x = torch.from_numpy(synth.make_images(B, H, H, seed=1337)).to(dev)
         t = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337, classes=seen)).to(dev)
         return m, ts, x, t
@@ -380,7 +380,7 @@ def sub_record(args):
             m = models.FCN32s(n_class=E)
             m.load_synthetic(1337, device=dev)
             m.train()
-            steps[name] = engine.TrainStep(m, emb_np, optimizer="adam", lr=1e-5, precision=torch.bfloat16, fused_head=True, **kw)
+            steps[name] = engine.TrainStep(m, emb_np, optimizer="adam", lr=1e-5, precision=torch.bfloat16, fused_head=True, keep_grads=False, **kw)
         n = max(args.steps, 10)
         times = {name: [] for name, _ in variants}
         for rnd in range(3):                                   # interleaved rounds: box drift hits every variant alike
@@ -522,7 +522,9 @@ def main():
     target_all = torch.from_numpy(synth.make_labels(B, H, H, K, seed=4337 + rank)).to(dev)
 
     def make_phase1():
-        return engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype,
+        # keep_grads=False like trainer_fcn.Trainer: the loop calls zero_grad() next (train.py:170-175), so fc6 / fc7's gradients --
+        # consumed by the Adam step inside their weight-gradient kernel on one rank -- are not also written out
+        return engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype, keep_grads=False,
                                 fused_head=not (args.unfused_head and args.arch == "fcn32s"))
 
     def make_phase1_fcn8s():

@@ -161,6 +161,22 @@ int szn_conv2d_dgrad_gemm_native(const szn_conv_desc_t* d, const void* dout, con
  * zero or hold a running gradient); accumulate == 0 zeroes dw first on the same stream.           */
 int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw,
                      int accumulate, szn_stream_t stream);
+/* Weight gradient + Adam step of the layer's weights in ONE launch (fc6 / fc7, i.e. the layers szn_conv2d_wgrad gives to
+ * conv_wgrad_wide: szn_conv2d_wgrad_adam_supported == 1).  Equivalent to szn_conv2d_wgrad(accumulate = 0) followed by szn_adam_step
+ * over the layer's slice (train.py:130-133,174-175: loss.backward(); optim.step()), bit for bit; only valid where the gradient
+ * is final when the kernel ends (one rank, no gradient accumulation, no dynamic loss scale).  param / exp_avg / exp_avg_sq (f32)
+ * and w_lp (optional image of the compute dtype) in the gradient's OHWI order; dw may be NULL (gradient not stored).
+ * SZN_ERR_UNSUPPORTED (nothing launched) for other layers.                                                              */
+typedef struct szn_adam_args {
+    float* param; float* exp_avg; float* exp_avg_sq;
+    void* w_lp; int w_lp_dtype;
+    float lr, beta1, beta2, eps, weight_decay;
+    int step;              /* 1-based, like szn_adam_step */
+    float grad_scale;
+} szn_adam_args_t;
+int szn_conv2d_wgrad_adam_supported(const szn_conv_desc_t* d);
+int szn_conv2d_wgrad_adam(const szn_conv_desc_t* d, const void* x, const void* dout, float* dw,
+                          const szn_adam_args_t* opt, szn_stream_t stream);
 
 /* db[n] (+)= sum_m dout[m][n], m < M rows with pixel stride ldd.                                  */
 int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,

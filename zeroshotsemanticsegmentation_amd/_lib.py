@@ -32,6 +32,13 @@ class DeviceInfo(C.Structure):
                 ("clock_mhz", C.c_int)]
 
 
+class AdamArgs(C.Structure):
+    """szn_adam_args_t (include/szn.h): state and hyper-parameters of the Adam step fused into szn_conv2d_wgrad_adam"""
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("w_lp", C.c_void_p),
+                ("w_lp_dtype", C.c_int), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("step", C.c_int), ("grad_scale", C.c_float)]
+
+
 MAX_CLASSES = 256           # SZN_MAX_CLASSES
 
 
@@ -74,6 +81,8 @@ SIGNATURES = {
     "szn_conv2d_dgrad_gemm_native_workspace_bytes": (C.c_size_t, [_D]),
     "szn_conv2d_dgrad_gemm_native": (_I, [_D, _P, _P, _P, _P]),
     "szn_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
+    "szn_conv2d_wgrad_adam_supported": (_I, [_D]),
+    "szn_conv2d_wgrad_adam": (_I, [_D, _P, _P, _P, C.POINTER(AdamArgs), _P]),
     "szn_bias_grad": (_I, [_I, _L, _I, _I, _P, _P, _I, _P]),
     "szn_bias_grad_slab": (_I, [_I, _L, _I, _I, _P, _P, _I, _P, _I, _P]),
     "szn_last_colsum_rows": (_I, []),

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include "../../include/szn.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -23,6 +24,26 @@ void szn_note_colsum_rows(int rows);             /* thread-local: partial rows t
 void szn_note_work_fraction(float f);            /* thread-local: fraction of the dense tiles the last conv call executed (constant-border hint) */
 #define SZN_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); szn_note_kernel(name); \
     if (e__ != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); } while (0)
+
+// ---- Adam, one element (torch.optim.Adam's scalar chain; no contraction: -ffp-contract=off).  Shared by adam_kernel
+//      (szn_elementwise.hip) and the epilogue of conv_wgrad_wide<T, true> (szn_conv2d_wgrad_adam): the same instructions on the same
+//      values, so the fused and the separate update agree bit for bit. ----
+__device__ __forceinline__ float adam_elem(float& pi, float gi, float& mi, float& vi, float b1, float b2, float eps, float wd,
+                                           float step_size, float inv_bc2_sqrt, float gscale) {
+    gi = gi * gscale;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    return pi;
+}
+// host side of the same step: step_size = lr / (1 - beta1^t), inv_bc2_sqrt = 1 / sqrt(1 - beta2^t)
+inline void szn_adam_scalars(float lr, float beta1, float beta2, int step, float* step_size, float* inv_bc2_sqrt) {
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    *step_size = (float)((double)lr / bc1);
+    *inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+}
 
 // ---- class sets ---------------------------------------------------------------------------
 // class sets travel as kernel arguments (4 words = SZN_MAX_CLASSES bits).  Words are picked by selects, not by a dynamic index

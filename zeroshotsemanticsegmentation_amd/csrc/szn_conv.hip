@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ Y
 
 static int launch_col2im(const szn_conv_desc_t* d, const float* Y, void* din, szn_stream_t stream);
 int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
-                            int min_tiles, szn_stream_t stream);
+                            int min_tiles, szn_stream_t stream, const szn_adam_args_t* opt = nullptr);
 
 extern "C" size_t szn_conv2d_dgrad_gemm_workspace_bytes(const szn_conv_desc_t* d) {
     if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->KH <= 0 || d->KW <= 0 || d->Ci <= 0) return 0;

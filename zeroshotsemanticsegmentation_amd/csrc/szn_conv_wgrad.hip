@@ -27,7 +27,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
                             int min_tiles_per_block, szn_stream_t stream);
 
 int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
-                            int min_tiles, szn_stream_t stream);
+                            int min_tiles, szn_stream_t stream, const szn_adam_args_t* opt = nullptr);
 
 namespace {
 
@@ -284,6 +284,42 @@ void launch_wg2(const Wg2Args& a, long blocks, hipStream_t st) {
 }
 
 }  // namespace
+
+// Weight gradient + Adam in one launch (fc6 / fc7: the layers that take conv_wgrad_wide, 89 % of the weights).  The separate optimizer
+// pass streams 30 B per weight (gradient, master, two moments in; master, moments, 16-bit image out) after the backward pass; here the
+// gradient tile is still in LDS when the update is applied, so 4 B per weight are never written and never read back, and the other 26
+// move while the other CUs are in their K loops.  Same arithmetic (adam_elem) on the same gradient values: bit-identical.
+extern "C" int szn_conv2d_wgrad_adam_supported(const szn_conv_desc_t* d) {
+    if (!d || !szn_is16(d->dtype) || d->Co < 256 || d->Ci < 256 || (d->ldi & 7) || (d->ldo & 7) || (d->Ci & 7)) return 0;
+    if (d->KH == 3 && d->KW == 3 && d->workspace) return 0;                  // the all-taps kernel takes these
+    const long cot = szn_div_up(d->Co, 256), cit = szn_div_up(d->Ci, 256);
+    const long tiles = cot * cit * d->KH * d->KW;
+    if (tiles < 96 || (long)d->B * d->Ho * d->Wo >= (1L << 22)) return 0;
+    if (cot * 256 * cit * 256 > (long)d->Co * d->Ci * 5 / 4) return 0;
+    return 1;
+}
+
+extern "C" int szn_conv2d_wgrad_adam(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw,
+                                     const szn_adam_args_t* opt, szn_stream_t stream) {
+    if (!d || !opt) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad_adam: null descriptor / optimizer arguments");
+    const size_t in_bytes = (size_t)d->B * d->Hi * d->Wi * d->ldi * 2;
+    const size_t dout_bytes = (size_t)d->B * d->Ho * d->Wo * d->ldo * 2;
+    const bool ok = szn_is16(d->dtype) && in && dout && d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Ci > 0 && d->Co > 0 && d->KH > 0 &&
+                    d->KW > 0 && d->pad >= 0 && d->Ho == d->Hi + 2 * d->pad - d->KH + 1 && d->Wo == d->Wi + 2 * d->pad - d->KW + 1 &&
+                    d->Ho > 0 && d->Wo > 0 && in_bytes < 0x7fff0000ul && dout_bytes < 0x7fff0000ul &&
+                    !(((uintptr_t)in | (uintptr_t)dout) & 15);
+    if (!ok) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad_adam: bad descriptor / operands");
+    if (!opt->param || !opt->exp_avg || !opt->exp_avg_sq || opt->step < 1)
+        SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad_adam: param / exp_avg / exp_avg_sq / step >= 1 are required");
+    if (((uintptr_t)opt->param | (uintptr_t)opt->exp_avg | (uintptr_t)opt->exp_avg_sq | (uintptr_t)dw) & 15 || ((uintptr_t)opt->w_lp & 7))
+        SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad_adam: master / moments / gradient must be 16-B aligned, the weight image 8-B");
+    if (opt->w_lp && opt->w_lp_dtype != d->dtype) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad_adam: the weight image must have the compute dtype");
+    if (!szn_conv2d_wgrad_adam_supported(d))
+        SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad_adam: this layer does not take conv_wgrad_wide (use szn_conv2d_wgrad + szn_adam_step)");
+    const int rc = szn_conv_wgrad_wide_try(d, in, dout, dw, 0, 96, stream, opt);
+    if (rc > 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad_adam: conv_wgrad_wide declined the layer");
+    return rc;
+}
 
 extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                                 szn_stream_t stream) {

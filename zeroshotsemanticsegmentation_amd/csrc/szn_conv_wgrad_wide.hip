@@ -37,6 +37,11 @@ struct WgwArgs {
     int use_tab;               // 1: pixel -> input-offset table of this block's tap in LDS behind the ring (M <= kTabMax)
     int shift;                 // 1: phase-shifted wave groups (SZN_WGW_SHIFT=0: lockstep)
     int xcd_order;             // 1: an XCD takes a contiguous share of the tiles, cout tile fastest (the B operand is the large one)
+    // conv_wgrad_wide<T, true> (szn_conv2d_wgrad_adam): the Adam step of this layer's weights in the epilogue -- fp32 master, both
+    // moments and the 16-bit weight image, all in the gradient's OHWI order; dw may then be NULL (gradient not stored)
+    float* p; float* m1; float* m2; uint16_t* wlp;
+    float b1, b2, eps, wd, step_size, inv_bc2_sqrt, gscale;
+    int stagger;               // <T, true>: s_sleep(127) units (~4 us) per phase step of the first-round blocks, see the kernel
 };
 
 constexpr unsigned kOOBg = 0x80000000u;
@@ -46,8 +51,8 @@ constexpr int NSTg = 4;
 constexpr int LDS_WGW = NSTg * STAGEg;               // 128 KiB
 constexpr int kTabMax = 8000;                        // pixels whose 4-B table entries fit behind the ring (160 KiB LDS)
 
-template <typename T>      // bf16_raw | f16_raw: only the MFMA opcode differs
-__global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
+template <typename T, bool ADAM>      // T = bf16_raw | f16_raw: only the MFMA opcode (and the weight image's packing) differs
+__global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -167,6 +172,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
     for (int j = 0; j < 4; ++j) offB[j] = KPg * 512 + kk * 512 + (((wn * 8 + j * 2) ^ sw) << 4) + sub;
 
     const int nK = (a.M + KPg - 1) / KPg;
+    if (ADAM && a.stagger > 0 && blockIdx.x < 256) {
+        // With the update in the epilogue a tile is a K loop (MFMA-bound, HBM idle) followed by 1.7 MB of master / moment traffic
+        // (HBM-bound, MFMA idle).  All CUs start together and every tile takes the same time, so the whole chip alternated between
+        // the two phases in lockstep and the launch took the SUM of both (940 us for fc6 at B = 8 against 476 + 523 separately).  The
+        // first block of every CU therefore starts 0 .. 7 eighths of a K loop late (blocks are dealt to the XCDs round-robin, so
+        // blockIdx >> 3 walks the CUs of an XCD): from then on an eighth of the CUs is in each phase of the cycle at any time.
+        const int phase = (blockIdx.x >> 3) & 7;
+        for (int i = 0; i < phase * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     prepare(); fire(0);
     prepare(); if (nK > 1) fire(1);
     prepare(); if (nK > 2) fire(2);
@@ -245,8 +259,35 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
     // ---- epilogue: D[co][ci] (lane: rows co = 4 g + e, column ci = r16) staged through LDS in four 64-row passes so that
     //      every store instruction covers whole 1-KiB rows of the OHWI gradient ----
     constexpr int PT = 256 + 4;
+    const unsigned nwb = (unsigned)a.Co * (unsigned)(a.KH * a.KW * a.Ci) * 4u;           // bytes of one f32 array of this layer
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)a.p, 0, ADAM ? (int)nwb : 0, 0x00020000);
+    const auto rsM = __builtin_amdgcn_make_buffer_rsrc((void*)a.m1, 0, ADAM ? (int)nwb : 0, 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)a.m2, 0, ADAM ? (int)nwb : 0, 0x00020000);
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)a.wlp, 0, ADAM ? (int)(nwb >> 1) : 0, 0x00020000);
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.dw, 0, ADAM ? (int)nwb : 0, 0x00020000);
     float* tile = (float*)smem;                       // 64 x 260 x 4 B = 66,560 B
+#pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
+        // ADAM: the 16-B groups of master / moments this thread updates in this pass (8 of the pass's 4096) are requested before the
+        // tile is staged, so that their latency runs under the LDS round trip; the requests of a block overlap with the K loops of
+        // the other CUs (the launch as a whole becomes HBM-bound: 26 B per weight instead of 4)
+        u32x4_t pq[8], mq[8], vq[8];
+        int eo[8];                                    // element offset in the OHWI gradient (< 2^29: checked by the launcher), -1 = outside
+        if (ADAM) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = tid + it * 512;
+                const int r = idx >> 6, c4 = (idx & 63) * 4;
+                const int co = co0 + pass * 64 + r, ci = ci0 + c4;
+                eo[it] = (co < a.Co && ci < a.Ci) ? ((co * a.KH + kh) * a.KW + kw) * a.Ci + ci : -1;       // Ci % 8 == 0: whole groups
+                // (buffer loads with a 32-bit byte offset: no 64-bit address pair per group has to stay live until the stores;
+                //  an outside group reads offset 0xFFFFFFF0 = out of range = zeros, and is not stored)
+                const unsigned off = eo[it] >= 0 ? (unsigned)eo[it] * 4u : 0xFFFFFFF0u;
+                pq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsP, off, 0, 0);
+                mq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsM, off, 0, 0);
+                vq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsV, off, 0, 0);
+            }
+        }
         __syncthreads();
         if (wm == (pass >> 1)) {
 #pragma unroll
@@ -258,6 +299,37 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
                         tile[(ii * 16 + g * 4 + e) * PT + wn * 64 + j * 16 + r16] = acc[(pass & 1) * 4 + ii][j][e];
         }
         __syncthreads();
+        if (ADAM) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                if (eo[it] < 0) continue;
+                const int idx = tid + it * 512;
+                const int r = idx >> 6, c4 = (idx & 63) * 4;
+                const f32x4_t gq = *(const f32x4_t*)(tile + r * PT + c4);
+                u32x4_t po, mo, vo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = __uint_as_float(pq[it][e]), me = __uint_as_float(mq[it][e]), ve = __uint_as_float(vq[it][e]);
+                    adam_elem(pe, gq[e], me, ve, a.b1, a.b2, a.eps, a.wd, a.step_size, a.inv_bc2_sqrt, a.gscale);
+                    po[e] = __float_as_uint(pe); mo[e] = __float_as_uint(me); vo[e] = __float_as_uint(ve);
+                }
+                const unsigned off = (unsigned)eo[it] * 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(mo, rsM, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(vo, rsV, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(po, rsP, off, 0, 0);
+                if (a.wlp) {
+                    u32x2_t pk;
+                    pk.x = pack2<T>(__uint_as_float(po[0]), __uint_as_float(po[1]));
+                    pk.y = pack2<T>(__uint_as_float(po[2]), __uint_as_float(po[3]));
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, rsL, off >> 1, 0, 0);
+                }
+                if (a.dw) {
+                    const u32x4_t go = u32x4_t{__float_as_uint(gq[0]), __float_as_uint(gq[1]), __float_as_uint(gq[2]), __float_as_uint(gq[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(go, rsG, off, 0, 0);
+                }
+            }
+            continue;
+        }
         for (int idx = tid; idx < 64 * 64; idx += 512) {              // 64 rows x 64 float4
             const int r = idx >> 6, c4 = (idx & 63) * 4;
             const int co = co0 + pass * 64 + r, ci = ci0 + c4;
@@ -282,9 +354,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wide(WgwArgs a) {
 
 // Called by szn_conv2d_wgrad after validation.  Returns 1 if the layer does not fit this kernel.
 int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
-                            int min_tiles, szn_stream_t stream) {
+                            int min_tiles, szn_stream_t stream, const szn_adam_args_t* opt) {
     if (!szn_is16(d->dtype) || d->Co < 256 || d->Ci < 256 || (d->ldi & 7) || (d->ldo & 7) || (d->Ci & 7)) return 1;
     WgwArgs a;
+    a.p = a.m1 = a.m2 = nullptr; a.wlp = nullptr;
+    a.b1 = a.b2 = a.eps = a.wd = a.step_size = a.inv_bc2_sqrt = a.gscale = 0.f;
+    if (opt) {
+        if ((long)d->Co * d->KH * d->KW * d->Ci >= (1L << 29)) return 1;      // 32-bit byte offsets into the f32 arrays (< 2 GiB each)
+        a.p = opt->param; a.m1 = opt->exp_avg; a.m2 = opt->exp_avg_sq; a.wlp = (uint16_t*)opt->w_lp;
+        a.b1 = opt->beta1; a.b2 = opt->beta2; a.eps = opt->eps; a.wd = opt->weight_decay; a.gscale = opt->grad_scale;
+        szn_adam_scalars(opt->lr, opt->beta1, opt->beta2, opt->step, &a.step_size, &a.inv_bc2_sqrt);
+    }
     a.cotiles = szn_div_up(d->Co, 256); a.citiles = szn_div_up(d->Ci, 256);
     const long tiles = (long)a.cotiles * a.citiles * d->KH * d->KW;
     if (tiles < min_tiles || tiles >= (1L << 31) || (long)d->B * d->Ho * d->Wo >= (1L << 22)) return 1;
@@ -300,17 +380,34 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGW_ABLATE"); } a.ablate = abl; }
     { static int tab = -1; if (tab < 0) { const char* e = getenv("SZN_WGW_TAB"); tab = e ? atoi(e) : 1; } a.use_tab = (tab && a.M <= kTabMax) ? 1 : 0; }
     { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_WGW_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
+    a.stagger = 0;
+    if (opt) {
+        // one K step (32 pixels) takes ~1 us per CU; the full stagger spans ~7/8 of a K loop: phase x nK / 32 sleeps of ~4 us
+        static int sg = -2; if (sg == -2) { const char* e = getenv("SZN_WGW_STAGGER"); sg = e ? atoi(e) : -1; }
+        const int nK = (a.M + KPg - 1) / KPg;
+        a.stagger = tiles < 3 * 256 ? 0 : (sg >= 0 ? sg : (nK + 8) / 16);     // (a one-round launch would only start late)
+    }
     { static int xo = -1; if (xo < 0) { const char* e = getenv("SZN_WGW_XCD"); xo = e ? atoi(e) : 1; }
       a.xcd_order = (xo && (size_t)a.in_bytes > 4 * (size_t)a.dout_bytes) ? 1 : 0; }
     const int lds = LDS_WGW + (a.use_tab ? kTabMax * 4 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<bf16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW + kTabMax * 4);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<f16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW + kTabMax * 4);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<bf16_raw, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW + kTabMax * 4);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<f16_raw, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW + kTabMax * 4);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<bf16_raw, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW + kTabMax * 4);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wide<f16_raw, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGW + kTabMax * 4);
         attr_done = true;
     }
-    if (d->dtype == SZN_F16) hipLaunchKernelGGL(conv_wgrad_wide<f16_raw>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv_wgrad_wide<bf16_raw>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)tiles);
+    hipStream_t st = (hipStream_t)stream;
+    if (opt) {
+        if (d->dtype == SZN_F16) hipLaunchKernelGGL((conv_wgrad_wide<f16_raw, true>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_wide<bf16_raw, true>), grid, dim3(512), lds, st, a);
+        SZN_CHECK_LAUNCH("conv_wgrad_wide_adam");
+        return SZN_OK;
+    }
+    if (d->dtype == SZN_F16) hipLaunchKernelGGL((conv_wgrad_wide<f16_raw, false>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_wide<bf16_raw, false>), grid, dim3(512), lds, st, a);
     SZN_CHECK_LAUNCH("conv_wgrad_wide");
     return SZN_OK;
 }

@@ -691,16 +691,7 @@ __global__ void dropout_mask_kernel(float* __restrict__ scale, long n, float p, 
 // Optimizer steps over the flat fp32 parameter / gradient / moment buffers: pure streaming (28-30 B per element), so each
 // lane moves 16 B per access (four elements) and keeps two such groups in flight; the per-element arithmetic is the
 // scalar chain of torch.optim (no contraction: -ffp-contract=off), identical for the vector body and the scalar tail.
-__device__ __forceinline__ float adam_elem(float& pi, float gi, float& mi, float& vi, float b1, float b2, float eps, float wd,
-                                           float step_size, float inv_bc2_sqrt, float gscale) {
-    gi = gi * gscale;
-    if (wd != 0.f) gi = fmaf(wd, pi, gi);
-    mi = b1 * mi + (1.f - b1) * gi;
-    vi = b2 * vi + (1.f - b2) * gi * gi;
-    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
-    pi -= step_size * (mi / denom);
-    return pi;
-}
+// (adam_elem: szn_common.h -- shared with the weight-gradient kernel that applies the update in its epilogue)
 
 template <typename LP>      // element type of the optional 16-bit weight image (bf16_raw | f16_raw)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -1072,9 +1063,8 @@ static int adam_impl(long n, float* param, const float* grad, float* exp_avg, fl
                      const float* dyn, szn_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) SZN_FAIL(SZN_ERR_ARG, "adam_step: bad argument");
     if (w_lp && !szn_is16(w_lp_dtype)) SZN_FAIL(SZN_ERR_ARG, "adam_step: the weight image must be SZN_BF16 or SZN_F16");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    float step_size, inv_bc2_sqrt;
+    szn_adam_scalars(lr, beta1, beta2, step, &step_size, &inv_bc2_sqrt);
     const int vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
                      (((uintptr_t)w_lp) & 7) == 0) ? 1 : 0;
     // one 16-B group per thread, no grid-stride loop: measured 6.1 TB/s on the 135 M-element buffer vs 5.6 with 16 Ki blocks

@@ -258,7 +258,8 @@ class TrainStep(object):
                  precision=torch.bfloat16, fused_head=True, loss="cos", process_group=None, bucket_mb=25,
                  train_metrics=True, betas=(0.9, 0.999), eps=1e-8, bias_lr=None, bias_weight_decay=0.0,
                  adam_weight_decay=0.0, grad_comm_dtype=None, loss_scale=None, dynamic_loss_scale=None,
-                 scale_growth=2.0, scale_backoff=0.5, scale_growth_interval=2000, force_comm=None, reserved_cus=None):
+                 scale_growth=2.0, scale_backoff=0.5, scale_growth_interval=2000, force_comm=None, reserved_cus=None,
+                 fused_adam=None, keep_grads=True):
         if loss not in ("cos", "mse") or (fused_head and loss != "cos"):
             raise L.SznError("TrainStep: fused head supports the cosine loss; use fused_head=False for mse")
         self.model = model
@@ -316,6 +317,16 @@ class TrainStep(object):
         self.loss = torch.zeros(1, device=self.dev)
         self.stats = None
         self._ws = None
+        # Adam for fc6 / fc7 (89 % of the weights) applied in the epilogue of their weight-gradient kernels (szn_conv2d_wgrad_adam):
+        # only where a gradient is final when its kernel ends -- one rank (no exchange), no dynamic loss scale -- and on the 16-bit
+        # paths (the kernel with that epilogue is a 16-bit MFMA kernel).  SZN_FUSED_ADAM=0 / fused_adam=False: the separate pass.
+        # keep_grads=False: the fused layers' gradients are not written to the flat gradient buffer at all (nothing reads them in
+        # a training loop that calls zero_grad() next, train.py:170-175); the default keeps .grad meaningful.
+        if fused_adam is None:
+            fused_adam = os.environ.get("SZN_FUSED_ADAM", "1") == "1"
+        self.fused_adam = bool(fused_adam and optimizer == "adam" and not self.dynamic and not self.buckets.active
+                               and self.flat_w_lp is not None and os.environ.get("SZN_EARLY_ADAM", "auto") != "1")
+        self.keep_grads = bool(keep_grads)
         self.keep_ctx = False        # tests: keep the forward state of the last step (activations stay alive one step longer)
         self.last_ctx = None
 
@@ -476,6 +487,7 @@ class TrainStep(object):
         if scaled:
             dcoarse = self._scale(dcoarse)
         self.stats = stats
+        self._fused_begin()
         self._backward(ctx, dcoarse, self._layer_done_hook(B * H * W))
         self.buckets.finish()
         self._optimizer_step()
@@ -566,6 +578,7 @@ class TrainStep(object):
             done("score_fr"); done("score_pool4"); done("score_pool3")
         # the bias gradients of the skip layers live in the flat bias buffer the engine zeroes first: re-apply them after
         saved = [(self.boff[n], self.skip[n]["gb"]) for n in ("score_pool3", "score_pool4")]
+        self._fused_begin()
         eng.backward(ctx, dcoarse, self.grads, backbone=True, layer_done=done, head_first=head_first, skips=skips)
         for (bo, bc), gb in saved:
             self.flat_gb[bo:bo + bc].copy_(gb[:E])
@@ -614,6 +627,30 @@ class TrainStep(object):
                 self._early = True
         return done
 
+    def _fused_begin(self):
+        """hand the engine the Adam arguments of the layers whose update rides in their weight-gradient kernel (this step = nstep + 1)"""
+        eng = self.eng
+        eng.fused_done = set()
+        eng.fused_opt = None
+        if not self.fused_adam:
+            return
+        m1, m2 = self.state["w"]
+        gs = 1.0 / (self.world * self._loss_scale0)
+        out = {}
+        # fc6 only by default: its 1,568 tiles run 6 rounds, so update traffic and K loops of different CUs overlap (852 us against
+        # 447 + 523 separately at B = 8); fc7's 256 tiles are one round -- K loop, then everybody's update: 155 us against 70 + 75
+        for n in os.environ.get("SZN_FUSED_ADAM_LAYERS", "fc6").split(","):
+            if n not in self.woff or n not in ("fc6", "fc7"):
+                continue
+            o, cnt = self.woff[n]
+            a = L.AdamArgs()
+            a.param, a.exp_avg, a.exp_avg_sq = self.flat_w[o:o + cnt].data_ptr(), m1[o:o + cnt].data_ptr(), m2[o:o + cnt].data_ptr()
+            a.w_lp, a.w_lp_dtype = self.flat_w_lp[o:o + cnt].data_ptr(), L.dtype_code(self.flat_w_lp.dtype)
+            a.lr, a.beta1, a.beta2, a.eps = float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps)
+            a.weight_decay, a.step, a.grad_scale = float(self.adam_wd), self.nstep + 1, gs
+            out[n] = (a, self.keep_grads)
+        eng.fused_opt = out
+
     def _opt_launch(self, key, lo, hi, nstep):
         """one optimizer launch over elements [lo, hi) of the flat weight ("w") or bias ("b") buffers, on the current stream"""
         if hi <= lo:
@@ -657,7 +694,16 @@ class TrainStep(object):
             torch.cuda.current_stream().wait_stream(self._side)
             whi = self.woff["fc6"][0]
             self._early = False
-        self._opt_launch("w", 0, whi, self.nstep)
+        # the weight ranges not already updated inside their weight-gradient kernels (_fused_begin)
+        lo = 0
+        for n in sorted(self.eng.fused_done, key=lambda n: self.woff[n][0]):
+            o, cnt = self.woff[n]
+            if o < whi:
+                self._opt_launch("w", lo, min(o, whi), self.nstep)
+                lo = o + cnt
+        self._opt_launch("w", lo, whi, self.nstep)
+        self.eng.fused_opt = None
+        self.eng.fused_done = set()
         self._opt_launch("b", 0, self.flat_b.numel(), self.nstep)
         if self.dynamic:
             g, b, iv, lo, hi = self.scale_cfg

@@ -102,6 +102,10 @@ class _Engine(object):
         # un-pooled store (pool_only; conv3x3_regw does: 516 + 258 MB per step neither written nor read back).  keep_prepool = True
         # (tests that inspect the forward state) keeps those tensors valid; SZN_POOL_CODES=0: the round-1/2 backward from the tensor.
         self.keep_prepool = False
+        # TrainStep, one rank: {layer: (AdamArgs, store the gradient too?)} -- the layer's weight update is applied in the epilogue of
+        # its weight-gradient kernel (szn_conv2d_wgrad_adam); fused_done collects the layers for which that happened
+        self.fused_opt = None
+        self.fused_done = set()
         self.reserved_cus = 0         # CUs the persistent backward kernels leave to the RCCL queue (szn_conv_desc_t.reserved_cus; TrainStep)
         self.pool_codes = os.environ.get("SZN_POOL_CODES", "1") != "0"
         self.head_fp8 = False         # forward of the projection head on the fp8 matrix cores (set_head_precision)
@@ -502,8 +506,9 @@ class _Engine(object):
             torch.cuda.current_stream().wait_stream(self._wg_stream)
         self._flush_colsum()
 
-    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None):
-        """dw (OHWI f32) = wgrad of one layer, on the wgrad stream; `after` (e.g. the DDP bucket hook) runs there too"""
+    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None, fuse=None):
+        """dw (OHWI f32) = wgrad of one layer, on the wgrad stream; `after` (e.g. the DDP bucket hook) runs there too.  fuse: layer
+        name under which self.fused_opt may hold the Adam step to apply in the kernel's epilogue"""
         B, Hi, Wi, _ = x.shape
         Ho, Wo = dout.shape[1:3]
         ldo = dout.shape[3] if ldo is None else ldo
@@ -519,7 +524,12 @@ class _Engine(object):
         d.workspace, d.workspace_bytes = self._wg_ws.data_ptr(), nb
         with self._wgrad_stream(x, dout):
             st = L.stream_ptr()
-            L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
+            opt = self.fused_opt.get(fuse) if (self.fused_opt and fuse) else None
+            if opt is not None and L.load().szn_conv2d_wgrad_adam_supported(C.byref(d)) == 1:
+                L.call("szn_conv2d_wgrad_adam", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw) if opt[1] else None, C.byref(opt[0]), st)
+                self.fused_done.add(fuse)
+            else:
+                L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
             if db is not None:
                 slab, rows = self._cs_slab(B * Ho * Wo, co, dout.device)
                 L.call("szn_bias_grad_slab", code, B * Ho * Wo, co, ldo, L.ptr(dout), L.ptr(db), 0, L.ptr(slab), rows, st)
@@ -630,11 +640,17 @@ class _Engine(object):
             d = self._head_dgrad_fp8(dc, feat, s7, grads["fc7"][1])
         else:
             d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7, colsum=grads["fc7"][1])
-        self._wgrad(ctx.relu6, d, grads["fc7"][0], None, F, F, 1, 0, after=lambda: done("fc7"))
+        self._wgrad(ctx.relu6, d, grads["fc7"][0], None, F, F, 1, 0, after=lambda: done("fc7"), fuse="fc7")
         d = self._dgrad(d, "fc7", ctx.relu6.shape, 0, gate=ctx.relu6, scale=s6, colsum=grads["fc6"][1])
         pool5 = ctx.pools[4][1]
-        self._wgrad(pool5, d, grads["fc6"][0], None, pool5.shape[3], F, 7, 0, after=lambda: done("fc6"))
-        d = self._dgrad(d, "fc6", pool5.shape, 0)
+        if self.fused_opt and "fc6" in self.fused_opt:
+            # the fused update rewrites fc6's 16-bit weight image, which fc6's dgrad reads in place: dgrad first
+            d6 = d
+            d = self._dgrad(d6, "fc6", pool5.shape, 0)
+            self._wgrad(pool5, d6, grads["fc6"][0], None, pool5.shape[3], F, 7, 0, after=lambda: done("fc6"), fuse="fc6")
+        else:
+            self._wgrad(pool5, d, grads["fc6"][0], None, pool5.shape[3], F, 7, 0, after=lambda: done("fc6"))
+            d = self._dgrad(d, "fc6", pool5.shape, 0)
         pi = 4
         prev_out = None
         items = _BACKBONE

@@ -189,7 +189,7 @@ class Trainer(object):
             return None
         self._step = _engine.TrainStep(self.model, self.embeddings, lr=gw['lr'], bias_lr=gb['lr'],
                                        bias_weight_decay=gb.get('weight_decay', 0.0), precision=self.precision,
-                                       fused_head=True, **kw)
+                                       fused_head=True, keep_grads=False, **kw)      # (zero_grad() comes next: train.py:170-175)
         self._step.import_optimizer_state(self.optim)       # resumed runs (train.py:135-136)
         return self._step
 
