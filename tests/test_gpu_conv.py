@@ -525,7 +525,7 @@ def test_8phase_kernel_equals_conv_igemm_wide_bit_for_bit():
     assert seen >= 7, runs
 
 
-@pytest.mark.parametrize("geom", [(8, 23, 512, 1024, 7), (4, 28, 128, 128, 5)])
+@pytest.mark.parametrize("geom", [(8, 23, 512, 1024, 7), (4, 28, 128, 128, 5), (1, 23, 512, 1024, 7), (1, 25, 512, 256, 7)])
 def test_dgrad_gemm_on_the_forward_weight_layout(geom):
     """szn_conv2d_dgrad_gemm_native (GEMM on the filter bank as the forward pass stores it, dout transposed instead) ==
     szn_conv2d_dgrad_gemm on the packed transpose, to fp32 accumulation order, and both == torch"""

@@ -716,6 +716,34 @@ static int launch_col2im(const szn_conv_desc_t* d, const float* Y, void* din, sz
     return SZN_OK;
 }
 
+// dout [M][C] (16-bit) -> doutT [C][Mp], Mp = M rounded up to 8 (columns M .. Mp - 1 zero): the K-major A operand of the native dgrad
+// GEMM below for pixel counts that are not a multiple of 8 (M = 289 at the reference's batch size of one image).  64 x 64 tiles through
+// LDS; C is a multiple of 64.
+__global__ __launch_bounds__(256) void transpose_pad16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int M, int Mp,
+                                                              int C) {
+    __shared__ uint16_t tile[64][66];
+    const int m0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int c8 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = r0 + 32 * p;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (m0 + r < M) v = *(const uint4*)(src + (long)(m0 + r) * C + c0 + c8 * 8);
+        uint32_t* d32 = (uint32_t*)&tile[r][c8 * 8];
+        d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = r0 + 32 * p;
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (uint32_t)tile[c8 * 8 + 2 * e][c] | ((uint32_t)tile[c8 * 8 + 2 * e + 1][c] << 16);
+        if (m0 + c8 * 8 < Mp) *(uint4*)(dst + (long)(c0 + c) * Mp + m0 + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ---- the same dgrad on the filter bank in its FORWARD layout (round 3) -------------------------------------------------------------
 // szn_conv2d_dgrad_gemm needs wG = the plain transpose of the [Co][KH*KW*Ci] forward image: for fc6 a 205 MB read + 205 MB write per
 // step (85 of the 115 us of szn_pack_weight_dgrad_batch) just to make co the contiguous index.  conv_wgrad_wide multiplies two
@@ -724,9 +752,13 @@ static int launch_col2im(const szn_conv_desc_t* d, const float* Y, void* din, sz
 static bool dgrad_native_shape_ok(const szn_conv_desc_t* d) {
     if (!d || !szn_is16(d->dtype) || d->KH != d->KW || d->ldo != d->Co || (d->Ci & 3)) return false;
     const long M = (long)d->B * d->Ho * d->Wo, N = (long)d->KH * d->KW * d->Ci;
-    if ((M & 7) || M < 256 || N < 256 || (N & 7) || (d->Co & 63) || M >= (1L << 22) || N >= (1L << 31)) return false;
+    if (M < 256 || N < 256 || (N & 7) || (d->Co & 63) || M >= (1L << 22) || N >= (1L << 31)) return false;
     const long cot = (M + 255) / 256, cit = (N + 255) / 256;
-    if (cot * cit < 96 || cot * 256 * cit * 256 > M * N * 5 / 4) return false;          // conv_wgrad_wide's own admission rules
+    if (cot * cit < 96) return false;                                                   // conv_wgrad_wide's own admission rule
+    // padding waste of the last pixel tile: at most a quarter -- or at most 256 blocks in all (one round of the chip: the launch then
+    // takes one K loop whatever the rows of its second pixel tile hold, M = 289 at B = 1, and re-transposing the 205 MB filter bank
+    // for the packed form costs as much as that K loop)
+    if (cot * 256 * cit * 256 > M * N * 5 / 4 && cot * cit > 256) return false;
     return (size_t)d->Co * N * 2 < 0xffff0000ul && (size_t)d->Co * M * 2 < 0xffff0000ul;
 }
 
@@ -735,7 +767,8 @@ extern "C" int szn_conv2d_dgrad_gemm_native_supported(const szn_conv_desc_t* d) 
 extern "C" size_t szn_conv2d_dgrad_gemm_native_workspace_bytes(const szn_conv_desc_t* d) {
     const size_t y = szn_conv2d_dgrad_gemm_workspace_bytes(d);
     if (!y) return 0;
-    return (y + 255) / 256 * 256 + (size_t)d->Co * d->B * d->Ho * d->Wo * 2;            // Y | dout^T
+    const size_t Mp = ((size_t)d->B * d->Ho * d->Wo + 7) / 8 * 8;
+    return (y + 255) / 256 * 256 + (size_t)d->Co * Mp * 2;                               // Y | dout^T (rows padded to 8 pixels)
 }
 
 extern "C" int szn_conv2d_dgrad_gemm_native(const szn_conv_desc_t* d, const void* dout, const void* w, void* din,
@@ -751,11 +784,19 @@ extern "C" int szn_conv2d_dgrad_gemm_native(const szn_conv_desc_t* d, const void
     const long N = (long)d->KH * d->KW * d->Ci;
     float* Y = (float*)d->workspace;
     void* doutT = (char*)d->workspace + (szn_conv2d_dgrad_gemm_workspace_bytes(d) + 255) / 256 * 256;
-    rc = szn_pack_weight_dgrad(d->dtype, M, 1, 1, d->Co, dout, doutT, stream);          // [M][Co] -> [Co][M]
-    if (rc) return rc;
+    const int Mp = (M + 7) / 8 * 8;
+    if (Mp == M) {
+        rc = szn_pack_weight_dgrad(d->dtype, M, 1, 1, d->Co, dout, doutT, stream);      // [M][Co] -> [Co][M]
+        if (rc) return rc;
+    } else {
+        if ((uintptr_t)dout & 15) SZN_FAIL(SZN_ERR_ARG, "conv2d_dgrad_gemm_native: dout must be 16-B aligned");
+        hipLaunchKernelGGL(transpose_pad16_kernel, dim3(d->Co / 64, (Mp + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout,
+                           (uint16_t*)doutT, M, Mp, d->Co);
+        SZN_CHECK_LAUNCH("transpose_pad16_kernel");
+    }
     szn_conv_desc_t g = {};
     g.dtype = d->dtype; g.B = 1; g.Hi = 1; g.Wi = d->Co; g.Ci = (int)N; g.Ho = 1; g.Wo = d->Co; g.Co = M;
-    g.KH = 1; g.KW = 1; g.pad = 0; g.ldi = (int)N; g.ldo = M; g.ldg = 0;
+    g.KH = 1; g.KW = 1; g.pad = 0; g.ldi = (int)N; g.ldo = Mp; g.ldg = 0;
     rc = szn_conv_wgrad_wide_try(&g, w, doutT, Y, 0, 1, stream);
     if (rc > 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_dgrad_gemm_native: conv_wgrad_wide refused the shape");
     if (rc) return rc;

@@ -368,8 +368,8 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     a.cotiles = szn_div_up(d->Co, 256); a.citiles = szn_div_up(d->Ci, 256);
     const long tiles = (long)a.cotiles * a.citiles * d->KH * d->KW;
     if (tiles < min_tiles || tiles >= (1L << 31) || (long)d->B * d->Ho * d->Wo >= (1L << 22)) return 1;
-    // padding waste of the last tiles must stay small
-    if ((long)a.cotiles * 256 * a.citiles * 256 > (long)d->Co * d->Ci * 5 / 4) return 1;
+    // padding waste of the last tiles must stay small (or the launch is a single round of the chip anyway: the native dgrad at B = 1)
+    if ((long)a.cotiles * 256 * a.citiles * 256 > (long)d->Co * d->Ci * 5 / 4 && !(min_tiles <= 1 && tiles <= 256)) return 1;
     a.dout = (const char*)dout; a.in = (const char*)in; a.dw = dw;
     a.dout_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->ldo * 2);
     a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->ldi * 2);
