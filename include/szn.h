@@ -103,7 +103,13 @@ typedef struct {
                          the gate tensor equals gate pixel (row r0 - 1, column c0) of image 0 (needs r0 >= 1) -- the kernel may read that
                          pixel instead; cb_const = the rows x columns of DIN the caller is going to read -- stores outside may be
                          skipped (DIN is undefined there; colsum still covers every pixel).  conv1_2's dgrad: its output feeds only
-                         szn_conv1_1_wgrad, whose read set szn_conv1_1_wgrad_reads() reports.                                    */
+                         szn_conv1_1_wgrad, whose read set szn_conv1_1_wgrad_reads() reports.
+                         szn_conv2d_wgrad (coordinates of the INPUT x): cb_rect = the rows x columns the image can influence, cb_const =
+                         the rows x columns outside of which zero padding is felt; the caller asserts that every pixel of x inside
+                         cb_const and outside cb_rect holds the same value per channel.  conv_wgrad_taps then runs only the 16 x 16
+                         output tiles whose input patch is not constant; the others contribute (their column sum of dout) x (that
+                         pixel) to all nine taps -- the same sum in a different order (fp32; <= 1e-5 relative against the dense
+                         result, tests/test_gpu_conv.py), ignored with accumulate != 0.  szn_last_work_fraction() reports it.       */
     int cb_rect[4];
     int cb_const[4];
     int reserved_cus;   /* optional (0 = none): compute units the persistent one-block-per-CU kernels (conv3x3_regw, conv_wgrad_taps)

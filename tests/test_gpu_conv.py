@@ -560,6 +560,58 @@ def test_dgrad_gemm_on_the_forward_weight_layout(geom):
     assert lib.szn_conv2d_dgrad_gemm_native_supported(C.byref(d3)) == 0
 
 
+@pytest.mark.parametrize("case", [(2, 262, 262, 64, 64, (98, 164), (0, 262)), (1, 355, 355, 128, 128, (48, 308), (2, 353)),
+                                  (2, 200, 230, 64, 128, (40, 120), (1, 199)), (1, 710, 710, 64, 64, (98, 612), (0, 710))])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_wgrad_constant_border_hint_equals_dense(case, dtype):
+    """szn_conv2d_wgrad with the constant-border hint (tiles whose whole input patch is one value per channel are replaced by a
+    rank-one term: column sum of dout x that value) against the same call without the hint: the same sums in a different fp32 order"""
+    B, H, W, Ci, Co, rect, const = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.relu(torch.randn(B, H, W, Ci, generator=g))
+    cval = torch.relu(torch.randn(Ci, generator=g)) + 0.25
+    # constant outside rect (inside const); the frame outside const holds other values again (what zero padding does to a layer)
+    inside = torch.zeros(H, W, dtype=torch.bool)
+    inside[rect[0]:rect[1], rect[0]:rect[1]] = True
+    frame = torch.ones(H, W, dtype=torch.bool)
+    frame[const[0]:const[1], const[0]:min(const[1], W)] = False
+    x = torch.where((inside | frame)[None, :, :, None], x, cval[None, None, None, :].expand(B, H, W, Ci)).to(dtype).cuda()
+    dout = (torch.randn(B, H, W, Co, generator=g) * 0.1).to(dtype).cuda()
+    dt = L.dtype_code(dtype)
+    ws = torch.empty(2 * 256 * 64 * 9 * 64 * 4, dtype=torch.uint8, device="cuda")
+
+    def run(hint):
+        d = L.ConvDesc(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, Ci, Co, 0, 0, 0)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        if hint:
+            d.cb_on = 1
+            d.cb_rect[0], d.cb_rect[1], d.cb_rect[2], d.cb_rect[3] = rect[0], rect[1], rect[0], rect[1]
+            d.cb_const[0], d.cb_const[1], d.cb_const[2], d.cb_const[3] = const[0], const[1], const[0], min(const[1], W)
+        dw = torch.full((Co, 3, 3, Ci), 7.0, device="cuda")
+        L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, L.stream_ptr())
+        torch.cuda.synchronize()
+        return dw, L.last_kernel(), L.load().szn_last_work_fraction()
+
+    dense, k0, f0 = run(False)
+    hinted, k1, f1 = run(True)
+    assert k0 == "wgrad_taps_reduce" and k1 == "wgrad_taps_reduce"
+    assert f1 < 0.95 or B * (H // 16) * (W // 16) < 600, f1    # tiles were really skipped (small maps: too few would be left, dense run)
+    err = float((hinted - dense).abs().max() / dense.abs().max())
+    assert err < 1e-5, err
+    again, _, _ = run(True)
+    assert torch.equal(again, hinted)                     # fixed-order sums: bit-reproducible
+    # accumulate != 0 ignores the hint (documented): the dense sum on top of what is there
+    d = L.ConvDesc(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, Ci, Co, 0, 0, 0)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    d.cb_on = 1
+    d.cb_rect[0], d.cb_rect[1], d.cb_rect[2], d.cb_rect[3] = rect[0], rect[1], rect[0], rect[1]
+    d.cb_const[0], d.cb_const[1], d.cb_const[2], d.cb_const[3] = const[0], const[1], const[0], min(const[1], W)
+    acc = dense.clone()
+    L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(acc), 1, L.stream_ptr())
+    torch.cuda.synchronize()
+    assert float((acc - 2 * dense).abs().max() / dense.abs().max()) < 1e-6
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("geom", [(2, 37, 41, 64, 64), (1, 710, 64, 64, 64), (2, 45, 45, 512, 512)])
 def test_pool_winner_codes(dtype, geom):

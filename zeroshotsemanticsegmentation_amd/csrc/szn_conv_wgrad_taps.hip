@@ -16,7 +16,9 @@
 //   * every block writes its fp32 partial [64][9][64] into its own slab of the caller's workspace with coalesced
 //     plain stores; wgrad_taps_reduce adds the slabs in a fixed order (deterministic, no atomics, no memset).
 #include "szn_common.h"
+#include "szn_cb.h"
 #include <stdlib.h>
+#include <algorithm>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
@@ -34,6 +36,15 @@ struct WtArgs {
     int accumulate;
     int xcd_mode;              // block -> (split, combo) mapping, see the kernel
     int ablate;                // debug (env SZN_WGT_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no reads / MFMA
+    // constant-border hint (szn_conv_desc_t.cb_on for szn_conv2d_wgrad): the tiles whose whole 18 x 18 input patch holds ONE value per
+    // channel are not run (cb numbers the others; ntiles = B * cb.per_image).  Their share of dW is a rank-one term, the same for
+    // all nine taps:  dW[co][tap][ci] += (sum of dout[px][co] over their pixels) * x_const[ci]  -- csum [Co] comes from
+    // wgrad_cb_colsum / wgrad_cb_colsum_reduce, x_const is read from the input at pixel cref; wgrad_taps_reduce adds the product.
+    CbGeom cb;
+    float* crow;               // [cb_rows][Co]: per-block sums over the skipped tiles (wgrad_cb_colsum)
+    float* csum;               // [Co]
+    unsigned cref;             // byte offset of the reference pixel in `in`
+    int is_f16;
 };
 
 constexpr unsigned kOOBt = 0x80000000u;
@@ -83,9 +94,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
     // barrier; spreading the ten loads over the K steps costs VGPRs the 18 accumulator fragments do not leave).
     unsigned vA[4], vB[6];
     auto prepare = [&](int t) {
-        int bb = t;
-        const int tx = bb % a.tiles_x; bb /= a.tiles_x;
-        const int ty = bb % a.tiles_y; const int b = bb / a.tiles_y;
+        int tx, ty, b;
+        if (a.cb.on) {
+            b = t / a.cb.per_image;
+            cb_decode(a.cb, t - b * a.cb.per_image, ty, tx);
+        } else {
+            int bb = t;
+            tx = bb % a.tiles_x; bb /= a.tiles_x;
+            ty = bb % a.tiles_y; b = bb / a.tiles_y;
+        }
         int q0v = q0;
         asm volatile("" : "+v"(q0v));               // per-call opaque: no per-slot constants in loop-carried VGPRs
         const unsigned baseA = (unsigned)(((b * a.Ho + ty * 16) * a.Wo + tx * 16) * a.ldd * 2) + coA;
@@ -293,12 +310,111 @@ __global__ __launch_bounds__(256) void wgrad_taps_reduce(WtArgs a) {
         const int h = w >> 2, c = w & 3, i = f / 9, tap = f - i * 9;
         const int co = cot * 64 + h * 32 + i * 16 + (lane >> 4) * 4 + e, ci = cit * 64 + c * 16 + (lane & 15);
         float* dst = a.dw + ((long)co * 9 + tap) * a.Ci + ci;
+        f32x4_t sv = s;
+        if (a.cb.on) {                                 // the skipped tiles: (their column sum of dout) x (the constant input pixel)
+            const uint16_t* xr = (const uint16_t*)(a.in + a.cref) + ci;
+            const float sc = a.csum[co];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sv[q] += sc * (a.is_f16 ? f16_bits_to_f32(xr[q]) : bf16_bits_to_f32(xr[q]));
+        }
         if (a.accumulate) {
             const f32x4_t o = *(const f32x4_t*)dst;
-            *(f32x4_t*)dst = o + s;
+            *(f32x4_t*)dst = o + sv;
         } else {
-            *(f32x4_t*)dst = s;
+            *(f32x4_t*)dst = sv;
         }
+    }
+}
+
+// Column sums of dout over the tiles conv_wgrad_taps skips under the constant-border hint.  The skipped tiles of an image are
+// numbered row-major (top band, the two side bands of the window rows, bottom band); a block takes `per` consecutive (image, tile)
+// units -- 256 pixels each, 16-B chunks of 8 channels per thread, pixels strided over the block, eight independent loads in flight
+// per thread -- and writes its sums to crow[block][Co] (fixed order: bit-reproducible).  HBM-bound: the skipped share of dout is read once.
+struct CbSkip { int ntop, nmid, per_image, nfw, nsw, nleft; };      // counts of the numbering above (host: cb_skip_counts)
+__host__ __device__ inline CbSkip cb_skip_counts(const CbGeom& c) {
+    CbSkip k;
+    k.nfw = c.fx1 - c.fx0; k.nleft = c.wx0 - c.fx0; k.nsw = k.nfw - (c.wx1 - c.wx0);
+    k.ntop = (c.wy0 - c.fy0) * k.nfw; k.nmid = (c.wy1 - c.wy0) * k.nsw;
+    k.per_image = k.ntop + k.nmid + (c.fy1 - c.wy1) * k.nfw;
+    return k;
+}
+__device__ __forceinline__ void cb_skip_decode(const CbGeom& c, const CbSkip& k, int v, int& ty, int& tx) {
+    if (v < k.ntop) { const int q = v / k.nfw; ty = c.fy0 + q; tx = c.fx0 + (v - q * k.nfw); return; }
+    v -= k.ntop;
+    if (v < k.nmid) {
+        const int q = v / k.nsw, j = v - q * k.nsw;
+        ty = c.wy0 + q; tx = j < k.nleft ? c.fx0 + j : c.wx1 + (j - k.nleft);
+        return;
+    }
+    v -= k.nmid;
+    const int q = v / k.nfw; ty = c.wy1 + q; tx = c.fx0 + (v - q * k.nfw);
+}
+
+__global__ __launch_bounds__(256) void wgrad_cb_colsum(WtArgs a, CbSkip k, int per, int units) {
+    __shared__ float red[256][9];
+    const int chunks = a.Co >> 3, ppi = 256 / chunks;                      // pixels per iteration (Co <= 2048)
+    const int ch = threadIdx.x % chunks, pl = threadIdx.x / chunks;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool is16 = a.is_f16 != 0;
+    auto add = [&](const uint4& v) {
+        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint16_t lo = (uint16_t)(wv[e] & 0xffffu), hi = (uint16_t)(wv[e] >> 16);
+            s[2 * e] += is16 ? f16_bits_to_f32(lo) : bf16_bits_to_f32(lo);
+            s[2 * e + 1] += is16 ? f16_bits_to_f32(hi) : bf16_bits_to_f32(hi);
+        }
+    };
+    const int u0 = blockIdx.x * per, u1 = min(u0 + per, units);
+    for (int u = u0; u < u1; ++u) {
+        const int b = u / k.per_image;
+        int ty, tx;
+        cb_skip_decode(a.cb, k, u - b * k.per_image, ty, tx);
+        const char* base = a.dout + ((size_t)((b * a.Ho + ty * 16) * a.Wo + tx * 16) * a.ldd + ch * 8) * 2;
+        auto addr = [&](int q) -> const uint4* { return (const uint4*)(base + (size_t)((q >> 4) * a.Wo + (q & 15)) * a.ldd * 2); };
+        if (pl < ppi) {
+            int q = pl;
+            for (; q + 7 * ppi < 256; q += 8 * ppi) {
+                uint4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *addr(q + i * ppi);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) add(v[i]);
+            }
+            for (; q < 256; q += ppi) add(*addr(q));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    for (int co = threadIdx.x; co < a.Co; co += 256) {
+        const int c8 = co >> 3, e = co & 7;
+        float t = 0.f;
+        for (int p = 0; p < ppi; ++p) t += red[p * chunks + c8][e];
+        a.crow[(size_t)blockIdx.x * a.Co + co] = t;
+    }
+}
+
+// csum[co] = sum of the rows of crow: a block owns 8 channels, 32 thread groups take the rows r = group (mod 32) with four running
+// sums each, then a fixed-order tree over the groups
+__global__ __launch_bounds__(256) void wgrad_cb_colsum_reduce(WtArgs a, int rows) {
+    __shared__ float part[32][8];
+    const int cl = threadIdx.x & 7, grp = threadIdx.x >> 3, co = blockIdx.x * 8 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (co < a.Co) {
+        int r = grp;
+        for (; r + 96 < rows; r += 128) {
+            s0 += a.crow[(size_t)r * a.Co + co]; s1 += a.crow[(size_t)(r + 32) * a.Co + co];
+            s2 += a.crow[(size_t)(r + 64) * a.Co + co]; s3 += a.crow[(size_t)(r + 96) * a.Co + co];
+        }
+        for (; r < rows; r += 32) s0 += a.crow[(size_t)r * a.Co + co];
+    }
+    part[grp][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (threadIdx.x < 8 && co < a.Co) {
+        float t = 0.f;
+        for (int g2 = 0; g2 < 32; ++g2) t += part[g2][cl];
+        a.csum[co] = t;
     }
 }
 
@@ -321,8 +437,46 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     }
     if (ncombo > ncu) return 1;
     a.tiles_x = szn_div_up(d->Wo, 16); a.tiles_y = szn_div_up(d->Ho, 16);
-    const long nt = (long)d->B * a.tiles_y * a.tiles_x;
+    long nt = (long)d->B * a.tiles_y * a.tiles_x;
     if (nt >= (1L << 30)) return 1;
+    // constant-border hint: cb_rect = the input rows x columns the image can influence, cb_const = the rows x columns outside of which
+    // the zero padding of the layers so far is felt (include/szn.h).  A tile is skipped when its input patch -- rows [16 ty - pad,
+    // 16 ty + 18 - pad) -- lies inside cb_const, does not meet cb_rect, and the tile is a full 16 x 16 one.
+    a.cb.on = 0; a.crow = a.csum = nullptr; a.cref = 0; a.is_f16 = d->dtype == SZN_F16;
+    {
+        static int cbon = -1;
+        if (cbon < 0) { const char* e = getenv("SZN_WGT_CB"); cbon = e ? atoi(e) : 1; }
+        if (cbon && d->cb_on && !accumulate) {
+            auto fdiv = [](int x, int y) { return x >= 0 ? x / y : -((-x + y - 1) / y); };       // floor
+            auto cdiv = [&](int x, int y) { return -fdiv(-x, y); };                              // ceil
+            CbGeom c;
+            c.on = 1; c.tiles_y = a.tiles_y; c.tiles_x = a.tiles_x;
+            const int p = d->pad;
+            c.fy0 = std::max(cdiv(d->cb_const[0] + p, 16), 0);
+            c.fy1 = std::min(fdiv(d->cb_const[1] - 18 + p, 16) + 1, d->Ho / 16);
+            c.fx0 = std::max(cdiv(d->cb_const[2] + p, 16), 0);
+            c.fx1 = std::min(fdiv(d->cb_const[3] - 18 + p, 16) + 1, d->Wo / 16);
+            c.wy0 = fdiv(d->cb_rect[0] - 18 + p, 16) + 1; c.wy1 = cdiv(d->cb_rect[1] + p, 16);
+            c.wx0 = fdiv(d->cb_rect[2] - 18 + p, 16) + 1; c.wx1 = cdiv(d->cb_rect[3] + p, 16);
+            if (c.fy1 > c.fy0 && c.fx1 > c.fx0 && d->cb_rect[1] > d->cb_rect[0] && d->cb_rect[3] > d->cb_rect[2]) {
+                cb_finish(c);
+                const long skipped = (long)a.tiles_y * a.tiles_x - c.per_image;
+                // first skipped tile (row-major) -> the reference pixel = the top-left pixel of its patch
+                int ry = -1, rx = -1;
+                for (int ty = c.fy0; ty < c.fy1 && ry < 0; ++ty)
+                    for (int tx = c.fx0; tx < c.fx1; ++tx)
+                        if (cb_skippable(c, ty, tx)) { ry = ty * 16 - p; rx = tx * 16 - p; break; }
+                // (not when the tiles that are left would be too few for this kernel: the dense run then beats conv_wgrad_v2)
+                const long left = (long)d->B * c.per_image / (min_tiles_per_block < 1 ? 1 : min_tiles_per_block);
+                const bool enough = std::min(left, (long)(ncu / ncombo)) * ncombo >= 32;
+                if (skipped * 20 >= (long)a.tiles_y * a.tiles_x && ry >= 0 && rx >= 0 && d->Co <= 2048 && enough) {      // worth two small launches
+                    a.cb = c;
+                    a.cref = (unsigned)(((size_t)ry * d->Wi + rx) * d->ldi * 2);
+                    nt = (long)d->B * c.per_image;
+                }
+            }
+        }
+    }
     a.ntiles = (int)nt;
     // pixel splits: one block per CU at most, at least min_tiles_per_block tiles each (the slab write + reduction
     // must amortise), slabs must fit the workspace; too little parallelism left -> conv_wgrad_v2
@@ -338,9 +492,23 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     if (min_tiles_per_block < 1) min_tiles_per_block = 1;
     if (ns > nt / min_tiles_per_block) ns = nt / min_tiles_per_block;
     const size_t slab_bytes = (size_t)ncombo * SLAB * sizeof(float);
-    if (ns > (long)(d->workspace_bytes / slab_bytes)) ns = (long)(d->workspace_bytes / slab_bytes);
+    int cb_rows = 0, cb_per = 1, cb_units = 0;
+    CbSkip ck = {};
+    if (a.cb.on) {          // ~1500 blocks of <= 8 tiles
+        ck = cb_skip_counts(a.cb);
+        cb_units = d->B * ck.per_image;
+        cb_per = std::max(1, std::min(8, cb_units / 1024));
+        cb_rows = szn_div_up(cb_units, cb_per);
+    }
+    const size_t cb_bytes = a.cb.on ? ((size_t)cb_rows + 1) * d->Co * sizeof(float) : 0;
+    if (cb_bytes + slab_bytes > d->workspace_bytes) return 1;
+    if (ns > (long)((d->workspace_bytes - cb_bytes) / slab_bytes)) ns = (long)((d->workspace_bytes - cb_bytes) / slab_bytes);
     if (ns < 1 || ns * ncombo < 32) return 1;
     a.nsplit = (int)ns;
+    if (a.cb.on) {                                     // behind the slabs
+        a.crow = (float*)d->workspace + (size_t)ns * ncombo * SLAB;
+        a.csum = a.crow + (size_t)cb_rows * d->Co;
+    }
     {
         static int xm = -1;
         if (xm < 0) { const char* e = getenv("SZN_WGT_XCD"); xm = e ? atoi(e) : 1; }
@@ -366,6 +534,12 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     if (d->dtype == SZN_F16) hipLaunchKernelGGL(conv_wgrad_taps<f16_raw>, dim3((unsigned)(ns * ncombo)), dim3(512), LDS_WT, st, a);
     else hipLaunchKernelGGL(conv_wgrad_taps<bf16_raw>, dim3((unsigned)(ns * ncombo)), dim3(512), LDS_WT, st, a);
     SZN_CHECK_LAUNCH("conv_wgrad_taps");
+    if (a.cb.on) {
+        hipLaunchKernelGGL(wgrad_cb_colsum, dim3((unsigned)cb_rows), dim3(256), 0, st, a, ck, cb_per, cb_units);
+        hipLaunchKernelGGL(wgrad_cb_colsum_reduce, dim3((unsigned)szn_div_up(d->Co, 8)), dim3(256), 0, st, a, cb_rows);
+        SZN_CHECK_LAUNCH("wgrad_cb_colsum");
+        szn_note_work_fraction((float)a.cb.per_image / (float)(a.tiles_y * a.tiles_x));
+    }
     const long total4 = (long)ncombo * (SLAB / 4);
     hipLaunchKernelGGL(wgrad_taps_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, a);
     SZN_CHECK_LAUNCH("wgrad_taps_reduce");

@@ -79,7 +79,7 @@ def _cb_pool(reg, n):
 
 class _Ctx(object):
     """what one forward pass leaves behind for its backward"""
-    __slots__ = ("x", "acts", "pools", "relu6", "relu7", "masks", "coarse", "B", "H", "W", "h", "w", "train")
+    __slots__ = ("x", "acts", "pools", "relu6", "relu7", "masks", "coarse", "B", "H", "W", "h", "w", "train", "cb_in")
 
 
 class _Engine(object):
@@ -353,12 +353,14 @@ class _Engine(object):
         acts, pools = ({"conv1_1": a} if keep else {}), []
         items = _BACKBONE[1:]
         regy, regx = _cb_conv1_1(H, PAD1), _cb_conv1_1(W, PAD1)         # constant-border regions of the current tensor, per axis
+        cb_in = ctx.cb_in = {}
         for i, item in enumerate(items):
             if item == "P":
                 regy, regx = _cb_pool(regy, a_hw[0]), _cb_pool(regx, a_hw[1])
                 continue                                  # pooled by the conv in front of it (pool_out)
             name, pad = item
             a_hw = (a.shape[1], a.shape[2])               # 3x3 / pad 1: the conv's output size
+            cb_in[name] = (regy, regx)                    # regions of this conv's INPUT (its weight gradient can use them)
             regy, regx = _cb_conv3x3(regy, a_hw[0]), _cb_conv3x3(regx, a_hw[1])
             cb = (regy, regx)
             if i + 1 < len(items) and items[i + 1] == "P":
@@ -506,7 +508,7 @@ class _Engine(object):
             torch.cuda.current_stream().wait_stream(self._wg_stream)
         self._flush_colsum()
 
-    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None, fuse=None):
+    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None, fuse=None, cb=None):
         """dw (OHWI f32) = wgrad of one layer, on the wgrad stream; `after` (e.g. the DDP bucket hook) runs there too.  fuse: layer
         name under which self.fused_opt may hold the Adam step to apply in the kernel's epilogue"""
         B, Hi, Wi, _ = x.shape
@@ -522,6 +524,11 @@ class _Engine(object):
         if self._wg_ws is None or self._wg_ws.device != x.device:
             self._wg_ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
         d.workspace, d.workspace_bytes = self._wg_ws.data_ptr(), nb
+        if cb is not None and _CONST_BORDER and self.dtype != torch.float32:
+            (ry, rx) = cb                                       # per-axis regions of this conv's INPUT x
+            d.cb_on = 1
+            d.cb_rect[0], d.cb_rect[1], d.cb_rect[2], d.cb_rect[3] = ry[0], ry[1], rx[0], rx[1]
+            d.cb_const[0], d.cb_const[1], d.cb_const[2], d.cb_const[3] = ry[2], ry[3], rx[2], rx[3]
         with self._wgrad_stream(x, dout):
             st = L.stream_ptr()
             opt = self.fused_opt.get(fuse) if (self.fused_opt and fuse) else None
@@ -687,7 +694,7 @@ class _Engine(object):
             xin = ctx.pools[pi][1] if prev == "P" else ctx.acts[prev[0]]
             layer = getattr(m, name)
             self._wgrad(xin, d, grads[name][0], None, layer.in_channels, layer.out_channels, 3, pad,
-                        after=lambda name=name: done(name))
+                        after=lambda name=name: done(name), cb=(getattr(ctx, "cb_in", None) or {}).get(name))
             # next d: wrt this conv's input; gate by the ReLU of the producing conv unless a pool sits in between
             if prev == "P":
                 d = self._dgrad(d, name, xin.shape, pad)
