@@ -82,7 +82,8 @@ def _conv_flops(d):
 
 def call_work(name, a):
     """-> (bound, work) with work in FLOP (mfma) or bytes (hbm); None for calls that are not accounted"""
-    if name in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm", "szn_conv2d_dgrad_gemm_native", "szn_conv2d_wgrad"):
+    if name in ("szn_conv2d_fwd", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm", "szn_conv2d_dgrad_gemm_native", "szn_conv2d_wgrad",
+                "szn_conv2d_wgrad_adam"):      # (the last one also moves 26 B per weight: fc6's Adam step rides in its epilogue)
         return "mfma", _conv_flops(a[0]._obj)
     if name == "szn_conv1_1_fwd":          # reads the f32 image once, writes B x (H+198)^2 x 64 activations
         code, B, H, W, pad = a[:5]
@@ -115,9 +116,9 @@ def call_work(name, a):
     if name == "szn_pack_weight_dgrad":
         code, co, kh, kw, ci = a[:5]
         return "hbm", 2.0 * co * kh * kw * ci * _esize(code)
-    if name == "szn_confusion_hist":
+    if name in ("szn_confusion_hist", "szn_confusion_hist_k"):
         return "hbm", a[0] * 16.0
-    if name == "szn_embed_argmax":         # E*s read + 8 B written per pixel
+    if name in ("szn_embed_argmax", "szn_embed_argmax_k"):         # E*s read + 8 B written per pixel
         B, E, H, W, K = a[:5]
         return "hbm", B * H * W * (E * 4.0 + 8.0)
     if name in ("szn_cosine_loss_fwd", "szn_mse_loss_fwd"):
@@ -302,13 +303,14 @@ def _conv_family(torch, L, mods, fn):
 
 
 def _skipped_flops_one_step(L, mods, step_fn):
-    """FLOPs of one step that the constant-border hint replaces by a broadcast (szn_last_work_fraction of every szn_conv2d_fwd call)"""
+    """FLOPs of one step that the constant-border hint replaces by a broadcast (forward) or a rank-one term (weight gradient):
+    szn_last_work_fraction of every szn_conv2d_fwd / szn_conv2d_wgrad call"""
     tot = [0.0]
     orig = L.call
 
     def hooked(name, *a):
         r = orig(name, *a)
-        if name == "szn_conv2d_fwd":
+        if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad"):
             tot[0] += _conv_flops(a[0]._obj) * (1.0 - L.last_work_fraction())
         return r
     for mod in mods:
@@ -592,11 +594,13 @@ def main():
         orig_call(name, *a)
         e1.record()
         kern = L.last_kernel()
-        if name == "szn_conv2d_fwd" and wk:                       # constant-border hint: only the executed tiles count as FLOPs
+        if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad") and wk:      # constant-border hint: only the executed tiles count as FLOPs
             wk = (wk[0], wk[1] * L.last_work_fraction())
         helper = {"splitk_epilogue": "+splitk", "col2im_kernel": "+col2im", "maxpool_fwd_kernel": "+maxpool",
                   "wgrad_taps_reduce": "+reduce", "conv1_1_wgrad_reduce": "+reduce"}.get(kern)
-        if helper:
+        if kern == "wgrad_taps_reduce":                            # (under the constant-border hint two column-sum launches sit in between)
+            kern = "conv_wgrad_taps+reduce"
+        elif helper:
             kern = L.prev_kernel() + helper
         elif name in ("szn_fused_head", "szn_fused_head_strided"):
             kern = "fused_head (fh_prep + fh_cell + fh_finalize + fh_gather)"

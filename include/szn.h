@@ -109,7 +109,10 @@ typedef struct {
                          cb_const and outside cb_rect holds the same value per channel.  conv_wgrad_taps then runs only the 16 x 16
                          output tiles whose input patch is not constant; the others contribute (their column sum of dout) x (that
                          pixel) to all nine taps -- the same sum in a different order (fp32; <= 1e-5 relative against the dense
-                         result, tests/test_gpu_conv.py), ignored with accumulate != 0.  szn_last_work_fraction() reports it.       */
+                         result, tests/test_gpu_conv.py), ignored with accumulate != 0.  szn_last_work_fraction() reports it.
+                         `colsum` (otherwise unused by szn_conv2d_wgrad) may then hold that column sum [Co], computed by the producer
+                         of dout over the tiles szn_conv2d_wgrad_cb_tiles() names (szn_maxpool2x2_ceil_bwd_code_cb); NULL = the
+                         call sums them itself.                                                                                   */
     int cb_rect[4];
     int cb_const[4];
     int reserved_cus;   /* optional (0 = none): compute units the persistent one-block-per-CU kernels (conv3x3_regw, conv_wgrad_taps)
@@ -246,6 +249,13 @@ int szn_maxpool2x2_ceil_fwd_code(int dtype, int B, int Hi, int Wi, int C, const 
                                  szn_stream_t stream);
 int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
                                  float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream);
+/* The same, also summing din over the 16 x 16 tiles the NEXT consumer of din -- the weight gradient of the conv in front of the pool --
+ * replaces by a rank-one term under the constant-border hint: skip_tiles[8] from szn_conv2d_wgrad_cb_tiles(), skip_sum [C] out (hand it
+ * to that szn_conv2d_wgrad call as szn_conv_desc_t.colsum), skip_slab [colsum_slab_rows][C] scratch.  colsum / colsum_slab required. */
+int szn_maxpool2x2_ceil_bwd_code_cb(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
+                                    float* colsum, float* colsum_slab, int colsum_slab_rows, const int* skip_tiles,
+                                    float* skip_sum, float* skip_slab, szn_stream_t stream);
+int szn_conv2d_wgrad_cb_tiles(const szn_conv_desc_t* d, int tiles[8]);
 
 /* ---- upscore: ConvTranspose2d(E,E,64,stride 32,bias=False) with the fixed bilinear kernel of
  * get_upsampling_weight (models.py:11-24,94,146) fused with the crop [19:19+H] (models.py:147).

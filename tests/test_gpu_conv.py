@@ -612,6 +612,74 @@ def test_wgrad_constant_border_hint_equals_dense(case, dtype):
     assert float((acc - 2 * dense).abs().max() / dense.abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_pool_backward_sums_the_tiles_the_weight_gradient_skips(dtype):
+    """szn_conv2d_wgrad_cb_tiles names the 16 x 16 tiles a hinted weight-gradient call replaces by a rank-one term;
+    szn_maxpool2x2_ceil_bwd_code_cb sums its output over exactly those tiles while writing it (same din, same bias sums as the plain
+    call), and the weight gradient that is handed the sum equals the one that sums for itself and the dense one"""
+    B, H, W, Ci, Co = 2, 710, 710, 64, 64
+    rect, const = (98, 612), (0, 710)
+    g = torch.Generator().manual_seed(41)
+    x = torch.relu(torch.randn(B, H, W, Ci, generator=g))
+    cval = torch.relu(torch.randn(Ci, generator=g)) + 0.25
+    inside = torch.zeros(H, W, dtype=torch.bool)
+    inside[rect[0]:rect[1], rect[0]:rect[1]] = True
+    x = torch.where(inside[None, :, :, None], x, cval[None, None, None, :].expand(B, H, W, Ci)).to(dtype).cuda()
+    Hp = (H + 1) // 2
+    dpool = (torch.randn(B, Hp, Hp, Co, generator=g) * 0.1).to(dtype).cuda()
+    code = torch.randint(0, 5, (B, Hp, Hp, Co), generator=g, dtype=torch.uint8).cuda()
+    dt = L.dtype_code(dtype)
+    lib = L.load()
+    ws = torch.empty(2 * 256 * 64 * 9 * 64 * 4, dtype=torch.uint8, device="cuda")
+
+    def desc(hint):
+        d = L.ConvDesc(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, Ci, Co, 0, 0, 0)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        if hint:
+            d.cb_on = 1
+            d.cb_rect[0], d.cb_rect[1], d.cb_rect[2], d.cb_rect[3] = rect[0], rect[1], rect[0], rect[1]
+            d.cb_const[0], d.cb_const[1], d.cb_const[2], d.cb_const[3] = const[0], const[1], const[0], const[1]
+        return d
+
+    tiles = (C.c_int * 8)()
+    assert lib.szn_conv2d_wgrad_cb_tiles(C.byref(desc(True)), tiles) == 1
+    assert lib.szn_conv2d_wgrad_cb_tiles(C.byref(desc(False)), tiles) == 0
+    fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1 = list(tiles)
+    assert 0 < fy0 < wy0 < wy1 < fy1 <= H // 16
+    rows = 512
+    st = L.stream_ptr()
+    din0, din1 = torch.empty(B, H, W, Co, device="cuda", dtype=dtype), torch.empty(B, H, W, Co, device="cuda", dtype=dtype)
+    cs0, cs1 = torch.zeros(Co, device="cuda"), torch.zeros(Co, device="cuda")
+    slab0, slab1, slab2 = (torch.zeros(rows * Co, device="cuda") for _ in range(3))
+    ssum = torch.full((Co,), 7.0, device="cuda")
+    L.call("szn_maxpool2x2_ceil_bwd_code", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(din0), L.ptr(cs0), L.ptr(slab0), rows, st)
+    L.call("szn_maxpool2x2_ceil_bwd_code_cb", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(din1), L.ptr(cs1), L.ptr(slab1), rows,
+           tiles, L.ptr(ssum), L.ptr(slab2), st)
+    assert L.last_kernel() == "slab_rows_sum_kernel" and L.prev_kernel() == "maxpool_bwd_code_kernel"
+    torch.cuda.synchronize()
+    assert torch.equal(din0, din1) and torch.equal(slab0, slab1)
+    mask = torch.zeros(H, W, dtype=torch.bool, device="cuda")
+    mask[16 * fy0:16 * fy1, 16 * fx0:16 * fx1] = True
+    mask[16 * wy0:16 * wy1, 16 * wx0:16 * wx1] = False
+    want = (din0.double() * mask[None, :, :, None]).sum(dim=(0, 1, 2))
+    assert float((ssum.double() - want).abs().max() / want.abs().max()) < 1e-5
+    # the three forms of the weight gradient
+    def wgrad(d):
+        dw = torch.empty(Co, 3, 3, Ci, device="cuda")
+        L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(din0), L.ptr(dw), 0, st)
+        torch.cuda.synchronize()
+        return dw, L.prev_kernel()
+    dense, _ = wgrad(desc(False))
+    own, k_own = wgrad(desc(True))
+    dh = desc(True)
+    dh.colsum = ssum.data_ptr()
+    given, k_given = wgrad(dh)
+    assert k_own == "wgrad_cb_colsum" and k_given == "conv_wgrad_taps"       # (the launch in front of wgrad_taps_reduce)
+    scale = float(dense.abs().max())
+    assert float((own - dense).abs().max()) / scale < 1e-5 and float((given - dense).abs().max()) / scale < 1e-5
+    assert float((given - own).abs().max()) / scale < 1e-6
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("geom", [(2, 37, 41, 64, 64), (1, 710, 64, 64, 64), (2, 45, 45, 512, 512)])
 def test_pool_winner_codes(dtype, geom):

@@ -324,6 +324,7 @@ extern "C" int szn_conv2d_wgrad_adam(const szn_conv_desc_t* d, const void* in, c
 extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                                 szn_stream_t stream) {
     if (!d) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad: null descriptor");
+    szn_note_work_fraction(1.f);
     const size_t es = szn_esize(d->dtype);
     const int ch = (int)(16 / es);
     const size_t in_bytes = (size_t)d->B * d->Hi * d->Wi * d->ldi * es;

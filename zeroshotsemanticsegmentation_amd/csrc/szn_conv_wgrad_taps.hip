@@ -420,6 +420,40 @@ __global__ __launch_bounds__(256) void wgrad_cb_colsum_reduce(WtArgs a, int rows
 
 }  // namespace
 
+// The constant-border hint of a weight-gradient call (szn_conv_desc_t.cb_on): cb_rect = the input rows x columns the image can influence,
+// cb_const = the rows x columns outside of which the zero padding of the layers so far is felt (include/szn.h).  A tile is skipped when its
+// input patch -- rows [16 ty - pad, 16 ty + 18 - pad) -- lies inside cb_const, does not meet cb_rect, and the tile is a full 16 x 16 one.
+// -> true + the tile bookkeeping + the reference pixel (top-left pixel of the first skipped tile's patch) when the hint is worth taking.
+static bool taps_cb_geometry(const szn_conv_desc_t* d, int ncombo, int ncu, int min_tiles_per_block, CbGeom& out, int& ry, int& rx) {
+    static int cbon = -1;
+    if (cbon < 0) { const char* e = getenv("SZN_WGT_CB"); cbon = e ? atoi(e) : 1; }
+    if (!cbon || !d->cb_on) return false;
+    auto fdiv = [](int x, int y) { return x >= 0 ? x / y : -((-x + y - 1) / y); };       // floor
+    auto cdiv = [&](int x, int y) { return -fdiv(-x, y); };                              // ceil
+    CbGeom c;
+    c.on = 1; c.tiles_y = szn_div_up(d->Ho, 16); c.tiles_x = szn_div_up(d->Wo, 16);
+    const int p = d->pad;
+    c.fy0 = std::max(cdiv(d->cb_const[0] + p, 16), 0);
+    c.fy1 = std::min(fdiv(d->cb_const[1] - 18 + p, 16) + 1, d->Ho / 16);
+    c.fx0 = std::max(cdiv(d->cb_const[2] + p, 16), 0);
+    c.fx1 = std::min(fdiv(d->cb_const[3] - 18 + p, 16) + 1, d->Wo / 16);
+    c.wy0 = fdiv(d->cb_rect[0] - 18 + p, 16) + 1; c.wy1 = cdiv(d->cb_rect[1] + p, 16);
+    c.wx0 = fdiv(d->cb_rect[2] - 18 + p, 16) + 1; c.wx1 = cdiv(d->cb_rect[3] + p, 16);
+    if (!(c.fy1 > c.fy0 && c.fx1 > c.fx0 && d->cb_rect[1] > d->cb_rect[0] && d->cb_rect[3] > d->cb_rect[2])) return false;
+    cb_finish(c);
+    const long all = (long)c.tiles_y * c.tiles_x, skipped = all - c.per_image;
+    ry = rx = -1;
+    for (int ty = c.fy0; ty < c.fy1 && ry < 0; ++ty)
+        for (int tx = c.fx0; tx < c.fx1; ++tx)
+            if (cb_skippable(c, ty, tx)) { ry = ty * 16 - p; rx = tx * 16 - p; break; }
+    // (not when the tiles that are left would be too few for this kernel: the dense run then beats conv_wgrad_v2)
+    const long left = (long)d->B * c.per_image / (min_tiles_per_block < 1 ? 1 : min_tiles_per_block);
+    const bool enough = std::min(left, (long)(ncu / ncombo)) * ncombo >= 32;
+    if (!(skipped * 20 >= all && ry >= 0 && rx >= 0 && d->Co <= 2048 && enough)) return false;      // worth the bookkeeping
+    out = c;
+    return true;
+}
+
 // Called by szn_conv2d_wgrad after validation.  Returns 1 if the layer / workspace does not fit this kernel.
 int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                             int min_tiles_per_block, szn_stream_t stream) {
@@ -444,37 +478,12 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     // 16 ty + 18 - pad) -- lies inside cb_const, does not meet cb_rect, and the tile is a full 16 x 16 one.
     a.cb.on = 0; a.crow = a.csum = nullptr; a.cref = 0; a.is_f16 = d->dtype == SZN_F16;
     {
-        static int cbon = -1;
-        if (cbon < 0) { const char* e = getenv("SZN_WGT_CB"); cbon = e ? atoi(e) : 1; }
-        if (cbon && d->cb_on && !accumulate) {
-            auto fdiv = [](int x, int y) { return x >= 0 ? x / y : -((-x + y - 1) / y); };       // floor
-            auto cdiv = [&](int x, int y) { return -fdiv(-x, y); };                              // ceil
-            CbGeom c;
-            c.on = 1; c.tiles_y = a.tiles_y; c.tiles_x = a.tiles_x;
-            const int p = d->pad;
-            c.fy0 = std::max(cdiv(d->cb_const[0] + p, 16), 0);
-            c.fy1 = std::min(fdiv(d->cb_const[1] - 18 + p, 16) + 1, d->Ho / 16);
-            c.fx0 = std::max(cdiv(d->cb_const[2] + p, 16), 0);
-            c.fx1 = std::min(fdiv(d->cb_const[3] - 18 + p, 16) + 1, d->Wo / 16);
-            c.wy0 = fdiv(d->cb_rect[0] - 18 + p, 16) + 1; c.wy1 = cdiv(d->cb_rect[1] + p, 16);
-            c.wx0 = fdiv(d->cb_rect[2] - 18 + p, 16) + 1; c.wx1 = cdiv(d->cb_rect[3] + p, 16);
-            if (c.fy1 > c.fy0 && c.fx1 > c.fx0 && d->cb_rect[1] > d->cb_rect[0] && d->cb_rect[3] > d->cb_rect[2]) {
-                cb_finish(c);
-                const long skipped = (long)a.tiles_y * a.tiles_x - c.per_image;
-                // first skipped tile (row-major) -> the reference pixel = the top-left pixel of its patch
-                int ry = -1, rx = -1;
-                for (int ty = c.fy0; ty < c.fy1 && ry < 0; ++ty)
-                    for (int tx = c.fx0; tx < c.fx1; ++tx)
-                        if (cb_skippable(c, ty, tx)) { ry = ty * 16 - p; rx = tx * 16 - p; break; }
-                // (not when the tiles that are left would be too few for this kernel: the dense run then beats conv_wgrad_v2)
-                const long left = (long)d->B * c.per_image / (min_tiles_per_block < 1 ? 1 : min_tiles_per_block);
-                const bool enough = std::min(left, (long)(ncu / ncombo)) * ncombo >= 32;
-                if (skipped * 20 >= (long)a.tiles_y * a.tiles_x && ry >= 0 && rx >= 0 && d->Co <= 2048 && enough) {      // worth two small launches
-                    a.cb = c;
-                    a.cref = (unsigned)(((size_t)ry * d->Wi + rx) * d->ldi * 2);
-                    nt = (long)d->B * c.per_image;
-                }
-            }
+        int ry = 0, rx = 0;
+        if (!accumulate && taps_cb_geometry(d, ncombo, ncu, min_tiles_per_block, a.cb, ry, rx)) {
+            a.cref = (unsigned)(((size_t)ry * d->Wi + rx) * d->ldi * 2);
+            nt = (long)d->B * a.cb.per_image;
+        } else {
+            a.cb.on = 0;
         }
     }
     a.ntiles = (int)nt;
@@ -505,9 +514,10 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     if (ns > (long)((d->workspace_bytes - cb_bytes) / slab_bytes)) ns = (long)((d->workspace_bytes - cb_bytes) / slab_bytes);
     if (ns < 1 || ns * ncombo < 32) return 1;
     a.nsplit = (int)ns;
+    const bool own_sum = a.cb.on && !d->colsum;        // d->colsum: the producer of dout already summed the skipped tiles (include/szn.h)
     if (a.cb.on) {                                     // behind the slabs
         a.crow = (float*)d->workspace + (size_t)ns * ncombo * SLAB;
-        a.csum = a.crow + (size_t)cb_rows * d->Co;
+        a.csum = own_sum ? a.crow + (size_t)cb_rows * d->Co : (float*)d->colsum;
     }
     {
         static int xm = -1;
@@ -535,13 +545,39 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     else hipLaunchKernelGGL(conv_wgrad_taps<bf16_raw>, dim3((unsigned)(ns * ncombo)), dim3(512), LDS_WT, st, a);
     SZN_CHECK_LAUNCH("conv_wgrad_taps");
     if (a.cb.on) {
-        hipLaunchKernelGGL(wgrad_cb_colsum, dim3((unsigned)cb_rows), dim3(256), 0, st, a, ck, cb_per, cb_units);
-        hipLaunchKernelGGL(wgrad_cb_colsum_reduce, dim3((unsigned)szn_div_up(d->Co, 8)), dim3(256), 0, st, a, cb_rows);
-        SZN_CHECK_LAUNCH("wgrad_cb_colsum");
+        if (own_sum) {
+            hipLaunchKernelGGL(wgrad_cb_colsum, dim3((unsigned)cb_rows), dim3(256), 0, st, a, ck, cb_per, cb_units);
+            hipLaunchKernelGGL(wgrad_cb_colsum_reduce, dim3((unsigned)szn_div_up(d->Co, 8)), dim3(256), 0, st, a, cb_rows);
+            SZN_CHECK_LAUNCH("wgrad_cb_colsum");
+        }
         szn_note_work_fraction((float)a.cb.per_image / (float)(a.tiles_y * a.tiles_x));
     }
     const long total4 = (long)ncombo * (SLAB / 4);
     hipLaunchKernelGGL(wgrad_taps_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, a);
     SZN_CHECK_LAUNCH("wgrad_taps_reduce");
     return SZN_OK;
+}
+
+// Which tiles a szn_conv2d_wgrad call with this descriptor (constant-border hint set, accumulate = 0) replaces by the rank-one term:
+// tiles[8] = 16 x 16 tile rows / columns {fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1} -- the tiles inside [fy0, fy1) x [fx0, fx1) and outside
+// [wy0, wy1) x [wx0, wx1).  Returns 1 (tiles filled) or 0 (the call runs dense).  For the producer of dout, which can sum those tiles
+// while it writes them (szn_maxpool2x2_ceil_bwd_code_cb) and hand the result to the call as szn_conv_desc_t.colsum.
+extern "C" int szn_conv2d_wgrad_cb_tiles(const szn_conv_desc_t* d, int tiles[8]) {
+    if (!d || !tiles || !szn_is16(d->dtype) || d->KH != 3 || d->KW != 3 || (d->Ci & 63) || (d->Co & 63) || d->pad > 2 || !d->workspace ||
+        (d->ldi & 7) || (d->ldo & 7))
+        return 0;
+    int ncu = 0, dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+    const int ncombo = (d->Co / 64) * (d->Ci / 64);
+    if (ncombo > ncu) return 0;
+    static int taps_min = -1;
+    if (taps_min < 0) { const char* e = getenv("SZN_WGT_MINTILES"); taps_min = e ? atoi(e) : 8; }
+    CbGeom c;
+    int ry, rx;
+    if (!taps_cb_geometry(d, ncombo, ncu, taps_min, c, ry, rx)) return 0;
+    tiles[0] = c.fy0; tiles[1] = c.fy1; tiles[2] = c.fx0; tiles[3] = c.fx1;
+    tiles[4] = c.wy0; tiles[5] = c.wy1; tiles[6] = c.wx0; tiles[7] = c.wx1;
+    return 1;
 }

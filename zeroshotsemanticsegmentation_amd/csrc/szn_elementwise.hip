@@ -614,17 +614,22 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 // instead of the pool's input: code 0 .. 3 = position 2 dy + dx of the first maximum, 4 = maximum not positive (no gradient: the
 // ReLU gate).  2.75 B instead of 4.5 B of traffic per input element, and the forward pass no longer has to store the un-pooled
 // tensor for this kernel alone.  Same result bit for bit.
-template <typename T>
+// SKIP: a second set of column sums over the 16 x 16 tiles of din inside sk = {fy0, fy1, fx0, fx1} and outside {wy0, wy1, wx0, wx1} -- the
+// tiles the weight gradient of the layer that reads din replaces by a rank-one term (szn_conv2d_wgrad_cb_tiles); a 2 x 2 window never
+// straddles a tile boundary.  Rows of cslab2 like cslab's.
+struct PoolSkip { int fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1; };
+template <typename T, bool SKIP>
 __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __restrict__ code, const T* __restrict__ dout,
                                                                T* __restrict__ din, int B, int Hi, int Wi, int C, int Ho, int Wo,
-                                                               float* __restrict__ colsum, float* __restrict__ cslab) {
+                                                               float* __restrict__ colsum, float* __restrict__ cslab, PoolSkip sk,
+                                                               float* __restrict__ cslab2) {
     constexpr int CH = elem<T>::kPer16B;
     __shared__ float red[256 * CH];
     const int cpp = C / CH;
     const long total = (long)B * Ho * Wo * cpp;
-    float cs[CH];
+    float cs[CH], cs2[CH];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) cs[e] = 0.f;
+    for (int e = 0; e < CH; ++e) { cs[e] = 0.f; cs2[e] = 0.f; }
     for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
         const int cc = (int)(gid % cpp);
         const long po = gid / cpp;
@@ -638,6 +643,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __
         const T* de = (const T*)&vd;
         const uint8_t* cp = code + po * C + cc * CH;
         const uint32_t clo = *(const uint32_t*)cp, chi = CH == 8 ? *(const uint32_t*)(cp + 4) : 0u;
+        const int ty = ih >> 4, tx = iw >> 4;
+        const bool skip = SKIP && ty >= sk.fy0 && ty < sk.fy1 && tx >= sk.fx0 && tx < sk.fx1 &&
+                          !(ty >= sk.wy0 && ty < sk.wy1 && tx >= sk.wx0 && tx < sk.wx1);
         u32x4_t o[4];
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
@@ -646,6 +654,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __
 #pragma unroll
             for (int k = 0; k < 4; ++k) elem<T>::st((T*)&o[k] + e, k == win ? dv : 0.f);
             cs[e] += win < 4 ? dv : 0.f;                           // what was stored (one non-zero term)
+            if (SKIP) cs2[e] += (skip && win < 4) ? dv : 0.f;
         }
         T* op = din + p00 * C + cc * CH;
         *(u32x4_t*)op = o[0];
@@ -664,6 +673,40 @@ __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __
             if (cslab) cslab[(long)blockIdx.x * C + c] = t;
             else if (t != 0.f) atomicAdd(colsum + c, t);
         }
+    }
+    if (SKIP) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = cs2[e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const int cc = c / CH, e = c - cc * CH;
+            float t = 0.f;
+            for (int r = cc; r < 256; r += cpp) t += red[r * CH + e];
+            cslab2[(long)blockIdx.x * C + c] = t;
+        }
+    }
+}
+
+// out[c] = sum over the rows of slab [rows][C], fixed order (four running sums per thread group, then a tree over 32 groups)
+__global__ __launch_bounds__(256) void slab_rows_sum_kernel(const float* __restrict__ slab, int rows, int C, float* __restrict__ out) {
+    __shared__ float part[32][8];
+    const int cl = threadIdx.x & 7, grp = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int r = grp;
+        for (; r + 96 < rows; r += 128) {
+            s0 += slab[(size_t)r * C + c]; s1 += slab[(size_t)(r + 32) * C + c];
+            s2 += slab[(size_t)(r + 64) * C + c]; s3 += slab[(size_t)(r + 96) * C + c];
+        }
+        for (; r < rows; r += 32) s0 += slab[(size_t)r * C + c];
+    }
+    part[grp][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (threadIdx.x < 8 && c < C) {
+        float t = 0.f;
+        for (int g2 = 0; g2 < 32; ++g2) t += part[g2][cl];
+        out[c] = t;
     }
 }
 
@@ -973,35 +1016,57 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
     return SZN_OK;
 }
 
-extern "C" int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
-                                            float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream) {
+static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din, float* colsum,
+                                 float* colsum_slab, int colsum_slab_rows, const int* skip_tiles, float* skip_sum, float* skip_slab,
+                                 szn_stream_t stream) {
     if (!code || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: bad argument");
     const int ch = szn_is16(dtype) ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_code: C must be a multiple of %d", ch);
     if (((uintptr_t)code) & 3) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: code must be 4-B aligned");
     const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
     const long total = (long)B * Ho * Wo * (C / ch);
-    if (colsum && (256 % (C / ch)) != 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_code: colsum needs C/%d to divide 256", ch);
+    const bool sums = colsum || skip_tiles;
+    if (sums && (256 % (C / ch)) != 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_code: colsum needs C/%d to divide 256", ch);
+    if (skip_tiles && (!skip_sum || !skip_slab || !colsum || !colsum_slab))
+        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_cb: skip_sum, skip_slab, colsum and colsum_slab are required");
     static int capx = -1;
     if (capx < 0) { const char* e = getenv("SZN_POOLBWD_BLOCKS"); capx = e ? atoi(e) : 512; if (capx < 1) capx = 1; }
-    const int grid = grid_for(total, 256, colsum ? capx : 65536);
+    const int grid = grid_for(total, 256, sums ? capx : 65536);
     float* cslab = colsum ? colsum_slab : nullptr;
     if (cslab && colsum_slab_rows < grid)
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: colsum_slab holds %d rows, %d needed", colsum_slab_rows, grid);
     szn_note_colsum_rows(cslab ? grid : 0);
-    if (dtype == SZN_BF16)
-        hipLaunchKernelGGL(maxpool_bwd_code_kernel<bf16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)code,
-                           (const bf16_raw*)dout, (bf16_raw*)din, B, Hi, Wi, C, Ho, Wo, colsum, cslab);
-    else if (dtype == SZN_F16)
-        hipLaunchKernelGGL(maxpool_bwd_code_kernel<f16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)code,
-                           (const f16_raw*)dout, (f16_raw*)din, B, Hi, Wi, C, Ho, Wo, colsum, cslab);
-    else if (dtype == SZN_F32)
-        hipLaunchKernelGGL(maxpool_bwd_code_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)code,
-                           (const float*)dout, (float*)din, B, Hi, Wi, C, Ho, Wo, colsum, cslab);
-    else
-        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: bad dtype %d", dtype);
+    PoolSkip sk = {};
+    if (skip_tiles) { sk.fy0 = skip_tiles[0]; sk.fy1 = skip_tiles[1]; sk.fx0 = skip_tiles[2]; sk.fx1 = skip_tiles[3];
+                      sk.wy0 = skip_tiles[4]; sk.wy1 = skip_tiles[5]; sk.wx0 = skip_tiles[6]; sk.wx1 = skip_tiles[7]; }
+    hipStream_t st = (hipStream_t)stream;
+#define SZN_POOLBWD_LAUNCH(TT, SK)                                                                                                      \
+    hipLaunchKernelGGL((maxpool_bwd_code_kernel<TT, SK>), dim3(grid), dim3(256), 0, st, (const uint8_t*)code, (const TT*)dout, (TT*)din, B, \
+                       Hi, Wi, C, Ho, Wo, colsum, cslab, sk, skip_slab)
+    if (dtype == SZN_BF16) { if (skip_tiles) SZN_POOLBWD_LAUNCH(bf16_raw, true); else SZN_POOLBWD_LAUNCH(bf16_raw, false); }
+    else if (dtype == SZN_F16) { if (skip_tiles) SZN_POOLBWD_LAUNCH(f16_raw, true); else SZN_POOLBWD_LAUNCH(f16_raw, false); }
+    else if (dtype == SZN_F32) { if (skip_tiles) SZN_POOLBWD_LAUNCH(float, true); else SZN_POOLBWD_LAUNCH(float, false); }
+    else SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: bad dtype %d", dtype);
+#undef SZN_POOLBWD_LAUNCH
     SZN_CHECK_LAUNCH("maxpool_bwd_code_kernel");
+    if (skip_tiles) {
+        hipLaunchKernelGGL(slab_rows_sum_kernel, dim3((unsigned)szn_div_up(C, 8)), dim3(256), 0, st, (const float*)skip_slab, grid, C, skip_sum);
+        SZN_CHECK_LAUNCH("slab_rows_sum_kernel");
+    }
     return SZN_OK;
+}
+
+extern "C" int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
+                                            float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream) {
+    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int szn_maxpool2x2_ceil_bwd_code_cb(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
+                                               float* colsum, float* colsum_slab, int colsum_slab_rows, const int* skip_tiles,
+                                               float* skip_sum, float* skip_slab, szn_stream_t stream) {
+    if (!skip_tiles) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_cb: skip_tiles is NULL (use szn_maxpool2x2_ceil_bwd_code)");
+    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, skip_tiles, skip_sum, skip_slab,
+                                 stream);
 }
 
 extern "C" int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, szn_stream_t stream) {

@@ -47,6 +47,7 @@ _BACKBONE = [("conv1_1", PAD1), ("conv1_2", 1), "P", ("conv2_1", 1), ("conv2_2",
 _TRUNK = [n for n, _, _, _ in synth.CONV_LAYERS]          # conv1_1 .. fc7
 _CONST_BORDER = os.environ.get("SZN_CONST_BORDER", "1") != "0"  # 0: no constant-border hint to the 710^2 / 355^2 forward convs
 _DGRAD_SPLIT = os.environ.get("SZN_DGRAD_SPLIT", "1") != "0"      # 0: few-tile dgrads keep their fused column sums (no split-K)
+_WGRAD_CB_FUSED = os.environ.get("SZN_WGRAD_CB_FUSED", "1") != "0"   # 0: the weight gradients sum their skipped tiles themselves
 _FC6_NATIVE = os.environ.get("SZN_FC6_NATIVE", "1") != "0"      # 0: fc6's dgrad GEMM on the packed transpose (rounds 1-2)
 _OPT_LAYERS = _TRUNK + ["score_fr"]                        # the layers train.get_parameters yields (train.py:302-331)
 _OPT_LAYERS8 = _TRUNK + ["score_pool3", "score_pool4", "score_fr"]       # ... for FCN8s (score_fr stays last: engine.TrainStep)
@@ -508,12 +509,12 @@ class _Engine(object):
             torch.cuda.current_stream().wait_stream(self._wg_stream)
         self._flush_colsum()
 
-    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None, fuse=None, cb=None):
-        """dw (OHWI f32) = wgrad of one layer, on the wgrad stream; `after` (e.g. the DDP bucket hook) runs there too.  fuse: layer
-        name under which self.fused_opt may hold the Adam step to apply in the kernel's epilogue"""
+    def _wgrad_desc(self, x, dout_shape, ci, co, k, pad, ldo=None, cb=None):
+        """the descriptor of one layer's szn_conv2d_wgrad call (with the slab workspace and, on the 16-bit paths, the constant-border
+        hint of the layer's INPUT x: cb = its per-axis regions)"""
         B, Hi, Wi, _ = x.shape
-        Ho, Wo = dout.shape[1:3]
-        ldo = dout.shape[3] if ldo is None else ldo
+        Ho, Wo = dout_shape[1:3]
+        ldo = dout_shape[3] if ldo is None else ldo
         code = L.dtype_code(self.dtype)
         d = L.ConvDesc(code, B, Hi, Wi, ci, Ho, Wo, co, k, k, pad, ci, ldo, 0, 0, 0)
         d.reserved_cus = self.reserved_cus
@@ -529,6 +530,19 @@ class _Engine(object):
             d.cb_on = 1
             d.cb_rect[0], d.cb_rect[1], d.cb_rect[2], d.cb_rect[3] = ry[0], ry[1], rx[0], rx[1]
             d.cb_const[0], d.cb_const[1], d.cb_const[2], d.cb_const[3] = ry[2], ry[3], rx[2], rx[3]
+        return d
+
+    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None, fuse=None, cb=None, csum=None):
+        """dw (OHWI f32) = wgrad of one layer, on the wgrad stream; `after` (e.g. the DDP bucket hook) runs there too.  fuse: layer
+        name under which self.fused_opt may hold the Adam step to apply in the kernel's epilogue.  cb / csum: constant-border regions
+        of x and, optionally, the column sums of dout over the tiles the hint skips (from the producer of dout)."""
+        B, Hi, Wi, _ = x.shape
+        Ho, Wo = dout.shape[1:3]
+        code = L.dtype_code(self.dtype)
+        d = self._wgrad_desc(x, dout.shape, ci, co, k, pad, ldo=ldo, cb=cb)
+        ldo = d.ldo
+        if csum is not None and d.cb_on:
+            d.colsum = csum.data_ptr()
         with self._wgrad_stream(x, dout):
             st = L.stream_ptr()
             opt = self.fused_opt.get(fuse) if (self.fused_opt and fuse) else None
@@ -660,6 +674,7 @@ class _Engine(object):
             d = self._dgrad(d, "fc6", pool5.shape, 0)
         pi = 4
         prev_out = None
+        cb_sums = {}
         items = _BACKBONE
         for idx in range(len(items) - 1, -1, -1):
             item = items[idx]
@@ -671,7 +686,25 @@ class _Engine(object):
                 B, Hi, Wi, Cc = ctx.pools[pi + 1][3] if pcode is not None else pin.shape
                 dn = torch.empty(B, Hi, Wi, Cc, device=d.device, dtype=pout.dtype)
                 slab, rows = self._cs_slab(B * Hi * Wi, Cc, d.device)
-                if pcode is not None:
+                # constant-border hint of the producer's weight gradient (which reads dn next): let this pass sum dn over the tiles
+                # that call is going to skip, instead of a second pass over them (szn_conv2d_wgrad_cb_tiles)
+                tiles = None
+                cbp = (getattr(ctx, "cb_in", None) or {}).get(producer)
+                if pcode is not None and cbp is not None and slab is not None and _WGRAD_CB_FUSED and idx >= 2:
+                    prev2 = items[idx - 2]
+                    xin2 = ctx.pools[pi][1] if prev2 == "P" else ctx.acts[prev2[0]]
+                    lay = getattr(m, producer)
+                    dd = self._wgrad_desc(xin2, (B, Hi, Wi, Cc), lay.in_channels, lay.out_channels, 3, items[idx - 1][1], cb=cbp)
+                    t8 = (C.c_int * 8)()
+                    if dd.cb_on and L.load().szn_conv2d_wgrad_cb_tiles(C.byref(dd), t8) == 1:
+                        tiles = t8
+                if tiles is not None:
+                    ssum = torch.empty(Cc, device=d.device)
+                    slab2 = torch.empty(rows * Cc, device=d.device)
+                    L.call("szn_maxpool2x2_ceil_bwd_code_cb", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), L.ptr(dn),
+                           L.ptr(grads[producer][1]), L.ptr(slab), rows, tiles, L.ptr(ssum), L.ptr(slab2), st)
+                    cb_sums[producer] = ssum
+                elif pcode is not None:
                     L.call("szn_maxpool2x2_ceil_bwd_code", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), L.ptr(dn),
                            L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
                 else:
@@ -694,7 +727,8 @@ class _Engine(object):
             xin = ctx.pools[pi][1] if prev == "P" else ctx.acts[prev[0]]
             layer = getattr(m, name)
             self._wgrad(xin, d, grads[name][0], None, layer.in_channels, layer.out_channels, 3, pad,
-                        after=lambda name=name: done(name), cb=(getattr(ctx, "cb_in", None) or {}).get(name))
+                        after=lambda name=name: done(name), cb=(getattr(ctx, "cb_in", None) or {}).get(name),
+                        csum=cb_sums.pop(name, None))
             # next d: wrt this conv's input; gate by the ReLU of the producing conv unless a pool sits in between
             if prev == "P":
                 d = self._dgrad(d, name, xin.shape, pad)
