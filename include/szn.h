@@ -182,6 +182,7 @@ typedef struct szn_adam_args {
     float lr, beta1, beta2, eps, weight_decay;
     int step;              /* 1-based, like szn_adam_step */
     float grad_scale;
+    int grad_optional;     /* 1: the caller does not read dw afterwards: the gradient is not stored even when dw != NULL */
 } szn_adam_args_t;
 int szn_conv2d_wgrad_adam_supported(const szn_conv_desc_t* d);
 int szn_conv2d_wgrad_adam(const szn_conv_desc_t* d, const void* x, const void* dout, float* dw,

@@ -69,6 +69,16 @@ def test_wgrad_adam_equals_wgrad_then_adam(case, keep):
         assert torch.equal(dwf, dw)
     else:
         assert float((dwf - 7.0).abs().max()) == 0.0              # untouched
+    # dw handed over but declared optional: not written
+    ph, m1h, m2h = p0.clone(), m10.clone(), m20.clone()
+    dwh = torch.full((n,), 7.0, device="cuda")
+    a.param, a.exp_avg, a.exp_avg_sq, a.grad_optional = ph.data_ptr(), m1h.data_ptr(), m2h.data_ptr(), 1
+    lph = torch.zeros(n, device="cuda", dtype=dt)
+    a.w_lp = lph.data_ptr()
+    L.call("szn_conv2d_wgrad_adam", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dwh), C.byref(a), st)
+    torch.cuda.synchronize()
+    assert torch.equal(ph, p) and torch.equal(lph, lp) and float((dwh - 7.0).abs().max()) == 0.0
+    a.grad_optional = 0
     # no weight image: masters and moments only
     pg, m1g, m2g = p0.clone(), m10.clone(), m20.clone()
     a.param, a.exp_avg, a.exp_avg_sq, a.w_lp = pg.data_ptr(), m1g.data_ptr(), m2g.data_ptr(), None

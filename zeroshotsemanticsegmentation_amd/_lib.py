@@ -36,7 +36,7 @@ class AdamArgs(C.Structure):
     """szn_adam_args_t (include/szn.h): state and hyper-parameters of the Adam step fused into szn_conv2d_wgrad_adam"""
     _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("w_lp", C.c_void_p),
                 ("w_lp_dtype", C.c_int), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("step", C.c_int), ("grad_scale", C.c_float)]
+                ("weight_decay", C.c_float), ("step", C.c_int), ("grad_scale", C.c_float), ("grad_optional", C.c_int)]
 
 
 MAX_CLASSES = 256           # SZN_MAX_CLASSES

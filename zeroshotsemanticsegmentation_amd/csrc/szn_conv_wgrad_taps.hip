@@ -512,7 +512,9 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     const size_t cb_bytes = a.cb.on ? ((size_t)cb_rows + 1) * d->Co * sizeof(float) : 0;
     if (cb_bytes + slab_bytes > d->workspace_bytes) return 1;
     if (ns > (long)((d->workspace_bytes - cb_bytes) / slab_bytes)) ns = (long)((d->workspace_bytes - cb_bytes) / slab_bytes);
-    if (ns < 1 || ns * ncombo < 32) return 1;
+    static int minblk = -1;
+    if (minblk < 0) { const char* e = getenv("SZN_WGT_MINBLOCKS"); minblk = e ? atoi(e) : 32; }
+    if (ns < 1 || ns * ncombo < minblk) return 1;
     a.nsplit = (int)ns;
     const bool own_sum = a.cb.on && !d->colsum;        // d->colsum: the producer of dout already summed the skipped tiles (include/szn.h)
     if (a.cb.on) {                                     // behind the slabs

@@ -401,6 +401,7 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     const dim3 grid((unsigned)tiles);
     hipStream_t st = (hipStream_t)stream;
     if (opt) {
+        if (opt->grad_optional) a.dw = nullptr;
         if (d->dtype == SZN_F16) hipLaunchKernelGGL((conv_wgrad_wide<f16_raw, true>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((conv_wgrad_wide<bf16_raw, true>), grid, dim3(512), lds, st, a);
         SZN_CHECK_LAUNCH("conv_wgrad_wide_adam");

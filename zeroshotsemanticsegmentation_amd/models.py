@@ -547,7 +547,8 @@ class _Engine(object):
             st = L.stream_ptr()
             opt = self.fused_opt.get(fuse) if (self.fused_opt and fuse) else None
             if opt is not None and L.load().szn_conv2d_wgrad_adam_supported(C.byref(d)) == 1:
-                L.call("szn_conv2d_wgrad_adam", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw) if opt[1] else None, C.byref(opt[0]), st)
+                opt[0].grad_optional = 0 if opt[1] else 1          # (dw is handed over either way: the follower form needs it)
+                L.call("szn_conv2d_wgrad_adam", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), C.byref(opt[0]), st)
                 self.fused_done.add(fuse)
             else:
                 L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
