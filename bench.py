@@ -97,7 +97,7 @@ def call_work(name, a):
     if name == "szn_maxpool2x2_ceil_bwd":  # pool input + pooled + d(pooled) in, d(input) out
         code, B, Hi, Wi, Cc = a[:5]
         return "hbm", B * Cc * _esize(code) * (2.0 * Hi * Wi + 2.0 * ((Hi + 1) // 2) * ((Wi + 1) // 2))
-    if name == "szn_maxpool2x2_ceil_bwd_code":   # d(pooled) + one code byte per pooled element in, d(input) out
+    if name in ("szn_maxpool2x2_ceil_bwd_code", "szn_maxpool2x2_ceil_bwd_code_cb"):   # d(pooled) + one code byte per pooled element in, d(input) out
         code, B, Hi, Wi, Cc = a[:5]
         return "hbm", B * Cc * (_esize(code) * (1.0 * Hi * Wi + ((Hi + 1) // 2) * ((Wi + 1) // 2)) + ((Hi + 1) // 2) * ((Wi + 1) // 2))
     if name == "szn_adam_step":            # p, g, m, v in; p, m, v out (+ the bf16 weight image when asked for)
@@ -600,6 +600,8 @@ def main():
                   "wgrad_taps_reduce": "+reduce", "conv1_1_wgrad_reduce": "+reduce"}.get(kern)
         if kern == "wgrad_taps_reduce":                            # (under the constant-border hint two column-sum launches sit in between)
             kern = "conv_wgrad_taps+reduce"
+        elif kern == "slab_rows_sum_kernel":                       # szn_maxpool2x2_ceil_bwd_code_cb: the pool's backward + its skipped-tile sums
+            kern = "maxpool_bwd_code_kernel"
         elif helper:
             kern = L.prev_kernel() + helper
         elif name in ("szn_fused_head", "szn_fused_head_strided"):
