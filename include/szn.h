@@ -111,7 +111,7 @@ typedef struct {
                          pixel) to all nine taps -- the same sum in a different order (fp32; <= 1e-5 relative against the dense
                          result, tests/test_gpu_conv.py), ignored with accumulate != 0.  szn_last_work_fraction() reports it.
                          `colsum` (otherwise unused by szn_conv2d_wgrad) may then hold that column sum [Co], computed by the producer
-                         of dout over the tiles szn_conv2d_wgrad_cb_tiles() names (szn_maxpool2x2_ceil_bwd_code_cb); NULL = the
+                         of dout over the region szn_conv2d_wgrad_cb_region() names (szn_maxpool2x2_ceil_bwd_code_cb); NULL = the
                          call sums them itself.                                                                                   */
     int cb_rect[4];
     int cb_const[4];
@@ -141,6 +141,16 @@ int szn_pack_weight_dgrad_batch(int dtype, int n, const void* const* w, void* co
  * factors that were applied to that input.  d->ldo is the pixel stride of DOUT, d->ldi of DIN.   */
 int szn_conv2d_dgrad(const szn_conv_desc_t* d, const void* dout, const void* wT, const void* gate,
                      const float* chan_scale, void* din, szn_stream_t stream);
+/* cb_on == 2 on a gated szn_conv2d_dgrad with colsum (conv1_2's dgrad: din feeds only szn_conv1_1_wgrad and conv1_1's bias gradient): the
+ * tiles that neither store anything (outside cb_const) nor see a varying gate (outside cb_rect) are not run; colsum then covers the
+ * tiles that ran, and szn_conv2d_dgrad_border_finish adds the rest from region sums of dout -- it is linear in dout there (one gate value
+ * per channel), so it needs skip_sum [Co] = sum of dout over the map outside szn_conv2d_dgrad_border_region()'s inner rectangle (from the
+ * producer of dout: szn_maxpool2x2_ceil_bwd_code_cb) and 1-pixel strips it reads itself.  Same value up to fp32 summation order.
+ * The caller checks szn_last_work_fraction() < 1 after the dgrad call before it calls finish (a kernel that ignores the hint computes the
+ * complete column sums).  workspace: 2 * 24 * B * Co floats, 16-B aligned.                                                                */
+int szn_conv2d_dgrad_border_region(const szn_conv_desc_t* d, int region[8]);
+int szn_conv2d_dgrad_border_finish(const szn_conv_desc_t* d, const void* dout, const void* wT, const void* gate,
+                                   const float* skip_sum, float* colsum, void* workspace, szn_stream_t stream);
 
 /* dgrad of a large-window convolution (models.py:84 fc6 = Conv2d(512, 4096, 7) backward) as GEMM + col2im: as a
  * convolution over the padded dout map szn_conv2d_dgrad executes 1.83x the algorithmic FLOPs of fc6's dgrad (most taps
@@ -250,13 +260,14 @@ int szn_maxpool2x2_ceil_fwd_code(int dtype, int B, int Hi, int Wi, int C, const 
                                  szn_stream_t stream);
 int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
                                  float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream);
-/* The same, also summing din over the 16 x 16 tiles the NEXT consumer of din -- the weight gradient of the conv in front of the pool --
- * replaces by a rank-one term under the constant-border hint: skip_tiles[8] from szn_conv2d_wgrad_cb_tiles(), skip_sum [C] out (hand it
- * to that szn_conv2d_wgrad call as szn_conv_desc_t.colsum), skip_slab [colsum_slab_rows][C] scratch.  colsum / colsum_slab required. */
+/* The same, also summing din over the regions its consumers -- the conv in front of the pool's weight gradient and dgrad -- do not run
+ * tile by tile under the constant-border hint: skip_regions [n_regions][8] (pixels, even) from szn_conv2d_wgrad_cb_region() /
+ * szn_conv2d_dgrad_border_region(), n_regions = 1 or 2, skip_sum [n_regions][C] out (szn_conv_desc_t.colsum of the weight-gradient call /
+ * skip_sum of szn_conv2d_dgrad_border_finish), skip_slab [n_regions][colsum_slab_rows][C] scratch.  colsum / colsum_slab required. */
 int szn_maxpool2x2_ceil_bwd_code_cb(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
-                                    float* colsum, float* colsum_slab, int colsum_slab_rows, const int* skip_tiles,
+                                    float* colsum, float* colsum_slab, int colsum_slab_rows, const int* skip_regions, int n_regions,
                                     float* skip_sum, float* skip_slab, szn_stream_t stream);
-int szn_conv2d_wgrad_cb_tiles(const szn_conv_desc_t* d, int tiles[8]);
+int szn_conv2d_wgrad_cb_region(const szn_conv_desc_t* d, int region[8]);
 
 /* ---- upscore: ConvTranspose2d(E,E,64,stride 32,bias=False) with the fixed bilinear kernel of
  * get_upsampling_weight (models.py:11-24,94,146) fused with the crop [19:19+H] (models.py:147).

@@ -614,7 +614,7 @@ def test_wgrad_constant_border_hint_equals_dense(case, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_pool_backward_sums_the_tiles_the_weight_gradient_skips(dtype):
-    """szn_conv2d_wgrad_cb_tiles names the 16 x 16 tiles a hinted weight-gradient call replaces by a rank-one term;
+    """szn_conv2d_wgrad_cb_region names the pixels (whole 16 x 16 tiles) a hinted weight-gradient call replaces by a rank-one term;
     szn_maxpool2x2_ceil_bwd_code_cb sums its output over exactly those tiles while writing it (same din, same bias sums as the plain
     call), and the weight gradient that is handed the sum equals the one that sums for itself and the dense one"""
     B, H, W, Ci, Co = 2, 710, 710, 64, 64
@@ -642,9 +642,10 @@ def test_pool_backward_sums_the_tiles_the_weight_gradient_skips(dtype):
         return d
 
     tiles = (C.c_int * 8)()
-    assert lib.szn_conv2d_wgrad_cb_tiles(C.byref(desc(True)), tiles) == 1
-    assert lib.szn_conv2d_wgrad_cb_tiles(C.byref(desc(False)), tiles) == 0
-    fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1 = list(tiles)
+    assert lib.szn_conv2d_wgrad_cb_region(C.byref(desc(True)), tiles) == 1
+    assert lib.szn_conv2d_wgrad_cb_region(C.byref(desc(False)), tiles) == 0
+    assert all(v % 16 == 0 for v in tiles)
+    fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1 = [v // 16 for v in tiles]
     assert 0 < fy0 < wy0 < wy1 < fy1 <= H // 16
     rows = 512
     st = L.stream_ptr()
@@ -654,7 +655,7 @@ def test_pool_backward_sums_the_tiles_the_weight_gradient_skips(dtype):
     ssum = torch.full((Co,), 7.0, device="cuda")
     L.call("szn_maxpool2x2_ceil_bwd_code", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(din0), L.ptr(cs0), L.ptr(slab0), rows, st)
     L.call("szn_maxpool2x2_ceil_bwd_code_cb", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(din1), L.ptr(cs1), L.ptr(slab1), rows,
-           tiles, L.ptr(ssum), L.ptr(slab2), st)
+           tiles, 1, L.ptr(ssum), L.ptr(slab2), st)
     assert L.last_kernel() == "slab_rows_sum_kernel" and L.prev_kernel() == "maxpool_bwd_code_kernel"
     torch.cuda.synchronize()
     assert torch.equal(din0, din1) and torch.equal(slab0, slab1)
@@ -678,6 +679,105 @@ def test_pool_backward_sums_the_tiles_the_weight_gradient_skips(dtype):
     scale = float(dense.abs().max())
     assert float((own - dense).abs().max()) / scale < 1e-5 and float((given - dense).abs().max()) / scale < 1e-5
     assert float((given - own).abs().max()) / scale < 1e-6
+
+
+@pytest.mark.parametrize("case", [(2, 710, 710, (98, 612), (97, 613)), (1, 262, 262, (98, 164), (96, 166)), (2, 355, 300, (48, 200), (40, 210)),
+                                  (1, 710, 710, (2, 708), (1, 709))])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dgrad_border_tiles_replaced_by_region_sums(case, dtype):
+    """szn_conv2d_dgrad with cb_on == 2 does not run the tiles that neither store anything nor see a varying gate;
+    szn_conv2d_dgrad_border_finish adds their share of the column sums from the sum of dout outside
+    szn_conv2d_dgrad_border_region()'s rectangle + 1-pixel strips it reads itself.  Against the same call with cb_on == 1 (every tile
+    run): din bit-equal where it is read, column sums equal to fp32 summation order; the region sum also through the pool's backward pass"""
+    B, H, W, grect, srect = case
+    Ci = Co = 64
+    g = torch.Generator().manual_seed(51)
+    gate = torch.randn(B, H, W, Ci, generator=g)                              # conv1_1's output: ReLU'd later = the gate is (gate > 0)
+    gconst = torch.randn(Ci, generator=g)
+    ins = torch.zeros(H, W, dtype=torch.bool)
+    ins[grect[0]:grect[1], grect[0]:min(grect[1], W)] = True
+    gate = torch.where(ins[None, :, :, None], gate, gconst[None, None, None, :].expand(B, H, W, Ci)).to(dtype).cuda()
+    Hp, Wp = (H + 1) // 2, (W + 1) // 2
+    dpool = (torch.randn(B, Hp, Wp, Co, generator=g) * 0.1).to(dtype).cuda()
+    code = torch.randint(0, 5, (B, Hp, Wp, Co), generator=g, dtype=torch.uint8).cuda()
+    wT = (torch.randn(Ci, 3, 3, Co, generator=g) / 24.0).to(dtype).cuda()
+    dt = L.dtype_code(dtype)
+    lib = L.load()
+    st = L.stream_ptr()
+
+    def desc(mode):
+        d = L.ConvDesc(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, Ci, Co, Ci, 0, 0)
+        d.cb_on = mode
+        d.cb_rect[0], d.cb_rect[1], d.cb_rect[2], d.cb_rect[3] = grect[0], grect[1], grect[0], min(grect[1], W)
+        d.cb_const[0], d.cb_const[1], d.cb_const[2], d.cb_const[3] = srect[0], srect[1], srect[0], min(srect[1], W)
+        return d
+
+    region = (C.c_int * 8)()
+    has = lib.szn_conv2d_dgrad_border_region(C.byref(desc(2)), region)
+    assert lib.szn_conv2d_dgrad_border_region(C.byref(desc(1)), region) == 0
+    if grect == (2, 708):
+        assert has == 0                                                    # (everything is read: nothing to skip)
+        return
+    assert has == 1
+    r = list(region)
+    assert r[0] == 0 and r[1] == H and r[2] == 0 and r[3] == W and r[4] <= min(grect[0], srect[0]) and r[5] >= min(max(grect[1], srect[1]), H)
+    # dout through the pool's backward pass, which also sums it outside the rectangle
+    rows = 512
+    dout = torch.empty(B, H, W, Co, device="cuda", dtype=dtype)
+    cs, slab = torch.zeros(Co, device="cuda"), torch.zeros(rows * Co, device="cuda")
+    ssum, slab2 = torch.full((1, Co), 7.0, device="cuda"), torch.zeros(rows * Co, device="cuda")
+    even = all(v % 2 == 0 for v in r)
+    if even:
+        L.call("szn_maxpool2x2_ceil_bwd_code_cb", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(dout), L.ptr(cs), L.ptr(slab), rows,
+               region, 1, L.ptr(ssum), L.ptr(slab2), st)
+    else:
+        L.call("szn_maxpool2x2_ceil_bwd_code", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(dout), L.ptr(cs), L.ptr(slab), rows, st)
+    torch.cuda.synchronize()
+    mask = torch.ones(H, W, dtype=torch.bool, device="cuda")
+    mask[r[4]:r[5], r[6]:r[7]] = False
+    want = (dout.double() * mask[None, :, :, None]).sum(dim=(0, 1, 2))
+    if even:
+        assert float((ssum[0].double() - want).abs().max() / want.abs().max()) < 1e-5
+    s0 = want.float().contiguous()
+
+    def run(mode):
+        d = desc(mode)
+        din = torch.full((B, H, W, Ci), 3.0, device="cuda", dtype=dtype)
+        colsum = torch.zeros(Ci, device="cuda")
+        d.colsum = colsum.data_ptr()
+        L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), None, L.ptr(din), st)
+        frac = lib.szn_last_work_fraction()
+        kern = L.last_kernel()
+        if mode == 2:
+            assert frac < 0.95
+            ws = torch.empty(2 * 24 * B * Co, device="cuda")
+            L.call("szn_conv2d_dgrad_border_finish", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(s0), L.ptr(colsum), L.ptr(ws), st)
+        torch.cuda.synchronize()
+        return din, colsum, kern
+
+    din1, cs1, k1 = run(1)
+    din2, cs2, k2 = run(2)
+    assert k1 == "conv3x3_regw" and k2 == "conv3x3_regw"
+    sy0, sy1, sx0, sx1 = srect[0], min(srect[1], H), srect[0], min(srect[1], W)
+    assert torch.equal(din1[:, sy0:sy1, sx0:sx1], din2[:, sy0:sy1, sx0:sx1])
+    # the reference value of the column sums: the dense gated dgrad in float64
+    x64 = dout.double().permute(0, 3, 1, 2)
+    w64 = wT.double().permute(0, 3, 1, 2)                                   # [Ci][Co][3][3]: din = conv(dout, wT), pad 1
+    ref = (torch.nn.functional.conv2d(x64.cpu(), w64.cpu(), padding=1) * (gate.double().permute(0, 3, 1, 2).cpu() > 0)).sum(dim=(0, 2, 3))
+    scale = float(ref.abs().max())
+    assert float((cs1.double().cpu() - ref).abs().max()) / scale < 2e-4      # (the kernel rounds din to 16 bits before it sums it)
+    assert float((cs2 - cs1).abs().max()) / scale < 2e-4
+    # tighter: the skipped part alone against float64 (no 16-bit rounding on either side)
+    m64 = mask.cpu()[None, None].double()
+    ref_skip = (torch.nn.functional.conv2d(x64.cpu(), w64.cpu(), padding=1) * (gate.double().permute(0, 3, 1, 2).cpu() > 0) * m64).sum(dim=(0, 2, 3))
+    ran = torch.zeros(Ci, device="cuda")
+    d = desc(2)
+    d.colsum = ran.data_ptr()
+    dinx = torch.empty(B, H, W, Ci, device="cuda", dtype=dtype)
+    L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), None, L.ptr(dinx), st)
+    torch.cuda.synchronize()
+    got_skip = (cs2 - ran).double().cpu()
+    assert float((got_skip - ref_skip).abs().max()) / float(ref_skip.abs().max() + 1e-30) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

@@ -75,6 +75,8 @@ SIGNATURES = {
     "szn_pack_weight_dgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
     "szn_pack_weight_dgrad_batch": (_I, [_I, _I, _P, _P, _P, _P, _P, _P]),
     "szn_conv2d_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "szn_conv2d_dgrad_border_region": (_I, [_D, _P]),
+    "szn_conv2d_dgrad_border_finish": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "szn_conv2d_dgrad_gemm_workspace_bytes": (C.c_size_t, [_D]),
     "szn_conv2d_dgrad_gemm": (_I, [_D, _P, _P, _P, _P]),
     "szn_conv2d_dgrad_gemm_native_supported": (_I, [_D]),
@@ -99,8 +101,8 @@ SIGNATURES = {
     "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "szn_maxpool2x2_ceil_fwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "szn_maxpool2x2_ceil_bwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
-    "szn_maxpool2x2_ceil_bwd_code_cb": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "szn_conv2d_wgrad_cb_tiles": (_I, [_D, _P]),
+    "szn_maxpool2x2_ceil_bwd_code_cb": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
+    "szn_conv2d_wgrad_cb_region": (_I, [_D, _P]),
     "szn_bilinear_up32_crop_fwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_bilinear_up32_crop_bwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_bilinear_up_crop_fwd": (_I, [_I] * 10 + [_P, _P, _P]),

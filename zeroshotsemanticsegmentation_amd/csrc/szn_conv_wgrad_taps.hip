@@ -560,12 +560,12 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     return SZN_OK;
 }
 
-// Which tiles a szn_conv2d_wgrad call with this descriptor (constant-border hint set, accumulate = 0) replaces by the rank-one term:
-// tiles[8] = 16 x 16 tile rows / columns {fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1} -- the tiles inside [fy0, fy1) x [fx0, fx1) and outside
-// [wy0, wy1) x [wx0, wx1).  Returns 1 (tiles filled) or 0 (the call runs dense).  For the producer of dout, which can sum those tiles
-// while it writes them (szn_maxpool2x2_ceil_bwd_code_cb) and hand the result to the call as szn_conv_desc_t.colsum.
-extern "C" int szn_conv2d_wgrad_cb_tiles(const szn_conv_desc_t* d, int tiles[8]) {
-    if (!d || !tiles || !szn_is16(d->dtype) || d->KH != 3 || d->KW != 3 || (d->Ci & 63) || (d->Co & 63) || d->pad > 2 || !d->workspace ||
+// Which part of dout a szn_conv2d_wgrad call with this descriptor (constant-border hint set, accumulate = 0) replaces by the rank-one term:
+// region[8] = pixel rows / columns {fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1} (multiples of 16) -- the pixels inside [fy0, fy1) x [fx0, fx1) and
+// outside [wy0, wy1) x [wx0, wx1).  Returns 1 (region filled) or 0 (the call runs dense).  For the producer of dout, which can sum that
+// region while it writes it (szn_maxpool2x2_ceil_bwd_code_cb) and hand the result to the call as szn_conv_desc_t.colsum.
+extern "C" int szn_conv2d_wgrad_cb_region(const szn_conv_desc_t* d, int region[8]) {
+    if (!d || !region || !szn_is16(d->dtype) || d->KH != 3 || d->KW != 3 || (d->Ci & 63) || (d->Co & 63) || d->pad > 2 || !d->workspace ||
         (d->ldi & 7) || (d->ldo & 7))
         return 0;
     int ncu = 0, dev = 0;
@@ -579,7 +579,7 @@ extern "C" int szn_conv2d_wgrad_cb_tiles(const szn_conv_desc_t* d, int tiles[8])
     CbGeom c;
     int ry, rx;
     if (!taps_cb_geometry(d, ncombo, ncu, taps_min, c, ry, rx)) return 0;
-    tiles[0] = c.fy0; tiles[1] = c.fy1; tiles[2] = c.fx0; tiles[3] = c.fx1;
-    tiles[4] = c.wy0; tiles[5] = c.wy1; tiles[6] = c.wx0; tiles[7] = c.wx1;
+    region[0] = c.fy0 * 16; region[1] = c.fy1 * 16; region[2] = c.fx0 * 16; region[3] = c.fx1 * 16;
+    region[4] = c.wy0 * 16; region[5] = c.wy1 * 16; region[6] = c.wx0 * 16; region[7] = c.wx1 * 16;
     return 1;
 }

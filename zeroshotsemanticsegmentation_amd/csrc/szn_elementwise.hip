@@ -614,22 +614,23 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 // instead of the pool's input: code 0 .. 3 = position 2 dy + dx of the first maximum, 4 = maximum not positive (no gradient: the
 // ReLU gate).  2.75 B instead of 4.5 B of traffic per input element, and the forward pass no longer has to store the un-pooled
 // tensor for this kernel alone.  Same result bit for bit.
-// SKIP: a second set of column sums over the 16 x 16 tiles of din inside sk = {fy0, fy1, fx0, fx1} and outside {wy0, wy1, wx0, wx1} -- the
-// tiles the weight gradient of the layer that reads din replaces by a rank-one term (szn_conv2d_wgrad_cb_tiles); a 2 x 2 window never
-// straddles a tile boundary.  Rows of cslab2 like cslab's.
+// SKIP = 1 / 2: one / two more sets of column sums, over the pixels of din inside rows x columns {fy0, fy1, fx0, fx1} and outside {wy0, wy1,
+// wx0, wx1} (all even: a 2 x 2 window never straddles them) -- the regions the consumers of din do not run tile by tile but replace by
+// region sums: the weight gradient of the conv in front of the pool (szn_conv2d_wgrad_cb_region) and that conv's dgrad
+// (szn_conv2d_dgrad_border_region).  Rows of cslab2 [SKIP][rows][C] like cslab's.
 struct PoolSkip { int fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1; };
-template <typename T, bool SKIP>
+template <typename T, int SKIP>
 __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __restrict__ code, const T* __restrict__ dout,
                                                                T* __restrict__ din, int B, int Hi, int Wi, int C, int Ho, int Wo,
                                                                float* __restrict__ colsum, float* __restrict__ cslab, PoolSkip sk,
-                                                               float* __restrict__ cslab2) {
+                                                               PoolSkip sk2, float* __restrict__ cslab2) {
     constexpr int CH = elem<T>::kPer16B;
     __shared__ float red[256 * CH];
     const int cpp = C / CH;
     const long total = (long)B * Ho * Wo * cpp;
-    float cs[CH], cs2[CH];
+    float cs[CH], cs2[CH], cs3[CH];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) { cs[e] = 0.f; cs2[e] = 0.f; }
+    for (int e = 0; e < CH; ++e) { cs[e] = 0.f; cs2[e] = 0.f; cs3[e] = 0.f; }
     for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
         const int cc = (int)(gid % cpp);
         const long po = gid / cpp;
@@ -643,9 +644,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __
         const T* de = (const T*)&vd;
         const uint8_t* cp = code + po * C + cc * CH;
         const uint32_t clo = *(const uint32_t*)cp, chi = CH == 8 ? *(const uint32_t*)(cp + 4) : 0u;
-        const int ty = ih >> 4, tx = iw >> 4;
-        const bool skip = SKIP && ty >= sk.fy0 && ty < sk.fy1 && tx >= sk.fx0 && tx < sk.fx1 &&
-                          !(ty >= sk.wy0 && ty < sk.wy1 && tx >= sk.wx0 && tx < sk.wx1);
+        const bool skip = SKIP >= 1 && ih >= sk.fy0 && ih < sk.fy1 && iw >= sk.fx0 && iw < sk.fx1 &&
+                          !(ih >= sk.wy0 && ih < sk.wy1 && iw >= sk.wx0 && iw < sk.wx1);
+        const bool skipb = SKIP >= 2 && ih >= sk2.fy0 && ih < sk2.fy1 && iw >= sk2.fx0 && iw < sk2.fx1 &&
+                           !(ih >= sk2.wy0 && ih < sk2.wy1 && iw >= sk2.wx0 && iw < sk2.wx1);
         u32x4_t o[4];
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
@@ -654,7 +656,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __
 #pragma unroll
             for (int k = 0; k < 4; ++k) elem<T>::st((T*)&o[k] + e, k == win ? dv : 0.f);
             cs[e] += win < 4 ? dv : 0.f;                           // what was stored (one non-zero term)
-            if (SKIP) cs2[e] += (skip && win < 4) ? dv : 0.f;
+            if (SKIP >= 1) cs2[e] += (skip && win < 4) ? dv : 0.f;
+            if (SKIP >= 2) cs3[e] += (skipb && win < 4) ? dv : 0.f;
         }
         T* op = din + p00 * C + cc * CH;
         *(u32x4_t*)op = o[0];
@@ -674,16 +677,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __
             else if (t != 0.f) atomicAdd(colsum + c, t);
         }
     }
-    if (SKIP) {
+#pragma unroll
+    for (int m = 0; m < SKIP; ++m) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = cs2[e];
+        for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = m == 0 ? cs2[e] : cs3[e];
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
             const int cc = c / CH, e = c - cc * CH;
             float t = 0.f;
             for (int r = cc; r < 256; r += cpp) t += red[r * CH + e];
-            cslab2[(long)blockIdx.x * C + c] = t;
+            cslab2[((long)m * gridDim.x + blockIdx.x) * C + c] = t;
         }
     }
 }
@@ -1017,8 +1021,8 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
 }
 
 static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din, float* colsum,
-                                 float* colsum_slab, int colsum_slab_rows, const int* skip_tiles, float* skip_sum, float* skip_slab,
-                                 szn_stream_t stream) {
+                                 float* colsum_slab, int colsum_slab_rows, const int* skip_tiles, int n_regions, float* skip_sum,
+                                 float* skip_slab, szn_stream_t stream) {
     if (!code || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: bad argument");
     const int ch = szn_is16(dtype) ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_code: C must be a multiple of %d", ch);
@@ -1027,8 +1031,11 @@ static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const 
     const long total = (long)B * Ho * Wo * (C / ch);
     const bool sums = colsum || skip_tiles;
     if (sums && (256 % (C / ch)) != 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_code: colsum needs C/%d to divide 256", ch);
-    if (skip_tiles && (!skip_sum || !skip_slab || !colsum || !colsum_slab))
-        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_cb: skip_sum, skip_slab, colsum and colsum_slab are required");
+    if (skip_tiles && (!skip_sum || !skip_slab || !colsum || !colsum_slab || n_regions < 1 || n_regions > 2))
+        SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_cb: skip_sum, skip_slab, colsum, colsum_slab and 1 or 2 regions are required");
+    if (skip_tiles)
+        for (int i = 0; i < 8 * n_regions; ++i)
+            if (skip_tiles[i] & 1) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_cb: region bounds must be even (2 x 2 windows must not straddle them)");
     static int capx = -1;
     if (capx < 0) { const char* e = getenv("SZN_POOLBWD_BLOCKS"); capx = e ? atoi(e) : 512; if (capx < 1) capx = 1; }
     const int grid = grid_for(total, 256, sums ? capx : 65536);
@@ -1036,21 +1043,27 @@ static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const 
     if (cslab && colsum_slab_rows < grid)
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: colsum_slab holds %d rows, %d needed", colsum_slab_rows, grid);
     szn_note_colsum_rows(cslab ? grid : 0);
-    PoolSkip sk = {};
+    PoolSkip sk = {}, sk2 = {};
     if (skip_tiles) { sk.fy0 = skip_tiles[0]; sk.fy1 = skip_tiles[1]; sk.fx0 = skip_tiles[2]; sk.fx1 = skip_tiles[3];
                       sk.wy0 = skip_tiles[4]; sk.wy1 = skip_tiles[5]; sk.wx0 = skip_tiles[6]; sk.wx1 = skip_tiles[7]; }
+    if (skip_tiles && n_regions == 2) { const int* q = skip_tiles + 8; sk2.fy0 = q[0]; sk2.fy1 = q[1]; sk2.fx0 = q[2]; sk2.fx1 = q[3];
+                                        sk2.wy0 = q[4]; sk2.wy1 = q[5]; sk2.wx0 = q[6]; sk2.wx1 = q[7]; }
+    const int nsk = skip_tiles ? n_regions : 0;
     hipStream_t st = (hipStream_t)stream;
 #define SZN_POOLBWD_LAUNCH(TT, SK)                                                                                                      \
     hipLaunchKernelGGL((maxpool_bwd_code_kernel<TT, SK>), dim3(grid), dim3(256), 0, st, (const uint8_t*)code, (const TT*)dout, (TT*)din, B, \
-                       Hi, Wi, C, Ho, Wo, colsum, cslab, sk, skip_slab)
-    if (dtype == SZN_BF16) { if (skip_tiles) SZN_POOLBWD_LAUNCH(bf16_raw, true); else SZN_POOLBWD_LAUNCH(bf16_raw, false); }
-    else if (dtype == SZN_F16) { if (skip_tiles) SZN_POOLBWD_LAUNCH(f16_raw, true); else SZN_POOLBWD_LAUNCH(f16_raw, false); }
-    else if (dtype == SZN_F32) { if (skip_tiles) SZN_POOLBWD_LAUNCH(float, true); else SZN_POOLBWD_LAUNCH(float, false); }
+                       Hi, Wi, C, Ho, Wo, colsum, cslab, sk, sk2, skip_slab)
+#define SZN_POOLBWD_BY_SKIP(TT) do { if (nsk == 2) SZN_POOLBWD_LAUNCH(TT, 2); else if (nsk == 1) SZN_POOLBWD_LAUNCH(TT, 1); else SZN_POOLBWD_LAUNCH(TT, 0); } while (0)
+    if (dtype == SZN_BF16) SZN_POOLBWD_BY_SKIP(bf16_raw);
+    else if (dtype == SZN_F16) SZN_POOLBWD_BY_SKIP(f16_raw);
+    else if (dtype == SZN_F32) SZN_POOLBWD_BY_SKIP(float);
     else SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: bad dtype %d", dtype);
+#undef SZN_POOLBWD_BY_SKIP
 #undef SZN_POOLBWD_LAUNCH
     SZN_CHECK_LAUNCH("maxpool_bwd_code_kernel");
-    if (skip_tiles) {
-        hipLaunchKernelGGL(slab_rows_sum_kernel, dim3((unsigned)szn_div_up(C, 8)), dim3(256), 0, st, (const float*)skip_slab, grid, C, skip_sum);
+    for (int m = 0; m < nsk; ++m) {
+        hipLaunchKernelGGL(slab_rows_sum_kernel, dim3((unsigned)szn_div_up(C, 8)), dim3(256), 0, st, (const float*)skip_slab + (size_t)m * grid * C,
+                           grid, C, skip_sum + (size_t)m * C);
         SZN_CHECK_LAUNCH("slab_rows_sum_kernel");
     }
     return SZN_OK;
@@ -1058,15 +1071,15 @@ static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const 
 
 extern "C" int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
                                             float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream) {
-    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, nullptr, nullptr, nullptr, stream);
+    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int szn_maxpool2x2_ceil_bwd_code_cb(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
-                                               float* colsum, float* colsum_slab, int colsum_slab_rows, const int* skip_tiles,
-                                               float* skip_sum, float* skip_slab, szn_stream_t stream) {
-    if (!skip_tiles) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_cb: skip_tiles is NULL (use szn_maxpool2x2_ceil_bwd_code)");
-    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, skip_tiles, skip_sum, skip_slab,
-                                 stream);
+                                               float* colsum, float* colsum_slab, int colsum_slab_rows, const int* skip_regions,
+                                               int n_regions, float* skip_sum, float* skip_slab, szn_stream_t stream) {
+    if (!skip_regions) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_cb: skip_regions is NULL (use szn_maxpool2x2_ceil_bwd_code)");
+    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, skip_regions, n_regions, skip_sum,
+                                 skip_slab, stream);
 }
 
 extern "C" int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, szn_stream_t stream) {

@@ -48,6 +48,7 @@ _TRUNK = [n for n, _, _, _ in synth.CONV_LAYERS]          # conv1_1 .. fc7
 _CONST_BORDER = os.environ.get("SZN_CONST_BORDER", "1") != "0"  # 0: no constant-border hint to the 710^2 / 355^2 forward convs
 _DGRAD_SPLIT = os.environ.get("SZN_DGRAD_SPLIT", "1") != "0"      # 0: few-tile dgrads keep their fused column sums (no split-K)
 _WGRAD_CB_FUSED = os.environ.get("SZN_WGRAD_CB_FUSED", "1") != "0"   # 0: the weight gradients sum their skipped tiles themselves
+_DGRAD_BORDER = os.environ.get("SZN_DGRAD_BORDER", "1") != "0"        # 0: conv1_2's dgrad runs the tiles nobody reads (for their column sums)
 _FC6_NATIVE = os.environ.get("SZN_FC6_NATIVE", "1") != "0"      # 0: fc6's dgrad GEMM on the packed transpose (rounds 1-2)
 _OPT_LAYERS = _TRUNK + ["score_fr"]                        # the layers train.get_parameters yields (train.py:302-331)
 _OPT_LAYERS8 = _TRUNK + ["score_pool3", "score_pool4", "score_fr"]       # ... for FCN8s (score_fr stays last: engine.TrainStep)
@@ -509,6 +510,19 @@ class _Engine(object):
             torch.cuda.current_stream().wait_stream(self._wg_stream)
         self._flush_colsum()
 
+    def _conv1_1_dgrad_cb(self, ctx):
+        """the constant-border hint of the dgrad that feeds conv1_1 (conv1_2's): (where the gate -- conv1_1's output -- varies, what
+        szn_conv1_1_wgrad reads of the result); None when that kernel reads everything"""
+        ry, rx = _cb_conv1_1(ctx.H, PAD1), _cb_conv1_1(ctx.W, PAD1)
+        # (returns 1 and a proper sub-rectangle only when szn_conv1_1_wgrad takes its fused kernel for these arguments -- otherwise
+        # `reads` is the whole map and nothing may be skipped; the library refuses to fall back to a kernel that reads more than it
+        # reported)
+        reads = (C.c_int * 4)()
+        sub = L.load().szn_conv1_1_wgrad_reads(L.dtype_code(self.dtype), ctx.B, ctx.H, ctx.W, PAD1, reads)
+        if sub not in (0, 1):
+            raise L.SznError("szn_conv1_1_wgrad_reads failed (%d)" % sub)
+        return ((ry[0], ry[1], rx[0], rx[1]), tuple(reads))
+
     def _wgrad_desc(self, x, dout_shape, ci, co, k, pad, ldo=None, cb=None):
         """the descriptor of one layer's szn_conv2d_wgrad call (with the slab workspace and, on the 16-bit paths, the constant-border
         hint of the layer's INPUT x: cb = its per-axis regions)"""
@@ -559,7 +573,7 @@ class _Engine(object):
             if after is not None:
                 after()
 
-    def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None, colsum=None, wT=None, cb=None):
+    def _dgrad(self, dout, name, in_shape, pad, gate=None, scale=None, colsum=None, wT=None, cb=None, border_sum=None):
         """din = conv(dout, flipped weights) with the ReLU gate / dropout factor of the producing layer fused; colsum
         (f32 [Ci], pre-zeroed) receives the column sums of din = that layer's bias gradient"""
         B, Hi, Wi, Ci = in_shape
@@ -610,10 +624,16 @@ class _Engine(object):
             self._workspace(d, M * Ci * 4, dout.device)
         if cb is not None and gate is not None and _CONST_BORDER and self.dtype != torch.float32:
             grect, srect = cb                                   # (r0, r1, c0, c1) each: where the gate varies / what the consumer reads
-            d.cb_on = 1
+            # border_sum: the sum of dout over the part of the map this call need not run (szn_conv2d_dgrad_border_region), from the
+            # producer of dout -- the tiles outside are then skipped and their column sums added by szn_conv2d_dgrad_border_finish
+            d.cb_on = 2 if (border_sum is not None and colsum is not None) else 1
             for i in range(4):
                 d.cb_rect[i], d.cb_const[i] = grect[i], srect[i]
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
+        if d.cb_on == 2 and L.load().szn_last_work_fraction() < 1.0:
+            bws = torch.empty(2 * 24 * B * Co, device=dout.device)
+            L.call("szn_conv2d_dgrad_border_finish", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(border_sum), L.ptr(colsum),
+                   L.ptr(bws), L.stream_ptr())
         if split_cs:
             slab, rows = self._cs_slab(M, Ci, dout.device)
             L.call("szn_bias_grad_slab", L.dtype_code(self.dtype), M, Ci, Ci, L.ptr(din), L.ptr(colsum), 1, L.ptr(slab), rows,
@@ -675,7 +695,7 @@ class _Engine(object):
             d = self._dgrad(d, "fc6", pool5.shape, 0)
         pi = 4
         prev_out = None
-        cb_sums = {}
+        cb_sums, border_sums = {}, {}
         items = _BACKBONE
         for idx in range(len(items) - 1, -1, -1):
             item = items[idx]
@@ -689,22 +709,39 @@ class _Engine(object):
                 slab, rows = self._cs_slab(B * Hi * Wi, Cc, d.device)
                 # constant-border hint of the producer's weight gradient (which reads dn next): let this pass sum dn over the tiles
                 # that call is going to skip, instead of a second pass over them (szn_conv2d_wgrad_cb_tiles)
-                tiles = None
+                regions, want = [], []
                 cbp = (getattr(ctx, "cb_in", None) or {}).get(producer)
-                if pcode is not None and cbp is not None and slab is not None and _WGRAD_CB_FUSED and idx >= 2:
+                if pcode is not None and slab is not None and _WGRAD_CB_FUSED and idx >= 2 and self.dtype != torch.float32 and _CONST_BORDER:
                     prev2 = items[idx - 2]
                     xin2 = ctx.pools[pi][1] if prev2 == "P" else ctx.acts[prev2[0]]
                     lay = getattr(m, producer)
-                    dd = self._wgrad_desc(xin2, (B, Hi, Wi, Cc), lay.in_channels, lay.out_channels, 3, items[idx - 1][1], cb=cbp)
-                    t8 = (C.c_int * 8)()
-                    if dd.cb_on and L.load().szn_conv2d_wgrad_cb_tiles(C.byref(dd), t8) == 1:
-                        tiles = t8
-                if tiles is not None:
-                    ssum = torch.empty(Cc, device=d.device)
-                    slab2 = torch.empty(rows * Cc, device=d.device)
+                    if cbp is not None:
+                        dd = self._wgrad_desc(xin2, (B, Hi, Wi, Cc), lay.in_channels, lay.out_channels, 3, items[idx - 1][1], cb=cbp)
+                        r8 = (C.c_int * 8)()
+                        if dd.cb_on and L.load().szn_conv2d_wgrad_cb_region(C.byref(dd), r8) == 1:
+                            regions += list(r8)
+                            want.append("w")
+                    # (from two 512 x 512 images on: the three small launches that replace the tiles cost what they save on one image)
+                    if prev2 != "P" and prev2[0] == "conv1_1" and _DGRAD_BORDER and B * Hi * Wi >= 1000000:
+                        # the producer's dgrad feeds conv1_1 only: the part of the map it can replace by region sums of dn
+                        grect, srect = self._conv1_1_dgrad_cb(ctx)
+                        ci2 = lay.in_channels
+                        dq = L.ConvDesc(code, B, Hi, Wi, ci2, Hi, Wi, Cc, 3, 3, items[idx - 1][1], ci2, Cc, ci2, 0, 0)
+                        dq.cb_on = 2
+                        for i in range(4):
+                            dq.cb_rect[i], dq.cb_const[i] = grect[i], srect[i]
+                        r8 = (C.c_int * 8)()
+                        if L.load().szn_conv2d_dgrad_border_region(C.byref(dq), r8) == 1 and all(v % 2 == 0 for v in r8):
+                            regions += list(r8)
+                            want.append("d")
+                if regions:
+                    n = len(want)
+                    ssum = torch.empty(n, Cc, device=d.device)
+                    slab2 = torch.empty(n * rows * Cc, device=d.device)
                     L.call("szn_maxpool2x2_ceil_bwd_code_cb", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), L.ptr(dn),
-                           L.ptr(grads[producer][1]), L.ptr(slab), rows, tiles, L.ptr(ssum), L.ptr(slab2), st)
-                    cb_sums[producer] = ssum
+                           L.ptr(grads[producer][1]), L.ptr(slab), rows, (C.c_int * len(regions))(*regions), n, L.ptr(ssum), L.ptr(slab2), st)
+                    for i, kind in enumerate(want):
+                        (cb_sums if kind == "w" else border_sums)[producer] = ssum[i]
                 elif pcode is not None:
                     L.call("szn_maxpool2x2_ceil_bwd_code", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), L.ptr(dn),
                            L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
@@ -737,19 +774,8 @@ class _Engine(object):
                 if side is not None:
                     d = d + side.to(d.dtype)
             else:
-                cb = None
-                if prev[0] == "conv1_1":
-                    # conv1_1's output is constant outside the image's reach, and this gradient is read by szn_conv1_1_wgrad only
-                    ry, rx = _cb_conv1_1(ctx.H, PAD1), _cb_conv1_1(ctx.W, PAD1)
-                    # (returns 1 and a proper sub-rectangle only when szn_conv1_1_wgrad takes its fused kernel for these
-                    # arguments -- otherwise `reads` is the whole map and nothing may be skipped; the library refuses to fall
-                    # back to a kernel that reads more than it reported)
-                    reads = (C.c_int * 4)()
-                    sub = L.load().szn_conv1_1_wgrad_reads(code, ctx.B, ctx.H, ctx.W, PAD1, reads)
-                    if sub not in (0, 1):
-                        raise L.SznError("szn_conv1_1_wgrad_reads failed (%d)" % sub)
-                    cb = ((ry[0], ry[1], rx[0], rx[1]), tuple(reads))
-                d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1], cb=cb)
+                cb = self._conv1_1_dgrad_cb(ctx) if prev[0] == "conv1_1" else None
+                d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1], cb=cb, border_sum=border_sums.pop(name, None))
         self._join_wgrad()
 
 
