@@ -304,13 +304,13 @@ def _conv_family(torch, L, mods, fn):
 
 def _skipped_flops_one_step(L, mods, step_fn):
     """FLOPs of one step that the constant-border hint replaces by a broadcast (forward) or a rank-one term (weight gradient):
-    szn_last_work_fraction of every szn_conv2d_fwd / szn_conv2d_wgrad call"""
+    szn_last_work_fraction of every szn_conv2d_fwd / szn_conv2d_wgrad / szn_conv2d_dgrad call (conv1_2's dgrad: region sums)"""
     tot = [0.0]
     orig = L.call
 
     def hooked(name, *a):
         r = orig(name, *a)
-        if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad"):
+        if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad", "szn_conv2d_dgrad"):
             tot[0] += _conv_flops(a[0]._obj) * (1.0 - L.last_work_fraction())
         return r
     for mod in mods:
@@ -594,7 +594,7 @@ def main():
         orig_call(name, *a)
         e1.record()
         kern = L.last_kernel()
-        if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad") and wk:      # constant-border hint: only the executed tiles count as FLOPs
+        if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad", "szn_conv2d_dgrad") and wk:      # constant-border hint: only the executed tiles count as FLOPs
             wk = (wk[0], wk[1] * L.last_work_fraction())
         helper = {"splitk_epilogue": "+splitk", "col2im_kernel": "+col2im", "maxpool_fwd_kernel": "+maxpool",
                   "wgrad_taps_reduce": "+reduce", "conv1_1_wgrad_reduce": "+reduce"}.get(kern)
