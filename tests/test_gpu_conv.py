@@ -466,7 +466,7 @@ for (B, Hi, Ci, Co, K, pad) in %s:
     k2 = L.last_kernel()
     torch.cuda.synchronize()
     h = hashlib.sha256(out.view(torch.int16).cpu().numpy().tobytes() + din.view(torch.int16).cpu().numpy().tobytes()).hexdigest()
-    out_lines.append("%%s %%s %%s %%.6e" %% (h, k1, k2, float(slab.sum())))
+    out_lines.append("%%s %%s %%s %%.6e %%.6e %%.6e" %% (h, k1, k2, float(slab.sum()), float(out.float().abs().sum()), float(din.float().abs().sum())))
 print("\n".join(out_lines))
 '''
 
@@ -486,7 +486,7 @@ def test_register_epilogue_equals_the_staged_epilogue_bit_for_bit():
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", _EPILOGUE_PROBE % (root, _PROBE_SHAPES)], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        runs[tag] = [ln.split() for ln in r.stdout.strip().splitlines() if len(ln.split()) == 4]
+        runs[tag] = [ln.split() for ln in r.stdout.strip().splitlines() if len(ln.split()) == 6]
     assert len(runs["direct"]) == 5 and len(runs["staged"]) == 5, (runs,)
     kernels = set()
     for a, b in zip(runs["direct"], runs["staged"]):
@@ -506,12 +506,22 @@ def test_8phase_kernel_equals_conv_igemm_wide_bit_for_bit():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = {}
-    for tag, env in (("8ph", {"SZN_IGEMM_8PH": "1"}), ("wide", {"SZN_WIDE_8PH": "0", "SZN_IGEMM_8PH": "0", "SZN_WIDE_ROWS": "0"})):
+    # (SZN_8PH_KORD=0: the tap-major K order of the kernels it is compared with; the shipped default walks the K tiles cin-chunk-major --
+    # other summation order, same sums: third run, compared by value)
+    for tag, env in (("8ph", {"SZN_IGEMM_8PH": "1", "SZN_8PH_KORD": "0"}), ("wide", {"SZN_WIDE_8PH": "0", "SZN_IGEMM_8PH": "0", "SZN_WIDE_ROWS": "0"}),
+                     ("8ph_chunk_major", {"SZN_IGEMM_8PH": "1", "SZN_8PH_KORD": "1"})):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", _EPILOGUE_PROBE % (root, _PROBE_SHAPES_8PH)], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        runs[tag] = [ln.split() for ln in r.stdout.strip().splitlines() if len(ln.split()) == 4]
-    assert len(runs["8ph"]) == 5 and len(runs["wide"]) == 5, (runs,)
+        runs[tag] = [ln.split() for ln in r.stdout.strip().splitlines() if len(ln.split()) == 6]
+    assert len(runs["8ph"]) == 5 and len(runs["wide"]) == 5 and len(runs["8ph_chunk_major"]) == 5, (runs,)
+    differs = 0
+    for a, c in zip(runs["8ph"], runs["8ph_chunk_major"]):
+        assert a[1] == c[1] and a[2] == c[2], (a, c)
+        differs += a[0] != c[0]
+        for i in (3, 4, 5):                              # column sums, sum |out|, sum |din|: a handful of 16-bit roundings apart
+            assert abs(float(a[i]) - float(c[i])) <= 2e-5 * max(1.0, abs(float(a[i]))), (a, c)
+    assert differs >= 3, runs                            # (K > 1 shapes really take the other order; the 1x1 shape has one order)
     seen = 0
     for a, b in zip(runs["8ph"], runs["wide"]):
         assert a[0] == b[0], (a, b)                      # outputs + input gradients: same bits

@@ -78,7 +78,7 @@ __device__ __forceinline__ void tile_epilogue_single(const Args& a, f32x4_t (&ac
 // reads, phase B = (P1,W1) + (P1,W0): 8; four LDS-DMA loads per phase.  The fragment reads are retired (s_waitcnt lgkmcnt(0)) BEFORE the
 // phase's first barrier, so a slot may be re-staged in the next phase: A stages W1, P1 of tile t + 1, B stages P0, W0 of t + 2; a unit
 // issued in phase p is waited for in p + 1 (vmcnt(4)) and read in p + 2.
-template <typename T, int NF0, int NF1, int MODE>
+template <typename T, int NF0, int NF1, int MODE, bool KORD = false>
 __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
     constexpr bool SPLIT = MODE == 1, LONG = MODE == 2;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -161,12 +161,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
             voffA[h][i] = ok ? baseA[h][i] + tapoff : kOOBx;
         }
     };
+    // KORD: K tiles in cin-chunk-major order (all taps of a 64-channel chunk, then the next chunk) instead of tap-major: the three kh
+    // passes over a tile's pixel rows then follow each other within 1 / (Ci / 64) of the tile's time, while the rows are still in the
+    // XCD's L2 (tap-major: a third of the tile's time apart, behind 4 MB of other tiles' patches).  Different summation order.
+    const int ntap = a.KH * a.KW;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int tap = kbeg / cpt;
-        akt[h] = kbeg; aic[h] = kbeg - tap * cpt; akh[h] = tap / a.KW; akw[h] = tap - akh[h] * a.KW;
+        const int tap = KORD ? kbeg % ntap : kbeg / cpt;
+        akt[h] = kbeg; aic[h] = KORD ? kbeg / ntap : kbeg - tap * cpt; akh[h] = tap / a.KW; akw[h] = tap - akh[h] * a.KW;
         set_tap(h);
     }
+    int wch[2], wtp[2];                                             // KORD: (chunk, tap) of the next K tile of the W0 / W1 streams
+    wch[0] = wch[1] = kbeg / ntap; wtp[0] = wtp[1] = kbeg % ntap;
     auto stageA = [&](int h, int buf, int part) {                 // h / buf / part are compile-time after unrolling; part 2 = both loads
         const unsigned kill = akt[h] < kend ? 0u : kOOBx;          // beyond the K range: zeros into a slot nobody reads (uniform vmcnt)
         char* dst = smem + buf * BUF + h * SLOT + (2 * w) * 1024;
@@ -175,7 +181,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
         if (part == 0) return;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(dst + 1024), 16, voffA[h][1] | kill, soff, 0, 0);
         ++akt[h];
-        if (++aic[h] == cpt) {
+        if (KORD) {
+            if (++akw[h] == a.KW) { akw[h] = 0; if (++akh[h] == a.KH) { akh[h] = 0; ++aic[h]; } }
+            set_tap(h);
+        } else if (++aic[h] == cpt) {
             aic[h] = 0;
             if (++akw[h] == a.KW) { akw[h] = 0; ++akh[h]; }
             set_tap(h);
@@ -183,7 +192,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_8ph(WideArgs a) {
     };
     auto stageB = [&](int h, int buf, int kt, int part) {         // weights [Co][KH][KW][Ci]: K tile kt starts kt * 128 B into a row
         const unsigned kill = kt < kend ? 0u : kOOBx;
-        const int soff = kt * 128;
+        const int soff = KORD ? (wtp[h] * cpt + wch[h]) * 128 : kt * 128;
+        if (KORD && part != 0) { if (++wtp[h] == ntap) { wtp[h] = 0; ++wch[h]; } }       // (the stream's last piece of this K tile)
         if (h == 0) {
             char* dst = smem + buf * BUF + OFF_W0 + (NF0 * w) * 1024;
 #pragma unroll
@@ -404,10 +414,21 @@ int launch_8ph_v(const WideArgs& a, hipStream_t st) {
     constexpr int lds = 2 * (2 * SLOT + 64 * (NF0 + NF1) * 128);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_8ph<T, NF0, NF1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_8ph<T, NF0, NF1, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (MODE == 2) (void)hipFuncSetAttribute((const void*)conv_igemm_8ph<T, NF0, NF1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_8ph<T, NF0, NF1, MODE>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
+    // SZN_8PH_KORD (default 1): cin-chunk-major K order for the K x K layers (MODE 2 only; see the kernel).  The kernel alone is 0-4 %
+    // slower that way, the step 0.17 ms FASTER (same box, eight alternating runs: 9.08-9.16 -> 8.93-8.96 ms): its fabric traffic no longer
+    // pushes everybody else's operands out of the caches.  0 = tap-major: bit-identical to conv_igemm_wide / conv_igemm_v2.
+    static int kord = -1;
+    if (kord < 0) { const char* e = getenv("SZN_8PH_KORD"); kord = e ? atoi(e) : 1; }
+    if (kord && MODE == 2 && a.KH * a.KW > 1) {
+        hipLaunchKernelGGL((conv_igemm_8ph<T, NF0, NF1, 2, true>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
+        SZN_CHECK_LAUNCH(NF0 + NF1 == 2 ? "conv_igemm_8ph_n128" : "conv_igemm_8ph");
+        return SZN_OK;
+    }
+    hipLaunchKernelGGL((conv_igemm_8ph<T, NF0, NF1, MODE, false>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
     SZN_CHECK_LAUNCH(NF0 + NF1 == 2 ? "conv_igemm_8ph_n128" : "conv_igemm_8ph");
     return SZN_OK;
 }
