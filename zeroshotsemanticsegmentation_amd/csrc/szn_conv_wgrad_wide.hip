@@ -23,6 +23,11 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 typedef __attribute__((address_space(3))) void* ldsptr_t;
 
+#ifndef SZN_WGW_ADAM_AUX
+#define SZN_WGW_ADAM_AUX 2      // cache policy of the update's loads / stores: 2 = non-temporal (0 = default policy: 0.075 ms per step slower,
+                                // profiles/r04_ablations.txt 18 -- 2.7 GB that nobody reads again soon stays out of the caches' way)
+#endif
+
 namespace {
 
 struct WgwArgs {
@@ -283,9 +288,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
                 // (buffer loads with a 32-bit byte offset: no 64-bit address pair per group has to stay live until the stores;
                 //  an outside group reads offset 0xFFFFFFF0 = out of range = zeros, and is not stored)
                 const unsigned off = eo[it] >= 0 ? (unsigned)eo[it] * 4u : 0xFFFFFFF0u;
-                pq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsP, off, 0, 0);
-                mq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsM, off, 0, 0);
-                vq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsV, off, 0, 0);
+                pq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsP, off, 0, SZN_WGW_ADAM_AUX);
+                mq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsM, off, 0, SZN_WGW_ADAM_AUX);
+                vq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsV, off, 0, SZN_WGW_ADAM_AUX);
             }
         }
         __syncthreads();
@@ -314,9 +319,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
                     po[e] = __float_as_uint(pe); mo[e] = __float_as_uint(me); vo[e] = __float_as_uint(ve);
                 }
                 const unsigned off = (unsigned)eo[it] * 4u;
-                __builtin_amdgcn_raw_buffer_store_b128(mo, rsM, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(vo, rsV, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(po, rsP, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(mo, rsM, off, 0, SZN_WGW_ADAM_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(vo, rsV, off, 0, SZN_WGW_ADAM_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(po, rsP, off, 0, SZN_WGW_ADAM_AUX);
                 if (a.wlp) {
                     u32x2_t pk;
                     pk.x = pack2<T>(__uint_as_float(po[0]), __uint_as_float(po[1]));

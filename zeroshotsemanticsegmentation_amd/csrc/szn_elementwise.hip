@@ -740,6 +740,10 @@ __global__ void dropout_mask_kernel(float* __restrict__ scale, long n, float p, 
 // scalar chain of torch.optim (no contraction: -ffp-contract=off), identical for the vector body and the scalar tail.
 // (adam_elem: szn_common.h -- shared with the weight-gradient kernel that applies the update in its epilogue)
 
+#ifndef SZN_ADAM_NT
+#define SZN_ADAM_NT 1      // non-temporal loads / stores of master, gradient and moments: 4 GB per step that nobody reads again before the next
+#endif                     // optimizer pass stays out of the caches' way (0 = default policy: the NEXT step's first kernels pay for it -- the
+                           // whole step 0.05 ms slower with fc6's update fused, 0.21 ms with the separate pass: profiles/r04_ablations.txt 18)
 template <typename LP>      // element type of the optional 16-bit weight image (bf16_raw | f16_raw)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
@@ -755,14 +759,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     const long n4 = vec ? (n >> 2) : 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+#if SZN_ADAM_NT
+        f32x4_t pq = __builtin_nontemporal_load((const f32x4_t*)p + i), gq = __builtin_nontemporal_load((const f32x4_t*)g + i),
+                mq = __builtin_nontemporal_load((const f32x4_t*)m + i), vq = __builtin_nontemporal_load((const f32x4_t*)v + i);
+#else
         f32x4_t pq = ((const f32x4_t*)p)[i], gq = ((const f32x4_t*)g)[i], mq = ((const f32x4_t*)m)[i], vq = ((const f32x4_t*)v)[i];
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float pe = pq[e], me = mq[e], ve = vq[e];
             adam_elem(pe, gq[e], me, ve, b1, b2, eps, wd, step_size, inv_bc2_sqrt, gscale);
             pq[e] = pe; mq[e] = me; vq[e] = ve;
         }
+#if SZN_ADAM_NT
+        __builtin_nontemporal_store(mq, (f32x4_t*)m + i); __builtin_nontemporal_store(vq, (f32x4_t*)v + i);
+        __builtin_nontemporal_store(pq, (f32x4_t*)p + i);
+#else
         ((f32x4_t*)m)[i] = mq; ((f32x4_t*)v)[i] = vq; ((f32x4_t*)p)[i] = pq;
+#endif
         if (wlp) {
             uint2 pk;
             pk.x = pack2<LP>(pq[0], pq[1]);
@@ -797,15 +811,24 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
     const long n4 = vec ? (n >> 2) : 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+#if SZN_ADAM_NT
+        f32x4_t pq = __builtin_nontemporal_load((const f32x4_t*)p + i), gq = __builtin_nontemporal_load((const f32x4_t*)g + i);
+        f32x4_t bq = first ? f32x4_t{0.f, 0.f, 0.f, 0.f} : __builtin_nontemporal_load((const f32x4_t*)buf + i);
+#else
         f32x4_t pq = ((const f32x4_t*)p)[i], gq = ((const f32x4_t*)g)[i];
         f32x4_t bq = first ? f32x4_t{0.f, 0.f, 0.f, 0.f} : ((const f32x4_t*)buf)[i];
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float pe = pq[e], be = bq[e];
             sgd_elem(pe, gq[e], be, lr, mom, wd, first, gscale);
             pq[e] = pe; bq[e] = be;
         }
+#if SZN_ADAM_NT
+        __builtin_nontemporal_store(bq, (f32x4_t*)buf + i); __builtin_nontemporal_store(pq, (f32x4_t*)p + i);
+#else
         ((f32x4_t*)buf)[i] = bq; ((f32x4_t*)p)[i] = pq;
+#endif
         if (wlp) {
             uint2 pk;
             pk.x = pack2<LP>(pq[0], pq[1]);
