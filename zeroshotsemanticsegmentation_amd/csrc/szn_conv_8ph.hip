@@ -423,7 +423,7 @@ int launch_8ph_v(const WideArgs& a, hipStream_t st) {
     // pushes everybody else's operands out of the caches.  0 = tap-major: bit-identical to conv_igemm_wide / conv_igemm_v2.
     static int kord = -1;
     if (kord < 0) { const char* e = getenv("SZN_8PH_KORD"); kord = e ? atoi(e) : 1; }
-    if (kord && MODE == 2 && a.KH * a.KW > 1) {
+    if (kord && MODE == 2 && a.KH * a.KW > 1 && !(kord == 2 && a.KH != 3)) {       // (2: the 3 x 3 layers only -- A/B of fc6's 7 x 7 forward)
         hipLaunchKernelGGL((conv_igemm_8ph<T, NF0, NF1, 2, true>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
         SZN_CHECK_LAUNCH(NF0 + NF1 == 2 ? "conv_igemm_8ph_n128" : "conv_igemm_8ph");
         return SZN_OK;
