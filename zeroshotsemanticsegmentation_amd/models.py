@@ -486,14 +486,16 @@ class _Engine(object):
 
     @contextlib.contextmanager
     def _wgrad_stream(self, *tensors):
-        """Weight gradients are leaves of the backward chain: they run on a second HIP stream (SZN_WGRAD_STREAM=0: on the main one),
-        so that the tail of a dgrad launch and the head of the weight-gradient launch beside it overlap.  Round 1 measured no gain at
-        B=8 (158.1 vs 158.8 Mpx/s); at the end of round 4 -- kernels 40 % faster, so the tails weigh more -- it is worth 0.07 ms per
-        step (8.91 -> 8.84, four alternating runs) and 0.08 ms at B = 1 (profiles/r04_ablations.txt 19).  Same kernels, same
-        values.  The side stream first waits for everything queued on the current stream (dout is produced there); `tensors`
+        """Weight gradients are leaves of the backward chain: with SZN_WGRAD_STREAM=1 they run on a second HIP stream, so that the tail
+        of a dgrad launch and the head of the weight-gradient launch beside it overlap.  Round 1 measured no gain at B=8 (158.1 vs
+        158.8 Mpx/s); at the end of round 4 -- kernels 40 % faster, so the tails weigh more -- it is worth 0.07 ms per step (8.91 ->
+        8.84, four alternating runs) and 0.09 ms at B = 1 (profiles/r04_ablations.txt 19).  Off by default all the same: two
+        kernels sharing the chip make every per-kernel time (the bench line's `roofline`, the rocprof tables) a measurement of the
+        pair, not of the kernel -- conv_igemm_8ph reads 0.34 of peak instead of 0.51 with it on.  Same kernels, same values.
+        The side stream first waits for everything queued on the current stream (dout is produced there); `tensors`
         are the operands whose memory must not be recycled before the side stream is done with them."""
         if self._wg_stream is None:
-            on = os.environ.get("SZN_WGRAD_STREAM", "1") == "1"
+            on = os.environ.get("SZN_WGRAD_STREAM", "0") == "1"
             self._wg_stream = torch.cuda.Stream(device=tensors[0].device) if on else False
         side = self._wg_stream
         if side is False:
