@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the kernels / projection / phase2 / fp32 / b1 sub-records")
+    ap.add_argument("--grad-comm", choices=["auto", "fp32", "bf16", "bf16-sharded", "off"], default="auto",
+                    help="N > 1: wire format of the gradient exchange.  auto = bf16 written by the weight-gradient kernels themselves on "
+                         "the 16-bit paths (271 MB per step instead of 542), fp32 on the fp32 path; bf16-sharded = reduce-scatter + "
+                         "rank-sharded Adam + all-gather of the weight image; the `comm` record times the alternatives beside it")
     ap.add_argument("--sub-record", choices=["fp32", "b1", "comm"], default=None,
                     help="(internal) measure one sub-record and print it as JSON; run by the main process as a child")
     return ap.parse_args()
@@ -325,6 +329,73 @@ def _skipped_flops_one_step(L, mods, step_fn):
     return tot[0]
 
 
+def _init_pg(dist, backend, dev=None, **kw):
+    """engine.init_process_group: RCCL's kernels on a high-priority HIP stream unless SZN_RCCL_HIPRI=0"""
+    from zeroshotsemanticsegmentation_amd import engine
+    return engine.init_process_group(backend, dev, **kw)
+
+
+def _comm_kwargs(kind):
+    import torch
+    return {"off": dict(exchange=False),
+            "fp32": dict(grad_comm_dtype=torch.float32),
+            "bf16": dict(grad_comm_dtype=torch.bfloat16, direct_wire=True),
+            "bf16-staged": dict(grad_comm_dtype=torch.bfloat16, direct_wire=False),
+            "bf16-sharded": dict(grad_comm_dtype=torch.bfloat16, direct_wire=True, sharded=True),
+            "fp32-sharded": dict(grad_comm_dtype=torch.float32, sharded=True)}[kind]
+
+
+def comm_record_world(args, torch, dist, dev, emb_np, seen, rank, world, headline_kind):
+    """N > 1, every rank: the step with the exchange off / fp32 wire / bf16 wire (direct) / bf16 reduce-scatter + sharded Adam, timed
+    like the headline (barrier + synchronize on both sides, max over ranks), plus per-bucket issue / wait times from HIP events on the
+    compute stream -- so that a SCALE record explains itself: exposed_comm_ms = step(variant) - step(off)."""
+    from zeroshotsemanticsegmentation_amd import engine, models, synth
+    E, H, B, K = args.embed_dim, args.size, args.batch, args.classes
+    x = torch.from_numpy(synth.make_images(B, H, H, seed=1337 + rank)).to(dev)
+    t = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337 + rank, classes=seen)).to(dev)
+    n = max(min(args.steps, 20), 5)
+    out = {"world": world, "backend": dist.get_backend(), "steps": n, "headline_wire": headline_kind,
+           "rccl_high_priority_stream": os.environ.get("SZN_RCCL_HIPRI", "1") == "1", "ms_per_step": {}, "buckets": {}}
+    kinds = ["off", "fp32", "bf16", "bf16-sharded"] if args.precision != "fp32" else ["off", "fp32", "fp32-sharded"]
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.precision]
+    for kind in kinds:
+        try:
+            torch.manual_seed(1337)
+            m = models.FCN32s(n_class=E)
+            m.load_synthetic(1337, device=dev)
+            m.train()
+            m._engine.dropout_seed = 1337 + 7919 * rank
+            ts = engine.TrainStep(m, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=True, keep_grads=False,
+                                  **_comm_kwargs(kind))
+            for _ in range(2):
+                ts.step(x, t)
+            ts.buckets.timing = kind != "off"
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                ts.step(x, t)
+            dist.barrier(); torch.cuda.synchronize()
+            dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            out["ms_per_step"][kind] = round(float(dt.item()) / n * 1e3, 3)
+            rep = ts.buckets.timing_report()
+            if rep:
+                out["buckets"][kind] = rep
+            if not np.isfinite(float(ts.loss.item())):
+                out["ms_per_step"][kind] = "non-finite loss"
+            del m, ts
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            out["ms_per_step"][kind] = "failed: %r" % (ex,)
+    off = out["ms_per_step"].get("off")
+    if isinstance(off, float):
+        out["exposed_comm_ms"] = {k: round(v - off, 3) for k, v in out["ms_per_step"].items() if k != "off" and isinstance(v, float)}
+        out["cost_frac"] = {k: round(v / off - 1.0, 4) for k, v in out["ms_per_step"].items() if k != "off" and isinstance(v, float)}
+    out["note"] = ("rank-0 view of the bucket events (issued_at_ms since the start of the backward pass; wait_ms = how long the compute "
+                   "stream stood still for that bucket in front of the optimizer); `off` = no exchange at all (ranks diverge: timing only)")
+    return out
+
+
 def sub_record(args):
     """child process: `fp32` = the headline workload at the reference's arithmetic; `b1` = at the reference's batch size
     (train.py:82-84), eager and replayed from a captured hipGraph (host pacing out).  Prints one JSON object."""
@@ -367,13 +438,13 @@ def sub_record(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        _init_pg(dist, "nccl", dev, rank=0, world_size=1)
         B = args.batch
         variants = [("comm_off", dict(force_comm=False)),
-                    ("fp32_wire", dict(force_comm=True, grad_comm_dtype=torch.float32, reserved_cus=0)),
-                    ("bf16_wire", dict(force_comm=True, grad_comm_dtype=torch.bfloat16, reserved_cus=0)),
-                    ("fp32_wire_reserved_16cu", dict(force_comm=True, grad_comm_dtype=torch.float32, reserved_cus=16)),
-                    ("fp32_wire_reserved_32cu", dict(force_comm=True, grad_comm_dtype=torch.float32, reserved_cus=32))]
+                    ("fp32_wire", dict(force_comm=True, grad_comm_dtype=torch.float32)),
+                    ("bf16_wire", dict(force_comm=True, grad_comm_dtype=torch.bfloat16, direct_wire=True)),
+                    ("bf16_wire_staged", dict(force_comm=True, grad_comm_dtype=torch.bfloat16, direct_wire=False)),
+                    ("bf16_sharded", dict(force_comm=True, grad_comm_dtype=torch.bfloat16, direct_wire=True, sharded=True))]
         x = torch.from_numpy(synth.make_images(B, H, H, seed=1337)).to(dev)
         t = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337, classes=seen)).to(dev)
         steps = {}
@@ -396,6 +467,10 @@ def sub_record(args):
                "bucket_mib": [round((e - o) * 4 / 2 ** 20, 1) for o, e, _ in bk.buckets],
                "allreduce_calls_per_step": len(bk.buckets) + 1,
                "rccl_kernel": "one-rank reduce (pre-multiplied sum x 1.0) over every bucket on RCCL's stream",
+               "rccl_high_priority_stream": os.environ.get("SZN_RCCL_HIPRI", "1") == "1",
+               "variants": "bf16_wire = the weight-gradient kernels write the bf16 wire image, RCCL sums it in place, Adam reads it "
+                           "(szn_adam_step_g16); bf16_wire_staged = round 4's two staging copies; bf16_sharded = the same wire with the "
+                           "rank-sharded optimizer (one rank owns every slice here)",
                "ms_per_step": {k: round(sorted(v)[1], 3) for k, v in times.items()},
                "rounds_ms": {k: [round(a, 3) for a in v] for k, v in times.items()}}
         off = out["ms_per_step"]["comm_off"]
@@ -494,8 +569,21 @@ def main():
     one_gpu = os.environ.get("SZN_TEST_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: re-exec under torch.distributed.run, one rank per GPU on this node
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torchrun with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d: the rank count must match" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -503,7 +591,7 @@ def main():
         if one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
+            _init_pg(dist, "nccl", dev)                       # backend "nccl" is RCCL on ROCm
     L.load()
 
     E, H, B, K = args.embed_dim, args.size, args.batch, args.classes
@@ -523,11 +611,17 @@ def main():
     target = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337 + rank, classes=seen)).to(dev)
     target_all = torch.from_numpy(synth.make_labels(B, H, H, K, seed=4337 + rank)).to(dev)
 
+    wire = args.grad_comm
+    if wire == "auto":
+        wire = "bf16" if (dtype == torch.bfloat16 and args.arch == "fcn32s") else "fp32"
+    if dtype == torch.float32 and wire.startswith("bf16"):
+        wire = "fp32"
+
     def make_phase1():
         # keep_grads=False like trainer_fcn.Trainer: the loop calls zero_grad() next (train.py:170-175), so fc6 / fc7's gradients --
         # consumed by the Adam step inside their weight-gradient kernel on one rank -- are not also written out
         return engine.TrainStep(model, emb_np, optimizer="adam", lr=1e-5, precision=dtype, keep_grads=False,
-                                fused_head=not (args.unfused_head and args.arch == "fcn32s"))
+                                fused_head=not (args.unfused_head and args.arch == "fcn32s"), **_comm_kwargs(wire))
 
     def make_phase1_fcn8s():
         # autograd path: forward (skip head, materialised score) -> cosine loss -> infer_lbl -> backward -> two-group Adam
@@ -720,6 +814,21 @@ def main():
                 out["roofline"]["step_mfma_frac"] = round(step_fl * args.steps / dt / 1e12 / peak, 4)
                 out["roofline"]["step_gflop_executed"] = round(step_fl / 1e9, 1)
                 out["roofline"]["step_gflop_skipped_constant_border"] = round(skipped[0] / 1e9, 1)
+
+    if world > 1 and args.phase == "fcn" and args.arch == "fcn32s" and not args.unfused_head and not args.no_extras:
+        if out is not None:
+            out["config"]["grad_wire"] = wire
+        L.call = orig_call
+        for mod in (models, engine):
+            mod.L.call = orig_call
+        del ts
+        torch.cuda.empty_cache()
+        try:
+            rec = comm_record_world(args, torch, dist, dev, emb_np, seen, rank, world, wire)
+        except Exception as ex:
+            rec = {"error": repr(ex)[:400]}
+        if out is not None:
+            out["comm"] = rec
 
     # ---- instrumented pass: every C-ABI call of 3 more steps (same state, not part of `value`) ----
     if not args.no_kernel_events and not args.no_extras and world == 1:

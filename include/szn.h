@@ -119,6 +119,14 @@ typedef struct {
                          leave idle for another queue -- under data parallelism the RCCL all-reduce of the gradient buckets runs on
                          its own stream while dgrad / wgrad continue (engine.GradBuckets; train.py has no counterpart: the reference
                          is single-GPU).  Tiled kernels ignore it (their blocks come and go; the hardware interleaves the queues).  */
+    void* dw_lp;        /* szn_conv2d_wgrad only, optional: deliver the weight gradient as a 16-bit image (dw_lp_dtype = SZN_BF16 |
+                         SZN_F16, OHWI like dw, 8-B aligned) -- the wire format of the data-parallel gradient exchange
+                         (engine.GradBuckets, SZN_GRAD_COMM=bf16; the reference is single-GPU: trainer_fcn.py:157-158 call
+                         loss.backward(); optim.step() back to back).  The kernels that own the final store of a gradient element
+                         (wgrad_taps_reduce, conv_wgrad_wide's epilogue, wgrad_slab_reduce) round it once from the fp32 sum and write
+                         2 B instead of 4; dw must still be valid fp32 memory of the full size (scratch for the paths that finish in
+                         fp32 and convert), its content is UNDEFINED afterwards.  Ignored with accumulate != 0 (error).          */
+    int dw_lp_dtype;
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
@@ -422,6 +430,15 @@ int szn_adam_step(long n, float* param, const float* grad, float* exp_avg, float
 int szn_sgd_momentum_step(long n, float* param, const float* grad, float* momentum_buf, float lr,
                           float momentum, float weight_decay, int first_step, float grad_scale,
                           void* w_lp, int w_lp_dtype, szn_stream_t stream);
+/* The same steps reading the gradient as a 16-bit image (grad_dtype = SZN_BF16 | SZN_F16) -- the summed wire buffer of the
+ * data-parallel exchange (szn_conv_desc_t.dw_lp -> all-reduce / reduce-scatter in place -> here): the widening copy back into an
+ * fp32 gradient buffer disappears and the pass reads 2 B per weight instead of 4.  Arithmetic after widening: identical.   */
+int szn_adam_step_g16(long n, float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      float grad_scale, void* w_lp, int w_lp_dtype, szn_stream_t stream);
+int szn_sgd_momentum_step_g16(long n, float* param, const void* grad, int grad_dtype, float* momentum_buf, float lr,
+                              float momentum, float weight_decay, int first_step, float grad_scale,
+                              void* w_lp, int w_lp_dtype, szn_stream_t stream);
 
 /* ---- dynamic loss scaling for the IEEE-half path (BASELINE configs[4]: "fp16 activations"; the reference is fp32 and has
  * no counterpart).  scale_state: device float[4] = {loss scale S, found_inf flag, optimizer steps applied, clean steps

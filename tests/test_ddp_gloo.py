@@ -98,3 +98,76 @@ def test_single_process_is_noop():
     gb = GradBuckets(flat, [("a", 0, 4), ("b", 4, 6)], bucket_elems=1)
     gb.layer_done("b"); gb.layer_done("a"); gb.finish()
     assert torch.equal(flat, torch.ones(10)) and gb.world == 1
+
+
+def _worker_sharded(rank, world, port, q):
+    """reduce-scatter + rank-sharded update + all-gather == all-reduce + replicated update, bit for bit (two ranks: the sum of two
+    terms does not depend on the order), for the fp32 wire, the staged bf16 wire and the direct bf16 wire; exchange off = untouched"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zeroshotsemanticsegmentation_amd.engine import GradBuckets
+    layers, off = [], 0
+    for i, n in enumerate([64, 4096, 128, 8192, 64, 32]):             # forward order; every bucket splits into 2 x whole 16-B groups
+        layers.append(("L%d" % i, off, n))
+        off += n
+    grads = [torch.randn(off, generator=torch.Generator().manual_seed(11 + r)) for r in range(world)]
+    w0 = torch.randn(off, generator=torch.Generator().manual_seed(5))
+
+    def run(sharded, comm, direct):
+        flat = grads[rank].clone()
+        gb = GradBuckets(flat, layers, bucket_elems=4000, comm_dtype=comm, sharded=sharded, direct=direct)
+        if gb.direct:                                                 # the kernels write the wire image themselves
+            gb.stage.copy_(flat)
+        for name, _, _ in reversed(layers):
+            gb.layer_done(name)
+        gb.finish()
+        g = gb.stage.float() if gb.direct else flat                   # what the optimizer reads
+        w = w0.clone()
+        if sharded:
+            for o, e, _ in gb.buckets:
+                lo, hi = gb.shard(o, e)
+                w[lo:hi] -= 0.1 * g[lo:hi] / world                    # this rank's slice only
+            for wk in gb.gather_weights(w):
+                wk.wait()
+        else:
+            w -= 0.1 * g / world
+        return w, gb
+
+    ok = True
+    for comm, direct in ((torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)):
+        wa, ga = run(False, comm, direct)
+        ws, gs = run(True, comm, direct)
+        ok = ok and torch.equal(wa, ws) and gs.sharded and not ga.sharded
+        ok = ok and gs.issued == 2 * len(gs.buckets) and ga.issued == len(ga.buckets)
+    exact = w0 - 0.1 * sum(grads) / world
+    wa, _ = run(False, torch.float32, False)
+    ok = ok and torch.allclose(wa, exact, rtol=0, atol=1e-6)
+    # exchange off: nothing is issued, the gradient stays this rank's
+    flat = grads[rank].clone()
+    gb = GradBuckets(flat, layers, bucket_elems=4000, enabled=False)
+    for name, _, _ in reversed(layers):
+        gb.layer_done(name)
+    gb.finish()
+    ok = ok and not gb.active and gb.issued == 0 and torch.equal(flat, grads[rank])
+    # a bucket that does not split into whole 16-B groups per rank is refused
+    try:
+        GradBuckets(torch.zeros(10), [("a", 0, 10)], bucket_elems=4, sharded=True)
+        ok = False
+    except Exception:
+        pass
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_equals_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 25500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]

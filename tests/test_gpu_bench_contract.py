@@ -66,6 +66,28 @@ def test_bench_two_ranks_code_path_on_one_gpu(arch):
     assert "cpu_baseline" not in d and "roofline" in d
 
 
+def test_bench_plain_gpus2_relaunches_itself_under_torchrun():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver called bench.py at N = 1): bench.py re-executes itself
+    under torch.distributed.run with two ranks (here both on device 0 over gloo) and the line carries the `comm` record of N > 1:
+    step time with the exchange off / fp32 wire / bf16 wire / sharded optimizer and the per-bucket issue / wait times"""
+    env = dict(os.environ, SZN_TEST_ONE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+                          "--size", "96"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["grad_wire"] == "bf16"
+    c = d["comm"]
+    assert c["world"] == 2 and set(c["ms_per_step"]) == {"off", "fp32", "bf16", "bf16-sharded"}
+    assert all(isinstance(v, float) and v > 0 for v in c["ms_per_step"].values()), c["ms_per_step"]
+    assert set(c["exposed_comm_ms"]) == {"fp32", "bf16", "bf16-sharded"}
+    b = c["buckets"]["bf16"]
+    assert b["steps"] >= 2 and len(b["buckets"]) >= 2 and all(r["wait_ms"] >= 0 and r["issued_at_ms"] >= 0 for r in b["buckets"])
+    assert b["buckets"][0]["bucket"] == "fc7" or b["buckets"][0]["issued_at_ms"] <= b["buckets"][-1]["issued_at_ms"]
+
+
 def test_train_cli_two_ranks_on_one_gpu(fast_tmp):
     """train.py under torchrun, 2 ranks (device 0, gloo): shared log directory, DistributedSampler shards, sharded validation with
     all-reduced histograms -- cfg 4 (20-d pascal embeddings, phase 1 only; the phase-2 reduction is engine.allreduce_param_grads,

@@ -201,3 +201,104 @@ def test_configs3_standin_two_ranks_b8_bf16_512(comm):
         assert e_abs < 2e-2 and e_sq < 4e-2 and e_probe < 0.15, (n, worst[n])
     print("two ranks x B=8 vs one process B=16 (%s wire): worst layer errors sum|g| %.2e, sum g^2 %.2e, probe %.2e"
           % (comm, max(v[0] for v in worst.values()), max(v[1] for v in worst.values()), max(v[2] for v in worst.values())))
+
+
+# ---- the wire formats and the sharded optimizer of round 5 -------------------------------------------------------------------
+# Two ranks (device 0, gloo), bf16 compute path, two steps each, one process group, five exchange modes run one after the other on
+# fresh models.  Every kernel on the path reduces in a fixed order and a two-term sum does not depend on its order, so:
+#   * fp32 wire, all-reduce + replicated Adam  ==  fp32 wire, reduce-scatter + rank-sharded Adam + all-gather     (bit for bit)
+#   * bf16 wire staged (round 4: copy in, all-reduce, copy out)  ==  bf16 wire written by the weight-gradient kernels themselves
+#     (szn_conv_desc_t.dw_lp) and read by szn_adam_step_g16  ==  the same with the sharded optimizer                (bit for bit)
+# and after gather_masters() both ranks hold identical fp32 masters and moments.
+MODES = {"fp32": dict(grad_comm_dtype=torch.float32),
+         "fp32-sharded": dict(grad_comm_dtype=torch.float32, sharded=True),
+         "bf16-staged": dict(grad_comm_dtype=torch.bfloat16, direct_wire=False),
+         "bf16-direct": dict(grad_comm_dtype=torch.bfloat16, direct_wire=True, keep_grads=False),
+         "bf16-direct-sharded": dict(grad_comm_dtype=torch.bfloat16, direct_wire=True, sharded=True, keep_grads=False)}
+
+
+def _worker_modes(rank, world, port, optname, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from zeroshotsemanticsegmentation_amd import _lib as L
+        from zeroshotsemanticsegmentation_amd import engine, models
+        x, t, emb = _data()
+        dev = torch.device("cuda", 0)
+        xr, tr = torch.from_numpy(x[rank:rank + 1]).to(dev), torch.from_numpy(t[rank:rank + 1]).to(dev)
+        out = {"rank": rank}
+        for mode, kw in MODES.items():
+            m = models.FCN32s(E)
+            m.load_synthetic(1337, device=dev)
+            m.eval()
+            # (SGD: a learning rate at which two steps move the bf16 weight image, or the comparison below would be vacuous)
+            ts = engine.TrainStep(m, emb, optimizer=optname, lr=1e-4 if optname == "adam" else 0.5, precision=torch.bfloat16,
+                                  fused_head=True, bucket_mb=1, **kw)
+            assert ts.buckets.active and ts.buckets.direct == ("direct" in mode) and ts.buckets.sharded == ("sharded" in mode), mode
+            kernels = set()
+            orig = L.call
+            lp_init = ts.flat_w_lp.clone()
+
+            def spy(name, *a):
+                orig(name, *a)
+                kernels.add(L.last_kernel())
+            engine.L.call = spy
+            try:
+                for _ in range(2):
+                    loss, _ = ts.step(xr, tr)
+            finally:
+                engine.L.call = orig
+            issued = ts.buckets.issued
+            moved = float((ts.flat_w_lp != lp_init).float().mean())
+            ts.gather_masters()
+            torch.cuda.synchronize()
+            out[mode] = {"loss": float(loss), "lp": ts.flat_w_lp.view(torch.int16).cpu().numpy(), "w": ts.flat_w.cpu().numpy(),
+                         "b": ts.flat_b.cpu().numpy(), "m1": ts.state["w"][0].cpu().numpy(),
+                         "g16": ("adam_kernel_g16" in kernels or "sgd_kernel_g16" in kernels), "issued": issued, "moved": moved,
+                         "nb": len(ts.buckets.buckets), "grad_none": m.fc6.weight.grad is None}
+            del m, ts
+        q.put(out)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as ex:
+        import traceback
+        q.put({"rank": rank, "error": "%r\n%s" % (ex, traceback.format_exc())})
+
+
+@pytest.mark.parametrize("optname", ["adam", "sgd"])
+def test_wire_modes_and_sharded_optimizer_bit_identical_two_ranks(optname):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 23700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_modes, args=(r, 2, port, optname, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        o = q.get(timeout=900)
+        assert "error" not in o, o.get("error")
+        res[o["rank"]] = o
+    for p in procs:
+        p.join(120)
+    for mode in MODES:                                      # both ranks end with the same weights, images, moments
+        for key in ("lp", "w", "b", "m1"):
+            assert np.array_equal(res[0][mode][key], res[1][mode][key]), (mode, key)
+        assert np.isfinite(res[0][mode]["loss"])
+    for a, b in (("fp32", "fp32-sharded"), ("bf16-staged", "bf16-direct"), ("bf16-direct", "bf16-direct-sharded")):
+        for key in ("lp", "w", "b", "m1"):
+            assert np.array_equal(res[0][a][key], res[0][b][key]), (a, b, key)
+        assert res[0][a]["loss"] == res[0][b]["loss"]
+    # the direct wire really took the 16-bit-gradient optimizer kernel and never stored fp32 weight gradients
+    assert res[0]["bf16-direct"]["g16"] and res[0]["bf16-direct-sharded"]["g16"] and not res[0]["bf16-staged"]["g16"]
+    assert res[0]["bf16-direct"]["grad_none"] and not res[0]["bf16-staged"]["grad_none"]
+    # sharded: one reduce-scatter + one all-gather per bucket and step (+ the bias all-reduce)
+    # (+ the all-gather of the first bucket's fp32 masters: conv1_1's kernel reads those)
+    nb = res[0]["fp32"]["nb"]
+    assert nb >= 4 and res[0]["fp32"]["issued"] == 2 * (nb + 1) and res[0]["fp32-sharded"]["issued"] == 2 * (2 * nb + 2)
+    assert all(res[0][mode]["moved"] > 0.3 for mode in MODES), {mode: res[0][mode]["moved"] for mode in MODES}
+    # bf16 wire vs fp32 wire: the same training step up to the 2^-9 rounding of the summed gradients
+    d = np.abs(res[0]["bf16-direct"]["w"] - res[0]["fp32"]["w"]).max()
+    assert d < 5e-4, d

@@ -23,7 +23,8 @@ class ConvDesc(C.Structure):
         "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")] + [
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p),
         ("colsum_slab", C.c_void_p), ("colsum_slab_rows", C.c_int), ("pool_code", C.c_void_p), ("pool_only", C.c_int),
-        ("cb_on", C.c_int), ("cb_rect", C.c_int * 4), ("cb_const", C.c_int * 4), ("reserved_cus", C.c_int)]
+        ("cb_on", C.c_int), ("cb_rect", C.c_int * 4), ("cb_const", C.c_int * 4), ("reserved_cus", C.c_int),
+        ("dw_lp", C.c_void_p), ("dw_lp_dtype", C.c_int)]
 
 
 class DeviceInfo(C.Structure):
@@ -133,6 +134,8 @@ SIGNATURES = {
     "szn_fused_head_strided": (_I, [_I] * 11 + [_P] * 6 + [_I, _P, _P, _P]),
     "szn_adam_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _P, _I, _P]),
     "szn_sgd_momentum_step": (_I, [_L, _P, _P, _P, _F, _F, _F, _I, _F, _P, _I, _P]),
+    "szn_adam_step_g16": (_I, [_L, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _F, _P, _I, _P]),
+    "szn_sgd_momentum_step_g16": (_I, [_L, _P, _P, _I, _P, _F, _F, _F, _I, _F, _P, _I, _P]),
     "szn_grad_check_finite": (_I, [_L, _P, _P, _P]),
     "szn_adam_step_scaled": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P, _F, _P, _I, _P]),
     "szn_sgd_momentum_step_scaled": (_I, [_L, _P, _P, _P, _F, _F, _F, _P, _F, _P, _I, _P]),

@@ -321,9 +321,23 @@ extern "C" int szn_conv2d_wgrad_adam(const szn_conv_desc_t* d, const void* in, c
     return rc;
 }
 
+static int wgrad_dispatch(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate, szn_stream_t stream,
+                          int* lp_native);
+
 extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate,
                                 szn_stream_t stream) {
     if (!d) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad: null descriptor");
+    if (d->dw_lp && (accumulate || !szn_is16(d->dw_lp_dtype) || ((uintptr_t)d->dw_lp & 7) || !dw))
+        SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad: dw_lp needs accumulate == 0, a 16-bit dw_lp_dtype, an 8-B aligned image and dw as fp32 scratch");
+    int lp_native = 0;
+    const int rc = wgrad_dispatch(d, in, dout, dw, accumulate, stream, &lp_native);
+    if (rc != SZN_OK || !d->dw_lp || lp_native) return rc;
+    // the kernel family that took the layer finishes in fp32 (head / skip layers, fp32 layers: a few MB): one conversion pass
+    return szn_cast(SZN_F32, d->dw_lp_dtype, (long)d->Co * d->KH * d->KW * d->Ci, dw, d->dw_lp, stream);
+}
+
+static int wgrad_dispatch(const szn_conv_desc_t* d, const void* in, const void* dout, float* dw, int accumulate, szn_stream_t stream,
+                          int* lp_native) {
     szn_note_work_fraction(1.f);
     const size_t es = szn_esize(d->dtype);
     const int ch = (int)(16 / es);
@@ -343,14 +357,14 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
         static int taps_min = -1;
         if (taps_min < 0) { const char* e = getenv("SZN_WGT_MINTILES"); taps_min = e ? atoi(e) : 8; }
         const int rc = szn_conv_wgrad_taps_try(d, in, dout, dw, accumulate, taps_min, stream);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { *lp_native = 1; return rc; }
     }
     // many channels, few pixels (fc6, fc7): 256 x 256 tiles, one pixel split (szn_conv_wgrad_wide.hip)
     {
         static int wide_min = -1;
         if (wide_min < 0) { const char* e = getenv("SZN_WGW_MINTILES"); wide_min = e ? atoi(e) : 96; }
         const int rc = szn_conv_wgrad_wide_try(d, in, dout, dw, accumulate, wide_min, stream);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { *lp_native = 1; return rc; }
     }
     const long nw = (long)d->Co * d->KH * d->KW * d->Ci;
     Wg2Args a;

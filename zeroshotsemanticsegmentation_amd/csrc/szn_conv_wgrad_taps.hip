@@ -28,6 +28,7 @@ namespace {
 
 struct WtArgs {
     const char* dout; const char* in; float* dw; float* ws;
+    uint16_t* dw_lp; int lp_f16;       // szn_conv_desc_t.dw_lp: the reduce kernel delivers the gradient as a 16-bit image instead
     unsigned dout_bytes, in_bytes;
     int B, Hi, Wi, Ci, Ho, Wo, Co, pad;
     int ldi, ldd;
@@ -317,7 +318,12 @@ __global__ __launch_bounds__(256) void wgrad_taps_reduce(WtArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) sv[q] += sc * (a.is_f16 ? f16_bits_to_f32(xr[q]) : bf16_bits_to_f32(xr[q]));
         }
-        if (a.accumulate) {
+        if (a.dw_lp) {                                 // the data-parallel wire image: rounded once, from the fp32 sum
+            uint2 pk;
+            if (a.lp_f16) { pk.x = pack2<f16_raw>(sv[0], sv[1]); pk.y = pack2<f16_raw>(sv[2], sv[3]); }
+            else { pk.x = pack2<bf16_raw>(sv[0], sv[1]); pk.y = pack2<bf16_raw>(sv[2], sv[3]); }
+            *(uint2*)(a.dw_lp + ((long)co * 9 + tap) * a.Ci + ci) = pk;
+        } else if (a.accumulate) {
             const f32x4_t o = *(const f32x4_t*)dst;
             *(f32x4_t*)dst = o + sv;
         } else {
@@ -531,6 +537,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
         }
     }
     a.dout = (const char*)dout; a.in = (const char*)in; a.dw = dw; a.ws = (float*)d->workspace;
+    a.dw_lp = accumulate ? nullptr : (uint16_t*)d->dw_lp; a.lp_f16 = d->dw_lp_dtype == SZN_F16;
     a.dout_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->ldo * 2);
     a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->ldi * 2);
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.pad = d->pad;

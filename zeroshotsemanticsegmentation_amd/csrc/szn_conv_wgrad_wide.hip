@@ -32,6 +32,7 @@ namespace {
 
 struct WgwArgs {
     const char* dout; const char* in; float* dw;
+    uint16_t* dw_lp; int lp_f16;       // szn_conv_desc_t.dw_lp (<T, false> only): the epilogue stores the gradient as a 16-bit image instead
     unsigned dout_bytes, in_bytes;
     int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, pad;
     int ldi, ldd;
@@ -341,6 +342,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
             if (co < a.Co && ci < a.Ci) {
                 float* dst = a.dw + ((long)(co * a.KH + kh) * a.KW + kw) * a.Ci + ci;
                 f32x4_t v = *(const f32x4_t*)(tile + r * PT + c4);
+                if (a.dw_lp) {                                            // Ci % 8 == 0: whole groups; 8-B aligned image
+                    uint2 pk;
+                    if (a.lp_f16) { pk.x = pack2<f16_raw>(v[0], v[1]); pk.y = pack2<f16_raw>(v[2], v[3]); }
+                    else { pk.x = pack2<bf16_raw>(v[0], v[1]); pk.y = pack2<bf16_raw>(v[2], v[3]); }
+                    *(uint2*)(a.dw_lp + ((long)(co * a.KH + kh) * a.KW + kw) * a.Ci + ci) = pk;
+                    continue;
+                }
                 if (ci + 4 <= a.Ci && ((((uintptr_t)dst) & 15) == 0)) {
                     if (a.accumulate) { const f32x4_t o = *(const f32x4_t*)dst; v += o; }
                     *(f32x4_t*)dst = v;
@@ -376,6 +384,7 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     // padding waste of the last tiles must stay small (or the launch is a single round of the chip anyway: the native dgrad at B = 1)
     if ((long)a.cotiles * 256 * a.citiles * 256 > (long)d->Co * d->Ci * 5 / 4 && !(min_tiles <= 1 && tiles <= 256)) return 1;
     a.dout = (const char*)dout; a.in = (const char*)in; a.dw = dw;
+    a.dw_lp = (accumulate || opt) ? nullptr : (uint16_t*)d->dw_lp; a.lp_f16 = d->dw_lp_dtype == SZN_F16;
     a.dout_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->ldo * 2);
     a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->ldi * 2);
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;

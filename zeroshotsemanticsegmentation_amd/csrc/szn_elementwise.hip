@@ -744,8 +744,34 @@ __global__ void dropout_mask_kernel(float* __restrict__ scale, long n, float p, 
 #define SZN_ADAM_NT 1      // non-temporal loads / stores of master, gradient and moments: 4 GB per step that nobody reads again before the next
 #endif                     // optimizer pass stays out of the caches' way (0 = default policy: the NEXT step's first kernels pay for it -- the
                            // whole step 0.05 ms slower with fc6's update fused, 0.21 ms with the separate pass: profiles/r04_ablations.txt 18)
-template <typename LP>      // element type of the optional 16-bit weight image (bf16_raw | f16_raw)
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+// the gradient as the optimizer kernels read it: fp32, or a 16-bit image (szn_*_step_g16: the summed wire buffer of the exchange)
+template <typename G> struct grad_src {
+    __device__ static __forceinline__ f32x4_t ld4(const void* g, long i) {
+#if SZN_ADAM_NT
+        return __builtin_nontemporal_load((const f32x4_t*)g + i);
+#else
+        return ((const f32x4_t*)g)[i];
+#endif
+    }
+    __device__ static __forceinline__ float ld1(const void* g, long i) { return ((const float*)g)[i]; }
+};
+template <typename G> __device__ __forceinline__ f32x4_t grad16_ld4(const void* g, long i) {
+    typedef __attribute__((ext_vector_type(2))) uint32_t g_u32x2_t;
+    const g_u32x2_t r = __builtin_nontemporal_load((const g_u32x2_t*)g + i);
+    return f32x4_t{from_bits16<G>((uint16_t)(r[0] & 0xffffu)), from_bits16<G>((uint16_t)(r[0] >> 16)),
+                   from_bits16<G>((uint16_t)(r[1] & 0xffffu)), from_bits16<G>((uint16_t)(r[1] >> 16))};
+}
+template <> struct grad_src<bf16_raw> {
+    __device__ static __forceinline__ f32x4_t ld4(const void* g, long i) { return grad16_ld4<bf16_raw>(g, i); }
+    __device__ static __forceinline__ float ld1(const void* g, long i) { return bf16_bits_to_f32(((const uint16_t*)g)[i]); }
+};
+template <> struct grad_src<f16_raw> {
+    __device__ static __forceinline__ f32x4_t ld4(const void* g, long i) { return grad16_ld4<f16_raw>(g, i); }
+    __device__ static __forceinline__ float ld1(const void* g, long i) { return f16_bits_to_f32(((const uint16_t*)g)[i]); }
+};
+
+template <typename LP, typename G = float>      // LP: element type of the optional 16-bit weight image (bf16_raw | f16_raw); G: the gradient's
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const void* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                    float b1, float b2, float eps, float wd, float step_size,
                                                    float inv_bc2_sqrt, float gscale, uint16_t* __restrict__ wlp, int vec,
@@ -759,11 +785,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     const long n4 = vec ? (n >> 2) : 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4_t gq = grad_src<G>::ld4(g, i);
 #if SZN_ADAM_NT
-        f32x4_t pq = __builtin_nontemporal_load((const f32x4_t*)p + i), gq = __builtin_nontemporal_load((const f32x4_t*)g + i),
+        f32x4_t pq = __builtin_nontemporal_load((const f32x4_t*)p + i),
                 mq = __builtin_nontemporal_load((const f32x4_t*)m + i), vq = __builtin_nontemporal_load((const f32x4_t*)v + i);
 #else
-        f32x4_t pq = ((const f32x4_t*)p)[i], gq = ((const f32x4_t*)g)[i], mq = ((const f32x4_t*)m)[i], vq = ((const f32x4_t*)v)[i];
+        f32x4_t pq = ((const f32x4_t*)p)[i], mq = ((const f32x4_t*)m)[i], vq = ((const f32x4_t*)v)[i];
 #endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -786,7 +813,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float pi = p[i], mi = m[i], vi = v[i];
-        adam_elem(pi, g[i], mi, vi, b1, b2, eps, wd, step_size, inv_bc2_sqrt, gscale);
+        adam_elem(pi, grad_src<G>::ld1(g, i), mi, vi, b1, b2, eps, wd, step_size, inv_bc2_sqrt, gscale);
         m[i] = mi; v[i] = vi; p[i] = pi;
         if (wlp) wlp[i] = to_bits16<LP>(pi);
     }
@@ -799,8 +826,8 @@ __device__ __forceinline__ void sgd_elem(float& pi, float gi, float& bi, float l
     pi -= lr * bi;
 }
 
-template <typename LP>
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+template <typename LP, typename G = float>
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const void* __restrict__ g,
                                                   float* __restrict__ buf, long n, float lr, float mom, float wd,
                                                   int first, float gscale, uint16_t* __restrict__ wlp, int vec,
                                                   const float* __restrict__ dyn) {
@@ -811,11 +838,12 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
     const long n4 = vec ? (n >> 2) : 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4_t gq = grad_src<G>::ld4(g, i);
 #if SZN_ADAM_NT
-        f32x4_t pq = __builtin_nontemporal_load((const f32x4_t*)p + i), gq = __builtin_nontemporal_load((const f32x4_t*)g + i);
+        f32x4_t pq = __builtin_nontemporal_load((const f32x4_t*)p + i);
         f32x4_t bq = first ? f32x4_t{0.f, 0.f, 0.f, 0.f} : __builtin_nontemporal_load((const f32x4_t*)buf + i);
 #else
-        f32x4_t pq = ((const f32x4_t*)p)[i], gq = ((const f32x4_t*)g)[i];
+        f32x4_t pq = ((const f32x4_t*)p)[i];
         f32x4_t bq = first ? f32x4_t{0.f, 0.f, 0.f, 0.f} : ((const f32x4_t*)buf)[i];
 #endif
 #pragma unroll
@@ -838,7 +866,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
     for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float pi = p[i], bi = first ? 0.f : buf[i];
-        sgd_elem(pi, g[i], bi, lr, mom, wd, first, gscale);
+        sgd_elem(pi, grad_src<G>::ld1(g, i), bi, lr, mom, wd, first, gscale);
         buf[i] = bi; p[i] = pi;
         if (wlp) wlp[i] = to_bits16<LP>(pi);
     }
@@ -1159,69 +1187,119 @@ extern "C" int szn_image_u8_to_bgr_f32(int B, int H, int W, const uint8_t* rgb_h
     return SZN_OK;
 }
 
-static int adam_impl(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+template <typename G>
+static void adam_launch(dim3 grid, hipStream_t st, int lp_f16, float* param, const void* grad, float* exp_avg, float* exp_avg_sq, long n,
+                        float lr, float beta1, float beta2, float eps, float wd, float step_size, float inv_bc2_sqrt, float gs,
+                        uint16_t* w_lp, int vec, const float* dyn) {
+    if (lp_f16)
+        hipLaunchKernelGGL((adam_kernel<f16_raw, G>), grid, dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, wd,
+                           step_size, inv_bc2_sqrt, gs, w_lp, vec, dyn);
+    else
+        hipLaunchKernelGGL((adam_kernel<bf16_raw, G>), grid, dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, wd,
+                           step_size, inv_bc2_sqrt, gs, w_lp, vec, dyn);
+}
+
+static int adam_impl(long n, float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step, float grad_scale, void* w_lp, int w_lp_dtype,
                      const float* dyn, szn_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) SZN_FAIL(SZN_ERR_ARG, "adam_step: bad argument");
     if (w_lp && !szn_is16(w_lp_dtype)) SZN_FAIL(SZN_ERR_ARG, "adam_step: the weight image must be SZN_BF16 or SZN_F16");
+    if (grad_dtype != SZN_F32 && !szn_is16(grad_dtype)) SZN_FAIL(SZN_ERR_ARG, "adam_step: the gradient must be SZN_F32, SZN_BF16 or SZN_F16");
     float step_size, inv_bc2_sqrt;
     szn_adam_scalars(lr, beta1, beta2, step, &step_size, &inv_bc2_sqrt);
-    const int vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
+    const uintptr_t galign = grad_dtype == SZN_F32 ? 15 : 7;
+    const int vec = ((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 && ((uintptr_t)grad & galign) == 0 &&
                      (((uintptr_t)w_lp) & 7) == 0) ? 1 : 0;
     // one 16-B group per thread, no grid-stride loop: measured 6.1 TB/s on the 135 M-element buffer vs 5.6 with 16 Ki blocks
     const dim3 grid(grid_for(vec ? (n + 3) / 4 : n, 256, 1 << 24));
-    if (w_lp && w_lp_dtype == SZN_F16)
-        hipLaunchKernelGGL(adam_kernel<f16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                           beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale, (uint16_t*)w_lp, vec, dyn);
+    const int lp16 = (w_lp && w_lp_dtype == SZN_F16) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_dtype == SZN_BF16)
+        adam_launch<bf16_raw>(grid, st, lp16, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
+                              grad_scale, (uint16_t*)w_lp, vec, dyn);
+    else if (grad_dtype == SZN_F16)
+        adam_launch<f16_raw>(grid, st, lp16, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
+                             grad_scale, (uint16_t*)w_lp, vec, dyn);
     else
-        hipLaunchKernelGGL(adam_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                           beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale, (uint16_t*)w_lp, vec, dyn);
-    SZN_CHECK_LAUNCH("adam_kernel");
+        adam_launch<float>(grid, st, lp16, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
+                           grad_scale, (uint16_t*)w_lp, vec, dyn);
+    SZN_CHECK_LAUNCH(grad_dtype == SZN_F32 ? "adam_kernel" : "adam_kernel_g16");
     return SZN_OK;
 }
 
 extern "C" int szn_adam_step(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                              void* w_lp, int w_lp_dtype, szn_stream_t stream) {
-    return adam_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale, w_lp, w_lp_dtype,
+    return adam_impl(n, param, grad, SZN_F32, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale, w_lp, w_lp_dtype,
                      nullptr, stream);
+}
+
+extern "C" int szn_adam_step_g16(long n, float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                 void* w_lp, int w_lp_dtype, szn_stream_t stream) {
+    if (!szn_is16(grad_dtype)) SZN_FAIL(SZN_ERR_ARG, "adam_step_g16: the gradient image must be SZN_BF16 or SZN_F16");
+    return adam_impl(n, param, grad, grad_dtype, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale, w_lp,
+                     w_lp_dtype, nullptr, stream);
 }
 
 extern "C" int szn_adam_step_scaled(long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                                     float beta1, float beta2, float eps, float weight_decay, const float* scale_state,
                                     float grad_scale, void* w_lp, int w_lp_dtype, szn_stream_t stream) {
     if (!scale_state) SZN_FAIL(SZN_ERR_ARG, "adam_step_scaled: scale_state is NULL");
-    return adam_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, 1, grad_scale, w_lp, w_lp_dtype,
+    return adam_impl(n, param, grad, SZN_F32, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, 1, grad_scale, w_lp, w_lp_dtype,
                      scale_state, stream);
 }
 
-static int sgd_impl(long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum, float weight_decay,
-                    int first_step, float grad_scale, void* w_lp, int w_lp_dtype, const float* dyn, szn_stream_t stream) {
+template <typename G>
+static void sgd_launch(dim3 grid, hipStream_t st, int lp_f16, float* param, const void* grad, float* buf, long n, float lr, float mom,
+                       float wd, int first, float gs, uint16_t* w_lp, int vec, const float* dyn) {
+    if (lp_f16)
+        hipLaunchKernelGGL((sgd_kernel<f16_raw, G>), grid, dim3(256), 0, st, param, grad, buf, n, lr, mom, wd, first, gs, w_lp, vec, dyn);
+    else
+        hipLaunchKernelGGL((sgd_kernel<bf16_raw, G>), grid, dim3(256), 0, st, param, grad, buf, n, lr, mom, wd, first, gs, w_lp, vec, dyn);
+}
+
+static int sgd_impl(long n, float* param, const void* grad, int grad_dtype, float* momentum_buf, float lr, float momentum,
+                    float weight_decay, int first_step, float grad_scale, void* w_lp, int w_lp_dtype, const float* dyn,
+                    szn_stream_t stream) {
     if (!param || !grad || !momentum_buf || n <= 0) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step: bad argument");
     if (w_lp && !szn_is16(w_lp_dtype)) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step: the weight image must be SZN_BF16 or SZN_F16");
-    const int vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) == 0 && (((uintptr_t)w_lp) & 7) == 0) ? 1 : 0;
+    if (grad_dtype != SZN_F32 && !szn_is16(grad_dtype)) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step: the gradient must be SZN_F32, SZN_BF16 or SZN_F16");
+    const uintptr_t galign = grad_dtype == SZN_F32 ? 15 : 7;
+    const int vec = ((((uintptr_t)param | (uintptr_t)momentum_buf) & 15) == 0 && ((uintptr_t)grad & galign) == 0 &&
+                     (((uintptr_t)w_lp) & 7) == 0) ? 1 : 0;
     const dim3 grid(grid_for(vec ? (n + 3) / 4 : n, 256, 1 << 24));
-    if (w_lp && w_lp_dtype == SZN_F16)
-        hipLaunchKernelGGL(sgd_kernel<f16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, n, lr, momentum,
-                           weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec, dyn);
+    const int lp16 = (w_lp && w_lp_dtype == SZN_F16) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_dtype == SZN_BF16)
+        sgd_launch<bf16_raw>(grid, st, lp16, param, grad, momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec, dyn);
+    else if (grad_dtype == SZN_F16)
+        sgd_launch<f16_raw>(grid, st, lp16, param, grad, momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec, dyn);
     else
-        hipLaunchKernelGGL(sgd_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, n, lr, momentum,
-                           weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec, dyn);
-    SZN_CHECK_LAUNCH("sgd_kernel");
+        sgd_launch<float>(grid, st, lp16, param, grad, momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale, (uint16_t*)w_lp, vec, dyn);
+    SZN_CHECK_LAUNCH(grad_dtype == SZN_F32 ? "sgd_kernel" : "sgd_kernel_g16");
     return SZN_OK;
 }
 
 extern "C" int szn_sgd_momentum_step(long n, float* param, const float* grad, float* momentum_buf, float lr,
                                      float momentum, float weight_decay, int first_step, float grad_scale, void* w_lp,
                                      int w_lp_dtype, szn_stream_t stream) {
-    return sgd_impl(n, param, grad, momentum_buf, lr, momentum, weight_decay, first_step, grad_scale, w_lp, w_lp_dtype, nullptr, stream);
+    return sgd_impl(n, param, grad, SZN_F32, momentum_buf, lr, momentum, weight_decay, first_step, grad_scale, w_lp, w_lp_dtype, nullptr, stream);
+}
+
+extern "C" int szn_sgd_momentum_step_g16(long n, float* param, const void* grad, int grad_dtype, float* momentum_buf, float lr,
+                                         float momentum, float weight_decay, int first_step, float grad_scale, void* w_lp,
+                                         int w_lp_dtype, szn_stream_t stream) {
+    if (!szn_is16(grad_dtype)) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step_g16: the gradient image must be SZN_BF16 or SZN_F16");
+    return sgd_impl(n, param, grad, grad_dtype, momentum_buf, lr, momentum, weight_decay, first_step, grad_scale, w_lp, w_lp_dtype, nullptr,
+                    stream);
 }
 
 extern "C" int szn_sgd_momentum_step_scaled(long n, float* param, const float* grad, float* momentum_buf, float lr,
                                             float momentum, float weight_decay, const float* scale_state, float grad_scale,
                                             void* w_lp, int w_lp_dtype, szn_stream_t stream) {
     if (!scale_state) SZN_FAIL(SZN_ERR_ARG, "sgd_momentum_step_scaled: scale_state is NULL");
-    return sgd_impl(n, param, grad, momentum_buf, lr, momentum, weight_decay, 0, grad_scale, w_lp, w_lp_dtype, scale_state, stream);
+    return sgd_impl(n, param, grad, SZN_F32, momentum_buf, lr, momentum, weight_decay, 0, grad_scale, w_lp, w_lp_dtype, scale_state, stream);
 }
 
 // ---- dynamic loss scaling (fp16 path) ------------------------------------------------------------------------------------------

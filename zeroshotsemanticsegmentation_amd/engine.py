@@ -19,6 +19,24 @@ from . import synth
 from .models import CROP, CROP_POOL3, CROP_POOL4, CROP_UP8, opt_layers
 
 
+def init_process_group(backend="nccl", device=None, **kw):
+    """torch.distributed.init_process_group for the data-parallel step.  On the `nccl` backend (RCCL on ROCm) the collectives go
+    to a HIGH-PRIORITY HIP stream (ProcessGroupNCCL.Options.is_high_priority_stream; SZN_RCCL_HIPRI=0 turns it off): the tile
+    kernels of the backward pass hold 128-156 KiB of every CU's LDS and keep thousands of workgroups pending, and at normal
+    priority RCCL's workgroups only got CUs when a compute kernel had drained -- measured with the one-rank communicator
+    (profiles/r05_comm_hipri.json): fp32 wire +10.7 % per step at normal priority, +6.1 % at high priority; bf16 wire +10.9 % ->
+    +2.4 %.  The reference is single-GPU (train.py:58,82-84) and has no counterpart."""
+    if backend == "nccl" and os.environ.get("SZN_RCCL_HIPRI", "1") == "1":
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            return dist.init_process_group(backend, device_id=device, pg_options=opts, **kw)
+        except (AttributeError, TypeError):
+            pass
+    if backend == "nccl":
+        return dist.init_process_group(backend, device_id=device, **kw)
+    return dist.init_process_group(backend, **kw)
+
+
 class GradBuckets(object):
     """Data-parallel exchange of the flat weight gradient: contiguous buckets in BACKWARD completion order.
 
@@ -28,23 +46,32 @@ class GradBuckets(object):
     bucket's earliest layer reports `layer_done`; `finish` waits for everything.  The 1/world scaling is applied by the
     optimizer kernel (grad_scale), not here.
 
-    comm_dtype=torch.bfloat16 halves the bytes on the xGMI links (271 MB instead of 542 MB per step at E = 300): the
-    bucket is rounded to bf16 into a staging buffer, summed there by the all-reduce and widened back into `flat` by
-    `finish` (gradient noise of 2^-9 relative per rank; the fp32 default is exact)."""
+    comm_dtype=torch.bfloat16 halves the bytes on the xGMI links (271 MB instead of 542 MB per step at E = 300).  Two forms:
+      staged (direct=False)  the fp32 bucket is rounded into a 16-bit staging buffer, summed there and widened back into `flat`
+                             by `finish` (two extra passes over the gradient; `.grad` stays fp32 and holds the sum);
+      direct (direct=True)   the weight-gradient kernels write the 16-bit image themselves (szn_conv_desc_t.dw_lp) into
+                             `self.stage`, the all-reduce sums it in place and the optimizer kernel reads it
+                             (szn_adam_step_g16): no copy in, no copy out, `flat` is never touched.
+    sharded=True: every bucket is reduce-scattered instead of all-reduced -- rank r then owns the summed slice
+    `shard(bucket)` of it, runs the optimizer over that slice only (1/world of the pass) and `gather_weights` all-gathers the
+    updated weight image (16-bit on the 16-bit paths: the same bytes on the links as a 16-bit all-reduce, 25 % fewer than an
+    fp32 one).  enabled=False: no exchange at all (bench.py's comm-off timing at world > 1)."""
 
-    def __init__(self, flat, layers, bucket_elems, extra=(), group=None, comm_dtype=torch.float32, force=None):
+    def __init__(self, flat, layers, bucket_elems, extra=(), group=None, comm_dtype=torch.float32, force=None, enabled=True,
+                 direct=False, sharded=False, tail=0):
         """force (default: SZN_FORCE_COMM=1): issue the bucket all-reduces even in a process group of ONE rank -- the whole
         exchange path (bucket slicing, RCCL's stream, the waits in front of the optimizer, the bf16 staging) then runs on a
         single GPU.  RCCL returns from an in-place sum over one rank without touching the device, so on the `nccl` backend the
         forced single-rank exchange uses the pre-multiplied sum (factor 1.0; AVG for 16-bit wire buffers): librccl's one-rank
         reduce kernel reads and writes every bucket on RCCL's stream while dgrad / wgrad keep running on the compute stream (same
-        bits as no exchange)."""
+        bits as no exchange).  tail: elements behind `flat` the staging buffer also needs (the fused head's padding rows)."""
         self.flat, self.extra, self.group = flat, list(extra), group
         ready = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if ready else 1
+        self.rank = dist.get_rank(group) if ready else 0
         if force is None:
             force = os.environ.get("SZN_FORCE_COMM", "0") == "1"
-        self.active = ready and (self.world > 1 or bool(force))
+        self.active = bool(enabled) and ready and (self.world > 1 or bool(force))
         self.op = dist.ReduceOp.SUM
         if self.active and self.world == 1 and dist.get_backend(group) == "nccl":
             # one rank: sum == average == x * 1.0.  RCCL skips an in-place SUM entirely; the pre-multiplied sum (fp32 buckets) and
@@ -65,34 +92,125 @@ class GradBuckets(object):
                 end = None
         self.ready_after = {name: (o, e) for o, e, name in self.buckets}
         self.works = []
-        self.issued = 0              # all-reduce calls handed to the backend so far (tests / bench)
+        self.issued = 0              # collective calls handed to the backend so far (tests / bench)
         self.comm_dtype = comm_dtype
         self.stage = None
+        self.direct = bool(direct) and self.active and comm_dtype != torch.float32
+        self.sharded = bool(sharded) and self.active
+        if self.sharded and any((e - o) % (4 * self.world) for o, e, _ in self.buckets):
+            raise L.SznError("sharded optimizer: every bucket must split into %d slices of whole 16-byte groups" % self.world)
         if self.active and comm_dtype != torch.float32:
-            self.stage = torch.empty(flat.numel(), dtype=comm_dtype, device=flat.device)
+            self.stage = torch.zeros(flat.numel() + tail, dtype=comm_dtype, device=flat.device)
+        # self-diagnosis (bench.py): per step, when each bucket was handed to the backend and how long the compute stream then
+        # stood still for it in finish() -- HIP events on the compute stream, read back by `timing_report`
+        self.timing = False
+        self._t0 = None
+        self._tlog = []
 
-    def _reduce(self, t):
+    # ---- what the exchange works on ------------------------------------------------------------------
+    def wire(self):
+        """the buffer the collectives run on (the 16-bit staging buffer, or `flat` itself)"""
+        return self.stage if self.stage is not None else self.flat
+
+    def shard(self, o, e):
+        """the slice [lo, hi) of bucket [o, e) whose sum this rank owns after a reduce-scatter"""
+        n = (e - o) // self.world
+        return o + self.rank * n, o + (self.rank + 1) * n
+
+    def _emulate(self, t):
+        """gloo has no reduce-scatter / all-gather-into-tensor for device memory (the one-GPU test harness runs CUDA tensors over
+        gloo): an all-reduce of the whole bucket leaves the right sum in this rank's slice, a list all-gather moves the slices"""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _collective(self, t, o, e):
         self.issued += 1
-        return dist.all_reduce(t, op=self.op, group=self.group, async_op=True)
+        if self.sharded and self.world > 1 and not self._emulate(t):
+            lo, hi = self.shard(o, e)
+            return dist.reduce_scatter_tensor(t[lo:hi], t[o:e], op=self.op, group=self.group, async_op=True)
+        # (sharded, one rank: it owns everything -- the forced single-rank exchange keeps the all-reduce kernel)
+        return dist.all_reduce(t[o:e], op=self.op, group=self.group, async_op=True)
+
+    def begin_step(self):
+        if self.timing and self.active:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record()
+            self._cur = []
 
     def layer_done(self, name):
         if self.active and name in self.ready_after:
             o, e = self.ready_after[name]
+            ev = None
+            if self.timing and self._t0 is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
             if self.stage is None:
-                self.works.append((self._reduce(self.flat[o:e]), None))
+                self.works.append((self._collective(self.flat, o, e), None, name, ev))
             else:
-                self.stage[o:e].copy_(self.flat[o:e])
-                self.works.append((self._reduce(self.stage[o:e]), (o, e)))
+                if not self.direct:
+                    self.stage[o:e].copy_(self.flat[o:e])
+                self.works.append((self._collective(self.stage, o, e), (o, e), name, ev))
 
     def finish(self):
         if self.active:
             for t in self.extra:
-                self.works.append((self._reduce(t), None))
-            for wk, span in self.works:
+                self.issued += 1
+                self.works.append((dist.all_reduce(t, op=self.op, group=self.group, async_op=True), None, "bias", None))
+            for wk, span, name, ev in self.works:
+                tm = self.timing and self._t0 is not None
+                if tm:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 wk.wait()
-                if span is not None:
-                    self.flat[span[0]:span[1]].copy_(self.stage[span[0]:span[1]])
+                if tm:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._cur.append((name, ev, e0, e1))
+                if span is not None and not self.direct:
+                    o, e = self.shard(*span) if (self.sharded and self.world > 1) else span
+                    self.flat[o:e].copy_(self.stage[o:e])
+            if self.timing and self._t0 is not None:
+                self._tlog.append((self._t0, self._cur))
+                self._t0 = None
         self.works = []
+
+    def gather_weights(self, image, first_only=False):
+        """sharded optimizer: all-gather the slices of `image` (a tensor laid out like `flat`: the 16-bit weight image, or the
+        fp32 masters) that the ranks just updated; returns the async works (wait before the next forward pass reads it).
+        first_only: the bucket of the first layers only (conv1_1 reads its fp32 master in the forward pass)"""
+        works = []
+        if self.sharded and self.world > 1:
+            for o, e, _ in list(reversed(self.buckets))[:1 if first_only else None]:       # forward order: conv1_1's bucket first
+                lo, hi = self.shard(o, e)
+                self.issued += 1
+                if self._emulate(image):
+                    n = (e - o) // self.world
+                    works.append(dist.all_gather([image[o + r * n:o + (r + 1) * n] for r in range(self.world)], image[lo:hi].clone(),
+                                                 group=self.group, async_op=True))
+                else:
+                    works.append(dist.all_gather_into_tensor(image[o:e], image[lo:hi], group=self.group, async_op=True))
+        return works
+
+    def timing_report(self):
+        """[{bucket, mib, issued_at_ms (since begin_step), wait_ms (compute stream stalled in finish)}] averaged over the logged
+        steps + the exposed total; call after a device synchronize.  Clears the log."""
+        log, self._tlog = self._tlog, []
+        if not log:
+            return None
+        acc = {}
+        order = []
+        for t0, cur in log:
+            for name, ev, e0, e1 in cur:
+                a = acc.setdefault(name, [0.0, 0.0, 0])
+                if name not in order:
+                    order.append(name)
+                a[0] += t0.elapsed_time(ev) if ev is not None else t0.elapsed_time(e0)
+                a[1] += e0.elapsed_time(e1)
+                a[2] += 1
+        esz = 2 if self.stage is not None else 4
+        size = {name: (e - o) * esz / 2.0 ** 20 for o, e, name in self.buckets}
+        rows = [{"bucket": n, "mib": round(size.get(n, sum(t.numel() * 4 for t in self.extra) / 2.0 ** 20), 2),
+                 "issued_at_ms": round(acc[n][0] / acc[n][2], 3), "wait_ms": round(acc[n][1] / acc[n][2], 3)} for n in order]
+        return {"buckets": rows, "exposed_wait_ms": round(sum(r["wait_ms"] for r in rows), 3), "steps": len(log)}
 
 
 def allreduce_param_grads(params, group=None):
@@ -259,7 +377,13 @@ class TrainStep(object):
                  train_metrics=True, betas=(0.9, 0.999), eps=1e-8, bias_lr=None, bias_weight_decay=0.0,
                  adam_weight_decay=0.0, grad_comm_dtype=None, loss_scale=None, dynamic_loss_scale=None,
                  scale_growth=2.0, scale_backoff=0.5, scale_growth_interval=2000, force_comm=None, reserved_cus=None,
-                 fused_adam=None, keep_grads=True):
+                 fused_adam=None, keep_grads=True, exchange=None, direct_wire=None, sharded=None):
+        """Data-parallel knobs (the reference is single-GPU): grad_comm_dtype (SZN_GRAD_COMM = fp32 | bf16) = the
+        wire format of the gradient buckets; exchange=False (SZN_GRAD_COMM=off) = no exchange at all (bench.py's comm-off timing);
+        direct_wire (default: on for a 16-bit wire with keep_grads=False; SZN_WIRE_DIRECT=0 turns it off) = the weight-gradient
+        kernels write the 16-bit wire image themselves and the optimizer kernel reads it (no staging copies; `.grad` of the
+        weights is then None); sharded (SZN_SHARDED_OPT=1) = reduce-scatter + rank-sharded optimizer + all-gather of the weight
+        image instead of all-reduce + replicated optimizer."""
         if loss not in ("cos", "mse") or (fused_head and loss != "cos"):
             raise L.SznError("TrainStep: fused head supports the cosine loss; use fused_head=False for mse")
         self.model = model
@@ -284,9 +408,16 @@ class TrainStep(object):
         self.adam_wd = adam_weight_decay
         self.bias_lr = 2 * lr if bias_lr is None else bias_lr
         self.bias_wd = bias_weight_decay
+        env_comm = os.environ.get("SZN_GRAD_COMM", "fp32")
         if grad_comm_dtype is None:
-            grad_comm_dtype = torch.bfloat16 if os.environ.get("SZN_GRAD_COMM", "fp32") == "bf16" else torch.float32
+            grad_comm_dtype = torch.bfloat16 if env_comm == "bf16" else torch.float32
         self.grad_comm_dtype = grad_comm_dtype
+        self.exchange = (env_comm != "off") if exchange is None else bool(exchange)
+        self.keep_grads = bool(keep_grads)
+        if direct_wire is None:
+            direct_wire = os.environ.get("SZN_WIRE_DIRECT", "1") == "1" and not self.keep_grads
+        self._want_direct = bool(direct_wire) and grad_comm_dtype != torch.float32
+        self._want_sharded = (os.environ.get("SZN_SHARDED_OPT", "0") == "1") if sharded is None else bool(sharded)
         self.fused_head, self.loss_kind = fused_head, loss
         # static loss scaling for the fp16 path: gradients below 6e-8 vanish in IEEE half, so d(loss)/d(coarse) is multiplied
         # by loss_scale in fp32 before it enters the 16-bit backward pass and the optimizer kernel divides it out again
@@ -326,7 +457,12 @@ class TrainStep(object):
             fused_adam = os.environ.get("SZN_FUSED_ADAM", "1") == "1"
         self.fused_adam = bool(fused_adam and optimizer == "adam" and not self.dynamic and not self.buckets.active
                                and self.flat_w_lp is not None and os.environ.get("SZN_EARLY_ADAM", "auto") != "1")
-        self.keep_grads = bool(keep_grads)
+        if self.fused_adam and not self.keep_grads:
+            # the fused layers' gradients are consumed inside their weight-gradient kernel and never stored: `.grad` must not
+            # look like a gradient (the reference keeps .grad valid until zero_grad(); keep_grads=True restores that)
+            for n in os.environ.get("SZN_FUSED_ADAM_LAYERS", "fc6").split(","):
+                if n in self.woff and n in ("fc6", "fc7"):
+                    getattr(model, n).weight.grad = None
         self.keep_ctx = False        # tests: keep the forward state of the last step (activations stay alive one step longer)
         self.last_ctx = None
 
@@ -437,8 +573,26 @@ class TrainStep(object):
 
     def _buckets(self, bucket_mb):
         layers = [(n,) + self.woff[n] for n in self.layers]
+        m = self.model
+        CP, E, F = m.head_width, m.n_class, m.fc7.out_channels
+        # direct 16-bit wire: bf16 compute path only (the kernels that write the image are the 16-bit weight-gradient kernels; the
+        # dynamic loss scale's overflow check reads fp32 gradients; the FCN8s skip layers copy theirs in from scratch buffers)
+        direct = self._want_direct and not self.dynamic and not self.is8 and self.eng.dtype != torch.float32
         self.buckets = GradBuckets(self.flat_gw, layers, bucket_mb * (1 << 20) // 4, extra=[self.flat_gb], group=self.pg,
-                                   comm_dtype=self.grad_comm_dtype, force=self.force_comm)
+                                   comm_dtype=self.grad_comm_dtype, force=self.force_comm, enabled=self.exchange, direct=direct,
+                                   sharded=self._want_sharded, tail=(CP - E) * F)
+        self._gather = []
+        if self.buckets.direct:
+            stage = self.buckets.stage
+            lp = {}
+            for n in self.layers[:-1]:
+                o, cnt = self.woff[n]
+                lp[n] = stage[o:o + cnt]
+                getattr(m, n).weight.grad = None         # never written on this path (the wire image is the gradient)
+            o, cnt = self.woff["score_fr"]
+            lp["head"] = stage[o:o + CP * F]
+            m.score_fr.weight.grad = None
+            self.grads["_lp"] = lp
 
     # ---- one training step -----------------------------------------------------------------------------
     def step(self, x, target):
@@ -488,9 +642,13 @@ class TrainStep(object):
             dcoarse = self._scale(dcoarse)
         self.stats = stats
         self._fused_begin()
-        self._backward(ctx, dcoarse, self._layer_done_hook(B * H * W))
-        self.buckets.finish()
-        self._optimizer_step()
+        try:
+            self.buckets.begin_step()
+            self._backward(ctx, dcoarse, self._layer_done_hook(B * H * W))
+            self.buckets.finish()
+            self._optimizer_step()
+        finally:                         # an error in between must not leave the engine armed with this step's Adam arguments
+            eng.fused_opt, eng.fused_done = None, set()
         if self.train_metrics:
             L.call("szn_confusion_hist_k", target.numel(), K, L.ptr(target), L.ptr(pred), None, L.ptr(self.hist), st)
         return self.loss.reshape(()), pred
@@ -579,11 +737,15 @@ class TrainStep(object):
         # the bias gradients of the skip layers live in the flat bias buffer the engine zeroes first: re-apply them after
         saved = [(self.boff[n], self.skip[n]["gb"]) for n in ("score_pool3", "score_pool4")]
         self._fused_begin()
-        eng.backward(ctx, dcoarse, self.grads, backbone=True, layer_done=done, head_first=head_first, skips=skips)
-        for (bo, bc), gb in saved:
-            self.flat_gb[bo:bo + bc].copy_(gb[:E])
-        self.buckets.finish()
-        self._optimizer_step()
+        try:
+            self.buckets.begin_step()
+            eng.backward(ctx, dcoarse, self.grads, backbone=True, layer_done=done, head_first=head_first, skips=skips)
+            for (bo, bc), gb in saved:
+                self.flat_gb[bo:bo + bc].copy_(gb[:E])
+            self.buckets.finish()
+            self._optimizer_step()
+        finally:
+            eng.fused_opt, eng.fused_done = None, set()
         if self.train_metrics:
             L.call("szn_confusion_hist_k", target.numel(), K, L.ptr(target), L.ptr(pred), None, L.ptr(self.hist), st)
         return self.loss.reshape(()), pred
@@ -659,6 +821,9 @@ class TrainStep(object):
         dyn = self.scale_state
         gs = 1.0 / self.world if self.dynamic else 1.0 / (self.world * self._loss_scale0)
         flat, grad = (self.flat_w, self.flat_gw) if key == "w" else (self.flat_b, self.flat_gb)
+        g16 = key == "w" and self.buckets.direct      # the summed 16-bit wire image IS the gradient (szn_*_step_g16)
+        if g16:
+            grad = self.buckets.stage
         lr, wd = (self.lr, self.wd) if key == "w" else (self.bias_lr, self.bias_wd)
         lp_on = key == "w" and self.flat_w_lp is not None
         lp_code = L.dtype_code(self.flat_w_lp.dtype) if self.flat_w_lp is not None else 0
@@ -667,7 +832,11 @@ class TrainStep(object):
         if self.opt == "adam":           # train.py:130-133 (Adam has no weight decay in the reference wiring)
             m1, m2 = self.state[key]
             awd = float(self.bias_wd if key == "b" else self.adam_wd)
-            if self.dynamic:
+            if g16:
+                L.call("szn_adam_step_g16", n, L.ptr(flat[lo:hi]), L.ptr(grad[lo:hi]), L.dtype_code(grad.dtype), L.ptr(m1[lo:hi]),
+                       L.ptr(m2[lo:hi]), float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), awd, nstep, gs, lp,
+                       lp_code, st)
+            elif self.dynamic:
                 L.call("szn_adam_step_scaled", n, L.ptr(flat[lo:hi]), L.ptr(grad[lo:hi]), L.ptr(m1[lo:hi]), L.ptr(m2[lo:hi]), float(lr),
                        float(self.betas[0]), float(self.betas[1]), float(self.eps), awd, L.ptr(dyn), gs, lp, lp_code, st)
             else:
@@ -675,7 +844,10 @@ class TrainStep(object):
                        float(self.betas[0]), float(self.betas[1]), float(self.eps), awd, nstep, gs, lp, lp_code, st)
         else:                            # train.py:126-129
             (buf,) = self.state[key]
-            if self.dynamic:
+            if g16:
+                L.call("szn_sgd_momentum_step_g16", n, L.ptr(flat[lo:hi]), L.ptr(grad[lo:hi]), L.dtype_code(grad.dtype), L.ptr(buf[lo:hi]),
+                       float(lr), float(self.momentum), float(wd), int(nstep == 1), gs, lp, lp_code, st)
+            elif self.dynamic:
                 L.call("szn_sgd_momentum_step_scaled", n, L.ptr(flat[lo:hi]), L.ptr(grad[lo:hi]), L.ptr(buf[lo:hi]), float(lr),
                        float(self.momentum), float(wd), L.ptr(dyn), gs, lp, lp_code, st)
             else:
@@ -694,14 +866,29 @@ class TrainStep(object):
             torch.cuda.current_stream().wait_stream(self._side)
             whi = self.woff["fc6"][0]
             self._early = False
-        # the weight ranges not already updated inside their weight-gradient kernels (_fused_begin)
-        lo = 0
-        for n in sorted(self.eng.fused_done, key=lambda n: self.woff[n][0]):
-            o, cnt = self.woff[n]
-            if o < whi:
-                self._opt_launch("w", lo, min(o, whi), self.nstep)
-                lo = o + cnt
-        self._opt_launch("w", lo, whi, self.nstep)
+        if self.buckets.sharded:
+            # reduce-scattered buckets: this rank holds the sum of one slice per bucket and updates only that (1/world of the pass);
+            # the updated slices of the weight image are all-gathered (16-bit on the 16-bit paths; the fp32 masters of the other
+            # ranks' slices go stale here -- gather_masters() before anything reads them: checkpoints)
+            for o, e, _ in self.buckets.buckets:
+                lo, hi = self.buckets.shard(o, e)
+                self._opt_launch("w", lo, hi, self.nstep)
+            image = self.flat_w_lp if self.flat_w_lp is not None else self.flat_w
+            works = self.buckets.gather_weights(image)
+            if self.flat_w_lp is not None:       # conv1_1's kernel reads the fp32 master (3 input channels: no 16-bit image): its bucket's too
+                works += self.buckets.gather_weights(self.flat_w, first_only=True)
+            for wk in works:
+                wk.wait()                # (the compute stream waits, not the host)
+            self._masters_stale = self.flat_w_lp is not None and self.buckets.world > 1
+        else:
+            # the weight ranges not already updated inside their weight-gradient kernels (_fused_begin)
+            lo = 0
+            for n in sorted(self.eng.fused_done, key=lambda n: self.woff[n][0]):
+                o, cnt = self.woff[n]
+                if o < whi:
+                    self._opt_launch("w", lo, min(o, whi), self.nstep)
+                    lo = o + cnt
+            self._opt_launch("w", lo, whi, self.nstep)
         self.eng.fused_opt = None
         self.eng.fused_done = set()
         self._opt_launch("b", 0, self.flat_b.numel(), self.nstep)
@@ -709,6 +896,17 @@ class TrainStep(object):
             g, b, iv, lo, hi = self.scale_cfg
             L.call("szn_loss_scale_update", L.ptr(dyn), g, b, iv, lo, hi, st)
         self.eng.mark_dirty()
+
+    def gather_masters(self):
+        """sharded optimizer on a 16-bit path: bring the fp32 masters and moments of the other ranks' slices up to date on this rank
+        (all-gather over the bucket slices).  Call before reading model parameters / optimizer state: checkpoints, export."""
+        if not getattr(self, "_masters_stale", False):
+            return
+        ts = [self.flat_w] + list(self.state["w"])
+        for t in ts:
+            for wk in self.buckets.gather_weights(t):
+                wk.wait()
+        self._masters_stale = False
 
     # ---- checkpoint compatibility (reference dict keys: trainer_fcn.py:281-288) ------------------------------
     def _param_slots(self):
@@ -725,6 +923,7 @@ class TrainStep(object):
     def export_optimizer_state(self, optim):
         """expose the flat moments as per-parameter state of a torch-style optimizer object (views, no copies), so that
         `optim.state_dict()` written into a checkpoint has the layout torch.optim.Adam / SGD would have produced"""
+        self.gather_masters()
         for p, key, view in self._param_slots():
             st = optim.state[p]
             if self.opt == "adam":

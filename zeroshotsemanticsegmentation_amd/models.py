@@ -549,15 +549,18 @@ class _Engine(object):
             d.cb_const[0], d.cb_const[1], d.cb_const[2], d.cb_const[3] = ry[2], ry[3], rx[2], rx[3]
         return d
 
-    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None, fuse=None, cb=None, csum=None):
+    def _wgrad(self, x, dout, dw, db, ci, co, k, pad, ldo=None, after=None, fuse=None, cb=None, csum=None, dw_lp=None):
         """dw (OHWI f32) = wgrad of one layer, on the wgrad stream; `after` (e.g. the DDP bucket hook) runs there too.  fuse: layer
         name under which self.fused_opt may hold the Adam step to apply in the kernel's epilogue.  cb / csum: constant-border regions
-        of x and, optionally, the column sums of dout over the tiles the hint skips (from the producer of dout)."""
+        of x and, optionally, the column sums of dout over the tiles the hint skips (from the producer of dout).  dw_lp: deliver the
+        gradient as a 16-bit image there instead (the wire buffer of the data-parallel exchange; dw is then scratch)."""
         B, Hi, Wi, _ = x.shape
         Ho, Wo = dout.shape[1:3]
         code = L.dtype_code(self.dtype)
         d = self._wgrad_desc(x, dout.shape, ci, co, k, pad, ldo=ldo, cb=cb)
         ldo = d.ldo
+        if dw_lp is not None:
+            d.dw_lp, d.dw_lp_dtype = dw_lp.data_ptr(), L.dtype_code(dw_lp.dtype)
         if csum is not None and d.cb_on:
             d.colsum = csum.data_ptr()
         with self._wgrad_stream(*([x, dout] + ([csum] if csum is not None else []))):
@@ -660,14 +663,17 @@ class _Engine(object):
         if flat_bias is not None and backbone:       # one fill, BEFORE the head hook copies score_fr's gradient into it
             flat_bias.zero_()
         fp8b = self.head_fp8_bwd and self.head_fp8
+        lp = grads.get("_lp") or {}                  # TrainStep, direct 16-bit wire: {layer: slice of the staging buffer}
         if "head" in grads:
             dwh, dbh = grads["head"]
             if fp8b:
                 self._head_wgrad_fp8(feat, dc, dwh, dbh)
+                if "head" in lp:
+                    L.call("szn_cast", L.SZN_F32, L.dtype_code(lp["head"].dtype), dwh.numel(), L.ptr(dwh), L.ptr(lp["head"]), st)
                 if head_first is not None:
                     head_first()
             else:
-                self._wgrad(feat, dc, dwh, dbh, F, m.head_width, 1, 0, after=head_first)
+                self._wgrad(feat, dc, dwh, dbh, F, m.head_width, 1, 0, after=head_first, dw_lp=lp.get("head"))
         if not backbone:
             self._join_wgrad()
             return
@@ -678,14 +684,14 @@ class _Engine(object):
         # of the next layer or the pool backward), so they start from zero here
         if flat_bias is None:
             for name in grads:
-                if name != "head":
+                if name != "head" and not name.startswith("_"):
                     grads[name][1].zero_()
         # d(fc7 pre-activation): ReLU gate (feat > 0) and dropout factor fused into the dgrad epilogue
         if fp8b:
             d = self._head_dgrad_fp8(dc, feat, s7, grads["fc7"][1])
         else:
             d = self._dgrad(dc, "head", feat.shape, 0, gate=feat, scale=s7, colsum=grads["fc7"][1])
-        self._wgrad(ctx.relu6, d, grads["fc7"][0], None, F, F, 1, 0, after=lambda: done("fc7"), fuse="fc7")
+        self._wgrad(ctx.relu6, d, grads["fc7"][0], None, F, F, 1, 0, after=lambda: done("fc7"), fuse="fc7", dw_lp=lp.get("fc7"))
         d = self._dgrad(d, "fc7", ctx.relu6.shape, 0, gate=ctx.relu6, scale=s6, colsum=grads["fc6"][1])
         pool5 = ctx.pools[4][1]
         if self.fused_opt and "fc6" in self.fused_opt:
@@ -694,7 +700,7 @@ class _Engine(object):
             d = self._dgrad(d6, "fc6", pool5.shape, 0)
             self._wgrad(pool5, d6, grads["fc6"][0], None, pool5.shape[3], F, 7, 0, after=lambda: done("fc6"), fuse="fc6")
         else:
-            self._wgrad(pool5, d, grads["fc6"][0], None, pool5.shape[3], F, 7, 0, after=lambda: done("fc6"))
+            self._wgrad(pool5, d, grads["fc6"][0], None, pool5.shape[3], F, 7, 0, after=lambda: done("fc6"), dw_lp=lp.get("fc6"))
             d = self._dgrad(d, "fc6", pool5.shape, 0)
         pi = 4
         prev_out = None
@@ -762,6 +768,8 @@ class _Engine(object):
                 with self._wgrad_stream(d, ws):
                     L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), None, 0,
                            L.ptr(ws), L.stream_ptr())          # db came from conv1_2's dgrad (colsum)
+                    if name in lp:                             # 1,728 elements: converted, not produced, as 16-bit
+                        L.call("szn_cast", L.SZN_F32, L.dtype_code(lp[name].dtype), dw.numel(), L.ptr(dw), L.ptr(lp[name]), L.stream_ptr())
                     done(name)
                 break
             prev = items[idx - 1]
@@ -769,7 +777,7 @@ class _Engine(object):
             layer = getattr(m, name)
             self._wgrad(xin, d, grads[name][0], None, layer.in_channels, layer.out_channels, 3, pad,
                         after=lambda name=name: done(name), cb=(getattr(ctx, "cb_in", None) or {}).get(name),
-                        csum=cb_sums.pop(name, None))
+                        csum=cb_sums.pop(name, None), dw_lp=lp.get(name))
             # next d: wrt this conv's input; gate by the ReLU of the producing conv unless a pool sits in between
             if prev == "P":
                 d = self._dgrad(d, name, xin.shape, pad)

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 import yaml
 
+from . import engine as _engine
 from . import models, trainer_fcn, trainer_seenmask
 from .configs import configurations
 from .optim import FusedAdam, FusedSGD
@@ -197,7 +198,7 @@ def main(argv=None):
         if one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=device)
+            _engine.init_process_group("nccl", device)      # RCCL on a high-priority stream (engine.init_process_group)
     torch.manual_seed(1337)
     torch.cuda.manual_seed(1337)
 

@@ -189,7 +189,10 @@ class Trainer(object):
             return None
         self._step = _engine.TrainStep(self.model, self.embeddings, lr=gw['lr'], bias_lr=gb['lr'],
                                        bias_weight_decay=gb.get('weight_decay', 0.0), precision=self.precision,
-                                       fused_head=True, keep_grads=False, **kw)      # (zero_grad() comes next: train.py:170-175)
+                                       fused_head=True, keep_grads=os.environ.get("SZN_KEEP_GRADS", "0") == "1", **kw)
+        # keep_grads=False (default; SZN_KEEP_GRADS=1 restores the reference's "`.grad` valid until zero_grad()"): the loop
+        # calls zero_grad() next (train.py:170-175) and nothing reads the weight gradients in between, so the layers whose Adam
+        # step rides in their weight-gradient kernel do not store theirs -- those `.grad`s are None, not stale
         self._step.import_optimizer_state(self.optim)       # resumed runs (train.py:135-136)
         return self._step
 
@@ -333,6 +336,8 @@ class Trainer(object):
         is_best = mean_iu > self.best_mean_iu
         if is_best:
             self.best_mean_iu = mean_iu
+        if self._step is not None:
+            self._step.gather_masters()          # sharded optimizer: a collective -- every rank, before rank 0 reads the parameters
         if self.rank == 0:
             if self._step is not None:
                 self._step.export_optimizer_state(self.optim)   # flat moments -> per-parameter torch optimizer state
