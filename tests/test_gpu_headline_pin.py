@@ -1,0 +1,122 @@
+"""The headline configuration of bench.py, pinned: bf16 operands, B = 8, 512 x 512, E = 300, K = 59 (49 seen),
+train mode, fused-from-coarse head, every shortcut of the throughput path on (constant-border hints of the forward / weight-gradient /
+dgrad kernels, cin-chunk-major K order of conv_igemm_8ph, pool-backward tile sums, fc6's Adam in its weight-gradient epilogue).
+
+Reference = the SAME step in fp32 through the HIP path, which tests/test_gpu_parity_full.py pins element by element to the oracle
+(the restatement of trainer_fcn.py:149-180 / models.py:114-160 / utils.py:75-102,159-185).  For every optimizer-visible tensor the
+relative L2 error and the cosine of the bf16 gradient are bounded (bounds = 1.5 x what was measured on MI355X, written below with
+the reason they grow towards the input), the loss agrees to 2e-2 and the class map to >= 0.99.  A second bf16 run in a child process with the hints off (SZN_CONST_BORDER=0 SZN_WGT_CB=0
+SZN_DGRAD_BORDER=0: environment variables are read once per process) shows that the hints move nothing beyond fp32 re-ordering."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+E, K, H, B = 300, 59, 512, 8
+
+
+def run_step(precision):
+    """one bench-configuration step -> (loss, pred (B,H,W) int64 cpu, {tensor name: gradient as float32 cpu tensor}, kernels seen)"""
+    from zeroshotsemanticsegmentation_amd import _lib as L
+    from zeroshotsemanticsegmentation_amd import engine, models, synth
+    dev = torch.device("cuda", 0)
+    emb = synth.make_embeddings(K, E)
+    m = models.FCN32s(E)
+    m.load_synthetic(1337, device=dev)
+    m.train()                                       # Dropout2d on: masks come from the engine's counter RNG, equal in every run
+    ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=precision, fused_head=True, keep_grads=True)
+    x = torch.from_numpy(synth.make_images(B, H, H, seed=1337)).to(dev)
+    t = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337, classes=list(range(49)))).to(dev)
+    kernels = set()
+    orig = L.call
+
+    def spy(name, *a):
+        orig(name, *a)
+        kernels.add(L.last_kernel())
+    engine.L.call = models.L.call = spy
+    try:
+        loss, pred = ts.step(x, t)
+    finally:
+        engine.L.call = models.L.call = orig
+    torch.cuda.synchronize()
+    grads = {}
+    for n in ts.layers:
+        o, cnt = ts.woff[n]
+        grads[n + ".weight"] = ts.flat_gw[o:o + cnt].float().cpu()
+        bo, bc = ts.boff[n]
+        grads[n + ".bias"] = ts.flat_gb[bo:bo + bc].float().cpu()
+    return float(loss), pred.cpu(), grads, kernels
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+# Relative L2 error of the bf16 gradient against the fp32 HIP step, per layer (weights and biases behave alike), as MEASURED on MI355X
+# in round 5 (the test prints the table), and the bound asserted = ~1.5 x that.  The error is small where the backward pass starts
+# (score_fr 3e-3, fc7 1.3e-2, fc6 2e-2) and grows towards the input (conv4_x 5-7e-2, conv3_x 8-12e-2, conv2_x 15-17e-2, conv1_2 0.27,
+# conv1_1 0.39).  That growth is not rounding noise adding up -- fp32 accumulation keeps each layer's own arithmetic at 2-3e-3
+# (tests/test_gpu_fullsize.py: every layer against torch fp32 on the same operands) -- it is the forward state: bf16 activations
+# differ from fp32 ones by ~4e-3, so ~0.3 % of the 10^8 ReLU gates / pooling winners per layer fall on the other side, each flip
+# moves whole gradient elements (relative L2 ~ sqrt(flip fraction) per layer), and the flips of all layers behind a tensor add up.
+# DESIGN.md section 2 ("Full-size gradients") measures the same mechanism between two CORRECT fp32 passes (forward difference 4e-6 ->
+# weight gradients differ by up to 7e-3 at 512 x 512); a forward difference 1000 x larger gives sqrt(1000) ~ 30 x that.  Synthetic
+# kaiming-uniform weights make it worse than a trained VGG would (dense, sign-symmetric pre-activations).  What the test pins is
+# therefore: (1) the error of every tensor stays inside the measured envelope, (2) the gradient DIRECTION is kept (cosine >= 0.9
+# everywhere, >= 0.995 from conv4_1 on), (3) loss and class map agree, (4) the shortcuts of the throughput path are NOT a source of
+# error: the same step without the hints agrees to fp32 re-ordering (<= 5e-5), three to four orders below the envelope.
+MEASURED = {"score_fr": 3.2e-3, "fc7": 1.35e-2, "fc6": 1.97e-2, "conv5_3": 2.43e-2, "conv5_2": 3.13e-2, "conv5_1": 4.16e-2,
+            "conv4_3": 4.88e-2, "conv4_2": 5.94e-2, "conv4_1": 6.76e-2, "conv3_3": 7.87e-2, "conv3_2": 9.41e-2, "conv3_1": 0.1245,
+            "conv2_2": 0.1474, "conv2_1": 0.1731, "conv1_2": 0.269, "conv1_1": 0.3875}
+BOUND = {k: 1.5 * v for k, v in MEASURED.items()}
+COS_MIN = {k: (0.995 if v < 7e-2 else 0.9) for k, v in MEASURED.items()}
+
+
+def cosine(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def test_headline_bf16_step_gradients_track_the_fp32_step(fast_tmp):
+    loss32, pred32, g32, k32 = run_step(torch.float32)
+    loss16, pred16, g16, k16 = run_step(torch.bfloat16)
+    # the kernels of the throughput path really ran (a silent fall-back to the generic kernels would pass the bounds too)
+    for k in ("conv_igemm_8ph", "conv3x3_regw", "wgrad_taps_reduce", "conv_wgrad_wide_adam", "maxpool_bwd_code_kernel"):
+        assert any(k in name for name in k16), (k, sorted(k16))
+    assert abs(loss16 - loss32) < 2e-2 * abs(loss32), (loss16, loss32)
+    agree = float((pred16 == pred32).float().mean())
+    assert agree >= 0.99, agree
+    rows = []
+    for name in g32:
+        layer, kind = name.rsplit(".", 1)
+        rows.append((name, rel_l2(g16[name], g32[name]), BOUND[layer], cosine(g16[name], g32[name]), COS_MIN[layer]))
+    print("\n".join("%-22s rel L2 %.3e  (bound %.2e)  cosine %.5f (>= %.3f)" % r for r in rows))
+    print("loss fp32 %.6f bf16 %.6f, class-map agreement %.5f" % (loss32, loss16, agree))
+    bad = [r for r in rows if not (r[1] <= r[2] and r[3] >= r[4])]
+    assert not bad, bad
+    # ---- the same bf16 step without the constant-border hints, in a child process
+    out = os.path.join(fast_tmp, "nohint.pt")
+    env = dict(os.environ, SZN_CONST_BORDER="0", SZN_WGT_CB="0", SZN_DGRAD_BORDER="0")
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), out], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = torch.load(out)
+    assert d["loss"] == loss16                                 # forward: the hint broadcasts the very value the dense tiles compute
+    assert torch.equal(d["pred"], pred16)
+    assert not any("border" in k for k in d["kernels"]) and any("border" in k or "cb" in k for k in k16)
+    worst = max((rel_l2(g16[name], d["grads"][name]), name) for name in g32)
+    print("hints on vs off: worst relative L2 %.3e (%s)" % worst)
+    # rank-one terms / region sums replace dense fp32 sums in another order: 1e-5 class, three orders below the bf16 error above
+    assert worst[0] < 5e-5, worst
+
+
+if __name__ == "__main__":          # child of the test above: the bf16 step under the caller's environment -> torch.save
+    loss, pred, grads, kernels = run_step(torch.bfloat16)
+    torch.save({"loss": loss, "pred": pred, "grads": grads, "kernels": sorted(kernels)}, sys.argv[1])
