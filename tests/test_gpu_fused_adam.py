@@ -33,9 +33,13 @@ def _operands(dt, B, Hi, Ci, Co, k, seed):
 
 
 @pytest.mark.parametrize("case", [(torch.bfloat16, 2, 9, 512, 4096, 7, 3), (torch.float16, 1, 8, 512, 4096, 7, 1),
-                                  (torch.bfloat16, 3, 5, 4096, 4096, 1, 2), (torch.bfloat16, 1, 7, 640, 4096, 7, 5)])
+                                  (torch.bfloat16, 3, 5, 4096, 4096, 1, 2), (torch.bfloat16, 1, 7, 640, 4096, 7, 5),
+                                  (torch.bfloat16, 8, 23, 512, 4096, 7, 2), (torch.bfloat16, 2, 9, 512, 4032, 7, 4)])
 @pytest.mark.parametrize("keep", [True, False])
-def test_wgrad_adam_equals_wgrad_then_adam(case, keep):
+@pytest.mark.parametrize("half", ["1", "0"])
+def test_wgrad_adam_equals_wgrad_then_adam(case, keep, half, monkeypatch):
+    # half = "1": conv_wgrad_half (round 5: 128 x 256 tiles, two four-wave blocks per CU), "0": conv_wgrad_wide<T, true> (round 4)
+    monkeypatch.setenv("SZN_WGW_HALF", half)
     dt, B, Hi, Ci, Co, k, step = case
     code = L.dtype_code(dt)
     x, dout, p0, m10, m20 = _operands(dt, B, Hi, Ci, Co, k, seed=11 + step)
@@ -61,7 +65,7 @@ def test_wgrad_adam_equals_wgrad_then_adam(case, keep):
     a.param, a.exp_avg, a.exp_avg_sq, a.w_lp, a.w_lp_dtype = pf.data_ptr(), m1f.data_ptr(), m2f.data_ptr(), lpf.data_ptr(), code
     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.step, a.grad_scale = hyp["lr"], hyp["b1"], hyp["b2"], hyp["eps"], hyp["wd"], step, hyp["gs"]
     L.call("szn_conv2d_wgrad_adam", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dwf) if keep else None, C.byref(a), st)
-    assert L.last_kernel() == "conv_wgrad_wide_adam"
+    assert L.last_kernel() == ("conv_wgrad_half_adam" if half == "1" else "conv_wgrad_wide_adam")
     torch.cuda.synchronize()
     assert float((p - p0).abs().max()) > 0
     assert torch.equal(pf, p) and torch.equal(m1f, m1) and torch.equal(m2f, m2) and torch.equal(lpf, lp)

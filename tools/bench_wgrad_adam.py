@@ -31,7 +31,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     args = ap.parse_args()
     L.load()
-    out = {"stagger_env": os.environ.get("SZN_WGW_STAGGER"), "batch": args.batch, "layers": {}}
+    out = {"stagger_env": os.environ.get("SZN_WGW_STAGGER"), "half": os.environ.get("SZN_WGW_HALF"), "half_stagger": os.environ.get("SZN_WGH_STAGGER"),
+           "batch": args.batch, "layers": {}}
     for name, Hi, Ci, Co, k in (("fc6", 23, 512, 4096, 7), ("fc7", 17, 4096, 4096, 1)):
         B, dt = args.batch, torch.bfloat16
         Ho = Hi - k + 1

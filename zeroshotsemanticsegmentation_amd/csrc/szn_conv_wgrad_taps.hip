@@ -37,6 +37,7 @@ struct WtArgs {
     int accumulate;
     int xcd_mode;              // block -> (split, combo) mapping, see the kernel
     int ablate;                // debug (env SZN_WGT_ABLATE, wrong results): 1 = no LDS-DMA in the loop, 2 = no reads / MFMA
+    int fill_mode;             // who issues the fill of the next tile when: 0 = wave pair p at K step p (p < 4), 1 = wave group g (waves 4 g .. 4 g + 3) at K step g
     // constant-border hint (szn_conv_desc_t.cb_on for szn_conv2d_wgrad): the tiles whose whole 18 x 18 input patch holds ONE value per
     // channel are not run (cb numbers the others; ntiles = B * cb.per_image).  Their share of dW is a rank-one term, the same for
     // all nine taps:  dW[co][tap][ci] += (sum of dout[px][co] over their pixels) * x_const[ci]  -- csum [Co] comes from
@@ -163,101 +164,132 @@ __global__ __launch_bounds__(512) void conv_wgrad_taps(WtArgs a) {
     const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of the dynamic segment
     int stage = 0;
     long long tw = 0, ti = 0, tc = 0, c0 = 0, c1 = 0, c2 = 0;   // SZN_WGT_ABLATE=9: cycles in wait+barrier / issue / compute
-    for (int t = first; t < last; ++t) {
-        if (a.ablate == 9) c0 = clock64();
+    // Fragment addresses = per-lane base + compile-time offset (the ds_read offset field), and reads issued ONE K step ahead.
+    // A patch read of row R at column shift kw touches flattened patch pixel q = s + kk with s = 18 R + kw known at compile
+    // time; its row swizzle ((q >> 1) & 3) is ((kk + (s & 1)) >> 1) + (s >> 1) mod 4, so eight per-lane bases Xb[s & 1][(s >> 1) & 3]
+    // cover every (R, kw) and the address costs no VALU work (the compiler had hoisted ~60 per-site offsets into VGPRs and
+    // then had no registers left to move the reads away from their MFMAs: each MFMA group waited out the LDS latency of reads
+    // issued a few instructions earlier -- the compute phase took 6,800 cycles per tile for 4,600 cycles of MFMA).
+    // The transpose reads are issued as inline asm: behind a `buffer_load ... lds` the compiler puts s_waitcnt vmcnt(0) in front
+    // of the next LDS read it knows about (the DMA might alias it), so the wave that had just issued the fill of tile t + 1
+    // sat out the whole HBM latency of that fill in the middle of its MFMAs -- once per tile, every wave.  The fill goes to the
+    // OTHER stage; the waits are explicit: lgkmcnt(0) behind the 18 MFMAs of a K step for the reads issued in front of them
+    // (tied to their destination registers), vmcnt(0) + barrier once per tile.
+    auto rd_tr = [&](int addr, int off) -> u32x2_t {
+        u32x2_t v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+        return v;
+    };
+    // B operand of tap (kh, kw) in K step p = patch rows 2p + kh (K half 0) and 2p + kh + 1 (K half 1) at column shift kw: one
+    // 4-register group U(r, kw) = {row r, row r + 1} with r = 2p + kh.  Step p multiplies U(2p), U(2p + 1), U(2p + 2); step p + 1
+    // needs U(2p + 2) again (tap kh = 2 of one step IS tap kh = 0 of the next) plus two new groups.  Round 5: every group is
+    // read from LDS straight into its own register quadruple (two ds_read_b64_tr_b16 each, 12 + 4 reads per step instead of
+    // 6 + 4) -- until round 4 a patch row was read once and the nine groups of a step were assembled from row PAIRS with ~12
+    // v_mov per step, each in front of the MFMA that consumed it (VALU write -> MFMA read hazard on the critical path of an
+    // in-order wave; compute-only form of the loop, SZN_WGT_ABLATE=1: 0.56 of the matrix peak).  LDS traffic 1.6 x, ~100 B/clk.
+    u32x4_t U[3][3];
+    u32x4_t Af[2][2];
+    // Round 5: the K steps run on ACROSS tile boundaries.  Until round 4 a tile began with vmcnt(0) + barrier, then all eight
+    // waves issued the fragment reads of K step 0 and waited for them with the matrix pipes idle.  Now the barrier of tile t sits
+    // between its K steps 6 and 7: by then every wave holds the fragments of step 7 in registers (reads run one step ahead), so
+    // nobody reads stage t any more, and the fill of tile t + 1 -- issued during steps 0 .. 3 -- has had three steps to land.
+    // Behind it step 7 issues the reads of tile t + 1's step 0 (from the other stage) in front of its own 18 MFMAs, exactly like
+    // steps 0 .. 6 do for their successor.  The fill of tile t + 2 goes into stage t during tile t + 1: behind this barrier too.
+    auto rdU = [&](int base, int r, int kw) -> u32x4_t {      // base = LDS address of the stage's patch image (without the per-lane part)
+        const int s0 = r * PWt + kw, s1 = (r + 1) * PWt + kw;
+        const u32x2_t lo = rd_tr(base + Xb[s0 & 1][(s0 >> 1) & 3], s0 * 128), hi = rd_tr(base + Xb[s1 & 1][(s1 >> 1) & 3], s1 * 128);
+        return u32x4_t{lo.x, lo.y, hi.x, hi.y};
+    };
+    auto rdA0 = [&](int base, int i) -> u32x4_t {
+        const u32x2_t l2 = rd_tr(base + offA[i], 0), h2 = rd_tr(base + offA[i], 2048);
+        return u32x4_t{l2.x, l2.y, h2.x, h2.y};
+    };
+    if (first < last) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (a.ablate == 9) { c1 = clock64(); tw += c1 - c0; }
-        const bool fill = t + 1 < last && a.ablate != 1;
-        if (a.ablate == 9) { c2 = clock64(); ti += c2 - c1; }
-        // Fragment addresses = per-lane base + compile-time offset (the ds_read offset field), and reads issued ONE K step ahead.
-        // A patch read of row R at column shift kw touches flattened patch pixel q = s + kk with s = 18 R + kw known at compile
-        // time; its row swizzle ((q >> 1) & 3) is ((kk + (s & 1)) >> 1) + (s >> 1) mod 4, so eight per-lane bases Xb[s & 1][(s >> 1) & 3]
-        // cover every (R, kw) and the address costs no VALU work (the compiler had hoisted ~60 per-site offsets into VGPRs and
-        // then had no registers left to move the reads away from their MFMAs: each MFMA group waited out the LDS latency of reads
-        // issued a few instructions earlier -- the compute phase took 6,800 cycles per tile for 4,600 cycles of MFMA).
-        const int sdo = stage * STAGEt;
-        int Xt[2][4], At[2];
 #pragma unroll
-        for (int par = 0; par < 2; ++par)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) Xt[par][m] = Xb[par][m] + sdo + DOUTB;
-        At[0] = offA[0] + sdo; At[1] = offA[1] + sdo;
-        // The transpose reads are issued as inline asm: behind a `buffer_load ... lds` the compiler puts s_waitcnt vmcnt(0) in front
-        // of the next LDS read it knows about (the DMA might alias it), so the wave that had just issued the fill of tile t + 1
-        // sat out the whole HBM latency of that fill in the middle of its MFMAs -- once per tile, every wave.  The fill goes to the
-        // OTHER stage; the waits are explicit: lgkmcnt(0) behind the 18 MFMAs of a K step for the reads issued in front of them
-        // (tied to their destination registers), vmcnt(0) + barrier at the top of a tile.
-        auto rd_tr = [&](int addr, int off) -> u32x2_t {
-            u32x2_t v;
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
-            return v;
-        };
-        auto rdA = [&](int p, int i) -> u32x4_t {
-            const u32x2_t l2 = rd_tr(smem_lds + At[i], p * 4096), h2 = rd_tr(smem_lds + At[i], p * 4096 + 2048);
-            return u32x4_t{l2.x, l2.y, h2.x, h2.y};
-        };
-        auto rdB = [&](int R, int kw) -> u32x2_t {          // patch row R (0..17), column shift kw, 16 pixels
-            const int sq = R * PWt + kw;
-            return rd_tr(smem_lds + Xt[sq & 1][(sq >> 1) & 3], sq * 128);
-        };
-        u32x2_t Br[6][3];
-        u32x4_t Af[2][2];
-#pragma unroll
-        for (int R = 0; R < 4; ++R)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) Br[R][kw] = rdB(R, kw);
-        Af[0][0] = rdA(0, 0); Af[0][1] = rdA(0, 1);
+            for (int kw = 0; kw < 3; ++kw) U[kh][kw] = rdU(smem_lds + DOUTB, kh, kw);
+        Af[0][0] = rdA0(smem_lds, 0); Af[0][1] = rdA0(smem_lds, 1);
         // the waits name the registers the reads are landing in ("+v"): nothing -- not even a register copy -- may touch them earlier
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(Br[0][0]), "+v"(Br[0][1]), "+v"(Br[0][2]), "+v"(Br[1][0]), "+v"(Br[1][1]), "+v"(Br[1][2]),
-                       "+v"(Br[2][0]), "+v"(Br[2][1]), "+v"(Br[2][2]), "+v"(Br[3][0]), "+v"(Br[3][1]), "+v"(Br[3][2]),
-                       "+v"(Af[0][0]), "+v"(Af[0][1]));
+                     : "+v"(U[0][0]), "+v"(U[0][1]), "+v"(U[0][2]), "+v"(U[1][0]), "+v"(U[1][1]), "+v"(U[1][2]),
+                       "+v"(U[2][0]), "+v"(U[2][1]), "+v"(U[2][2]), "+v"(Af[0][0]), "+v"(Af[0][1]));
+    }
+    for (int t = first; t < last; ++t) {
+        if (a.ablate == 9) c0 = clock64();
+        const bool fill = t + 1 < last && a.ablate != 1;
+        const int sdo = smem_lds + stage * STAGEt, sdn = smem_lds + (stage ^ 1) * STAGEt;
         if (a.ablate != 2)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             // The fill of tile t + 1 is issued by wave pair p at K step p (p < 4): ten 1-KiB LDS-DMA loads stall their wave
-            // at VMEM issue for ~1800 cycles (SZN_WGT_ABLATE=9), so the waves take turns and the other waves of the
+            // at VMEM issue for a few hundred cycles (SZN_WGT_ABLATE=9), so the waves take turns and the other waves of the
             // CU -- in particular the SIMD partner w +- 4 -- keep the MFMA pipe busy meanwhile.
-            if (p < 4 && fill && (w >> 1) == p) {
+            if (p < 4 && fill && (a.fill_mode ? (p < 2 && (w >> 2) == p) : (w >> 1) == p)) {
                 prepare(t + 1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) fireA(q, stage ^ 1);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) fireB(q, stage ^ 1);
             }
-            // fetch rows 2p + 4, 2p + 5 and the dout fragments of the NEXT step while this step's 18 MFMAs run
+            // the groups and dout fragments of the NEXT step, fetched while this step's 18 MFMAs run
+            u32x4_t N[3][3], An[2];
+            const bool nxt = p < 7 || fill;
             if (p < 7) {
 #pragma unroll
-                for (int R = 4; R < 6; ++R)
+                for (int kh = 1; kh < 3; ++kh)
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) Br[R][kw] = rdB(2 * p + R, kw);
-                Af[(p + 1) & 1][0] = rdA(p + 1, 0); Af[(p + 1) & 1][1] = rdA(p + 1, 1);
+                    for (int kw = 0; kw < 3; ++kw) N[kh][kw] = rdU(sdo + DOUTB, 2 * (p + 1) + kh, kw);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const u32x2_t l2 = rd_tr(sdo + offA[i], (p + 1) * 4096), h2 = rd_tr(sdo + offA[i], (p + 1) * 4096 + 2048);
+                    An[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+                }
+            } else if (fill) {
+                // every wave's share of tile t + 1 has landed and nobody reads this stage any more (see above)
+                if (a.ablate == 9) c1 = clock64();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (a.ablate == 9) tw += clock64() - c1;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) N[kh][kw] = rdU(sdn + DOUTB, kh, kw);
+                An[0] = rdA0(sdn, 0); An[1] = rdA0(sdn, 1);
             }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const u32x4_t xf = u32x4_t{Br[kh][kw].x, Br[kh][kw].y, Br[kh + 1][kw].x, Br[kh + 1][kw].y};
+                for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        acc[i][kh * 3 + kw] = mfma16<T>(Af[p & 1][i], xf, acc[i][kh * 3 + kw]);
-                }
+                        acc[i][kh * 3 + kw] = mfma16<T>(Af[p & 1][i], U[kh][kw], acc[i][kh * 3 + kw]);
             if (p < 7) {
                 // behind this step's MFMAs (acc[1][8] is the last one's result): the reads issued in front of them have landed
                 asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(Br[4][0]), "+v"(Br[4][1]), "+v"(Br[4][2]), "+v"(Br[5][0]), "+v"(Br[5][1]), "+v"(Br[5][2]),
-                               "+v"(Af[(p + 1) & 1][0]), "+v"(Af[(p + 1) & 1][1]), "+v"(acc[1][8]));
+                             : "+v"(N[1][0]), "+v"(N[1][1]), "+v"(N[1][2]), "+v"(N[2][0]), "+v"(N[2][1]), "+v"(N[2][2]),
+                               "+v"(An[0]), "+v"(An[1]), "+v"(acc[1][8]));
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) { U[0][kw] = U[2][kw]; U[1][kw] = N[1][kw]; U[2][kw] = N[2][kw]; }
+                Af[(p + 1) & 1][0] = An[0]; Af[(p + 1) & 1][1] = An[1];
+            } else if (fill) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(N[0][0]), "+v"(N[0][1]), "+v"(N[0][2]), "+v"(N[1][0]), "+v"(N[1][1]), "+v"(N[1][2]),
+                               "+v"(N[2][0]), "+v"(N[2][1]), "+v"(N[2][2]), "+v"(An[0]), "+v"(An[1]), "+v"(acc[1][8]));
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) U[kh][kw] = N[kh][kw];
+                Af[0][0] = An[0]; Af[0][1] = An[1];
             }
-#pragma unroll
-            for (int R = 0; R < 4; ++R)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) Br[R][kw] = Br[R + 2][kw];
+            (void)nxt;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (a.ablate == 9) tc += clock64() - c2;
+        if (a.ablate == 9) tc += clock64() - c0;
         stage ^= 1;
     }
+    (void)ti; (void)c2;
 
     // ---- partial -> slab [wave][fragment f = 9 i + tap][e][lane], 256 contiguous bytes per store instruction ----
     float* slab = a.ws + (size_t)slab_id * SLAB + (size_t)w * (18 * 256) + lane;
@@ -543,6 +575,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.pad = d->pad;
     a.ldi = d->ldi; a.ldd = d->ldo; a.accumulate = accumulate;
     { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGT_ABLATE"); } a.ablate = abl; }
+    { static int fm = -1; if (fm < 0) { const char* e = getenv("SZN_WGT_FILL"); fm = e ? atoi(e) : 0; } a.fill_mode = fm; }
     hipStream_t st = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {

@@ -75,8 +75,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
         // fabric once instead of once per cout tile: XCD x takes the contiguous range of tiles, cout tile fastest
         const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        cot = lid % a.cotiles; lid /= a.cotiles;
-        cit = lid % a.citiles; tap = lid / a.citiles;
+        if (a.xcd_order == 2) {           // tap fastest: the 32 CUs of an XCD share ONE (cout tile, cin tile) pair's operand slices
+            const int ntap = a.KH * a.KW;
+            tap = lid % ntap; lid /= ntap;
+            cot = lid % a.cotiles; cit = lid / a.cotiles;
+        } else {
+            cot = lid % a.cotiles; lid /= a.cotiles;
+            cit = lid % a.citiles; tap = lid / a.citiles;
+        }
     } else {
         cit = bid % a.citiles; bid /= a.citiles;
         cot = bid % a.cotiles; tap = bid / a.cotiles;
@@ -363,6 +369,274 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
 #endif
 }
 
+
+// ---- conv_wgrad_half<T>: the Adam form on 128 x 256 tiles, TWO blocks per CU (round 5) ---------------------------------------------
+// conv_wgrad_wide<T, true> runs one block per CU (160 KiB of LDS, 2 waves per SIMD x ~207 VGPRs): a CU alternates between a K loop
+// (matrix pipes busy, memory idle) and 1.7 MB of master / moment / image traffic per tile (memory busy, matrix pipes idle), and the
+// launch takes nearly the sum of the two (fc6 at B = 8: 447 us of K loops + ~350 us of update traffic = 792 us; the update alone
+// streams at 4.4 TB/s at B = 1).  Here a block is FOUR waves (one per SIMD) on a 128 cout x 256 cin tile -- each wave still owns
+// 128 x 64 outputs (8 x 4 accumulator fragments, the same per-wave body and the same summation order: bit-identical gradients) --
+// with a 3-stage ring of 24-KiB stages (72 KiB), so two blocks share a CU: while one streams its update the other multiplies.
+//   * A = dout rows [32 px][128 co] (256 B per pixel), B = shifted input rows [32 px][256 ci] (512 B); 16-B chunk index XOR
+//     (row & 7) << 1 on the DMA source side for both; six 1-KiB LDS-DMA pieces per wave and stage (2 A + 4 B);
+//   * four waves in lockstep: per K step { vmcnt: stage k landed; barrier; fire stage k + 2 into the buffer of step k - 1;
+//     24 transpose reads (inline asm); 32 MFMA };
+//   * pixel -> input-pixel-index table of the block's tap as uint16 behind the ring (M <= 3840, B Hi Wi < 65535), else computed;
+//   * epilogue: two 64-row passes, each in four batches of 4 x 16-B groups per thread with the next batch's master / moment loads
+//     in flight while the current one is updated (adam_elem, non-temporal policy as in <T, true>);
+//   * the blocks that fill the SECOND slot of every CU (blockIdx 256 .. 511) start half a K loop late, so that a CU's two
+//     blocks alternate between the two phases from the first tile on.
+constexpr int STAGEh = KPg * (256 + 512);            // 24 KiB
+constexpr int NSTh = 3;
+constexpr int LDS_WGH = NSTh * STAGEh;               // 72 KiB
+constexpr int kTabMaxH = 3840;                       // uint16 entries behind the ring: 72 KiB + 7.5 KiB < 80 KiB
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_half(WgwArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave -> cins 64 w .. + 63 (all 128 couts)
+    const int g = lane >> 4, r16 = lane & 15;
+
+    int bid = blockIdx.x;
+    int cit, cot, tap;
+    if (a.xcd_order == 2) {
+        const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int ntap = a.KH * a.KW;
+        tap = lid % ntap; lid /= ntap;
+        cot = lid % a.cotiles; cit = lid / a.cotiles;
+    } else {
+        cit = bid % a.citiles; bid /= a.citiles;
+        cot = bid % a.cotiles;
+        tap = bid / a.cotiles;
+    }
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int co0 = cot * 128, ci0 = cit * 256;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, (int)a.dout_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+
+    const int HW = a.Ho * a.Wo;
+    const float invHW = 1.0f / (float)HW, invW = 1.0f / (float)a.Wo;
+    auto divq = [](int m, int d, float inv) -> int {               // floor(m / d) for 0 <= m < 2^22
+        int q = (int)((float)m * inv);
+        q -= (q * d > m) ? 1 : 0;
+        q += ((q + 1) * d <= m) ? 1 : 0;
+        return q;
+    };
+    const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto tap_pixel = [&](int m) -> unsigned {                      // input pixel index under this block's tap, 0xFFFF = outside
+        const int b = divq(m, HW, invHW), r = m - b * HW;
+        const int oh = divq(r, a.Wo, invW), ow = r - oh * a.Wo;
+        const int ih = oh + kh - a.pad, iw = ow + kw - a.pad;
+        const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+        return ok ? (unsigned)((b * a.Hi + ih) * a.Wi + iw) : 0xFFFFu;
+    };
+    if (a.use_tab) {
+        uint16_t* tab = (uint16_t*)(smem + LDS_WGH);
+        for (int m = tid; m < a.M; m += 256) tab[m] = (uint16_t)tap_pixel(m);
+        __syncthreads();
+    }
+    // DMA slots.  A piece i (0..1) of wave w = stage rows 8 w + 4 i + (lane >> 4), 16 slots of 16 B; B piece i (0..3) = rows
+    // 8 w + 2 i + (lane >> 5), 32 slots.  (row & 7) = 4 i + (lane >> 4) resp. 2 i + (lane >> 5).
+    unsigned vA[2], vB[4], vAn[2], tb[4];
+    int mA[2], mB[4];
+    int kbase = 0;                                                  // first pixel of the step being prepared
+    const unsigned pxb = (unsigned)(a.ldi * 2);
+    auto prepare_issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = 4 * i + (lane >> 4);
+            const int m = kbase + 8 * w + rr;
+            mA[i] = m;
+            const int chunk = (lane & 15) ^ ((rr & 7) << 1);
+            const int co = co0 + chunk * 8;
+            vAn[i] = (m < a.M && co < a.Co && co + 8 <= a.ldd) ? (unsigned)m * (unsigned)(a.ldd * 2) + (unsigned)(co * 2) : kOOBg;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = kbase + 8 * w + 2 * i + (lane >> 5);
+            mB[i] = m;
+            if (a.use_tab) {
+                const int addr = smem_lds + LDS_WGH + 2 * min(m, a.M - 1);
+                asm volatile("ds_read_u16 %0, %1" : "=v"(tb[i]) : "v"(addr));
+            }
+        }
+        kbase += KPg;
+    };
+    auto prepare_finish = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = 2 * i + (lane >> 5);
+            const int m = mB[i];
+            const int chunk = (lane & 31) ^ ((rr & 7) << 1);
+            const int ci = ci0 + chunk * 8;
+            const unsigned t = a.use_tab ? tb[i] : tap_pixel(min(m, a.M - 1));
+            vB[i] = (m < a.M && ci < a.Ci && t != 0xFFFFu) ? t * pxb + (unsigned)(ci * 2) : kOOBg;
+        }
+        vA[0] = vAn[0]; vA[1] = vAn[1];
+    };
+    auto prepare = [&]() {
+        prepare_issue();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]));
+        prepare_finish();
+    };
+    auto fire = [&](int stage) {
+        char* sb = smem + stage * STAGEh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + (2 * w + i) * 1024), 16, vA[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + KPg * 256 + (4 * w + i) * 1024), 16, vB[i], 0, 0, 0);
+    };
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane transpose-read offsets: this lane supplies row kk (of a 16-row block) and 8 B = 4 channels
+    const int kk = g * 4 + (r16 >> 2);
+    const int sub = (r16 & 3) * 8;
+    const int sw = (kk & 7) << 1;                    // same for kk + 16
+    int offA[8], offB[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) offA[i] = kk * 256 + (((i * 2) ^ sw) << 4) + sub;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offB[j] = KPg * 256 + kk * 512 + (((w * 8 + j * 2) ^ sw) << 4) + sub;
+
+    const int nK = (a.M + KPg - 1) / KPg;
+    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    prepare(); fire(0);
+    prepare(); if (nK > 1) fire(1);
+    prepare();                                        // offsets of step 2
+    int stage = 0;
+    for (int kc = 0; kc < nK; ++kc) {
+        // six LDS-DMA instructions per wave per stage: only stage kc + 1 may stay in flight here
+        if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kc + 2 < nK) fire(stage == 0 ? 2 : stage - 1);          // (stage + 2) % 3: the buffer of step kc - 1
+        prepare_issue();                              // offsets of step kc + 3
+        const int sbo = smem_lds + stage * STAGEh;
+        auto rd_tr = [&](int addr, int off) -> u32x2_t {
+            u32x2_t v;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+            return v;
+        };
+        u32x2_t dl[8], dh[8], xl[4], xh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xl[j] = rd_tr(sbo + offB[j], 0); xh[j] = rd_tr(sbo + offB[j], 16 * 512); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dl[i] = rd_tr(sbo + offA[i], 0); dh[i] = rd_tr(sbo + offA[i], 16 * 256); }
+#pragma unroll
+        for (int i = 4; i < 8; ++i) { dl[i] = rd_tr(sbo + offA[i], 0); dh[i] = rd_tr(sbo + offA[i], 16 * 256); }
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]), "+v"(xl[0]), "+v"(xh[0]), "+v"(xl[1]), "+v"(xh[1]), "+v"(xl[2]),
+                       "+v"(xh[2]), "+v"(xl[3]), "+v"(xh[3]), "+v"(dl[0]), "+v"(dh[0]), "+v"(dl[1]), "+v"(dh[1]), "+v"(dl[2]), "+v"(dh[2]),
+                       "+v"(dl[3]), "+v"(dh[3]));
+        u32x4_t xf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[j] = u32x4_t{xl[j].x, xl[j].y, xh[j].x, xh[j].y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4_t df = u32x4_t{dl[i].x, dl[i].y, dh[i].x, dh[i].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(df, xf[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dl[4]), "+v"(dh[4]), "+v"(dl[5]), "+v"(dh[5]), "+v"(dl[6]), "+v"(dh[6]), "+v"(dl[7]), "+v"(dh[7]),
+                       "+v"(acc[3][3]));
+#pragma unroll
+        for (int i = 4; i < 8; ++i) {
+            const u32x4_t df = u32x4_t{dl[i].x, dl[i].y, dh[i].x, dh[i].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(df, xf[j], acc[i][j]);
+        }
+        prepare_finish();
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+
+    // ---- epilogue: two passes of 64 rows x 256 columns; thread -> 16 groups of 4 columns per pass, in four batches of four ----
+    constexpr int PT = 256 + 4;
+    const unsigned nwb = (unsigned)a.Co * (unsigned)(a.KH * a.KW * a.Ci) * 4u;
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)a.p, 0, (int)nwb, 0x00020000);
+    const auto rsM = __builtin_amdgcn_make_buffer_rsrc((void*)a.m1, 0, (int)nwb, 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)a.m2, 0, (int)nwb, 0x00020000);
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)a.wlp, 0, (int)(nwb >> 1), 0x00020000);
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.dw, 0, (int)nwb, 0x00020000);
+    float* tile = (float*)smem;                       // 64 x 260 x 4 B = 66,560 B (the ring is drained: vmcnt(0) + the barriers below)
+    u32x4_t pq[2][4], mq[2][4], vq[2][4];
+    int eo[2][4];
+    auto load_batch = [&](int pass, int bt, int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + (bt * 4 + it) * 256;
+            const int r = idx >> 6, c4 = (idx & 63) * 4;
+            const int co = co0 + pass * 64 + r, ci = ci0 + c4;
+            eo[buf][it] = (co < a.Co && ci < a.Ci) ? ((co * a.KH + kh) * a.KW + kw) * a.Ci + ci : -1;
+            const unsigned off = eo[buf][it] >= 0 ? (unsigned)eo[buf][it] * 4u : 0xFFFFFFF0u;
+            pq[buf][it] = __builtin_amdgcn_raw_buffer_load_b128(rsP, off, 0, SZN_WGW_ADAM_AUX);
+            mq[buf][it] = __builtin_amdgcn_raw_buffer_load_b128(rsM, off, 0, SZN_WGW_ADAM_AUX);
+            vq[buf][it] = __builtin_amdgcn_raw_buffer_load_b128(rsV, off, 0, SZN_WGW_ADAM_AUX);
+        }
+    };
+    auto update_batch = [&](int bt, int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (eo[buf][it] < 0) continue;
+            const int idx = tid + (bt * 4 + it) * 256;
+            const int r = idx >> 6, c4 = (idx & 63) * 4;
+            const f32x4_t gq = *(const f32x4_t*)(tile + r * PT + c4);
+            u32x4_t po, mo, vo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = __uint_as_float(pq[buf][it][e]), me = __uint_as_float(mq[buf][it][e]), ve = __uint_as_float(vq[buf][it][e]);
+                adam_elem(pe, gq[e], me, ve, a.b1, a.b2, a.eps, a.wd, a.step_size, a.inv_bc2_sqrt, a.gscale);
+                po[e] = __float_as_uint(pe); mo[e] = __float_as_uint(me); vo[e] = __float_as_uint(ve);
+            }
+            const unsigned off = (unsigned)eo[buf][it] * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(mo, rsM, off, 0, SZN_WGW_ADAM_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(vo, rsV, off, 0, SZN_WGW_ADAM_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(po, rsP, off, 0, SZN_WGW_ADAM_AUX);
+            if (a.wlp) {
+                u32x2_t pk;
+                pk.x = pack2<T>(__uint_as_float(po[0]), __uint_as_float(po[1]));
+                pk.y = pack2<T>(__uint_as_float(po[2]), __uint_as_float(po[3]));
+                __builtin_amdgcn_raw_buffer_store_b64(pk, rsL, off >> 1, 0, 0);
+            }
+            if (a.dw) {
+                const u32x4_t go = u32x4_t{__float_as_uint(gq[0]), __float_as_uint(gq[1]), __float_as_uint(gq[2]), __float_as_uint(gq[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(go, rsG, off, 0, 0);
+            }
+        }
+    };
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        load_batch(pass, 0, 0);                       // in flight across the LDS round trip of the gradient tile
+        __syncthreads();                              // ring / previous pass fully consumed
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    tile[(ii * 16 + g * 4 + e) * PT + w * 64 + j * 16 + r16] = acc[pass * 4 + ii][j][e];
+        __syncthreads();
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) {
+            if (bt + 1 < 4) load_batch(pass, bt + 1, (bt + 1) & 1);
+            update_batch(bt, bt & 1);
+        }
+    }
+#endif
+}
+
 }  // namespace
 
 // Called by szn_conv2d_wgrad after validation.  Returns 1 if the layer does not fit this kernel.
@@ -402,7 +676,10 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
         a.stagger = tiles < 3 * 256 ? 0 : (sg >= 0 ? sg : (nK + 8) / 16);     // (a one-round launch would only start late)
     }
     { static int xo = -1; if (xo < 0) { const char* e = getenv("SZN_WGW_XCD"); xo = e ? atoi(e) : 1; }
-      a.xcd_order = (xo && (size_t)a.in_bytes > 4 * (size_t)a.dout_bytes) ? 1 : 0; }
+      a.xcd_order = (xo && (size_t)a.in_bytes > 4 * (size_t)a.dout_bytes) ? 1 : 0;
+      // many taps (fc6's weight gradient: 49): experiment SZN_WGW_XCD2=1 -- an XCD's CUs walk the taps of one (cout, cin) tile pair
+      const char* e2 = getenv("SZN_WGW_XCD2");
+      if (!a.xcd_order && e2 && atoi(e2) != 0 && d->KH * d->KW >= 9) a.xcd_order = 2; }
     const int lds = LDS_WGW + (a.use_tab ? kTabMax * 4 : 0);
     static bool attr_done = false;
     if (!attr_done) {
@@ -416,6 +693,35 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     hipStream_t st = (hipStream_t)stream;
     if (opt) {
         if (opt->grad_optional) a.dw = nullptr;
+        // round 5: 128 x 256 tiles, two four-wave blocks per CU (conv_wgrad_half).  Measured (profiles/r05_ablations.txt 3): the
+        // update streams better (fc6 at B = 1, where the K loop is 289 pixels: 550 -> 517 us, the one-image step 2.85 -> 2.82 ms)
+        // but with a long K loop the smaller tile's extra operand traffic costs what the overlap gains (B = 8: 842 -> 864 us), so it
+        // takes the launches whose K loop is short.  SZN_WGW_HALF = 0 / 1 forces conv_wgrad_wide<T, true> / this kernel
+        // (read per call: the tests run both).
+        const char* eh = getenv("SZN_WGW_HALF");
+        const long cot_h = szn_div_up(d->Co, 128);
+        const bool want_half = eh ? atoi(eh) != 0 : a.M <= 1024;
+        if (want_half && cot_h * a.citiles * d->KH * d->KW < (1L << 31)) {
+            WgwArgs h = a;
+            h.cotiles = (int)cot_h;
+            h.use_tab = (a.M <= kTabMaxH && (long)d->B * d->Hi * d->Wi < 65535) ? a.use_tab : 0;
+            const long tiles_h = cot_h * a.citiles * d->KH * d->KW;
+            // the second-slot blocks start half a K loop late: one K step of a lone four-wave block ~0.25 us, s_sleep(127) ~3.4 us
+            static int sgh = -2; if (sgh == -2) { const char* e = getenv("SZN_WGH_STAGGER"); sgh = e ? atoi(e) : -1; }
+            const int nKh = (a.M + KPg - 1) / KPg;
+            h.stagger = tiles_h < 2 * 512 ? 0 : (sgh >= 0 ? sgh : (nKh + 16) / 32);
+            const int ldsh = LDS_WGH + (h.use_tab ? kTabMaxH * 2 : 0);
+            static bool attr_h = false;
+            if (!attr_h) {
+                (void)hipFuncSetAttribute((const void*)conv_wgrad_half<bf16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGH + kTabMaxH * 2);
+                (void)hipFuncSetAttribute((const void*)conv_wgrad_half<f16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WGH + kTabMaxH * 2);
+                attr_h = true;
+            }
+            if (d->dtype == SZN_F16) hipLaunchKernelGGL((conv_wgrad_half<f16_raw>), dim3((unsigned)tiles_h), dim3(256), ldsh, st, h);
+            else hipLaunchKernelGGL((conv_wgrad_half<bf16_raw>), dim3((unsigned)tiles_h), dim3(256), ldsh, st, h);
+            SZN_CHECK_LAUNCH("conv_wgrad_half_adam");
+            return SZN_OK;
+        }
         if (d->dtype == SZN_F16) hipLaunchKernelGGL((conv_wgrad_wide<f16_raw, true>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((conv_wgrad_wide<bf16_raw, true>), grid, dim3(512), lds, st, a);
         SZN_CHECK_LAUNCH("conv_wgrad_wide_adam");
