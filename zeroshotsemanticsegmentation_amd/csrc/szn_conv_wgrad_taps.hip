@@ -537,7 +537,14 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     const int cus = (d->reserved_cus > 0 && ncu - d->reserved_cus >= ncombo) ? ncu - d->reserved_cus : ncu;
     long ns = (long)cus * oversub / ncombo;
     if (min_tiles_per_block < 1) min_tiles_per_block = 1;
-    if (ns > nt / min_tiles_per_block) ns = nt / min_tiles_per_block;
+    if (ns > nt / min_tiles_per_block) {
+        // few tiles (conv5_x of ONE image: 9 tiles, 64 combos): the min_tiles rule would leave three quarters of the chip idle while 64
+        // blocks walk 9 tiles each; down to two tiles per block the extra slabs cost less than the idle CUs (round 5, B = 1)
+        static int small = -1;
+        if (small < 0) { const char* e = getenv("SZN_WGT_SMALLSPLIT"); small = e ? atoi(e) : 1; }
+        const long relaxed = small ? std::max<long>(nt / min_tiles_per_block, std::min<long>(ns, nt / 2)) : nt / min_tiles_per_block;
+        ns = relaxed;
+    }
     const size_t slab_bytes = (size_t)ncombo * SLAB * sizeof(float);
     int cb_rows = 0, cb_per = 1, cb_units = 0;
     CbSkip ck = {};

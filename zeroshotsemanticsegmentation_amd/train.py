@@ -81,20 +81,24 @@ def update_cfg_with_args(cfg, args):
     return cfg
 
 
+# configuration sanity rules (the reference's checks, train.py:232-251, with its messages: the CLI contract): (broken?, message)
+_ONE_HOT_WIDTH = {"pascal": 21, "context": 33}      # classes of the dataset = width of a one-hot class embedding
+_CFG_RULES = (
+    (lambda c: c['one_hot_embed'] and c['embed_dim'] != _ONE_HOT_WIDTH.get(c['dataset'], c['embed_dim']),
+     'joint-embedding space must be size of one-hot embedding space'),
+    (lambda c: not c['load_fcn_path'] and (c['mode'] in ('test_fcn', 'test_all') or c['fcn_epochs'] < 1),
+     'must load model path via -r flag for test mode'),
+    (lambda c: c['seenmask_epochs'] > 0 and not c['train_unseen'],
+     "can't train the seenmask classifier without train_unseen specified"),
+    (lambda c: c['embed_dim'] == 0 and c['fcn_loss'] in ('cos', 'mse'),
+     "invalid loss function because pixel embedding dimensionality not defined"),
+)
+
+
 def validate_cfg(cfg):
-    """reference :232-251"""
-    if cfg['one_hot_embed'] and cfg['embed_dim'] != 21 and cfg['dataset'] == "pascal":
-        raise Exception('joint-embedding space must be size of one-hot embedding space')
-    if cfg['one_hot_embed'] and cfg['embed_dim'] != 33 and cfg['dataset'] == "context":
-        raise Exception('joint-embedding space must be size of one-hot embedding space')
-    if cfg['mode'] in ['test_fcn', 'test_all'] and not cfg['load_fcn_path']:
-        raise Exception('must load model path via -r flag for test mode')
-    if cfg['fcn_epochs'] < 1 and not cfg['load_fcn_path']:
-        raise Exception('must load model path via -r flag for test mode')
-    if cfg['seenmask_epochs'] > 0 and len(cfg['train_unseen']) < 1:
-        raise Exception("can't train the seenmask classifier without train_unseen specified")
-    if cfg['embed_dim'] == 0 and cfg['fcn_loss'] in ['cos', 'mse']:
-        raise Exception("invalid loss function because pixel embedding dimensionality not defined")
+    for broken, message in _CFG_RULES:
+        if broken(cfg):
+            raise Exception(message)
 
 
 def get_log_dir(model_name, cfg_num, cfg, data_dir, now=None):
