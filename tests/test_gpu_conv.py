@@ -934,3 +934,60 @@ def test_constant_border_hint_of_a_gated_dgrad(case):
     assert not (dense == 7.0).all(dim=-1).any()
     untouched = (hint == 7.0).all(dim=-1)                                # pixels the hinted run did not store
     assert untouched.float().mean() > 0.2 and not untouched[:, r0:r1, c0:c1].any()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("geom", [(1, 45, 512, 512), (1, 89, 512, 256), (2, 23, 512, 256)])
+def test_splitk_epilogue_with_column_sums(dtype, geom):
+    """Few output tiles + a long K range (conv4_x / conv5_x dgrads of a one-image step): the library splits K, and since round 5 the split-K
+    epilogue also delivers the column sums of the tensor it stores (splitk_epilogue_cs) -- the bias gradient of the producing layer,
+    models.py:117-143 backward -- from the fp32 values.  The tensor equals the one the plain split-K epilogue writes bit for bit; the
+    column sums equal those of the unsplit kernel's epilogue to fp32 re-ordering and are bit-reproducible (slab + fixed-order reduce)."""
+    B, H, Cin, Cout = geom                          # a dgrad call: "Ci" = channels of dout, "Co" = channels of din
+    g = torch.Generator(device="cuda").manual_seed(7 + H)
+    dout = (torch.randn(B, H, H, Cin, device="cuda", generator=g) * 0.1).to(dtype)
+    wT = (torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5).to(dtype)
+    gate = torch.randn(B, H, H, Cout, device="cuda", generator=g).to(dtype)
+    code = L.dtype_code(dtype)
+    st = L.stream_ptr()
+    ws = torch.empty(16 * B * H * H * Cout * 4, dtype=torch.uint8, device="cuda")
+
+    def run(colsum, workspace, slab_rows=0):
+        d = L.ConvDesc(code, B, H, H, Cin, H, H, Cout, 3, 3, 1, Cin, Cout, Cout, 0, 0)
+        out = torch.full((B, H, H, Cout), float("nan"), device="cuda", dtype=dtype)
+        cs = torch.zeros(Cout, device="cuda")
+        slab = torch.zeros(max(slab_rows, 1) * Cout, device="cuda")
+        if workspace:
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        if colsum:
+            d.colsum = cs.data_ptr()
+            if slab_rows:
+                d.colsum_slab, d.colsum_slab_rows = slab.data_ptr(), slab_rows
+        L.call("szn_conv2d_fwd", C.byref(d), L.ptr(dout), L.ptr(wT), None, L.ptr(gate), None, L.ptr(out), st)
+        kern = L.last_kernel()
+        rows = L.load().szn_last_colsum_rows()
+        if colsum and slab_rows:
+            assert float(cs.abs().max()) == 0.0 and rows > 0
+            L.call("szn_colsum_reduce_batch", 1, (C.c_void_p * 1)(slab.data_ptr()), (C.c_int * 1)(rows), (C.c_int * 1)(Cout),
+                   (C.c_void_p * 1)(cs.data_ptr()), st)
+        torch.cuda.synchronize()
+        return out, cs, kern
+
+    o_plain, _, k_plain = run(False, True)
+    assert k_plain == "splitk_epilogue", k_plain                  # the shape really takes the split-K path
+    o_cs, cs_slab, k_cs = run(True, True, slab_rows=1024)
+    assert k_cs == "splitk_epilogue_cs", k_cs
+    o_cs2, cs_slab2, _ = run(True, True, slab_rows=1024)
+    o_at, cs_atomic, k_at = run(True, True)                       # no slab: fp32 atomics on colsum
+    assert k_at == "splitk_epilogue_cs", k_at
+    o_uns, cs_uns, k_uns = run(True, False, slab_rows=1024)       # no scratch: the unsplit kernel and its own epilogue sums
+    assert "splitk" not in k_uns
+    assert torch.equal(o_cs, o_plain) and torch.equal(o_at, o_plain) and torch.equal(o_cs2, o_plain)
+    assert torch.equal(cs_slab, cs_slab2)                         # bit-reproducible
+    scale = float(cs_uns.abs().max())
+    assert float((cs_slab - cs_uns).abs().max()) < 2e-5 * scale + 1e-6
+    assert float((cs_atomic - cs_uns).abs().max()) < 2e-5 * scale + 1e-6
+    # and they are the column sums of the stored tensor (16-bit storage: to its rounding)
+    ref = o_plain.float().sum(dim=(0, 1, 2))
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
+    assert float((cs_slab - ref).abs().max()) < tol * float(o_plain.float().abs().sum(dim=(0, 1, 2)).max())

@@ -477,6 +477,54 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__
     }
 }
 
+// The same epilogue with the column sums of the stored tensor (= the bias gradient of the layer that produced the gate): block b owns
+// rows [b * rpb, (b + 1) * rpb), a thread owns one group of four couts and every (256 / (Co / 4))-th row of the block, so that its
+// running sums stay in registers; the row lanes are combined through LDS in ascending order and the block's partial row goes to row b of
+// the caller's slab (szn_colsum_reduce_batch adds the rows in a fixed order) or, without a slab, to colsum by fp32 atomics.  Until round 5
+// a dgrad that wanted column sums could not split its K range (few-tile layers of a one-image step) or paid a separate pass over the
+// 16-bit din (szn_bias_grad_slab); here the sums come from the fp32 values, like in the unsplit kernels' epilogues.  Same additions
+// in the same order as splitk_epilogue for the tensor itself.  Needs Co % 4 == 0, Co / 4 <= 256, 256 % (Co / 4) == 0, the 16-B path.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_cs(const float* __restrict__ ws, Conv2Args a, int rpb) {
+    __shared__ f32x4_t part[256];
+    const long total = (long)a.M * a.Co;
+    const T* __restrict__ gate = (const T*)a.gate;
+    const int c4n = a.Co >> 2, RL = 256 / c4n;
+    const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n, n = c4 * 4;
+    const long m0 = (long)blockIdx.x * rpb, m1 = m0 + rpb < a.M ? m0 + rpb : a.M;
+    f32x4_t cs = {0.f, 0.f, 0.f, 0.f};
+    for (long m = m0 + rl; m < m1; m += RL) {
+        const long i4 = m * c4n + c4;
+        f32x4_t x = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < a.nsplit; ++sp) x += *(const f32x4_t*)(ws + (long)sp * total + i4 * 4);
+        if (a.bias) x += *(const f32x4_t*)(a.bias + n);
+        if (a.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+        if (gate) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = (elem<T>::ld(gate + m * a.ldg + n + e) > 0.f) ? x[e] : 0.f;
+        }
+        if (a.cscale) x *= *(const f32x4_t*)(a.cscale + (m / a.HoWo) * a.Co + n);
+        cs += x;
+        if (a.out_f32 || sizeof(T) == 4) *(f32x4_t*)((float*)a.out + m * a.ldo + n) = x;
+        else {
+            uint2 o;
+            o.x = pack2<T>(x[0], x[1]); o.y = pack2<T>(x[2], x[3]);
+            *(uint2*)((uint16_t*)a.out + m * a.ldo + n) = o;
+        }
+    }
+    part[threadIdx.x] = cs;
+    __syncthreads();
+    if (rl == 0) {
+        f32x4_t t = part[c4];
+        for (int r = 1; r < RL; ++r) t += part[r * c4n + c4];
+        if (a.cslab) *(f32x4_t*)(a.cslab + (long)blockIdx.x * a.Co + n) = t;
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (t[e] != 0.f) atomicAdd(a.colsum + n + e, t[e]);
+        }
+    }
+}
+
 template <typename T, int WNF, int ABL>
 void launch_abl(const Conv2Args& a, size_t lds, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_v2<T, WNF, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -599,7 +647,17 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     // kernel sums the slabs in a fixed order + epilogue.  ns minimises a simple time model: MFMA time / wave
     // efficiency + slab traffic.
     bool use_wide = false;                            // split-K on the 256 x 256 tile kernel (szn_conv_wide.hip)
-    if (d->workspace && nK >= 64 && !d->colsum) {
+    // column sums under split-K: splitk_epilogue_cs (its conditions are checked here; the slab must hold its row count)
+    const bool out32_ = d->out_f32 || d->dtype == SZN_F32;
+    const int cs_rpb = 32;
+    const long cs_rows = ((long)a.M + cs_rpb - 1) / cs_rpb;
+    static int cs_split = -1;
+    if (cs_split < 0) { const char* e = getenv("SZN_SPLITK_COLSUM"); cs_split = e ? atoi(e) : 1; }
+    const bool cs_ok = d->colsum && cs_split && !(d->Co & 3) && (d->Co >> 2) <= 256 && 256 % (d->Co >> 2) == 0 && !(d->ldo & 3) &&
+                       (!gate || !(d->ldg & 3)) && !((uintptr_t)d->workspace & 15) && !((uintptr_t)bias & 15) && !((uintptr_t)chan_scale & 15) &&
+                       !((uintptr_t)out & (out32_ ? 15 : 7)) && (!d->colsum_slab || d->colsum_slab_rows >= cs_rows) &&
+                       (long)a.mtiles * a.ntiles < 128;
+    if (d->workspace && nK >= 64 && (!d->colsum || cs_ok)) {
         static int ncu = 0;
         if (!ncu) {
             int dev = 0; hipDeviceProp_t p;
@@ -671,6 +729,18 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
         else if (d->dtype == SZN_F16) rc = narrow ? launch_v2<f16_raw, 2>(a, st) : launch_v2<f16_raw, 4>(a, st);
         else rc = narrow ? launch_v2<float, 2>(a, st) : launch_v2<float, 4>(a, st);
         if (rc) return rc;
+    }
+    if (a.nsplit > 1 && a.colsum) {
+        a.cslab = d->colsum_slab;
+        szn_note_colsum_rows(a.cslab ? (int)cs_rows : 0);
+        if (d->dtype == SZN_BF16)
+            hipLaunchKernelGGL(splitk_epilogue_cs<bf16_raw>, dim3((unsigned)cs_rows), dim3(256), 0, st, (const float*)a.ws, a, cs_rpb);
+        else if (d->dtype == SZN_F16)
+            hipLaunchKernelGGL(splitk_epilogue_cs<f16_raw>, dim3((unsigned)cs_rows), dim3(256), 0, st, (const float*)a.ws, a, cs_rpb);
+        else
+            hipLaunchKernelGGL(splitk_epilogue_cs<float>, dim3((unsigned)cs_rows), dim3(256), 0, st, (const float*)a.ws, a, cs_rpb);
+        SZN_CHECK_LAUNCH("splitk_epilogue_cs");
+        return SZN_OK;
     }
     if (a.nsplit > 1) {
         long blocks = ((long)a.M * a.Co / 4 + 255) / 256;

@@ -271,11 +271,12 @@ class _Engine(object):
         self._cs_off += n
         return slab, rows
 
-    def _cs_register(self, slab, Cc, out):
-        """after a call that was handed `slab`: remember how many rows it wrote"""
+    def _cs_register(self, slab, Cc, out, rows=None):
+        """after a call that was handed `slab`: remember how many rows it wrote (rows: already read from szn_last_colsum_rows)"""
         if slab is None:
             return
-        rows = L.load().szn_last_colsum_rows()
+        if rows is None:
+            rows = L.load().szn_last_colsum_rows()
         if rows > 0:
             self._cs_jobs.append((slab, rows, Cc, out))
 
@@ -615,18 +616,17 @@ class _Engine(object):
         d = L.ConvDesc(L.dtype_code(self.dtype), B, Hi, Wi, Ci, Ho, Wo, Co, k, k, pad, Ci, Co, Ci, 0, 0)
         d.reserved_cus = self.reserved_cus
         slab = None
-        # Few output tiles and a long reduction (conv4_x / conv5_x at the reference's batch size of one image: 32 .. 124 tiles of
-        # 256 x 128 on 256 CUs): the library's deterministic split-K needs the epilogue to itself, so the column sums (= the producer
-        # layer's bias gradient) come from a pass over the small din instead of the dgrad epilogue
         M = B * Hi * Wi
-        split_cs = (colsum is not None and cb is None and self.dtype != torch.float32 and
-                    ((M + 255) // 256) * ((Ci + 127) // 128) < 128 and k * k * Co >= 64 * 64 and _DGRAD_SPLIT)
-        if colsum is not None and not split_cs:
+        if colsum is not None:
             d.colsum = colsum.data_ptr()
             slab, rows = self._cs_slab(M, Ci, dout.device)
             if slab is not None:
                 d.colsum_slab, d.colsum_slab_rows = slab.data_ptr(), rows
-        else:
+        # Few output tiles and a long reduction (conv4_x / conv5_x at the reference's batch size of one image: 32 .. 124 tiles of
+        # 256 x 128 on 256 CUs): the library may split the K range (deterministic slabs); since round 5 its split-K epilogue also
+        # produces the column sums (= the producer layer's bias gradient) from the fp32 values (splitk_epilogue_cs), so the
+        # scratch is handed over whether or not column sums are asked for and the decision is the library's alone
+        if colsum is None or (cb is None and _DGRAD_SPLIT):
             self._workspace(d, M * Ci * 4, dout.device)
         if cb is not None and gate is not None and _CONST_BORDER and self.dtype != torch.float32:
             grect, srect = cb                                   # (r0, r1, c0, c1) each: where the gate varies / what the consumer reads
@@ -636,15 +636,12 @@ class _Engine(object):
             for i in range(4):
                 d.cb_rect[i], d.cb_const[i] = grect[i], srect[i]
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
+        cs_rows = L.load().szn_last_colsum_rows()      # (thread-local "last call" state: read before any other library call)
         if d.cb_on == 2 and L.load().szn_last_work_fraction() < 1.0:
             bws = torch.empty(2 * 24 * B * Co, device=dout.device)
             L.call("szn_conv2d_dgrad_border_finish", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(border_sum), L.ptr(colsum),
                    L.ptr(bws), L.stream_ptr())
-        if split_cs:
-            slab, rows = self._cs_slab(M, Ci, dout.device)
-            L.call("szn_bias_grad_slab", L.dtype_code(self.dtype), M, Ci, Ci, L.ptr(din), L.ptr(colsum), 1, L.ptr(slab), rows,
-                   L.stream_ptr())
-        self._cs_register(slab, Ci, colsum)
+        self._cs_register(slab, Ci, colsum, rows=cs_rows)
         return din
 
     def backward(self, ctx, dcoarse, grads, backbone=True, layer_done=None, head_first=None, skips=None):
