@@ -495,13 +495,12 @@ class _Engine(object):
         pair, not of the kernel -- conv_igemm_8ph reads 0.34 of peak instead of 0.51 with it on.  Same kernels, same values.
         The side stream first waits for everything queued on the current stream (dout is produced there); `tensors`
         are the operands whose memory must not be recycled before the side stream is done with them."""
-        if self._wg_stream is None:
-            on = os.environ.get("SZN_WGRAD_STREAM", "0") == "1"
-            self._wg_stream = torch.cuda.Stream(device=tensors[0].device) if on else False
-        side = self._wg_stream
-        if side is False:
+        if not getattr(self, "_wg_on", False):
             yield
             return
+        if self._wg_stream is None:
+            self._wg_stream = torch.cuda.Stream(device=tensors[0].device)
+        side = self._wg_stream
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             yield
@@ -510,7 +509,7 @@ class _Engine(object):
 
     def _join_wgrad(self):
         """end of a backward pass: the weight-gradient stream (if any) rejoins, the pending bias-gradient rows are reduced"""
-        if self._wg_stream:
+        if self._wg_stream and getattr(self, "_wg_on", False):
             torch.cuda.current_stream().wait_stream(self._wg_stream)
         self._flush_colsum()
 
@@ -653,6 +652,16 @@ class _Engine(object):
         dt = self.dtype
         code = L.dtype_code(dt)
         st = L.stream_ptr()
+        # weight gradients on a second stream (see _wgrad_stream): SZN_WGRAD_STREAM = 1 always, 0 never, auto (default) = small steps
+        # only (at most two 512 x 512 images: the reference's one-image step, train.py:82-84) -- there the backward kernels run on
+        # 8-124 tiles and leave most of the chip idle, so a dgrad and the weight gradient beside it really overlap (B = 1: -0.09 ms);
+        # at B = 8 every kernel fills the chip, the gain is 0.07 ms and the per-kernel timings of bench.py / rocprof would describe
+        # pairs of kernels
+        mode = os.environ.get("SZN_WGRAD_STREAM", "auto")
+        # (not while a hipGraph is being captured: replayed with the cross-stream edges the one-image step measured 2.90 ms against
+        #  2.78 without them and 2.71 eager with them -- profiles/r05_ablations.txt 8)
+        self._wg_on = (mode == "1" or (mode == "auto" and ctx.B * ctx.H * ctx.W <= 2 * 512 * 512)) and \
+            not (mode != "1" and torch.cuda.is_current_stream_capturing())
         dc = dcoarse if dcoarse.dtype == dt else dcoarse.to(dt)      # tiny (B*h*w*CP)
         feat = ctx.relu7
         F = m.fc7.out_channels
