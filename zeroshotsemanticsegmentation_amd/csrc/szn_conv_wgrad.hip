@@ -262,20 +262,41 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_v2(Wg2Args a) {
 #endif
 }
 
-// dw[i] (+)= sum_s slab[s][i], four elements per thread, splits added in ascending order
+// dw[i] (+)= sum_s slab[s][i].  A block owns 256 / SL groups of four consecutive elements; the SL "split lanes" of a group each add a
+// contiguous share of the splits with four independent running sums and lane 0 combines the SL partial sums in ascending order --
+// a fixed association for a given (nsplit, SL), so two runs agree bit for bit.  (Round 5: until then ONE thread added all the splits of its
+// group one after the other -- conv1_1's fp32 weight gradient, 2,048 elements x 3,072 splits, took 1.03 ms in two blocks of dependent
+// loads; profiles/r05_ablations.txt 9.)  Optionally also delivers the 16-bit wire image (szn_conv_desc_t.dw_lp).
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_slab_reduce(const float* __restrict__ slab, float* __restrict__ dw, long nw, int nsplit,
                                                          int accumulate) {
+    __shared__ f32x4_t part[256];
+    constexpr int GPB = 256 / SL;                     // groups per block
+    const int gl = threadIdx.x % GPB, sl = threadIdx.x / GPB;
     const long n4 = nw >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        f32x4_t s = accumulate ? ((const f32x4_t*)dw)[i] : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < nsplit; ++k) s += ((const f32x4_t*)(slab + (long)k * nw))[i];
-        ((f32x4_t*)dw)[i] = s;
+    const int sp0 = (int)((long)nsplit * sl / SL), sp1 = (int)((long)nsplit * (sl + 1) / SL);
+    for (long base = (long)blockIdx.x * GPB; base < n4; base += (long)gridDim.x * GPB) {
+        const long i = base + gl;
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        if (i < n4) {
+            const f32x4_t* p = (const f32x4_t*)slab + i;
+            int k = sp0;
+            for (; k + 4 <= sp1; k += 4) {
+                s0 += p[(long)k * n4]; s1 += p[(long)(k + 1) * n4]; s2 += p[(long)(k + 2) * n4]; s3 += p[(long)(k + 3) * n4];
+            }
+            for (; k < sp1; ++k) s0 += p[(long)k * n4];
+        }
+        part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (sl == 0 && i < n4) {
+            f32x4_t s = accumulate ? ((const f32x4_t*)dw)[i] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < SL; ++r) s += part[r * GPB + gl];
+            ((f32x4_t*)dw)[i] = s;
+        }
+        __syncthreads();
     }
-    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < nw; i += (long)gridDim.x * 256) {
-        float s = accumulate ? dw[i] : 0.f;
-        for (int k = 0; k < nsplit; ++k) s += slab[(long)k * nw + i];
-        dw[i] = s;
-    }
+    // (nw % 4 != 0 never reaches this kernel: the launcher requires whole 16-B groups for the slab form)
 }
 
 template <typename T, int FA, int FB>
@@ -424,9 +445,14 @@ static int wgrad_dispatch(const szn_conv_desc_t* d, const void* in, const void* 
     }
     SZN_CHECK_LAUNCH("conv_wgrad_v2");
     if (a.slab) {
-        const long n4 = (nw + 3) / 4;
-        hipLaunchKernelGGL(wgrad_slab_reduce, dim3((unsigned)std::min<long>((n4 + 255) / 256, 4096L)), dim3(256), 0, st,
-                           (const float*)a.slab, dw, nw, a.nsplit, accumulate);
+        const long n4 = nw / 4;                        // (the slab form requires nw % 4 == 0, see above)
+        // many splits of a small gradient: sixteen split lanes per group; else four
+        if (a.nsplit >= 64 && n4 * 16 <= 4096L * 256)
+            hipLaunchKernelGGL(wgrad_slab_reduce<16>, dim3((unsigned)std::min<long>((n4 + 15) / 16, 8192L)), dim3(256), 0, st,
+                               (const float*)a.slab, dw, nw, a.nsplit, accumulate);
+        else
+            hipLaunchKernelGGL(wgrad_slab_reduce<4>, dim3((unsigned)std::min<long>((n4 + 63) / 64, 8192L)), dim3(256), 0, st,
+                               (const float*)a.slab, dw, nw, a.nsplit, accumulate);
         SZN_CHECK_LAUNCH("wgrad_slab_reduce");
     }
     return SZN_OK;
