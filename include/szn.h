@@ -459,6 +459,16 @@ int szn_sgd_momentum_step_scaled(long n, float* param, const float* grad, float*
 int szn_loss_scale_update(float* scale_state, float growth, float backoff, int growth_interval, float min_scale,
                           float max_scale, szn_stream_t stream);
 
+/* ---- row / column remapping of an NHWC map (the constant band of the pad-100 network inside the conv3 block) --------------
+ * models.py:43 pads conv1_1 by 100: at 1/4 resolution most rows / columns between the tensor edge and the image's reach hold one
+ * value per channel, and conv3_1 .. conv3_3 (models.py:56-62,123-128) need not compute them.  One kernel does the four index maps
+ * the caller needs (crop, put the pooled rows back, and their two backward forms):
+ *     out[b][y][x][c] = sum over sy in [ytab[2y], ytab[2y] + ytab[2y+1]), sx in [xtab[2x], xtab[2x] + xtab[2x+1]) of in[b][sy][sx][c]
+ * (count 0 = zeros; fp32 accumulation in ascending order; a single source is moved bit for bit).  in [B][Hi][Wi][C], out
+ * [B][Ho][Wo][C] dense, 16-B aligned, C a multiple of 8 (16-bit) / 4 (f32); ytab [Ho][2], xtab [Wo][2] int32 on the device.          */
+int szn_band_remap(int dtype, int B, int Hi, int Wi, int Ho, int Wo, int C, const void* in, void* out, const int* ytab,
+                   const int* xtab, szn_stream_t stream);
+
 /* ---- small utilities -------------------------------------------------------------------------------- */
 int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, szn_stream_t stream);
 /* Dropout2d factors: scale[i] = (u_i >= p) ? 1/(1-p) : 0 with a counter-based generator (seed, i)   */

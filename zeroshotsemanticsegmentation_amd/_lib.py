@@ -141,6 +141,7 @@ SIGNATURES = {
     "szn_sgd_momentum_step_scaled": (_I, [_L, _P, _P, _P, _F, _F, _F, _P, _F, _P, _I, _P]),
     "szn_loss_scale_update": (_I, [_P, _F, _F, _I, _F, _F, _P]),
     "szn_cast": (_I, [_I, _I, _L, _P, _P, _P]),
+    "szn_band_remap": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "szn_dropout2d_mask": (_I, [_L, _F, _U64, _U64, _P, _P]),
     "szn_proj_fp8_workspace_bytes": (_SZ, [_L, _I, _I]),
     "szn_proj_fp8_fwd": (_I, [_I, _I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

@@ -79,9 +79,87 @@ def _cb_pool(reg, n):
     return (r0 // 2, min((r1 + 1) // 2, npool), (c0 + 1) // 2, npool if c1 >= n else c1 // 2)
 
 
+# ---- the constant band inside the conv3 block (round 5) -------------------------------------------------------------------------------
+# At 1/4 resolution (conv3_1 .. conv3_3: 178 x 178 for a 512 x 512 image) the rows / columns between the tensor edge and the image's
+# reach -- 21 per side -- hold one value per channel (the regions above).  A 3x3 convolution maps equal neighbourhoods to equal outputs,
+# so an interval [a, e) of them can be REMOVED before conv3_1 as long as, through all L = 3 layers, the rows on both sides of the cut are
+# still "pure" (neither the zero padding of the layers so far nor the image has reached them): the kept rows then see the same values
+# they would see in the full map and come out bit for bit the same.  a and e are even, so the 2x2 pooling windows keep their partners;
+# behind pool3 the removed pooled rows are copies of a pure pooled row next to the cut.  12 rows / columns per side at 512 x 512:
+# 154^2 instead of 178^2 pixels through conv3_x forward, dgrad and wgrad (-25 %).  Backward: the gradient of the copies is summed into
+# the representative row / column (every parameter gradient upstream depends on the band only through such sums: the band pixels are
+# produced by identical computations on identical values), the removed input rows get zero -- equal to the full computation up to the
+# order of fp32 additions, like the other constant-border hints.  SZN_BAND_CROP=0 turns it off.
+_BAND_CROP = os.environ.get("SZN_BAND_CROP", "1") != "0"
+_BAND_BLOCK = ("conv3_1", "conv3_2", "conv3_3")
+
+
+def _band_cut(reg, n, L=3):
+    """one axis: region (r0, r1, c0, c1) of the block's input map of size n -> [(a, e, rep_pooled, first_pooled_source), ...] for the
+    top / left and bottom / right band (intervals of full rows to remove), possibly empty"""
+    r0, r1, c0, c1 = reg
+    cuts = []
+    a = c0 + L + 2
+    a += a & 1
+    e = (r0 - L) & ~1
+    if e - a >= 4:
+        cuts.append((a, e, a // 2 - 1, a // 2 - 1))                    # representative pooled row = the one in front of the cut
+    a2 = r1 + L
+    a2 += a2 & 1
+    e2 = (min(c1, n) - L - 2) & ~1
+    if e2 - a2 >= 4 and c1 <= n:
+        cuts.append((a2, e2, e2 // 2, a2 // 2))                        # ... = the one behind the cut
+    return cuts
+
+
+class _BandPlan(object):
+    """index tables (device int32 [n][2] = start, count) of the four maps of szn_band_remap for one (regions, size) geometry"""
+
+    def __init__(self, regy, regx, H, W, device):
+        self.H, self.W = H, W
+        ty, tx = self._axis(regy, H), self._axis(regx, W)
+        self.ok = ty is not None and tx is not None and (ty["n"] < H or tx["n"] < W)
+        if not self.ok:
+            return
+        self.Hc, self.Wc = ty["n"], tx["n"]                             # cropped size
+        self.Hp, self.Wp = (H + 1) // 2, (W + 1) // 2                   # pooled, full
+        self.Hpc, self.Wpc = (self.Hc + 1) // 2, (self.Wc + 1) // 2    # pooled, cropped
+        dev = lambda t: torch.tensor(t, dtype=torch.int32, device=device).contiguous()
+        self.tabs = {k: (dev(ty[k]), dev(tx[k])) for k in ("crop", "crop_bwd", "uncrop", "uncrop_bwd")}
+        self.x = None
+
+    @staticmethod
+    def _axis(reg, n):
+        cuts = _band_cut(reg, n)
+        removed = set()
+        for a, e, _, _ in cuts:
+            removed.update(range(a, e))
+        kept = [y for y in range(n) if y not in removed]
+        pos = {y: i for i, y in enumerate(kept)}
+        npool = (n + 1) // 2
+        removed_p, rep_of = set(), {}
+        for a, e, rep, _ in cuts:
+            for p in range(a // 2, e // 2):
+                removed_p.add(p)
+                rep_of[p] = rep
+        kept_p = [p for p in range(npool) if p not in removed_p]
+        pos_p = {p: i for i, p in enumerate(kept_p)}
+        if len(kept_p) != (len(kept) + 1) // 2:
+            return None
+        t = {"n": len(kept)}
+        t["crop"] = [[y, 1] for y in kept]
+        t["crop_bwd"] = [[pos[y], 1] if y in pos else [0, 0] for y in range(n)]
+        t["uncrop"] = [[pos_p[p] if p in pos_p else pos_p[rep_of[p]], 1] for p in range(npool)]
+        ub = [[p, 1] for p in kept_p]
+        for a, e, rep, first in cuts:
+            ub[pos_p[rep]] = [first, (e - a) // 2 + 1]
+        t["uncrop_bwd"] = ub
+        return t
+
+
 class _Ctx(object):
     """what one forward pass leaves behind for its backward"""
-    __slots__ = ("x", "acts", "pools", "relu6", "relu7", "masks", "coarse", "B", "H", "W", "h", "w", "train", "cb_in")
+    __slots__ = ("x", "acts", "pools", "relu6", "relu7", "masks", "coarse", "B", "H", "W", "h", "w", "train", "cb_in", "crop")
 
 
 class _Engine(object):
@@ -290,6 +368,21 @@ class _Engine(object):
         L.call("szn_colsum_reduce_batch", n, VP(*[j[0].data_ptr() for j in jobs]), IA(*[j[1] for j in jobs]),
                IA(*[j[2] for j in jobs]), VP(*[j[3].data_ptr() for j in jobs]), L.stream_ptr())
 
+    def _band_remap(self, x, plan, which, Ho, Wo):
+        B, Hi, Wi, Cc = x.shape
+        x = x.contiguous()
+        out = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
+        ty, tx = plan.tabs[which]
+        L.call("szn_band_remap", L.dtype_code(x.dtype), B, Hi, Wi, Ho, Wo, Cc, L.ptr(x), L.ptr(out), L.ptr(ty), L.ptr(tx), L.stream_ptr())
+        return out
+
+    def _band_plan(self, regy, regx, H, W, device):
+        key = (regy, regx, H, W, str(device))
+        cache = self.__dict__.setdefault("_band_plans", {})
+        if key not in cache:
+            cache[key] = _BandPlan(regy, regx, H, W, device)
+        return cache[key] if cache[key].ok else None
+
     # ---- kernels ---------------------------------------------------------------------------------
     def _conv(self, x, name, pad, relu=True, scale=None, out_f32=False, w=None, b=None, co=None, k=None, pool=False, codes=False,
               pool_only=False, cb=None):
@@ -357,26 +450,39 @@ class _Engine(object):
         items = _BACKBONE[1:]
         regy, regx = _cb_conv1_1(H, PAD1), _cb_conv1_1(W, PAD1)         # constant-border regions of the current tensor, per axis
         cb_in = ctx.cb_in = {}
+        ctx.crop = None
+        band = None
         for i, item in enumerate(items):
             if item == "P":
                 regy, regx = _cb_pool(regy, a_hw[0]), _cb_pool(regx, a_hw[1])
                 continue                                  # pooled by the conv in front of it (pool_out)
             name, pad = item
-            a_hw = (a.shape[1], a.shape[2])               # 3x3 / pad 1: the conv's output size
-            cb_in[name] = (regy, regx)                    # regions of this conv's INPUT (its weight gradient can use them)
+            if name == _BAND_BLOCK[0] and _BAND_CROP and not self.keep_prepool and (self.pool_codes or not keep):
+                # the constant band inside the conv3 block: remove most of it (see _band_cut), put the pooled rows back behind pool3
+                band = self._band_plan(regy, regx, a.shape[1], a.shape[2], a.device)
+                if band is not None:
+                    a = self._band_remap(a, band, "crop", band.Hc, band.Wc)
+                    ctx.crop = (band, a)                  # (the block's cropped input: conv3_1's weight gradient reads it)
+            a_hw = (a.shape[1], a.shape[2]) if band is None else (band.H, band.W)       # 3x3 / pad 1: the conv's output size (full map)
+            cb_in[name] = (regy, regx) if band is None else None    # regions of this conv's INPUT (its weight gradient can use them)
             regy, regx = _cb_conv3x3(regy, a_hw[0]), _cb_conv3x3(regx, a_hw[1])
-            cb = (regy, regx)
+            cb = (regy, regx) if band is None else None
             if i + 1 < len(items) and items[i + 1] == "P":
                 if keep and self.pool_codes:
                     pin, a, code = self._conv(a, name, pad, pool=True, codes=True, pool_only=not self.keep_prepool, cb=cb)
                     acts[name] = pin if self.keep_prepool else None       # (may be unwritten: the backward pass takes the codes)
+                    if band is not None:
+                        a = self._band_remap(a, band, "uncrop", band.Hp, band.Wp)
                     pools.append((acts[name], a, code, tuple(pin.shape)))
                 else:
                     pin, a = self._conv(a, name, pad, pool=True, pool_only=not keep, cb=cb)
+                    if band is not None:
+                        a = self._band_remap(a, band, "uncrop", band.Hp, band.Wp)
                     if keep:
                         acts[name] = pin
                         pools.append((pin, a))
                 del pin
+                band = None
             else:
                 a = self._conv(a, name, pad, cb=cb)
                 if keep:
@@ -719,6 +825,9 @@ class _Engine(object):
                 pcode = ctx.pools[pi][2] if len(ctx.pools[pi]) > 2 else None
                 pi -= 1
                 producer = items[idx - 1][0]                   # the conv whose (ReLU'd) output this pool reads
+                if ctx.crop is not None and producer == _BAND_BLOCK[-1]:
+                    band = ctx.crop[0]                         # the pooled rows that were copies: their gradients are summed
+                    d = self._band_remap(d, band, "uncrop_bwd", band.Hpc, band.Wpc)
                 B, Hi, Wi, Cc = ctx.pools[pi + 1][3] if pcode is not None else pin.shape
                 dn = torch.empty(B, Hi, Wi, Cc, device=d.device, dtype=pout.dtype)
                 slab, rows = self._cs_slab(B * Hi * Wi, Cc, d.device)
@@ -780,6 +889,9 @@ class _Engine(object):
                 break
             prev = items[idx - 1]
             xin = ctx.pools[pi][1] if prev == "P" else ctx.acts[prev[0]]
+            cropped_in = ctx.crop is not None and name == _BAND_BLOCK[0]
+            if cropped_in:
+                xin = ctx.crop[1]
             layer = getattr(m, name)
             self._wgrad(xin, d, grads[name][0], None, layer.in_channels, layer.out_channels, 3, pad,
                         after=lambda name=name: done(name), cb=(getattr(ctx, "cb_in", None) or {}).get(name),
@@ -787,6 +899,9 @@ class _Engine(object):
             # next d: wrt this conv's input; gate by the ReLU of the producing conv unless a pool sits in between
             if prev == "P":
                 d = self._dgrad(d, name, xin.shape, pad)
+                if cropped_in:                                 # the removed rows / columns of the block's input get no gradient
+                    band = ctx.crop[0]
+                    d = self._band_remap(d, band, "crop_bwd", band.H, band.W)
                 side = skips.get(pi) if skips else None
                 if side is not None:
                     d = d + side.to(d.dtype)
