@@ -88,25 +88,28 @@ def _step(crop, precision, size, B, monkeypatch, train=True):
     return float(loss), pred.cpu(), ts.flat_gw.clone(), ts.flat_gb.clone(), ts, seen.count("szn_band_remap")
 
 
-@pytest.mark.parametrize("precision,size,B,exact", [(torch.float32, 64, 2, False), (torch.float32, 150, 1, False), (torch.bfloat16, 96, 2, False),
-                                                    (torch.bfloat16, 512, 8, True)])
+@pytest.mark.parametrize("precision,size,B,exact", [(torch.float32, 64, 2, False), (torch.float32, 150, 1, False), (torch.float32, 300, 1, False),
+                                                    (torch.bfloat16, 512, 3, True), (torch.bfloat16, 512, 8, True)])
 def test_train_step_with_the_band_removed_equals_the_full_step(precision, size, B, exact, monkeypatch):
-    """exact: at the bench configuration the conv3 launches take the same kernel with and without the band (conv_igemm_8ph, no split-K:
-    741 vs 990 tiles), so a kept pixel's K terms are added in the same order and the forward pass is bit-identical.  At small sizes the
-    smaller map changes the dispatcher's choices (tile kernel, split-K count): equal values, another fp32 summation order."""
+    """exact: at the bench configuration the conv2_x / conv3_x launches take the same kernels with and without the band (conv3x3_regw;
+    conv_igemm_8ph without split-K: 741 vs 990 tiles), so a kept pixel's K terms are added in the same order and the forward pass is
+    bit-identical.  At small sizes the smaller maps change the dispatcher's choices (tile kernel, split-K count): equal values, another
+    fp32 summation order -- compared in fp32, where that is a 1e-6 effect (on the 16-bit paths a last-bit difference of an activation
+    flips ReLU gates downstream: the mechanism tests/test_gpu_headline_pin.py measures; tools/diag_band.py prints both)."""
     l0, p0, gw0, gb0, ts0, n0 = _step(False, precision, size, B, monkeypatch, train=exact)
     l1, p1, gw1, gb1, ts1, n1 = _step(True, precision, size, B, monkeypatch, train=exact)
-    assert n0 == 0 and n1 == 4                               # crop, uncrop, and their two backward forms
+    # crop, uncrop and their two backward forms per block: conv2 + conv3 blocks on the 16-bit paths, conv1_2's too in fp32
+    assert n0 == 0 and n1 == (12 if precision == torch.float32 else 8)
     if exact:
         assert l1 == l0 and torch.equal(p1, p0)              # forward: bit for bit
-        o = ts0.woff["conv4_1"][0]                           # ... and so is everything behind the block (conv4_1 .. score_fr)
+        o = ts0.woff["conv4_1"][0]                           # ... and so is everything behind the blocks (conv4_1 .. score_fr)
         assert torch.equal(gw1[o:], gw0[o:])
     else:
-        assert abs(l1 - l0) < (2e-6 if precision == torch.float32 else 2e-3) * abs(l0)
-        assert float((p1 == p0).float().mean()) > (0.9999 if precision == torch.float32 else 0.98)
+        assert abs(l1 - l0) < 2e-6 * abs(l0)
+        assert float((p1 == p0).float().mean()) > 0.9999
     # fp32: re-ordering only.  bf16: one more rounding of the summed band gradient -- and, where the dispatcher changed kernels, activations
     # that differ in their last bf16 bit flip a few ReLU gates (tests/test_gpu_headline_pin.py explains the mechanism and its size)
-    tol = 3e-5 if precision == torch.float32 else (6e-3 if exact else 4e-2)
+    tol = 3e-5 if precision == torch.float32 else 6e-3
     for n in ts0.layers:
         o, cnt = ts0.woff[n]
         a, b = gw1[o:o + cnt].double(), gw0[o:o + cnt].double()

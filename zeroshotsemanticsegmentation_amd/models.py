@@ -90,8 +90,13 @@ def _cb_pool(reg, n):
 # the representative row / column (every parameter gradient upstream depends on the band only through such sums: the band pixels are
 # produced by identical computations on identical values), the removed input rows get zero -- equal to the full computation up to the
 # order of fp32 additions, like the other constant-border hints.  SZN_BAND_CROP=0 turns it off.
+# The same holds for the conv2 block (conv2_1, conv2_2 at 355 x 355: 47 band rows per side, 40 removable: 275^2 pixels, -40 %; its kernels
+# then run without the constant-border hint, which skipped 30 % of the forward tiles and none of the dgrad tiles) and, on the fp32 path
+# -- whose kernels take no hints at all -- for conv1_2 (710 -> 526 rows / columns, -45 %).  On the 16-bit paths conv1_2 keeps its hints:
+# cropping conv1_1's 516 MB output would cost what it saves.
 _BAND_CROP = os.environ.get("SZN_BAND_CROP", "1") != "0"
-_BAND_BLOCK = ("conv3_1", "conv3_2", "conv3_3")
+_BAND_BLOCKS = {"conv1_2": ("conv1_2",), "conv2_1": ("conv2_1", "conv2_2"), "conv3_1": ("conv3_1", "conv3_2", "conv3_3")}   # first layer -> block
+_BAND_16BIT = os.environ.get("SZN_BAND_BLOCKS16", "conv2_1,conv3_1").split(",")      # blocks cropped on the 16-bit paths (fp32: all)
 
 
 def _band_cut(reg, n, L=3):
@@ -115,9 +120,9 @@ def _band_cut(reg, n, L=3):
 class _BandPlan(object):
     """index tables (device int32 [n][2] = start, count) of the four maps of szn_band_remap for one (regions, size) geometry"""
 
-    def __init__(self, regy, regx, H, W, device):
+    def __init__(self, regy, regx, H, W, device, L=3):
         self.H, self.W = H, W
-        ty, tx = self._axis(regy, H), self._axis(regx, W)
+        ty, tx = self._axis(regy, H, L), self._axis(regx, W, L)
         self.ok = ty is not None and tx is not None and (ty["n"] < H or tx["n"] < W)
         if not self.ok:
             return
@@ -129,8 +134,8 @@ class _BandPlan(object):
         self.x = None
 
     @staticmethod
-    def _axis(reg, n):
-        cuts = _band_cut(reg, n)
+    def _axis(reg, n, L=3):
+        cuts = _band_cut(reg, n, L)
         removed = set()
         for a, e, _, _ in cuts:
             removed.update(range(a, e))
@@ -376,11 +381,11 @@ class _Engine(object):
         L.call("szn_band_remap", L.dtype_code(x.dtype), B, Hi, Wi, Ho, Wo, Cc, L.ptr(x), L.ptr(out), L.ptr(ty), L.ptr(tx), L.stream_ptr())
         return out
 
-    def _band_plan(self, regy, regx, H, W, device):
-        key = (regy, regx, H, W, str(device))
+    def _band_plan(self, regy, regx, H, W, device, L):
+        key = (regy, regx, H, W, str(device), L)
         cache = self.__dict__.setdefault("_band_plans", {})
         if key not in cache:
-            cache[key] = _BandPlan(regy, regx, H, W, device)
+            cache[key] = _BandPlan(regy, regx, H, W, device, L)
         return cache[key] if cache[key].ok else None
 
     # ---- kernels ---------------------------------------------------------------------------------
@@ -450,19 +455,24 @@ class _Engine(object):
         items = _BACKBONE[1:]
         regy, regx = _cb_conv1_1(H, PAD1), _cb_conv1_1(W, PAD1)         # constant-border regions of the current tensor, per axis
         cb_in = ctx.cb_in = {}
-        ctx.crop = None
+        ctx.crop = {}
         band = None
         for i, item in enumerate(items):
             if item == "P":
                 regy, regx = _cb_pool(regy, a_hw[0]), _cb_pool(regx, a_hw[1])
                 continue                                  # pooled by the conv in front of it (pool_out)
             name, pad = item
-            if name == _BAND_BLOCK[0] and _BAND_CROP and not self.keep_prepool and (self.pool_codes or not keep):
-                # the constant band inside the conv3 block: remove most of it (see _band_cut), put the pooled rows back behind pool3
-                band = self._band_plan(regy, regx, a.shape[1], a.shape[2], a.device)
+            if name in _BAND_BLOCKS and _BAND_CROP and not self.keep_prepool and (self.pool_codes or not keep) and \
+                    (self.dtype == torch.float32 or name in _BAND_16BIT):
+                # the constant band inside a conv block: remove most of it (see _band_cut), put the pooled rows back behind the block's pool
+                blk = _BAND_BLOCKS[name]
+                band = self._band_plan(regy, regx, a.shape[1], a.shape[2], a.device, len(blk))
                 if band is not None:
                     a = self._band_remap(a, band, "crop", band.Hc, band.Wc)
-                    ctx.crop = (band, a)                  # (the block's cropped input: conv3_1's weight gradient reads it)
+                    ctx.crop[("in", name)] = (band, a)    # (the block's cropped input: its first layer's weight gradient reads it)
+                    ctx.crop[("out", blk[-1])] = band
+                    if i == 0 and keep:
+                        acts["conv1_1"] = None            # conv1_1's full output: nothing reads it any more (fp32: 1 GB at B = 8)
             a_hw = (a.shape[1], a.shape[2]) if band is None else (band.H, band.W)       # 3x3 / pad 1: the conv's output size (full map)
             cb_in[name] = (regy, regx) if band is None else None    # regions of this conv's INPUT (its weight gradient can use them)
             regy, regx = _cb_conv3x3(regy, a_hw[0]), _cb_conv3x3(regx, a_hw[1])
@@ -825,8 +835,8 @@ class _Engine(object):
                 pcode = ctx.pools[pi][2] if len(ctx.pools[pi]) > 2 else None
                 pi -= 1
                 producer = items[idx - 1][0]                   # the conv whose (ReLU'd) output this pool reads
-                if ctx.crop is not None and producer == _BAND_BLOCK[-1]:
-                    band = ctx.crop[0]                         # the pooled rows that were copies: their gradients are summed
+                if ctx.crop and ("out", producer) in ctx.crop:
+                    band = ctx.crop[("out", producer)]         # the pooled rows that were copies: their gradients are summed
                     d = self._band_remap(d, band, "uncrop_bwd", band.Hpc, band.Wpc)
                 B, Hi, Wi, Cc = ctx.pools[pi + 1][3] if pcode is not None else pin.shape
                 dn = torch.empty(B, Hi, Wi, Cc, device=d.device, dtype=pout.dtype)
@@ -889,9 +899,9 @@ class _Engine(object):
                 break
             prev = items[idx - 1]
             xin = ctx.pools[pi][1] if prev == "P" else ctx.acts[prev[0]]
-            cropped_in = ctx.crop is not None and name == _BAND_BLOCK[0]
+            cropped_in = bool(ctx.crop) and ("in", name) in ctx.crop
             if cropped_in:
-                xin = ctx.crop[1]
+                xin = ctx.crop[("in", name)][1]
             layer = getattr(m, name)
             self._wgrad(xin, d, grads[name][0], None, layer.in_channels, layer.out_channels, 3, pad,
                         after=lambda name=name: done(name), cb=(getattr(ctx, "cb_in", None) or {}).get(name),
@@ -900,14 +910,17 @@ class _Engine(object):
             if prev == "P":
                 d = self._dgrad(d, name, xin.shape, pad)
                 if cropped_in:                                 # the removed rows / columns of the block's input get no gradient
-                    band = ctx.crop[0]
+                    band = ctx.crop[("in", name)][0]
                     d = self._band_remap(d, band, "crop_bwd", band.H, band.W)
                 side = skips.get(pi) if skips else None
                 if side is not None:
                     d = d + side.to(d.dtype)
             else:
-                cb = self._conv1_1_dgrad_cb(ctx) if prev[0] == "conv1_1" else None
+                cb = self._conv1_1_dgrad_cb(ctx) if (prev[0] == "conv1_1" and not cropped_in) else None
                 d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1], cb=cb, border_sum=border_sums.pop(name, None))
+                if cropped_in:                                 # (fp32: conv1_2's block; conv1_1's weight gradient reads the full map)
+                    band = ctx.crop[("in", name)][0]
+                    d = self._band_remap(d, band, "crop_bwd", band.H, band.W)
         self._join_wgrad()
 
 
