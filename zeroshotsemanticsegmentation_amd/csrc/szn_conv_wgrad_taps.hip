@@ -615,10 +615,13 @@ extern "C" int szn_conv2d_wgrad_cb_region(const szn_conv_desc_t* d, int region[8
     if (!d || !region || !szn_is16(d->dtype) || d->KH != 3 || d->KW != 3 || (d->Ci & 63) || (d->Co & 63) || d->pad > 2 || !d->workspace ||
         (d->ldi & 7) || (d->ldo & 7))
         return 0;
-    int ncu = 0, dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
+    static int ncu = 0;                              // (cached: this query sits on the host-bound one-image path)
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
     const int ncombo = (d->Co / 64) * (d->Ci / 64);
     if (ncombo > ncu) return 0;
     static int taps_min = -1;

@@ -48,6 +48,7 @@ struct WgwArgs {
     float* p; float* m1; float* m2; uint16_t* wlp;
     float b1, b2, eps, wd, step_size, inv_bc2_sqrt, gscale;
     int stagger;               // <T, true>: s_sleep(127) units (~4 us) per phase step of the first-round blocks, see the kernel
+    int ncu;                   // compute units of the device (the first-round blocks are blockIdx < ncu)
 };
 
 constexpr unsigned kOOBg = 0x80000000u;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
     for (int j = 0; j < 4; ++j) offB[j] = KPg * 512 + kk * 512 + (((wn * 8 + j * 2) ^ sw) << 4) + sub;
 
     const int nK = (a.M + KPg - 1) / KPg;
-    if (ADAM && a.stagger > 0 && blockIdx.x < 256) {
+    if (ADAM && a.stagger > 0 && (int)blockIdx.x < a.ncu) {
         // With the update in the epilogue a tile is a K loop (MFMA-bound, HBM idle) followed by 1.7 MB of master / moment traffic
         // (HBM-bound, MFMA idle).  All CUs start together and every tile takes the same time, so the whole chip alternated between
         // the two phases in lockstep and the launch took the SUM of both (940 us for fc6 at B = 8 against 476 + 523 separately).  The
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_half(WgwArgs a) {
     for (int j = 0; j < 4; ++j) offB[j] = KPg * 256 + kk * 512 + (((w * 8 + j * 2) ^ sw) << 4) + sub;
 
     const int nK = (a.M + KPg - 1) / KPg;
-    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    if (a.stagger > 0 && (int)blockIdx.x >= a.ncu && (int)blockIdx.x < 2 * a.ncu)
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     prepare(); fire(0);
     prepare(); if (nK > 1) fire(1);
@@ -669,11 +670,20 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     { static int tab = -1; if (tab < 0) { const char* e = getenv("SZN_WGW_TAB"); tab = e ? atoi(e) : 1; } a.use_tab = (tab && a.M <= kTabMax) ? 1 : 0; }
     { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_WGW_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
     a.stagger = 0;
+    {
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0; hipDeviceProp_t p;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+            if (ncu <= 0) ncu = 256;
+        }
+        a.ncu = ncu;
+    }
     if (opt) {
         // one K step (32 pixels) takes ~1 us per CU; the full stagger spans ~7/8 of a K loop: phase x nK / 32 sleeps of ~4 us
         static int sg = -2; if (sg == -2) { const char* e = getenv("SZN_WGW_STAGGER"); sg = e ? atoi(e) : -1; }
         const int nK = (a.M + KPg - 1) / KPg;
-        a.stagger = tiles < 3 * 256 ? 0 : (sg >= 0 ? sg : (nK + 8) / 16);     // (a one-round launch would only start late)
+        a.stagger = tiles < 3L * a.ncu ? 0 : (sg >= 0 ? sg : (nK + 8) / 16);     // (a one-round launch would only start late)
     }
     { static int xo = -1; if (xo < 0) { const char* e = getenv("SZN_WGW_XCD"); xo = e ? atoi(e) : 1; }
       a.xcd_order = (xo && (size_t)a.in_bytes > 4 * (size_t)a.dout_bytes) ? 1 : 0;
@@ -709,7 +719,7 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
             // the second-slot blocks start half a K loop late: one K step of a lone four-wave block ~0.25 us, s_sleep(127) ~3.4 us
             static int sgh = -2; if (sgh == -2) { const char* e = getenv("SZN_WGH_STAGGER"); sgh = e ? atoi(e) : -1; }
             const int nKh = (a.M + KPg - 1) / KPg;
-            h.stagger = tiles_h < 2 * 512 ? 0 : (sgh >= 0 ? sgh : (nKh + 16) / 32);
+            h.stagger = tiles_h < 4L * a.ncu ? 0 : (sgh >= 0 ? sgh : (nKh + 16) / 32);
             const int ldsh = LDS_WGH + (h.use_tab ? kTabMaxH * 2 : 0);
             static bool attr_h = false;
             if (!attr_h) {

@@ -131,6 +131,11 @@ class _BandPlan(object):
         self.Hpc, self.Wpc = (self.Hc + 1) // 2, (self.Wc + 1) // 2    # pooled, cropped
         dev = lambda t: torch.tensor(t, dtype=torch.int32, device=device).contiguous()
         self.tabs = {k: (dev(ty[k]), dev(tx[k])) for k in ("crop", "crop_bwd", "uncrop", "uncrop_bwd")}
+        # the gradient of the copied pooled rows in two separable passes (rows, then columns): a corner representative has
+        # (n/2 + 1)^2 sources (441 in the conv2 block) -- one thread adding them all made that launch 132 us; 21 + 21 take 2 x 15
+        ident = lambda n: dev([[i, 1] for i in range(n)])
+        self.tabs["uncrop_bwd_y"] = (self.tabs["uncrop_bwd"][0], ident(self.Wp))
+        self.tabs["uncrop_bwd_x"] = (ident(self.Hpc), self.tabs["uncrop_bwd"][1])
         self.x = None
 
     @staticmethod
@@ -837,7 +842,8 @@ class _Engine(object):
                 producer = items[idx - 1][0]                   # the conv whose (ReLU'd) output this pool reads
                 if ctx.crop and ("out", producer) in ctx.crop:
                     band = ctx.crop[("out", producer)]         # the pooled rows that were copies: their gradients are summed
-                    d = self._band_remap(d, band, "uncrop_bwd", band.Hpc, band.Wpc)
+                    d = self._band_remap(d, band, "uncrop_bwd_y", band.Hpc, band.Wp)
+                    d = self._band_remap(d, band, "uncrop_bwd_x", band.Hpc, band.Wpc)
                 B, Hi, Wi, Cc = ctx.pools[pi + 1][3] if pcode is not None else pin.shape
                 dn = torch.empty(B, Hi, Wi, Cc, device=d.device, dtype=pout.dtype)
                 slab, rows = self._cs_slab(B * Hi * Wi, Cc, d.device)
