@@ -2,7 +2,8 @@
 """bench.py -- train-step throughput of the SZN pixel-embedding path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|fp32] [--size 512] [--classes 59]
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    (N > 1: `python bench.py --gpus N` re-executes itself under torch.distributed.run, one rank per GPU; the driver's own
+     `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` form works as well)
 
 One "step" = the reference's hot-loop body (trainer_fcn.py:149-180) on one synthetic batch already resident in HBM:
 FCN32s forward (train mode, Dropout2d on) -> cosine loss -> train-time infer_lbl -> backward -> gradient all-reduce
@@ -13,7 +14,7 @@ drawn from the seen classes), E = 300, bf16 operands / fp32 accumulate / fp32 ma
 is its FCN32s.)
 
 Prints ONE JSON line: metric train_Mpixels_per_sec (whole job) plus
-  roofline      the dominant kernel (conv3x3_wide_rows: conv3_x / conv4_x forward + dgrad): algorithmic FLOPs of
+  roofline      the dominant kernel (conv_igemm_8ph: conv3_x / conv4_x forward + dgrad, fc6 forward): algorithmic FLOPs of
                 its launches / their HIP-event-measured duration INSIDE the timed region, against the dense MFMA peak;
                 `traffic` = HBM bytes per launch from the committed PMC passes (source file named; null if none matches)
   kernels       per kernel family, MFMA-class and HBM-class, from 3 extra instrumented steps after the timed region
@@ -21,9 +22,10 @@ Prints ONE JSON line: metric train_Mpixels_per_sec (whole job) plus
   projection    the three labelled MFMA numbers SURVEY 8-d asks for (true shape, step aggregate, nominal shape)
   phase2        BASELINE configs[2]: the seen-mask step (engine.SeenmaskStep: frozen backbone forward, fused-from-coarse
                 2-class head, head-only backward + Adam), three repeats, its own roofline record
-  comm          BASELINE configs[3]'s gradient exchange forced through a one-rank RCCL communicator on this GPU (child process):
-                step time with the real buckets going through librccl on its own stream vs without, fp32 / bf16 wire, and with CUs
-                reserved for RCCL by the persistent kernels
+  comm          N = 1: BASELINE configs[3]'s gradient exchange forced through a one-rank RCCL communicator on this GPU (child process):
+                step time with the real buckets going through librccl on its own high-priority stream vs without, fp32 / bf16 wire
+                (written by the weight-gradient kernels / through staging copies) / sharded optimizer.  N > 1: the same variants
+                measured across the ranks, exposed-comm ms and per-bucket issue / wait times (the line explains its own scaling)
   fp32, b1      measured in a child process after the headline (a crash there cannot lose the line): the same step at the
                 reference's arithmetic (fp32, B = 8, against the 157.3 TF fp32 MFMA peak) and at the reference's batch size
                 (B = 1, bf16 and fp32, eager and replayed from a captured hipGraph)

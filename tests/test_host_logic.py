@@ -219,3 +219,51 @@ def test_vgg16_pretrained_file_round_trip(tmp_path):
     assert torch.equal(m.fc6.bias, sd["classifier.0.bias"]) and torch.equal(m.fc7.bias, sd["classifier.3.bias"])
     # the kernels read the weights in OHWI order: the copy must keep channels_last storage
     assert m.fc6.weight.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_band_cut_tables_are_consistent():
+    """models._band_cut / _BandPlan (round 5: the constant band removed from the conv blocks of the pad-100 network, models.py:43): for every
+    image size the four index maps are mutually consistent -- crop keeps exactly the rows crop_bwd maps back, every pooled row is either kept
+    or a copy of a kept pure row, uncrop_bwd is the transpose of uncrop -- and the cuts respect the purity margins they were derived from."""
+    import numpy as np
+    from zeroshotsemanticsegmentation_amd import models as M
+
+    for H in (1, 31, 64, 96, 150, 321, 500, 512, 768):
+        n = H + 198
+        reg = M._cb_conv1_1(H, 100)
+        blocks = [("conv1_2", 1), ("conv2_1", 2), ("conv3_1", 3)]
+        for name, L in blocks:
+            plan = M._BandPlan(reg, reg, n, n, "cpu", L)
+            cuts = M._band_cut(reg, n, L)
+            r0, r1, c0, c1 = reg
+            for a, e, rep, first in cuts:
+                assert a % 2 == 0 and e % 2 == 0 and e - a >= 4
+                if e <= r0:          # top / left band: the rows next to the cut stay pure through L layers, the representative too
+                    assert a - 2 >= c0 + L and e <= r0 - L and rep == a // 2 - 1
+                else:                # bottom / right band
+                    assert a >= r1 + L and e + 1 < min(c1, n) - L and rep == e // 2
+            if plan.ok:
+                ty = {k: v[0].numpy() for k, v in plan.tabs.items()}
+                kept = ty["crop"][:, 0]
+                assert len(kept) == plan.Hc and np.all(np.diff(kept) > 0)
+                back = ty["crop_bwd"]
+                for i, y in enumerate(kept):
+                    assert tuple(back[y]) == (i, 1)
+                assert int((back[:, 1] == 0).sum()) == n - plan.Hc
+                up, ub = ty["uncrop"], ty["uncrop_bwd"]
+                A = np.zeros((plan.Hp, plan.Hpc))
+                for p in range(plan.Hp):
+                    A[p, up[p, 0]] = 1
+                At = np.zeros((plan.Hpc, plan.Hp))
+                for q in range(plan.Hpc):
+                    At[q, ub[q, 0]:ub[q, 0] + ub[q, 1]] = 1
+                assert np.array_equal(A.T, At)
+                assert plan.Hpc == (plan.Hc + 1) // 2 and plan.Hp == (n + 1) // 2
+            # the block's own layers + its pool: regions of the next block's input
+            for _ in range(L):
+                reg = M._cb_conv3x3(reg, n)
+            reg = M._cb_pool(reg, n)
+            n = (n + 1) // 2
+    # the bench shape: 12 rows per side at 1/4 resolution, 40 at 1/2, 92 at full resolution
+    n, reg = 710, M._cb_conv1_1(512, 100)
+    assert [(a, e) for a, e, _, _ in M._band_cut(reg, n, 1)] == [(4, 96), (614, 706)]
