@@ -97,6 +97,7 @@ def _cb_pool(reg, n):
 _BAND_CROP = os.environ.get("SZN_BAND_CROP", "1") != "0"
 _BAND_BLOCKS = {"conv1_2": ("conv1_2",), "conv2_1": ("conv2_1", "conv2_2"), "conv3_1": ("conv3_1", "conv3_2", "conv3_3")}   # first layer -> block
 _BAND_16BIT = os.environ.get("SZN_BAND_BLOCKS16", "conv2_1,conv3_1").split(",")      # blocks cropped on the 16-bit paths (fp32: all)
+_BAND_FUSE = os.environ.get("SZN_BAND_FUSE", "1") != "0"      # 0: every block copies its pooled rows back before the next block crops again
 
 
 def _band_cut(reg, n, L=3):
@@ -131,12 +132,40 @@ class _BandPlan(object):
         self.Hpc, self.Wpc = (self.Hc + 1) // 2, (self.Wc + 1) // 2    # pooled, cropped
         dev = lambda t: torch.tensor(t, dtype=torch.int32, device=device).contiguous()
         self.tabs = {k: (dev(ty[k]), dev(tx[k])) for k in ("crop", "crop_bwd", "uncrop", "uncrop_bwd")}
+        self.host = {k: (ty[k], tx[k]) for k in ("crop", "crop_bwd", "uncrop", "uncrop_bwd")}
+        self._dev, self._fused = dev, {}
         # the gradient of the copied pooled rows in two separable passes (rows, then columns): a corner representative has
         # (n/2 + 1)^2 sources (441 in the conv2 block) -- one thread adding them all made that launch 132 us; 21 + 21 take 2 x 15
         ident = lambda n: dev([[i, 1] for i in range(n)])
         self.tabs["uncrop_bwd_y"] = (self.tabs["uncrop_bwd"][0], ident(self.Wp))
         self.tabs["uncrop_bwd_x"] = (ident(self.Hpc), self.tabs["uncrop_bwd"][1])
         self.x = None
+
+    def fused_with(self, nxt):
+        """this block's pooled, cropped output -> the NEXT block's cropped input in one map (and back), instead of copying the pooled rows
+        back into the full map only to remove most of them again: tables {"fwd": one source per element, "bwd_y" / "bwd_x": the two
+        separable passes of the transposed map}"""
+        key = id(nxt)
+        if key not in self._fused:
+            dev = self._dev
+            out = {}
+            per_axis = []
+            for ax in (0, 1):
+                un, ub = self.host["uncrop"][ax], self.host["uncrop_bwd"][ax]
+                cr, cb = nxt.host["crop"][ax], nxt.host["crop_bwd"][ax]
+                fwd = [[un[y][0], 1] for y, _ in cr]
+                bwd = []
+                for s0, cnt in ub:
+                    kept = [p for p in range(s0, s0 + cnt) if cb[p][1] == 1]
+                    assert all(cb[kept[i + 1]][0] == cb[kept[i]][0] + 1 for i in range(len(kept) - 1))
+                    bwd.append([cb[kept[0]][0], len(kept)] if kept else [0, 0])
+                per_axis.append((fwd, bwd))
+            ident = lambda n: [[i, 1] for i in range(n)]
+            out["fwd"] = (dev(per_axis[0][0]), dev(per_axis[1][0]))
+            out["bwd_y"] = (dev(per_axis[0][1]), dev(ident(nxt.Wc)))
+            out["bwd_x"] = (dev(ident(self.Hpc)), dev(per_axis[1][1]))
+            self._fused[key] = out
+        return self._fused[key]
 
     @staticmethod
     def _axis(reg, n, L=3):
@@ -382,9 +411,31 @@ class _Engine(object):
         B, Hi, Wi, Cc = x.shape
         x = x.contiguous()
         out = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
-        ty, tx = plan.tabs[which]
+        ty, tx = which if isinstance(which, tuple) else plan.tabs[which]
         L.call("szn_band_remap", L.dtype_code(x.dtype), B, Hi, Wi, Ho, Wo, Cc, L.ptr(x), L.ptr(out), L.ptr(ty), L.ptr(tx), L.stream_ptr())
         return out
+
+    def _band_close(self, ctx, a, band, name, items, i, regy, regx):
+        """behind a cropped block's pool: copy the pooled rows back into the full map -- unless the next block is cropped too: then the
+        pooled map stays as it is and the next block's entry maps it straight into its own cropped coordinates (_BandPlan.fused_with).
+        -> (tensor, pending)"""
+        nxt = items[i + 2][0] if (i + 2 < len(items) and items[i + 2] != "P") else None
+        if nxt in _BAND_BLOCKS and _BAND_FUSE and (self.dtype == torch.float32 or nxt in _BAND_16BIT):
+            ny, nx = _cb_pool(regy, band.H), _cb_pool(regx, band.W)
+            nplan = self._band_plan(ny, nx, band.Hp, band.Wp, a.device, len(_BAND_BLOCKS[nxt]))
+            if nplan is not None:
+                ctx.crop[("fusedout", name)] = True
+                ctx.crop[("pool", name)] = band       # (pool_output() rebuilds the full map for callers that want it)
+                return a, (band, nplan)
+        return self._band_remap(a, band, "uncrop", band.Hp, band.Wp), None
+
+    def pool_output(self, ctx, i):
+        """the i-th pooling layer's output (NHWC, full map) of a forward pass that kept its state: ctx.pools[i][1], with the rows / columns a
+        fused band map left out (conv2 -> conv3 blocks) copied back"""
+        t = ctx.pools[i][1]
+        producers = [it[0] for k, it in enumerate(_BACKBONE[:-1]) if _BACKBONE[k + 1] == "P"]
+        band = (ctx.crop or {}).get(("pool", producers[i]))
+        return t if band is None else self._band_remap(t, band, "uncrop", band.Hp, band.Wp)
 
     def _band_plan(self, regy, regx, H, W, device, L):
         key = (regy, regx, H, W, str(device), L)
@@ -461,7 +512,7 @@ class _Engine(object):
         regy, regx = _cb_conv1_1(H, PAD1), _cb_conv1_1(W, PAD1)         # constant-border regions of the current tensor, per axis
         cb_in = ctx.cb_in = {}
         ctx.crop = {}
-        band = None
+        band = pending = None
         for i, item in enumerate(items):
             if item == "P":
                 regy, regx = _cb_pool(regy, a_hw[0]), _cb_pool(regx, a_hw[1])
@@ -471,9 +522,16 @@ class _Engine(object):
                     (self.dtype == torch.float32 or name in _BAND_16BIT):
                 # the constant band inside a conv block: remove most of it (see _band_cut), put the pooled rows back behind the block's pool
                 blk = _BAND_BLOCKS[name]
-                band = self._band_plan(regy, regx, a.shape[1], a.shape[2], a.device, len(blk))
+                if pending is not None:                   # the previous block's pooled output is still in ITS cropped coordinates
+                    prev_band, band = pending
+                    a = self._band_remap(a, band, prev_band.fused_with(band)["fwd"], band.Hc, band.Wc)
+                    ctx.crop[("fused", name)] = prev_band
+                    pending = None
+                else:
+                    band = self._band_plan(regy, regx, a.shape[1], a.shape[2], a.device, len(blk))
+                    if band is not None:
+                        a = self._band_remap(a, band, "crop", band.Hc, band.Wc)
                 if band is not None:
-                    a = self._band_remap(a, band, "crop", band.Hc, band.Wc)
                     ctx.crop[("in", name)] = (band, a)    # (the block's cropped input: its first layer's weight gradient reads it)
                     ctx.crop[("out", blk[-1])] = band
                     if i == 0 and keep:
@@ -487,12 +545,12 @@ class _Engine(object):
                     pin, a, code = self._conv(a, name, pad, pool=True, codes=True, pool_only=not self.keep_prepool, cb=cb)
                     acts[name] = pin if self.keep_prepool else None       # (may be unwritten: the backward pass takes the codes)
                     if band is not None:
-                        a = self._band_remap(a, band, "uncrop", band.Hp, band.Wp)
+                        a, pending = self._band_close(ctx, a, band, name, items, i, regy, regx)
                     pools.append((acts[name], a, code, tuple(pin.shape)))
                 else:
                     pin, a = self._conv(a, name, pad, pool=True, pool_only=not keep, cb=cb)
                     if band is not None:
-                        a = self._band_remap(a, band, "uncrop", band.Hp, band.Wp)
+                        a, pending = self._band_close(ctx, a, band, name, items, i, regy, regx)
                     if keep:
                         acts[name] = pin
                         pools.append((pin, a))
@@ -840,7 +898,7 @@ class _Engine(object):
                 pcode = ctx.pools[pi][2] if len(ctx.pools[pi]) > 2 else None
                 pi -= 1
                 producer = items[idx - 1][0]                   # the conv whose (ReLU'd) output this pool reads
-                if ctx.crop and ("out", producer) in ctx.crop:
+                if ctx.crop and ("out", producer) in ctx.crop and not ctx.crop.get(("fusedout", producer)):
                     band = ctx.crop[("out", producer)]         # the pooled rows that were copies: their gradients are summed
                     d = self._band_remap(d, band, "uncrop_bwd_y", band.Hpc, band.Wp)
                     d = self._band_remap(d, band, "uncrop_bwd_x", band.Hpc, band.Wpc)
@@ -917,7 +975,13 @@ class _Engine(object):
                 d = self._dgrad(d, name, xin.shape, pad)
                 if cropped_in:                                 # the removed rows / columns of the block's input get no gradient
                     band = ctx.crop[("in", name)][0]
-                    d = self._band_remap(d, band, "crop_bwd", band.H, band.W)
+                    prev_band = ctx.crop.get(("fused", name))
+                    if prev_band is not None:                  # ... straight into the previous block's pooled, cropped coordinates
+                        ft = prev_band.fused_with(band)
+                        d = self._band_remap(d, band, ft["bwd_y"], prev_band.Hpc, band.Wc)
+                        d = self._band_remap(d, band, ft["bwd_x"], prev_band.Hpc, prev_band.Wpc)
+                    else:
+                        d = self._band_remap(d, band, "crop_bwd", band.H, band.W)
                 side = skips.get(pi) if skips else None
                 if side is not None:
                     d = d + side.to(d.dtype)
