@@ -239,6 +239,15 @@ int szn_gemm_proj_wgrad(int dtype, long M, int K, int N, int ldd, const void* x,
  * fp32 on pixel-valued inputs 4e-3 / 6e-4 of the output range); SZN_CONV1_1_F32MMA=1 keeps fp32 operands there too.             */
 int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const float* x_nchw, const float* w,
                     const float* bias, void* out, szn_stream_t stream);
+/* The same forward pass writing a CROPPED map (round 5): cut = {ya, ye, ya2, ye2, xa, xe, xa2, xe2}, output rows [ya, ye) and [ya2, ye2) and
+ * columns [xa, xe), [xa2, xe2) are not stored -- the constant band the caller removes in front of conv1_2 (models._band_cut; models.py:43 pads
+ * by 100, so those rows hold relu(bias) and a 3x3 convolution behind them needs only a few of them); out is [B][Hc][Wc][64].  Staged 16-bit
+ * kernel only (SZN_ERR_UNSUPPORTED otherwise: crop the full map with szn_band_remap).  szn_conv1_1_wgrad_c reads its dout in that
+ * cropped layout (the removed pixels see no image pixel and contribute nothing); db is not produced (column sums of conv1_2's dgrad).   */
+int szn_conv1_1_fwd_c(int dtype, int B, int H, int W, int pad, const float* x_nchw, const float* w,
+                      const float* bias, void* out, const int cut[8], szn_stream_t stream);
+int szn_conv1_1_wgrad_c(int dtype, int B, int H, int W, int pad, const float* x_nchw, const void* dout, float* dw,
+                        int accumulate, void* workspace, const int cut[8], szn_stream_t stream);
 /* dw[64][3][3][3], db[64] from dout (already ReLU-gated) -- no dgrad: the image needs no gradient.
  * bf16: a fused MFMA kernel (taps gathered from the image in registers, padding-only pixels skipped, fp32 slabs in
  * `workspace`, deterministic); f32: an MFMA wgrad over the im2col image (27 taps padded to 32) in `workspace`.  */

@@ -98,9 +98,10 @@ def test_train_step_with_the_band_removed_equals_the_full_step(precision, size, 
     flips ReLU gates downstream: the mechanism tests/test_gpu_headline_pin.py measures; tools/diag_band.py prints both)."""
     l0, p0, gw0, gb0, ts0, n0 = _step(False, precision, size, B, monkeypatch, train=exact)
     l1, p1, gw1, gb1, ts1, n1 = _step(True, precision, size, B, monkeypatch, train=exact)
-    # bf16: crop (conv2 block), the fused map into the conv3 block's coordinates, copy back behind pool3; backward: the gradient of the
-    # copies in two passes, the fused map's transpose in two passes, zero-fill of the removed input rows.  fp32: one more block in front
-    assert n0 == 0 and n1 == (11 if precision == torch.float32 else 8)
+    # bf16: conv1_1 writes its map cropped (no launch), the fused maps conv1_2 -> conv2 -> conv3 blocks, copy back behind pool3; backward: the
+    # gradient of the copies in two passes, the two fused maps' transposes in two passes each (conv1_1's weight gradient reads the cropped
+    # gradient).  fp32: a crop in front and a zero-fill behind instead (its conv1_1 kernels take no cut)
+    assert n0 == 0 and n1 == (11 if precision == torch.float32 else 9)
     if exact:
         assert l1 == l0 and torch.equal(p1, p0)              # forward: bit for bit
         o = ts0.woff["conv4_1"][0]                           # ... and so is everything behind the blocks (conv4_1 .. score_fr)
@@ -134,3 +135,42 @@ def test_inference_forward_with_the_band_removed(monkeypatch):
     # (fp32, one small image: the smaller conv3 maps change the dispatcher's split-K counts -- same values, another summation order)
     for a, b in zip(out[0], out[1]):
         assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [(2, 96, 80), (1, 512, 512), (3, 33, 47)])
+def test_conv1_1_cropped_forms_equal_the_full_ones(dt, geom):
+    """szn_conv1_1_fwd_c == the kept rows / columns of szn_conv1_1_fwd, bit for bit; szn_conv1_1_wgrad_c on the cropped gradient == szn_conv1_1_wgrad
+    on the full one (the removed pixels see no image pixel: their products are exact zeros), bit for bit"""
+    B, H, W = geom
+    code = L.dtype_code(dt)
+    g = torch.Generator(device="cuda").manual_seed(H)
+    x = (torch.rand(B, 3, H, W, device="cuda", generator=g) * 255 - 120).contiguous()
+    w = torch.randn(64, 3, 3, 3, device="cuda", generator=g) * 0.1
+    bias = torch.randn(64, device="cuda", generator=g) * 0.1
+    Ho, Wo = H + 198, W + 198
+    plan = models._BandPlan(models._cb_conv1_1(H, 100), models._cb_conv1_1(W, 100), Ho, Wo, torch.device("cuda", 0), 1)
+    assert plan.ok
+    st = L.stream_ptr()
+    full = torch.empty(B, Ho, Wo, 64, device="cuda", dtype=dt)
+    L.call("szn_conv1_1_fwd", code, B, H, W, 100, L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(full), st)
+    crop = torch.full((B, plan.Hc, plan.Wc, 64), 9.0, device="cuda", dtype=dt)
+    L.call("szn_conv1_1_fwd_c", code, B, H, W, 100, L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(crop), plan.cut8, st)
+    ky = plan.tabs["crop"][0][:, 0].long()
+    kx = plan.tabs["crop"][1][:, 0].long()
+    assert torch.equal(crop, full[:, ky][:, :, kx])
+    # weight gradient
+    dfull = (torch.randn(B, Ho, Wo, 64, device="cuda", generator=g) * 0.01).to(dt)
+    dcrop = dfull[:, ky][:, :, kx].contiguous()
+    nb = L.load().szn_conv1_1_wgrad_workspace_bytes(code, B, H, W, 100)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    dw0, dw1 = torch.zeros(64, 3, 3, 3, device="cuda"), torch.zeros(64, 3, 3, 3, device="cuda")
+    L.call("szn_conv1_1_wgrad", code, B, H, W, 100, L.ptr(x), L.ptr(dfull), L.ptr(dw0), None, 0, L.ptr(ws), st)
+    L.call("szn_conv1_1_wgrad_c", code, B, H, W, 100, L.ptr(x), L.ptr(dcrop), L.ptr(dw1), 0, L.ptr(ws), plan.cut8, st)
+    torch.cuda.synchronize()
+    assert float(dw0.abs().max()) > 0 and torch.equal(dw0, dw1)
+    # fp32 has no cropped form: refused, nothing written
+    out32 = torch.full((B, plan.Hc, plan.Wc, 64), 5.0, device="cuda")
+    assert L.load().szn_conv1_1_fwd_c(L.SZN_F32, B, H, W, 100, L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(out32), plan.cut8, st) != 0
+    torch.cuda.synchronize()
+    assert float(out32.min()) == 5.0

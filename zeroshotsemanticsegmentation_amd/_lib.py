@@ -95,6 +95,8 @@ SIGNATURES = {
     "szn_gemm_proj_dgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "szn_gemm_proj_wgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _I, _P]),
     "szn_conv1_1_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "szn_conv1_1_fwd_c": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "szn_conv1_1_wgrad_c": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "szn_conv1_1_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "szn_conv1_1_wgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "szn_conv1_1_wgrad_reads": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_int)]),

@@ -53,4 +53,15 @@ __device__ __forceinline__ void cb_decode(const CbGeom& c, int v, int& ty, int& 
     tx = k < c.fx0 ? k : k + (c.fx1 - c.fx0);
 }
 
+// rows / columns removed from a map (the constant band, models._band_cut): [ya, ye) and [ya2, ye2) per axis, ya <= ye <= ya2 <= ye2
+struct BandCut {
+    int ya, ye, ya2, ye2, xa, xe, xa2, xe2;
+};
+__host__ __device__ __forceinline__ int band_map(int v, int a, int e, int a2, int e2) {        // full index -> cropped index, -1 = removed
+    return v < a ? v : (v < e ? -1 : (v < a2 ? v - (e - a) : (v < e2 ? -1 : v - (e - a) - (e2 - a2))));
+}
+__host__ __device__ __forceinline__ int band_unmap(int c, int a, int e, int a2, int e2) {      // cropped index -> full index
+    return c < a ? c : (c < a2 - (e - a) ? c + (e - a) : c + (e - a) + (e2 - a2));
+}
+
 }  // namespace

@@ -17,6 +17,7 @@
 //     LDS and write one fp32 slab [64][32] per block; conv1_1_wgrad_reduce sums the slabs in a fixed order
 //     (deterministic) into dw[64][27].
 #include "szn_common.h"
+#include "szn_cb.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
@@ -30,6 +31,8 @@ struct C11Args {
     int B, H, W, pad, Ho, Wo;
     int oh_lo, nrows, seg_lo, nsegx;       // touching rows [oh_lo, oh_lo + nrows), segments [seg_lo, seg_lo + nsegx) of 32 px
     long nseg;                             // B * nrows * nsegx
+    BandCut cut;                           // dout is the cropped map [B][Hc][Wc][64] (szn_conv1_1_wgrad_c); empty cut = the full map
+    int Hc, Wc;
 };
 
 constexpr unsigned kOOB1 = 0x80000000u;
@@ -88,7 +91,9 @@ __global__ __launch_bounds__(256) void conv1_1_wgrad_kernel(C11Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ow = ow0 + 8 * j + rsub;
-            const unsigned v = ow < a.Wo ? (unsigned)(((b * a.Ho + oh) * a.Wo + ow) * 128) + chunkoff : kOOB1;
+            const int yc = band_map(oh, a.cut.ya, a.cut.ye, a.cut.ya2, a.cut.ye2);
+            const int xc = ow < a.Wo ? band_map(ow, a.cut.xa, a.cut.xe, a.cut.xa2, a.cut.xe2) : -1;     // removed / outside: zeros
+            const unsigned v = (xc >= 0 && yc >= 0) ? (unsigned)(((b * a.Hc + yc) * a.Wc + xc) * 128) + chunkoff : kOOB1;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsptr_t)(sb + j * 1024), 16, v, 0, 0, 0);
         }
     };
@@ -310,12 +315,15 @@ extern "C" int szn_conv1_1_wgrad_reads(int dtype, int B, int H, int W, int pad, 
 
 // bf16 path of szn_conv1_1_wgrad (szn_elementwise.hip).  workspace: >= nblocks * 8 KiB.  Returns 1 if not applicable.
 int szn_conv1_1_wgrad_fused_try(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
-                                void* workspace, size_t workspace_bytes, szn_stream_t stream) {
+                                void* workspace, size_t workspace_bytes, szn_stream_t stream, const int* cutv) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     int oh_lo, oh_hi, seg_lo, seg_hi;
     if (!c11_geometry(dtype, B, H, W, pad, oh_lo, oh_hi, seg_lo, seg_hi)) return 1;
-    const size_t dout_bytes = (size_t)B * Ho * Wo * 128, x_bytes = (size_t)B * 3 * H * W * 4;
     C11Args a;
+    a.cut = BandCut{0, 0, Ho, Ho, 0, 0, Wo, Wo};
+    if (cutv) a.cut = BandCut{cutv[0], cutv[1], cutv[2], cutv[3], cutv[4], cutv[5], cutv[6], cutv[7]};
+    a.Hc = Ho - (a.cut.ye - a.cut.ya) - (a.cut.ye2 - a.cut.ya2); a.Wc = Wo - (a.cut.xe - a.cut.xa) - (a.cut.xe2 - a.cut.xa2);
+    const size_t dout_bytes = (size_t)B * a.Hc * a.Wc * 128, x_bytes = (size_t)B * 3 * H * W * 4;
     a.dout = (const char*)dout; a.x = x; a.ws = (float*)workspace;
     a.dout_bytes = (unsigned)dout_bytes; a.x_bytes = (unsigned)x_bytes;
     a.B = B; a.H = H; a.W = W; a.pad = pad; a.Ho = Ho; a.Wo = Wo;

@@ -4,6 +4,7 @@
 // Reference sites: models.py:43-47 (conv1_1, pools), models.py:86,91 (Dropout2d), train.py:126-133,174-175
 // (torch.optim.SGD / Adam with two parameter groups).
 #include "szn_common.h"
+#include "szn_cb.h"
 #include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
@@ -300,9 +301,12 @@ constexpr int PATCHF = 9 * PSF;                          // floats per wave
 template <typename T, bool AHEAD>      // AHEAD: the next run's image loads are issued before this run's segments (19 more live VGPRs)
 __global__ __launch_bounds__(256) void conv1_1_fwd16s_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, T* __restrict__ out, int B,
-                                                             int H, int W, int pad, int Ho, int Wo, unsigned x_bytes) {
+                                                             int H, int W, int pad, int Ho, int Wo, unsigned x_bytes, BandCut cut) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(sizeof(T) == 2, "16-bit storage only");
+    // cut (round 5): rows / columns of the OUTPUT that are not stored at all -- the constant band the engine removes in front of conv1_2
+    // (szn_conv1_1_fwd_c); the output is then [B][Hc][Wc][64].  An empty cut (all zeros / ends) = the full map.
+    const int Hc = Ho - (cut.ye - cut.ya) - (cut.ye2 - cut.ya2), Wc = Wo - (cut.xe - cut.xa) - (cut.xe2 - cut.xa2);
     __shared__ float spatch[4 * PATCHF];
     const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
     float* const patch = spatch + (threadIdx.x >> 6) * PATCHF;
@@ -342,19 +346,19 @@ __global__ __launch_bounds__(256) void conv1_1_fwd16s_kernel(const float* __rest
     }
     constexpr int SEGS = 8, NLD = 19;                    // 19 x 64 >= 9 x 130 patch elements
     const int nsx = (Wo + 15) >> 4, nch = (nsx + SEGS - 1) / SEGS;
-    const int ntask = B * Ho * nch;
+    const int ntask = B * Hc * nch;                      // (rows enumerated in cropped coordinates)
     const int nwaves = (int)gridDim.x * 4;
     const int wave0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
     // does the run see the image at all (wave-uniform)?
     auto run_touches = [&](int task) {
-        const int ch = task % nch, oh = (task / nch) % Ho;
+        const int ch = task % nch, oh = band_unmap((task / nch) % Hc, cut.ya, cut.ye, cut.ya2, cut.ye2);
         const int ih0 = oh - pad, iwA = ch * (SEGS * 16) - pad;
         return (ih0 + 2 >= 0) && (ih0 < H) && (iwA + SEGS * 16 + 1 >= 0) && (iwA < W);
     };
     float xr[NLD];
     auto stage_load = [&](int task) {
         const int ch = task % nch, rowid = task / nch;
-        const int oh = rowid % Ho, b = rowid / Ho;
+        const int oh = band_unmap(rowid % Hc, cut.ya, cut.ye, cut.ya2, cut.ye2), b = rowid / Hc;
         const int ih0 = oh - pad, iwA = ch * (SEGS * 16) - pad;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
@@ -380,11 +384,12 @@ __global__ __launch_bounds__(256) void conv1_1_fwd16s_kernel(const float* __rest
     if (AHEAD && wave0 < ntask && run_touches(wave0)) { stage_load(wave0); have = true; }
     for (int task = wave0; task < ntask; task += nwaves) {
       const int ch = task % nch, rowid = task / nch;
-      const int oh = rowid % Ho, b = rowid / Ho;
+      const int ohc = rowid % Hc, b = rowid / Hc;
+      const int oh = band_unmap(ohc, cut.ya, cut.ye, cut.ya2, cut.ye2);
       const int ih0 = oh - pad;
       const int sx0 = ch * SEGS, sx_end = min(nsx, sx0 + SEGS);
       const bool rowhit = (ih0 + 2 >= 0) && (ih0 < H);
-      T* orow = out + (((long)b * Ho + oh) * Wo) * 64 + (lo ? cst[0] : cst[1]);
+      T* orow = out + (((long)b * Hc + ohc) * Wc) * 64 + (lo ? cst[0] : cst[1]);
       if constexpr (!AHEAD) {
           if (run_touches(task)) { stage_load(task); have = true; }
       }
@@ -398,11 +403,12 @@ __global__ __launch_bounds__(256) void conv1_1_fwd16s_kernel(const float* __rest
       for (int sx = sx0; sx < sx_end; ++sx) {
         const int iw0 = sx * 16 - pad;
         const int owa = sx * 16 + (r16 & 7);
-        T* op = orow + (long)owa * 64;
+        const int xca = owa < Wo ? band_map(owa, cut.xa, cut.xe, cut.xa2, cut.xe2) : -1;          // cropped columns of this lane's two pixels
+        const int xcb = owa + 8 < Wo ? band_map(owa + 8, cut.xa, cut.xe, cut.xa2, cut.xe2) : -1;
         const bool touches = rowhit && (iw0 + 17 >= 0) && (iw0 < W);                            // wave-uniform
         if (!touches) {
-            if (owa < Wo) *(u32x4_t*)op = cpiece;
-            if (owa + 8 < Wo) *(u32x4_t*)(op + 8 * 64) = cpiece;
+            if (xca >= 0) *(u32x4_t*)(orow + (long)xca * 64) = cpiece;
+            if (xcb >= 0) *(u32x4_t*)(orow + (long)xcb * 64) = cpiece;
             continue;
         }
         const float* pp = patch + (sx - sx0) * 16;
@@ -435,8 +441,8 @@ __global__ __launch_bounds__(256) void conv1_1_fwd16s_kernel(const float* __rest
         recv.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.z, 0x128, 0xf, 0xf, false);
         recv.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send.w, 0x128, 0xf, 0xf, false);
         const u32x4_t va = lo ? v2[0] : recv, vb = lo ? recv : v2[1];
-        if (owa < Wo) *(u32x4_t*)op = va;
-        if (owa + 8 < Wo) *(u32x4_t*)(op + 8 * 64) = vb;
+        if (xca >= 0) *(u32x4_t*)(orow + (long)xca * 64) = va;
+        if (xcb >= 0) *(u32x4_t*)(orow + (long)xcb * 64) = vb;
       }
     }
 #endif
@@ -881,10 +887,34 @@ inline int grid_for(long n, int per_block = 256, int cap = 8192) {
 
 }  // namespace
 
+static bool c11_cut_ok(const int* c, int Ho, int Wo, BandCut& cut) {
+    cut = BandCut{0, 0, Ho, Ho, 0, 0, Wo, Wo};
+    if (!c) return true;
+    cut = BandCut{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]};
+    return 0 <= cut.ya && cut.ya <= cut.ye && cut.ye <= cut.ya2 && cut.ya2 <= cut.ye2 && cut.ye2 <= Ho &&
+           0 <= cut.xa && cut.xa <= cut.xe && cut.xe <= cut.xa2 && cut.xa2 <= cut.xe2 && cut.xe2 <= Wo;
+}
+
+static int conv1_1_fwd_impl(int dtype, int B, int H, int W, int pad, const float* x, const float* w, const float* bias, void* out,
+                            const int* cutv, szn_stream_t stream);
+
 extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const float* x, const float* w,
                                const float* bias, void* out, szn_stream_t stream) {
+    return conv1_1_fwd_impl(dtype, B, H, W, pad, x, w, bias, out, nullptr, stream);
+}
+
+extern "C" int szn_conv1_1_fwd_c(int dtype, int B, int H, int W, int pad, const float* x, const float* w,
+                                 const float* bias, void* out, const int cut[8], szn_stream_t stream) {
+    if (!cut) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd_c: cut is NULL");
+    return conv1_1_fwd_impl(dtype, B, H, W, pad, x, w, bias, out, cut, stream);
+}
+
+static int conv1_1_fwd_impl(int dtype, int B, int H, int W, int pad, const float* x, const float* w, const float* bias, void* out,
+                            const int* cutv, szn_stream_t stream) {
     if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || pad < 0) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd: bad argument");
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    BandCut cut;
+    if (!c11_cut_ok(cutv, Ho, Wo, cut)) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd_c: cut intervals must be ordered and inside the map");
     if (Ho <= 0 || Wo <= 0) SZN_FAIL(SZN_ERR_ARG, "conv1_1_fwd: empty output");
     if ((long)3 * H * W >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd: image plane too large");
     const long nseg = (long)B * Ho * ((Wo + 15) / 16);     // 16-pixel segments, one wave each (grid-stride)
@@ -906,18 +936,20 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
     if (ahead < 0) { const char* e = getenv("SZN_C11_FWD_AHEAD"); ahead = e ? atoi(e) : 1; }
     if (sblocks < 0) { const char* e = getenv("SZN_C11_FWD_BLOCKS"); sblocks = e ? atoi(e) : 1024; }
     if (staged && sblocks > 0 && blocks16 > sblocks) blocks16 = sblocks;
+    if (cutv && !(szn_is16(dtype) && mm16 && staged))
+        SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd_c: only the staged 16-bit kernel writes a cropped map");
     if (dtype == SZN_BF16 && mm16 && staged && ahead)
         hipLaunchKernelGGL((conv1_1_fwd16s_kernel<bf16_raw, true>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                           (bf16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes);
+                           (bf16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes, cut);
     else if (dtype == SZN_BF16 && mm16 && staged)
         hipLaunchKernelGGL((conv1_1_fwd16s_kernel<bf16_raw, false>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                           (bf16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes);
+                           (bf16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes, cut);
     else if (dtype == SZN_F16 && mm16 && staged && ahead)
         hipLaunchKernelGGL((conv1_1_fwd16s_kernel<f16_raw, true>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                           (f16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes);
+                           (f16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes, cut);
     else if (dtype == SZN_F16 && mm16 && staged)
         hipLaunchKernelGGL((conv1_1_fwd16s_kernel<f16_raw, false>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                           (f16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes);
+                           (f16_raw*)out, B, H, W, pad, Ho, Wo, (unsigned)x_bytes, cut);
     else if (dtype == SZN_BF16 && mm16)
         hipLaunchKernelGGL(conv1_1_fwd16_kernel<bf16_raw>, dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                            (bf16_raw*)out, B, H, W, pad, Ho, Wo);
@@ -940,7 +972,7 @@ extern "C" int szn_conv1_1_fwd(int dtype, int B, int H, int W, int pad, const fl
 }
 
 int szn_conv1_1_wgrad_fused_try(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw, int accumulate,
-                                void* workspace, size_t workspace_bytes, szn_stream_t stream);
+                                void* workspace, size_t workspace_bytes, szn_stream_t stream, const int* cut = nullptr);
 
 static constexpr size_t kC11SlabBytes = (size_t)32 << 20;
 extern "C" size_t szn_conv1_1_wgrad_workspace_bytes(int dtype, int B, int H, int W, int pad) {
@@ -948,6 +980,22 @@ extern "C" size_t szn_conv1_1_wgrad_workspace_bytes(int dtype, int B, int H, int
     const size_t Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     // im2col image + the [64][32] fp32 result + room for the fixed-order pixel-split slabs of the GEMM behind it (8 KiB per split)
     return (size_t)B * Ho * Wo * 32 * szn_esize(dtype) + 64 * 32 * sizeof(float) + kC11SlabBytes;
+}
+
+// dout given as the CROPPED map [B][Hc][Wc][64] that szn_conv1_1_fwd_c wrote the activations of (same cut): the removed rows / columns hold no
+// image pixel in their windows, so they contribute nothing to dw.  16-bit fused kernel only; db must be NULL (it comes from column sums).
+extern "C" int szn_conv1_1_wgrad_c(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw,
+                                   int accumulate, void* workspace, const int cut[8], szn_stream_t stream) {
+    if (!x || !dout || !dw || !workspace || !cut || B <= 0 || H <= 0 || W <= 0 || pad < 0)
+        SZN_FAIL(SZN_ERR_ARG, "conv1_1_wgrad_c: bad argument");
+    if ((uintptr_t)workspace & 15) SZN_FAIL(SZN_ERR_ARG, "conv1_1_wgrad_c: workspace must be 16-B aligned");
+    BandCut bc;
+    if (!c11_cut_ok(cut, H + 2 * pad - 2, W + 2 * pad - 2, bc)) SZN_FAIL(SZN_ERR_ARG, "conv1_1_wgrad_c: bad cut");
+    if (!szn_is16(dtype)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_wgrad_c: 16-bit gradients only");
+    const int rc = szn_conv1_1_wgrad_fused_try(dtype, B, H, W, pad, x, dout, dw, accumulate, workspace,
+                                               szn_conv1_1_wgrad_workspace_bytes(dtype, B, H, W, pad), stream, cut);
+    if (rc > 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_wgrad_c: the fused kernel declined this shape");
+    return rc;
 }
 
 extern "C" int szn_conv1_1_wgrad(int dtype, int B, int H, int W, int pad, const float* x, const void* dout, float* dw,

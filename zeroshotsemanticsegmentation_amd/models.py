@@ -97,6 +97,7 @@ def _cb_pool(reg, n):
 _BAND_CROP = os.environ.get("SZN_BAND_CROP", "1") != "0"
 _BAND_BLOCKS = {"conv1_2": ("conv1_2",), "conv2_1": ("conv2_1", "conv2_2"), "conv3_1": ("conv3_1", "conv3_2", "conv3_3")}   # first layer -> block
 _BAND_16BIT = os.environ.get("SZN_BAND_BLOCKS16", "conv2_1,conv3_1").split(",")      # blocks cropped on the 16-bit paths (fp32: all)
+_BAND_C11 = os.environ.get("SZN_BAND_C11", "1") != "0"       # 16-bit paths: conv1_1 writes its output cropped (szn_conv1_1_fwd_c) and conv1_2's block runs on it
 _BAND_FUSE = os.environ.get("SZN_BAND_FUSE", "1") != "0"      # 0: every block copies its pooled rows back before the next block crops again
 
 
@@ -124,6 +125,16 @@ class _BandPlan(object):
     def __init__(self, regy, regx, H, W, device, L=3):
         self.H, self.W = H, W
         ty, tx = self._axis(regy, H, L), self._axis(regx, W, L)
+        cut8 = []
+        for reg, n in ((regy, H), (regx, W)):       # {a, e, a2, e2} per axis for the kernels that take a cut (szn_conv1_1_fwd_c / _wgrad_c)
+            top, bot = (0, 0), (n, n)
+            for a, e, _, _ in _band_cut(reg, n, L):
+                if e <= reg[0]:
+                    top = (a, e)
+                else:
+                    bot = (a, e)
+            cut8 += [top[0], top[1], bot[0], bot[1]]
+        self.cut8 = (C.c_int * 8)(*cut8)
         self.ok = ty is not None and tx is not None and (ty["n"] < H or tx["n"] < W)
         if not self.ok:
             return
@@ -504,14 +515,27 @@ class _Engine(object):
         ctx = _Ctx()
         ctx.x, ctx.B, ctx.H, ctx.W, ctx.train = x, B, H, W, train
         H1, W1 = H + 2 * PAD1 - 2, W + 2 * PAD1 - 2
-        a = torch.empty(B, H1, W1, 64, device=x.device, dtype=self.dtype)
-        L.call("szn_conv1_1_fwd", code, B, H, W, PAD1, L.ptr(x), L.ptr(self._images["conv1_1.w"]),
-               L.ptr(self._images["conv1_1.b"]), L.ptr(a), L.stream_ptr())
+        regy, regx = _cb_conv1_1(H, PAD1), _cb_conv1_1(W, PAD1)         # constant-border regions of the current tensor, per axis
+        ctx.crop = {}
+        a = c11 = None
+        if _BAND_CROP and _BAND_C11 and self.dtype != torch.float32 and not self.keep_prepool and (self.pool_codes or not keep):
+            # 16-bit paths: conv1_1 never stores the rows / columns of the constant band that conv1_2's block does without (92 per side
+            # at 512 x 512: 526^2 instead of 710^2 pixels written here, read by conv1_2, pooled, and walked by the backward pass)
+            c11 = self._band_plan(regy, regx, H1, W1, x.device, len(_BAND_BLOCKS["conv1_2"]))
+            if c11 is not None:
+                a = torch.empty(B, c11.Hc, c11.Wc, 64, device=x.device, dtype=self.dtype)
+                try:
+                    L.call("szn_conv1_1_fwd_c", code, B, H, W, PAD1, L.ptr(x), L.ptr(self._images["conv1_1.w"]),
+                           L.ptr(self._images["conv1_1.b"]), L.ptr(a), c11.cut8, L.stream_ptr())
+                except L.SznError:                                      # (a kernel variant that writes full maps only)
+                    a = c11 = None
+        if a is None:
+            a = torch.empty(B, H1, W1, 64, device=x.device, dtype=self.dtype)
+            L.call("szn_conv1_1_fwd", code, B, H, W, PAD1, L.ptr(x), L.ptr(self._images["conv1_1.w"]),
+                   L.ptr(self._images["conv1_1.b"]), L.ptr(a), L.stream_ptr())
         acts, pools = ({"conv1_1": a} if keep else {}), []
         items = _BACKBONE[1:]
-        regy, regx = _cb_conv1_1(H, PAD1), _cb_conv1_1(W, PAD1)         # constant-border regions of the current tensor, per axis
         cb_in = ctx.cb_in = {}
-        ctx.crop = {}
         band = pending = None
         for i, item in enumerate(items):
             if item == "P":
@@ -519,10 +543,13 @@ class _Engine(object):
                 continue                                  # pooled by the conv in front of it (pool_out)
             name, pad = item
             if name in _BAND_BLOCKS and _BAND_CROP and not self.keep_prepool and (self.pool_codes or not keep) and \
-                    (self.dtype == torch.float32 or name in _BAND_16BIT):
+                    (self.dtype == torch.float32 or name in _BAND_16BIT or (i == 0 and c11 is not None)):
                 # the constant band inside a conv block: remove most of it (see _band_cut), put the pooled rows back behind the block's pool
                 blk = _BAND_BLOCKS[name]
-                if pending is not None:                   # the previous block's pooled output is still in ITS cropped coordinates
+                if i == 0 and c11 is not None:            # conv1_1 wrote the cropped map itself
+                    band = c11
+                    ctx.crop["c11cut"] = c11.cut8
+                elif pending is not None:                 # the previous block's pooled output is still in ITS cropped coordinates
                     prev_band, band = pending
                     a = self._band_remap(a, band, prev_band.fused_with(band)["fwd"], band.Hc, band.Wc)
                     ctx.crop[("fused", name)] = prev_band
@@ -920,7 +947,8 @@ class _Engine(object):
                             regions += list(r8)
                             want.append("w")
                     # (from two 512 x 512 images on: the three small launches that replace the tiles cost what they save on one image)
-                    if prev2 != "P" and prev2[0] == "conv1_1" and _DGRAD_BORDER and B * Hi * Wi >= 1000000:
+                    if prev2 != "P" and prev2[0] == "conv1_1" and _DGRAD_BORDER and B * Hi * Wi >= 1000000 and \
+                            ("in", producer) not in (ctx.crop or {}):
                         # the producer's dgrad feeds conv1_1 only: the part of the map it can replace by region sums of dn
                         grect, srect = self._conv1_1_dgrad_cb(ctx)
                         ci2 = lay.in_channels
@@ -955,8 +983,12 @@ class _Engine(object):
                 nb = L.load().szn_conv1_1_wgrad_workspace_bytes(code, ctx.B, ctx.H, ctx.W, PAD1)
                 ws = torch.empty(nb, dtype=torch.uint8, device=d.device)
                 with self._wgrad_stream(d, ws):
-                    L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), None, 0,
-                           L.ptr(ws), L.stream_ptr())          # db came from conv1_2's dgrad (colsum)
+                    if ctx.crop and "c11cut" in ctx.crop:      # d is the cropped map conv1_2's dgrad wrote
+                        L.call("szn_conv1_1_wgrad_c", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), 0,
+                               L.ptr(ws), ctx.crop["c11cut"], L.stream_ptr())
+                    else:
+                        L.call("szn_conv1_1_wgrad", code, ctx.B, ctx.H, ctx.W, PAD1, L.ptr(ctx.x), L.ptr(d), L.ptr(dw), None, 0,
+                               L.ptr(ws), L.stream_ptr())      # db came from conv1_2's dgrad (colsum)
                     if name in lp:                             # 1,728 elements: converted, not produced, as 16-bit
                         L.call("szn_cast", L.SZN_F32, L.dtype_code(lp[name].dtype), dw.numel(), L.ptr(dw), L.ptr(lp[name]), L.stream_ptr())
                     done(name)
@@ -988,7 +1020,7 @@ class _Engine(object):
             else:
                 cb = self._conv1_1_dgrad_cb(ctx) if (prev[0] == "conv1_1" and not cropped_in) else None
                 d = self._dgrad(d, name, xin.shape, pad, gate=xin, colsum=grads[prev[0]][1], cb=cb, border_sum=border_sums.pop(name, None))
-                if cropped_in:                                 # (fp32: conv1_2's block; conv1_1's weight gradient reads the full map)
+                if cropped_in and "c11cut" not in ctx.crop:    # (fp32: conv1_2's block; conv1_1's weight gradient reads the full map)
                     band = ctx.crop[("in", name)][0]
                     d = self._band_remap(d, band, "crop_bwd", band.H, band.W)
         self._join_wgrad()
