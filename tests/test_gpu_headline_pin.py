@@ -1,12 +1,13 @@
 """The headline configuration of bench.py, pinned: bf16 operands, B = 8, 512 x 512, E = 300, K = 59 (49 seen),
-train mode, fused-from-coarse head, every shortcut of the throughput path on (constant-border hints of the forward / weight-gradient /
-dgrad kernels, cin-chunk-major K order of conv_igemm_8ph, pool-backward tile sums, fc6's Adam in its weight-gradient epilogue).
+train mode, fused-from-coarse head, every shortcut of the throughput path on (the constant band removed from the conv1_2 / conv2 / conv3 blocks, cin-chunk-major K order of
+conv_igemm_8ph, fc6's Adam in its weight-gradient epilogue).
 
 Reference = the SAME step in fp32 through the HIP path, which tests/test_gpu_parity_full.py pins element by element to the oracle
 (the restatement of trainer_fcn.py:149-180 / models.py:114-160 / utils.py:75-102,159-185).  For every optimizer-visible tensor the
 relative L2 error and the cosine of the bf16 gradient are bounded (bounds = 1.5 x what was measured on MI355X, written below with
-the reason they grow towards the input), the loss agrees to 2e-2 and the class map to >= 0.99.  A second bf16 run in a child process with the hints off (SZN_CONST_BORDER=0 SZN_WGT_CB=0
-SZN_DGRAD_BORDER=0: environment variables are read once per process) shows that the hints move nothing beyond fp32 re-ordering."""
+the reason they grow towards the input), the loss agrees to 2e-2 and the class map to >= 0.99.  Two more bf16 runs in child processes -- full maps with the tile-skipping hints (SZN_BAND_CROP=0) and fully dense
+(also SZN_CONST_BORDER=0 SZN_WGT_CB=0 SZN_DGRAD_BORDER=0: environment variables are read once per process) -- show that the band removal
+and the hints move nothing beyond fp32 re-ordering."""
 import os
 import subprocess
 import sys
@@ -102,19 +103,29 @@ def test_headline_bf16_step_gradients_track_the_fp32_step(fast_tmp):
     print("loss fp32 %.6f bf16 %.6f, class-map agreement %.5f" % (loss32, loss16, agree))
     bad = [r for r in rows if not (r[1] <= r[2] and r[3] >= r[4])]
     assert not bad, bad
-    # ---- the same bf16 step without the constant-border hints, in a child process
-    out = os.path.join(fast_tmp, "nohint.pt")
-    env = dict(os.environ, SZN_CONST_BORDER="0", SZN_WGT_CB="0", SZN_DGRAD_BORDER="0")
-    p = subprocess.run([sys.executable, os.path.abspath(__file__), out], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-3000:]
-    d = torch.load(out)
-    assert d["loss"] == loss16                                 # forward: the hint broadcasts the very value the dense tiles compute
-    assert torch.equal(d["pred"], pred16)
-    assert not any("border" in k for k in d["kernels"]) and any("border" in k or "cb" in k for k in k16)
-    worst = max((rel_l2(g16[name], d["grads"][name]), name) for name in g32)
-    print("hints on vs off: worst relative L2 %.3e (%s)" % worst)
-    # rank-one terms / region sums replace dense fp32 sums in another order: 1e-5 class, three orders below the bf16 error above
-    assert worst[0] < 5e-5, worst
+    # ---- the same bf16 step without the shortcuts, in child processes (the switches are read once per process):
+    #      "hints": the full maps with the tile-skipping hints of rounds 3-4 (SZN_BAND_CROP=0), "dense": neither band removal nor hints
+    assert any("band_remap" in k for k in k16)                 # the default path removes the band (round 5)
+    for tag, env_extra in (("hints", dict(SZN_BAND_CROP="0")),
+                           ("dense", dict(SZN_BAND_CROP="0", SZN_CONST_BORDER="0", SZN_WGT_CB="0", SZN_DGRAD_BORDER="0"))):
+        out = os.path.join(fast_tmp, tag + ".pt")
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), out], env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                           timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        d = torch.load(out)
+        assert d["loss"] == loss16                             # forward: a kept pixel sees the very values it would see in the full map
+        assert torch.equal(d["pred"], pred16)
+        assert not any("band_remap" in k for k in d["kernels"])
+        if tag == "hints":
+            assert any("border" in k or "cb" in k for k in d["kernels"])
+        else:
+            assert not any("border" in k for k in d["kernels"])
+        worst_w = max((rel_l2(g16[name], d["grads"][name]), name) for name in g32 if name.endswith(".weight"))
+        worst_b = max((rel_l2(g16[name], d["grads"][name]), name) for name in g32 if name.endswith(".bias"))
+        print("default vs %s: worst relative L2 weights %.3e (%s), biases %.3e (%s)" % ((tag,) + worst_w + worst_b))
+        # rank-one terms / region sums / summed band gradients replace dense fp32 sums in another order (weights: 1e-6 class); the summed band
+        # gradient passes through one more bf16 rounding before it reaches the bias sums (1e-4 class) -- orders below the bf16 envelope above
+        assert worst_w[0] < 5e-5 and worst_b[0] < 2e-3, (worst_w, worst_b)
 
 
 if __name__ == "__main__":          # child of the test above: the bf16 step under the caller's environment -> torch.save
