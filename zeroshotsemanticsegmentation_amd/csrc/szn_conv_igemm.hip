@@ -493,15 +493,20 @@ __global__ __launch_bounds__(256) void splitk_epilogue_cs(const float* __restric
     const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n, n = c4 * 4;
     const long m0 = (long)blockIdx.x * rpb, m1 = m0 + rpb < a.M ? m0 + rpb : a.M;
     f32x4_t cs = {0.f, 0.f, 0.f, 0.f};
-    for (long m = m0 + rl; m < m1; m += RL) {
-        const long i4 = m * c4n + c4;
-        f32x4_t x = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < a.nsplit; ++sp) x += *(const f32x4_t*)(ws + (long)sp * total + i4 * 4);
+    // four rows in flight per thread: all their slab / gate loads go out before the first is used (one row at a time, this kernel was a
+    // chain of dependent round trips: 41 us for conv3_x's dgrad of a one-image step against ~10 us for the plain epilogue)
+    auto finish = [&](long m, f32x4_t x, uint2 gq) {
         if (a.bias) x += *(const f32x4_t*)(a.bias + n);
         if (a.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
         if (gate) {
+            if (sizeof(T) == 2) {
+                const uint16_t g0 = (uint16_t)(gq.x & 0xffffu), g1 = (uint16_t)(gq.x >> 16), g2 = (uint16_t)(gq.y & 0xffffu), g3 = (uint16_t)(gq.y >> 16);
+                x[0] = from_bits16<T>(g0) > 0.f ? x[0] : 0.f; x[1] = from_bits16<T>(g1) > 0.f ? x[1] : 0.f;
+                x[2] = from_bits16<T>(g2) > 0.f ? x[2] : 0.f; x[3] = from_bits16<T>(g3) > 0.f ? x[3] : 0.f;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = (elem<T>::ld(gate + m * a.ldg + n + e) > 0.f) ? x[e] : 0.f;
+                for (int e = 0; e < 4; ++e) x[e] = (elem<T>::ld(gate + m * a.ldg + n + e) > 0.f) ? x[e] : 0.f;
+            }
         }
         if (a.cscale) x *= *(const f32x4_t*)(a.cscale + (m / a.HoWo) * a.Co + n);
         cs += x;
@@ -511,6 +516,29 @@ __global__ __launch_bounds__(256) void splitk_epilogue_cs(const float* __restric
             o.x = pack2<T>(x[0], x[1]); o.y = pack2<T>(x[2], x[3]);
             *(uint2*)((uint16_t*)a.out + m * a.ldo + n) = o;
         }
+    };
+    long m = m0 + rl;
+    for (; m + 3L * RL < m1; m += 4L * RL) {
+        f32x4_t x[4];
+        uint2 gq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i4 = (m + (long)u * RL) * c4n + c4;
+            x[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < a.nsplit; ++sp) x[u] += *(const f32x4_t*)(ws + (long)sp * total + i4 * 4);
+            gq[u] = uint2{0u, 0u};
+            if (gate && sizeof(T) == 2) gq[u] = *(const uint2*)((const uint16_t*)gate + (m + (long)u * RL) * a.ldg + n);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) finish(m + (long)u * RL, x[u], gq[u]);
+    }
+    for (; m < m1; m += RL) {
+        const long i4 = m * c4n + c4;
+        f32x4_t x = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < a.nsplit; ++sp) x += *(const f32x4_t*)(ws + (long)sp * total + i4 * 4);
+        uint2 gq = {0u, 0u};
+        if (gate && sizeof(T) == 2) gq = *(const uint2*)((const uint16_t*)gate + m * a.ldg + n);
+        finish(m, x, gq);
     }
     part[threadIdx.x] = cs;
     __syncthreads();
