@@ -55,6 +55,12 @@ typedef struct {
     int clock_mhz;
 } szn_device_info_t;
 int szn_device_info(int device, szn_device_info_t* out /* host */);
+/* A stream confined to the compute units of `mask` (bit i of word i / 32 = CU i; n_words x 32 bits) -- what
+ * torch.cuda.Stream() would be for the reference if it split its one-image step (train.py:82-84) over two queues: the engine
+ * runs fc6's HBM-bound weight gradient + Adam step there while the few-tile dgrads of conv5_x .. conv3_x use the other CUs.
+ * The handle is a hipStream_t: wrap it (torch.cuda.ExternalStream) or pass it as `stream` to any entry point. */
+int szn_stream_create_cu_mask(int n_words, const uint32_t* mask /* host */, szn_stream_t* out /* host */);
+int szn_stream_destroy(szn_stream_t stream);
 
 /* ---- stride-1 convolution as implicit GEMM on MFMA --------------------------------------------
  * Replaces nn.Conv2d forward/backward for conv1_2..conv5_3 (3x3 pad 1), fc6 (7x7 valid), fc7 and

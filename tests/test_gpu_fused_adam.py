@@ -178,3 +178,59 @@ def test_fused_adam_is_off_where_the_gradient_is_not_final():
         m = models.FCN32s(E).load_synthetic(1337).cuda().eval()
         ts = engine.TrainStep(m, emb, **kw)
         assert not ts.fused_adam
+
+
+def test_cu_masked_stream_entry_points():
+    """szn_stream_create_cu_mask / szn_stream_destroy: a kernel runs on the masked stream; bad arguments are refused"""
+    info = L.DeviceInfo()
+    L.call("szn_device_info", 0, C.byref(info))
+    words = (info.compute_units + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for cu in range(info.compute_units // 2):
+        mask[cu // 32] |= 1 << (cu % 32)
+    h = C.c_void_p()
+    L.call("szn_stream_create_cu_mask", words, mask, C.byref(h))
+    assert h.value
+    x = torch.randn(1 << 20, device="cuda")
+    y = torch.empty(1 << 20, device="cuda", dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    L.call("szn_cast", L.SZN_F32, L.SZN_BF16, x.numel(), L.ptr(x), L.ptr(y), h)
+    s = torch.cuda.ExternalStream(h.value)
+    s.synchronize()
+    assert torch.equal(y, x.to(torch.bfloat16))
+    del s
+    L.call("szn_stream_destroy", h)
+    empty = (C.c_uint32 * words)()
+    with pytest.raises(L.SznError):
+        L.call("szn_stream_create_cu_mask", words, empty, C.byref(h))
+    with pytest.raises(L.SznError):
+        L.call("szn_stream_create_cu_mask", 0, mask, C.byref(h))
+    with pytest.raises(L.SznError):
+        L.call("szn_stream_destroy", None)
+
+
+@pytest.mark.parametrize("caller", ["null", "own"])
+def test_small_step_on_a_cu_masked_stream_is_bit_identical(caller, monkeypatch):
+    """SZN_FC6_CUMASK: fc6's weight gradient + Adam of a small step on a stream confined to half of the CUs -- same kernels, same values,
+    whether the caller sits on the null stream (the step moves to a stream of its own) or on a non-blocking one"""
+    monkeypatch.setenv("SZN_FC6_CUMASK", "0")
+    ref, l0 = _run_steps(True, False, torch.bfloat16, 3)
+    monkeypatch.setenv("SZN_FC6_CUMASK", "128:low")
+    assert models.masked_stream_wanted(2 * 96 * 96) and not models.masked_stream_wanted(8 * 512 * 512)
+    if caller == "own":
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            msk, l1 = _run_steps(True, False, torch.bfloat16, 3)
+        torch.cuda.current_stream().wait_stream(side)
+        assert msk._own_stream is None
+    else:
+        msk, l1 = _run_steps(True, False, torch.bfloat16, 3)
+        assert msk._own_stream is not None
+    assert msk.eng._wg_masked                                     # the masked stream was made and used
+    assert l0 == l1
+    for name in ("flat_w", "flat_b", "flat_w_lp"):
+        assert torch.equal(getattr(msk, name), getattr(ref, name)), name
+    for key in ("w", "b"):
+        for u, v in zip(msk.state[key], ref.state[key]):
+            assert torch.equal(u, v)

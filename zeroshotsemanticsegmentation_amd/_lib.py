@@ -72,6 +72,8 @@ SIGNATURES = {
     "szn_prev_kernel": (C.c_char_p, []),
     "szn_version": (_I, []),
     "szn_device_info": (_I, [_I, C.POINTER(DeviceInfo)]),
+    "szn_stream_create_cu_mask": (_I, [_I, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),
+    "szn_stream_destroy": (_I, [C.c_void_p]),
     "szn_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "szn_pack_weight_dgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
     "szn_pack_weight_dgrad_batch": (_I, [_I, _I, _P, _P, _P, _P, _P, _P]),

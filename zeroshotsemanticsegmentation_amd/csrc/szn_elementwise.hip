@@ -50,6 +50,27 @@ extern "C" int szn_device_info(int device, szn_device_info_t* out) {
     return SZN_OK;
 }
 
+// A stream whose kernels only run on the compute units of `mask` (bit i of word i / 32 = CU i; hipExtStreamCreateWithCUMask).  The
+// engine confines the HBM-bound weight gradient + Adam step of fc6 in a ONE-image step to part of the chip with it, so that the few-tile
+// dgrads of conv5_x .. conv3_x run beside it instead of queueing for its LDS (models._Engine._side_stream).
+extern "C" int szn_stream_create_cu_mask(int n_words, const uint32_t* mask, szn_stream_t* out) {
+    if (!out || !mask || n_words <= 0) SZN_FAIL(SZN_ERR_ARG, "stream_create_cu_mask: null / empty argument");
+    bool any = false;
+    for (int i = 0; i < n_words; ++i) any = any || mask[i] != 0u;
+    if (!any) SZN_FAIL(SZN_ERR_ARG, "stream_create_cu_mask: the mask selects no compute unit");
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask);
+    if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "stream_create_cu_mask: %s", hipGetErrorString(e));
+    *out = (szn_stream_t)s;
+    return SZN_OK;
+}
+extern "C" int szn_stream_destroy(szn_stream_t stream) {
+    if (!stream) SZN_FAIL(SZN_ERR_ARG, "stream_destroy: null stream");
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "stream_destroy: %s", hipGetErrorString(e));
+    return SZN_OK;
+}
+
 namespace {
 
 // ---- conv1_1: 3 -> 64, 3x3, pad P, reads NCHW f32, writes NHWC T ---------------------------------

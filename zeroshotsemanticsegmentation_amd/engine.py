@@ -16,6 +16,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from . import synth
+from . import models as _models
 from .models import CROP, CROP_POOL3, CROP_POOL4, CROP_UP8, opt_layers
 
 
@@ -455,6 +456,7 @@ class TrainStep(object):
         # a training loop that calls zero_grad() next, train.py:170-175); the default keeps .grad meaningful.
         if fused_adam is None:
             fused_adam = os.environ.get("SZN_FUSED_ADAM", "1") == "1"
+        self._own_stream = None          # see step(): the non-blocking stream of a small step
         self.fused_adam = bool(fused_adam and optimizer == "adam" and not self.dynamic and not self.buckets.active
                                and self.flat_w_lp is not None and os.environ.get("SZN_EARLY_ADAM", "auto") != "1")
         if self.fused_adam and not self.keep_grads:
@@ -598,6 +600,34 @@ class TrainStep(object):
     def step(self, x, target):
         """x (B,3,H,W) f32 NCHW, target (B,H,W) int64 (-1 ignore), both on the GPU.
         Returns (loss 0-dim device tensor, pred (B,H,W) int64 device tensor)."""
+        work = self._small_step_stream(x)
+        if work is None:
+            return self._step(x, target)
+        # A small step (the reference's one image per step, train.py:82-84) whose fc6 update rides in its weight-gradient kernel: that
+        # kernel goes to a stream confined to part of the CUs (models._Engine._masked_stream).  Such a stream is a BLOCKING one -- it
+        # synchronises with the null stream launch by launch (measured: 2.57 -> 3.5 ms) -- so when the caller is on the null stream the
+        # whole step moves to a non-blocking stream of its own, forked from and joined to the caller's.
+        cur = torch.cuda.current_stream(self.dev)
+        work.wait_stream(cur)
+        with torch.cuda.stream(work):
+            out = self._step(x, target)
+        cur.wait_stream(work)
+        for t in out:
+            t.record_stream(cur)
+        return out
+
+    def _small_step_stream(self, x):
+        if not self.fused_adam or self.eng.dtype == torch.float32 or torch.cuda.is_current_stream_capturing():
+            return None
+        if not _models.masked_stream_wanted(x.shape[0] * x.shape[2] * x.shape[3]):
+            return None
+        if torch.cuda.current_stream(self.dev) != torch.cuda.default_stream(self.dev):
+            return None                  # already on a non-blocking stream of the caller's
+        if self._own_stream is None:
+            self._own_stream = torch.cuda.Stream(device=self.dev)
+        return self._own_stream
+
+    def _step(self, x, target):
         m, eng = self.model, self.eng
         B, _, H, W = x.shape
         st = L.stream_ptr()

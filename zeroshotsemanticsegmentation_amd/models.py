@@ -14,6 +14,7 @@ HIP kernel reached through the C-ABI of include/szn.h (no torch.nn.functional co
 The layer objects subclass torch.nn.Conv2d / ConvTranspose2d / ReLU / MaxPool2d / Dropout2d purely as typed
 parameter containers so that `train.get_parameters` (reference train.py:302-331) classifies them the same way.
 """
+import atexit
 import contextlib
 import ctypes as C
 import math
@@ -99,6 +100,41 @@ _BAND_BLOCKS = {"conv1_2": ("conv1_2",), "conv2_1": ("conv2_1", "conv2_2"), "con
 _BAND_16BIT = os.environ.get("SZN_BAND_BLOCKS16", "conv2_1,conv3_1").split(",")      # blocks cropped on the 16-bit paths (fp32: all)
 _BAND_C11 = os.environ.get("SZN_BAND_C11", "1") != "0"       # 16-bit paths: conv1_1 writes its output cropped (szn_conv1_1_fwd_c) and conv1_2's block runs on it
 _BAND_FUSE = os.environ.get("SZN_BAND_FUSE", "1") != "0"      # 0: every block copies its pooled rows back before the next block crops again
+# default of SZN_FC6_CUMASK (see _Engine._masked_stream): CUs of the stream fc6's weight gradient + Adam runs on in a small step.  Off:
+# measured on three boxes, "128:low" moved the one-image step by -0.13 / -0.04 ms for a caller on a non-blocking stream and by -0.05 / +0.02 ms
+# for a caller on the null stream (profiles/r05_ablations.txt 15) -- inside the box-to-box spread
+_FC6_CUMASK = "0"
+_SMALL_STEP_PX = 2 * 512 * 512
+
+
+def _cumask_spec():
+    """SZN_FC6_CUMASK = "<n>[:low|:even]" -> (n, how); n = 0: off"""
+    n, _, how = os.environ.get("SZN_FC6_CUMASK", _FC6_CUMASK).partition(":")
+    try:
+        return max(int(n or 0), 0), (how or "low")
+    except ValueError:
+        raise L.SznError("SZN_FC6_CUMASK: expected <n>[:low|:even], got %r" % os.environ.get("SZN_FC6_CUMASK"))
+
+
+_MASKED_HANDLES = []             # hipStream_t of every masked stream made (torch's ExternalStream does not own its handle)
+
+
+@atexit.register
+def _destroy_masked_streams():
+    # before the HIP runtime's own teardown: a profiler's finalizer otherwise walks a queue the runtime has half taken down
+    while _MASKED_HANDLES:
+        h = _MASKED_HANDLES.pop()
+        try:
+            torch.cuda.synchronize()
+            L.call("szn_stream_destroy", h)
+        except Exception:
+            pass
+
+
+def masked_stream_wanted(pixels):
+    """does a training step over `pixels` input pixels put fc6's fused weight gradient + Adam on a CU-masked stream?  (The same rule
+    as the second stream of the weight gradients: small steps only, SZN_WGRAD_STREAM not 0.)"""
+    return _cumask_spec()[0] > 0 and pixels <= _SMALL_STEP_PX and os.environ.get("SZN_WGRAD_STREAM", "auto") != "0"
 
 
 def _band_cut(reg, n, L=3):
@@ -227,6 +263,7 @@ class _Engine(object):
         self._gemm_ws = None          # fp32 Y of the GEMM + col2im dgrad (fc6)
         self._wg_ws = None            # slab workspace of the wgrad kernels (they run on their own stream)
         self._wg_stream = None        # torch.cuda.Stream, or False when disabled (SZN_WGRAD_STREAM=0)
+        self._wg_masked = None        # torch.cuda.ExternalStream on part of the CUs (see _masked_stream); False = off
         # The un-pooled outputs of conv1_2 .. conv5_3 are read by nobody but the pool's backward pass: the forward pass writes a
         # one-byte winner code per pooled element instead (szn_conv_desc_t.pool_code) and tells the conv kernel it may skip the
         # un-pooled store (pool_only; conv3x3_regw does: 516 + 258 MB per step neither written nor read back).  keep_prepool = True
@@ -692,7 +729,7 @@ class _Engine(object):
         return dcoarse, dup
 
     @contextlib.contextmanager
-    def _wgrad_stream(self, *tensors):
+    def _wgrad_stream(self, *tensors, heavy=False):
         """Weight gradients are leaves of the backward chain: with SZN_WGRAD_STREAM=1 they run on a second HIP stream, so that the tail
         of a dgrad launch and the head of the weight-gradient launch beside it overlap.  Round 1 measured no gain at B=8 (158.1 vs
         158.8 Mpx/s); at the end of round 4 -- kernels 40 % faster, so the tails weigh more -- it is worth 0.07 ms per step (8.91 ->
@@ -707,16 +744,45 @@ class _Engine(object):
         if self._wg_stream is None:
             self._wg_stream = torch.cuda.Stream(device=tensors[0].device)
         side = self._wg_stream
+        dev = tensors[0].device
+        if heavy and torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev):      # (never next to the null stream: see TrainStep.step)
+            side = self._masked_stream(dev) or side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             yield
         for t in tensors:
             t.record_stream(side)
 
+    def _masked_stream(self, dev):
+        """The stream of the ONE launch of a small step that would otherwise take every CU for half a millisecond: fc6's weight gradient
+        + Adam step (2.7 GB of optimizer state streamed once, HBM-bound; two 72-KiB blocks per CU, so that the 120-KiB dgrad kernels of
+        conv5_x .. conv3_x -- 8-124 tiles each -- found no CU to start on and the main stream stood still behind it: #48 / #49 of
+        profiles/r05_g_b1_timeline.md).  On a stream confined to SZN_FC6_CUMASK = "<n>[:low|:even]" compute units (szn_stream_create_cu_mask)
+        it leaves the rest of the chip to the backward chain.  0 = the plain side stream.  None when masking is off / unavailable."""
+        if self._wg_masked is None:
+            self._wg_masked = False
+            n, how = _cumask_spec()
+            info = L.DeviceInfo()
+            L.call("szn_device_info", dev.index or 0, C.byref(info))
+            ncu = info.compute_units
+            if 0 < n < ncu:
+                words = (ncu + 31) // 32
+                mask = (C.c_uint32 * words)()
+                picked = range(n) if how == "low" else sorted({(i * ncu) // n for i in range(n)})
+                for cu in picked:
+                    mask[cu // 32] |= 1 << (cu % 32)
+                h = C.c_void_p()
+                L.call("szn_stream_create_cu_mask", words, mask, C.byref(h))
+                self._wg_masked = torch.cuda.ExternalStream(h.value, device=dev)
+                _MASKED_HANDLES.append(h)
+        return self._wg_masked or None
+
     def _join_wgrad(self):
-        """end of a backward pass: the weight-gradient stream (if any) rejoins, the pending bias-gradient rows are reduced"""
+        """end of a backward pass: the weight-gradient streams (if any) rejoin, the pending bias-gradient rows are reduced"""
         if self._wg_stream and getattr(self, "_wg_on", False):
             torch.cuda.current_stream().wait_stream(self._wg_stream)
+            if self._wg_masked:
+                torch.cuda.current_stream().wait_stream(self._wg_masked)
         self._flush_colsum()
 
     def _conv1_1_dgrad_cb(self, ctx):
@@ -769,10 +835,12 @@ class _Engine(object):
             d.dw_lp, d.dw_lp_dtype = dw_lp.data_ptr(), L.dtype_code(dw_lp.dtype)
         if csum is not None and d.cb_on:
             d.colsum = csum.data_ptr()
-        with self._wgrad_stream(*([x, dout] + ([csum] if csum is not None else []))):
+        opt = self.fused_opt.get(fuse) if (self.fused_opt and fuse) else None
+        if opt is not None and L.load().szn_conv2d_wgrad_adam_supported(C.byref(d)) != 1:
+            opt = None
+        with self._wgrad_stream(*([x, dout] + ([csum] if csum is not None else [])), heavy=opt is not None):
             st = L.stream_ptr()
-            opt = self.fused_opt.get(fuse) if (self.fused_opt and fuse) else None
-            if opt is not None and L.load().szn_conv2d_wgrad_adam_supported(C.byref(d)) == 1:
+            if opt is not None:
                 opt[0].grad_optional = 0 if opt[1] else 1          # (dw is handed over either way: the follower form needs it)
                 L.call("szn_conv2d_wgrad_adam", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), C.byref(opt[0]), st)
                 self.fused_done.add(fuse)
@@ -866,7 +934,7 @@ class _Engine(object):
         mode = os.environ.get("SZN_WGRAD_STREAM", "auto")
         # (not while a hipGraph is being captured: replayed with the cross-stream edges the one-image step measured 2.90 ms against
         #  2.78 without them and 2.71 eager with them -- profiles/r05_ablations.txt 8)
-        self._wg_on = (mode == "1" or (mode == "auto" and ctx.B * ctx.H * ctx.W <= 2 * 512 * 512)) and \
+        self._wg_on = (mode == "1" or (mode == "auto" and ctx.B * ctx.H * ctx.W <= _SMALL_STEP_PX)) and \
             not (mode != "1" and torch.cuda.is_current_stream_capturing())
         dc = dcoarse if dcoarse.dtype == dt else dcoarse.to(dt)      # tiny (B*h*w*CP)
         feat = ctx.relu7
