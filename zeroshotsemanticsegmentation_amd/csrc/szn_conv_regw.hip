@@ -42,6 +42,7 @@ struct RwArgs {
     int dg_on, gy0, gy1, gx0, gx1, sy0, sy1, sx0, sx1;
     unsigned gref;
     unsigned in_bytes, gate_bytes;
+    unsigned out_bytes, pool_bytes;    // (< 0xffff0000: the stores go through buffer descriptors with 32-bit offsets, masked lanes by an out-of-range one)
     int Hp, Wp;
     int B, Hi, Wi, Ho, Wo, pad;
     int ldi, ldo, ldg, relu;
@@ -56,6 +57,7 @@ struct RwArgs {
 #endif
 
 constexpr unsigned kOOBr = 0x80000000u;
+constexpr unsigned kOOBst = 0xfffffff0u;                // store offset beyond any output this kernel takes (out_bytes, pool_bytes < 0xffff0000)
 constexpr int PWr = 18;
 
 __device__ __forceinline__ float row16_sum(float x) {                      // sum over the 16 lanes of a DPP row
@@ -114,6 +116,12 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
     const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)(GATED ? a.gate : a.in), 0, (int)(GATED ? a.gate_bytes : 0u), 0x00020000);
+    // stores: one 32-bit offset per lane (a lane that stores nothing gets an out-of-range one) instead of 64-bit address arithmetic and an
+    // exec-mask branch around every store -- ~40 VALU / SALU instructions per tile and wave less in the epilogue (profiles/r05_ablations.txt 17)
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)a.out_bytes, 0x00020000);
+    // (pooling only exists in the un-gated kernels: no descriptor SGPRs for it in the gated ones, which hold rsG)
+    const auto rsPo = __builtin_amdgcn_make_buffer_rsrc((void*)((!GATED && a.pool) ? a.pool : a.out), 0, (int)((!GATED && a.pool) ? a.pool_bytes : 0u), 0x00020000);
+    const auto rsPc = __builtin_amdgcn_make_buffer_rsrc((void*)((!GATED && a.pcode) ? (char*)a.pcode : a.out), 0, (int)((!GATED && a.pcode) ? a.pool_bytes >> 1 : 0u), 0x00020000);
 
     // ---- the filter bank of this wave: A fragments W[tap][s][i], lane (g, r16) = cout 32 cog + 16 i + r16, channels
     //      64 cig + 32 s + 8 g .. + 7 (OHWI) ----
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
     float cst[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cst[e] = 0.f;
+    const float relu_lo = a.relu ? 0.f : -__builtin_inff();
     int buf = 0;
     for (int t = first; t < last; ++t) {
         const bool more = t + NBUF - 1 < last;
@@ -347,8 +356,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float x = v[e] + bv[e];
-                if (a.relu) x = fmaxf(x, 0.f);
+                float x = fmaxf(v[e] + bv[e], relu_lo);             // (one v_max_f32; `if (a.relu)` cost a v_cndmask per element)
                 if constexpr (GATED) {
                     const uint32_t gw = gq[e >> 1];
                     const float gv = __uint_as_float((e & 1) ? (gw & 0xffff0000u) : (gw << 16));
@@ -362,7 +370,8 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             pk.y = pack2<T>(v[2], v[3]);
             pk.z = pack2<T>(v[4], v[5]);
             pk.w = pack2<T>(v[6], v[7]);
-            if (ok && !RW_ABL(2) && !a.skip_x && !nostore) *(u32x4_t*)(a.out + ((size_t)(m0 + j * a.Wo) * a.ldo + cstart) * 2) = pk;
+            if (!RW_ABL(2) && !a.skip_x && !nostore)             // (wave-uniform conditions)
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rsO, ok ? ((m0 + j * a.Wo) * a.ldo + cstart) * 2u : kOOBst, 0, 0);
             if constexpr (!GATED) {
                 if (a.pool && a.pcode) {
                     // pooling on the packed 16-bit patterns (post-ReLU values are >= 0: they order like unsigned integers)
@@ -391,13 +400,14 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                             Co4[i] = code;
                         }
                         const int poh = (oh0 + j) >> 1, pw = ow >> 1;
-                        if ((r16 & 1) == 0 && okw && poh < a.Hp && !RW_ABL(2)) {
-                            const size_t pe = (size_t)((b * a.Hp + poh) * a.Wp + pw) * (32 * COG) + cstart;
-                            *(u32x4_t*)(a.pool + pe * 2) = Mo;
+                        if (!RW_ABL(2)) {
+                            const bool pst = (r16 & 1) == 0 && okw && poh < a.Hp;
+                            const unsigned pe = (unsigned)((b * a.Hp + poh) * a.Wp + pw) * (32 * COG) + cstart;
+                            __builtin_amdgcn_raw_buffer_store_b128(Mo, rsPo, pst ? pe * 2u : kOOBst, 0, 0);
                             u32x2_t cb;
                             cb.x = __builtin_amdgcn_perm(Co4[1], Co4[0], 0x06040200u);
                             cb.y = __builtin_amdgcn_perm(Co4[3], Co4[2], 0x06040200u);
-                            *(u32x2_t*)(a.pcode + pe) = cb;
+                            __builtin_amdgcn_raw_buffer_store_b64(cb, rsPc, pst ? pe : kOOBst, 0, 0);
                         }
                     }
                 } else
@@ -566,6 +576,8 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.pcode = a.pool ? (unsigned char*)d->pool_code : nullptr;
     a.skip_x = (a.pool && d->pool_only) ? 1 : 0;
     a.in_bytes = (unsigned)in_bytes; a.gate_bytes = (unsigned)gate_bytes;
+    a.out_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->ldo * 2);
+    a.pool_bytes = a.pool ? (unsigned)((size_t)d->B * a.Hp * a.Wp * d->Co * 2) : 0u;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.pad = d->pad;
     a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg; a.relu = d->relu;
     a.tiles_x = szn_div_up(d->Wo, 16); a.tiles_y = szn_div_up(d->Ho, tr);
