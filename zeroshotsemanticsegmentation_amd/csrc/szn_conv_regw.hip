@@ -232,7 +232,18 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
     for (int e = 0; e < 8; ++e) cst[e] = 0.f;
     const float relu_lo = a.relu ? 0.f : -__builtin_inff();
     int buf = 0;
+#ifdef SZN_ABLATE_BUILD
+    // SZN_REGW_ABLATE bit 8 (tools/probe_regw_cycles.py): clock64 split of the tile loop per wave -- top (gate / patch DMA issue), MFMA phase,
+    // counted wait, group B's barrier, epilogue, group A's barrier -- written over the first bytes of `out` (which is garbage then)
+    long long pc[6] = {0, 0, 0, 0, 0, 0}, pk0 = 0;
+#define RW_PROBE(i) do { if (a.ablate & 8) { const long long now_ = clock64(); pc[i] += now_ - pk0; pk0 = now_; } } while (0)
+#else
+#define RW_PROBE(i) do { } while (0)
+#endif
     for (int t = first; t < last; ++t) {
+#ifdef SZN_ABLATE_BUILD
+        if (a.ablate & 8) pk0 = clock64();
+#endif
         const bool more = t + NBUF - 1 < last;
         const int b = cb_b, ty = cb_ty, tx = cb_tx;
         step(cb_b, cb_ty, cb_tx);
@@ -258,6 +269,7 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
             }
         }
         if (more && !RW_ABL(4)) issue((buf + NBUF - 1) % NBUF);
+        RW_PROBE(0);
 
         f32x4_t acc[2][4];
 #pragma unroll
@@ -331,13 +343,16 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
         float bv[8];
         *(f32x4_t*)&bv[0] = *(const f32x4_t*)(smem + G_::OFF_BIAS + cstart * 4);
         *(f32x4_t*)&bv[4] = *(const f32x4_t*)(smem + G_::OFF_BIAS + cstart * 4 + 16);
+        RW_PROBE(1);
         // retire the gate pieces of t, the patch pieces of t + 1 and the stores of t - 1
         if (NBUF == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SLOTS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RW_PROBE(2);
         if (grpB) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+        RW_PROBE(3);
         float pm[8];                                                       // pooling: the even row of the current row pair
         u32x4_t pkm = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -438,12 +453,23 @@ __global__ __launch_bounds__(512) void conv3x3_regw(RwArgs a) {
                 }
             }
         }
+        RW_PROBE(4);
         if (!grpB) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+        RW_PROBE(5);
         buf = (buf == NBUF - 1) ? 0 : buf + 1;
     }
+#ifdef SZN_ABLATE_BUILD
+    if ((a.ablate & 8) && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* pr = (float*)a.out + ((size_t)blockIdx.x * 8 + w) * 8;
+        for (int i = 0; i < 6; ++i) pr[i] = (float)pc[i];
+        pr[6] = (float)(last - first);
+        pr[7] = 1.f;
+    }
+#endif
     if constexpr (COLSUM) {
         // lane (g, r16 == 0) of wave w holds, after the row sum, the 8 couts cstart .. cstart + 7 of its wave: 8 waves x 4 rows x 8
         // values go to LDS (the patch buffers are free behind the barrier) and thread c adds the waves that own cout c in
