@@ -267,3 +267,27 @@ def test_band_cut_tables_are_consistent():
     # the bench shape: 12 rows per side at 1/4 resolution, 40 at 1/2, 92 at full resolution
     n, reg = 710, M._cb_conv1_1(512, 100)
     assert [(a, e) for a, e, _, _ in M._band_cut(reg, n, 1)] == [(4, 96), (614, 706)]
+
+
+def test_cu_mask_spec_parsing(monkeypatch):
+    """SZN_FC6_CUMASK = "<n>[:low|:even]": which steps ask for the masked stream (models.masked_stream_wanted; off by default, small steps only,
+    never with SZN_WGRAD_STREAM=0) -- host logic, no GPU"""
+    from zeroshotsemanticsegmentation_amd import _lib as L
+    from zeroshotsemanticsegmentation_amd import models
+    monkeypatch.delenv("SZN_FC6_CUMASK", raising=False)
+    monkeypatch.delenv("SZN_WGRAD_STREAM", raising=False)
+    assert models._cumask_spec() == (0, "low") and not models.masked_stream_wanted(512 * 512)
+    monkeypatch.setenv("SZN_FC6_CUMASK", "128:low")
+    assert models._cumask_spec() == (128, "low")
+    assert models.masked_stream_wanted(512 * 512) and models.masked_stream_wanted(2 * 512 * 512)
+    assert not models.masked_stream_wanted(8 * 512 * 512)
+    monkeypatch.setenv("SZN_WGRAD_STREAM", "0")
+    assert not models.masked_stream_wanted(512 * 512)
+    monkeypatch.delenv("SZN_WGRAD_STREAM")
+    monkeypatch.setenv("SZN_FC6_CUMASK", "96:even")
+    assert models._cumask_spec() == (96, "even")
+    monkeypatch.setenv("SZN_FC6_CUMASK", "-5")
+    assert models._cumask_spec()[0] == 0
+    monkeypatch.setenv("SZN_FC6_CUMASK", "half")
+    with pytest.raises(L.SznError):
+        models._cumask_spec()
