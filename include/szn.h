@@ -283,6 +283,13 @@ int szn_maxpool2x2_ceil_fwd_code(int dtype, int B, int Hi, int Wi, int C, const 
                                  szn_stream_t stream);
 int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
                                  float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream);
+/* The same pass with dout given in the coordinates of the NEXT conv block's cropped input, [B][Hs][Ws][C] (szn_band_remap): the transposed band map is
+ * applied while reading -- pooled pixel (oh, ow) takes the fp32 sum of source rows ytab[oh] = {start, count} x columns xtab[ow] = {start, count}
+ * (device int tables of (Hi + 1) / 2 and (Wi + 1) / 2 pairs; almost every pair is {shifted index, 1}), rounded once.  Replaces the two szn_band_remap
+ * passes the engine ran in front of szn_maxpool2x2_ceil_bwd_code at every cropped block boundary. */
+int szn_maxpool2x2_ceil_bwd_code_gather(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dsrc, int Hs, int Ws,
+                                        const int* ytab, const int* xtab, void* din, float* colsum, float* colsum_slab,
+                                        int colsum_slab_rows, szn_stream_t stream);
 /* The same, also summing din over the regions its consumers -- the conv in front of the pool's weight gradient and dgrad -- do not run
  * tile by tile under the constant-border hint: skip_regions [n_regions][8] (pixels, even) from szn_conv2d_wgrad_cb_region() /
  * szn_conv2d_dgrad_border_region(), n_regions = 1 or 2, skip_sum [n_regions][C] out (szn_conv_desc_t.colsum of the weight-gradient call /
@@ -483,6 +490,10 @@ int szn_loss_scale_update(float* scale_state, float growth, float backoff, int g
  * [B][Ho][Wo][C] dense, 16-B aligned, C a multiple of 8 (16-bit) / 4 (f32); ytab [Ho][2], xtab [Wo][2] int32 on the device.          */
 int szn_band_remap(int dtype, int B, int Hi, int Wi, int Ho, int Wo, int C, const void* in, void* out, const int* ytab,
                    const int* xtab, szn_stream_t stream);
+/* In place: every run {start, count} of `runs` (device int [n_runs][2]) summed (fp32, ascending) into its first row (axis 0) / column (axis 1) of
+ * d [B][H][W][C].  The summing rows / columns of a transposed band map are few; folded first, the map is a one-source gather that
+ * szn_maxpool2x2_ceil_bwd_code_gather applies while reading (rows, then columns = the two szn_band_remap passes, bit for bit). */
+int szn_band_fold(int dtype, int B, int H, int W, int C, void* d, int axis, const int* runs, int n_runs, szn_stream_t stream);
 
 /* ---- small utilities -------------------------------------------------------------------------------- */
 int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, szn_stream_t stream);

@@ -85,7 +85,8 @@ def _step(crop, precision, size, B, monkeypatch, train=True):
     finally:
         models.L.call = orig
     torch.cuda.synchronize()
-    return float(loss), pred.cpu(), ts.flat_gw.clone(), ts.flat_gb.clone(), ts, seen.count("szn_band_remap")
+    return float(loss), pred.cpu(), ts.flat_gw.clone(), ts.flat_gb.clone(), ts, (seen.count("szn_band_remap"),
+                                                                                 seen.count("szn_maxpool2x2_ceil_bwd_code_gather"))
 
 
 @pytest.mark.parametrize("precision,size,B,exact", [(torch.float32, 64, 2, False), (torch.float32, 150, 1, False), (torch.float32, 300, 1, False),
@@ -99,9 +100,10 @@ def test_train_step_with_the_band_removed_equals_the_full_step(precision, size, 
     l0, p0, gw0, gb0, ts0, n0 = _step(False, precision, size, B, monkeypatch, train=exact)
     l1, p1, gw1, gb1, ts1, n1 = _step(True, precision, size, B, monkeypatch, train=exact)
     # bf16: conv1_1 writes its map cropped (no launch), the fused maps conv1_2 -> conv2 -> conv3 blocks, copy back behind pool3; backward: the
-    # gradient of the copies in two passes, the two fused maps' transposes in two passes each (conv1_1's weight gradient reads the cropped
-    # gradient).  fp32: a crop in front and a zero-fill behind instead (its conv1_1 kernels take no cut)
-    assert n0 == 0 and n1 == (11 if precision == torch.float32 else 9)
+    # transposed maps are applied by the three pools' backward passes while they read (szn_maxpool2x2_ceil_bwd_code_gather: no launch of their
+    # own; conv1_1's weight gradient reads the cropped gradient).  fp32: a crop in front and a zero-fill behind instead (its conv1_1 kernels
+    # take no cut)
+    assert n0 == (0, 0) and n1 == ((5, 3) if precision == torch.float32 else (3, 3))
     if exact:
         assert l1 == l0 and torch.equal(p1, p0)              # forward: bit for bit
         o = ts0.woff["conv4_1"][0]                           # ... and so is everything behind the blocks (conv4_1 .. score_fr)
@@ -174,3 +176,57 @@ def test_conv1_1_cropped_forms_equal_the_full_ones(dt, geom):
     assert L.load().szn_conv1_1_fwd_c(L.SZN_F32, B, H, W, 100, L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(out32), plan.cut8, st) != 0
     torch.cuda.synchronize()
     assert float(out32.min()) == 5.0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pool_backward_reads_through_the_transposed_band_map(dt):
+    """szn_band_fold (rows, then columns, in place) + szn_maxpool2x2_ceil_bwd_code_gather == the two separable szn_band_remap passes followed by
+    szn_maxpool2x2_ceil_bwd_code, bit for bit -- din and the column sums (the producer's bias gradient); the multi-source form of the gather
+    (no fold) gives the same sums up to fp32 association / one bf16 rounding instead of two"""
+    B, H, W, Cc = 2, 178, 170, 64
+    plan = models._BandPlan((23, 155, 2, 176), (21, 151, 2, 168), H, W, torch.device("cuda", 0), 3)
+    assert plan.ok and plan.gather_uncrop["runs_y"] is not None and plan.gather_uncrop["runs_x"] is not None
+    g = torch.Generator(device="cuda").manual_seed(2)
+    d = torch.randn(B, plan.Hp, plan.Wp, Cc, device="cuda", generator=g).to(dt)          # gradient of the FULL pooled map
+    codes = torch.randint(0, 5, (B, plan.Hpc, plan.Wpc, Cc), device="cuda", generator=g, dtype=torch.uint8)
+    code = L.dtype_code(dt)
+    Hi, Wi = plan.Hc, plan.Wc                                                            # the pool's (cropped) input
+
+    def run(form):
+        dn = torch.full((B, Hi, Wi, Cc), 3.0, device="cuda", dtype=dt)
+        db = torch.zeros(Cc, device="cuda")
+        slab = torch.zeros(1024, Cc, device="cuda")
+        if form == "two passes":
+            t = d
+            for which, ho, wo in (("uncrop_bwd_y", plan.Hpc, plan.Wp), ("uncrop_bwd_x", plan.Hpc, plan.Wpc)):
+                ty, tx = plan.tabs[which]
+                out = torch.empty(B, ho, wo, Cc, device="cuda", dtype=dt)
+                L.call("szn_band_remap", code, B, t.shape[1], t.shape[2], ho, wo, Cc, L.ptr(t), L.ptr(out), L.ptr(ty), L.ptr(tx), L.stream_ptr())
+                t = out
+            L.call("szn_maxpool2x2_ceil_bwd_code", code, B, Hi, Wi, Cc, L.ptr(codes), L.ptr(t), L.ptr(dn), L.ptr(db), L.ptr(slab), 1024,
+                   L.stream_ptr())
+        else:
+            t = d.clone()
+            ty, tx = plan.tabs["uncrop_bwd"]
+            if form == "fold":
+                gf = plan.gather_uncrop
+                for axis, runs in ((0, gf["runs_y"]), (1, gf["runs_x"])):
+                    L.call("szn_band_fold", code, B, plan.Hp, plan.Wp, Cc, L.ptr(t), axis, L.ptr(runs), runs.shape[0], L.stream_ptr())
+                ty, tx = gf["tabs"]
+            L.call("szn_maxpool2x2_ceil_bwd_code_gather", code, B, Hi, Wi, Cc, L.ptr(codes), L.ptr(t), plan.Hp, plan.Wp, L.ptr(ty), L.ptr(tx),
+                   L.ptr(dn), L.ptr(db), L.ptr(slab), 1024, L.stream_ptr())
+        rows = L.load().szn_last_colsum_rows()
+        torch.cuda.synchronize()
+        return dn, slab[:rows].clone()
+    (a, ca), (b, cb), (m, cm) = run("fold"), run("two passes"), run("multi-source")
+    assert torch.equal(a, b) and torch.equal(ca, cb)
+    assert not (a == 3.0).all(dim=-1).any()
+    ty, tx = (torch.tensor(t) for t in plan.host["uncrop_bwd"])
+    single = (ty[:, 1] == 1)[:, None] & (tx[:, 1] == 1)[None, :]                         # pooled pixels with one source
+    single = single.repeat_interleave(2, 0)[:Hi].repeat_interleave(2, 1)[:, :Wi].cuda()
+    assert 0.8 < float(single.float().mean()) < 1.0
+    assert torch.equal(m[:, single], b[:, single])
+    tol = 1e-6 if dt == torch.float32 else 1.6e-2
+    assert float((m.float() - b.float()).abs().max()) <= tol * float(b.float().abs().max())
+    with pytest.raises(L.SznError):
+        L.call("szn_band_fold", code, B, plan.Hp, plan.Wp, Cc, L.ptr(d), 2, L.ptr(plan.gather_uncrop["runs_y"]), 1, L.stream_ptr())

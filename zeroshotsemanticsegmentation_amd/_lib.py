@@ -106,6 +106,7 @@ SIGNATURES = {
     "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "szn_maxpool2x2_ceil_fwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "szn_maxpool2x2_ceil_bwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "szn_maxpool2x2_ceil_bwd_code_gather": (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "szn_maxpool2x2_ceil_bwd_code_cb": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
     "szn_conv2d_wgrad_cb_region": (_I, [_D, _P]),
     "szn_bilinear_up32_crop_fwd": (_I, [_I] * 9 + [_P, _P, _P]),
@@ -146,6 +147,7 @@ SIGNATURES = {
     "szn_loss_scale_update": (_I, [_P, _F, _F, _I, _F, _F, _P]),
     "szn_cast": (_I, [_I, _I, _L, _P, _P, _P]),
     "szn_band_remap": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "szn_band_fold": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "szn_dropout2d_mask": (_I, [_L, _F, _U64, _U64, _P, _P]),
     "szn_proj_fp8_workspace_bytes": (_SZ, [_L, _I, _I]),
     "szn_proj_fp8_fwd": (_I, [_I, _I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

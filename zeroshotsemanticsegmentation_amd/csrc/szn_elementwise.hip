@@ -646,11 +646,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 // region sums: the weight gradient of the conv in front of the pool (szn_conv2d_wgrad_cb_region) and that conv's dgrad
 // (szn_conv2d_dgrad_border_region).  Rows of cslab2 [SKIP][rows][C] like cslab's.
 struct PoolSkip { int fy0, fy1, fx0, fx1, wy0, wy1, wx0, wx1; };
-template <typename T, int SKIP>
+// GATHER (round 5, szn_maxpool2x2_ceil_bwd_code_gather): the gradient of pooled pixel (oh, ow) is not dout[oh][ow] but the SUM of the source block
+// rows ytab[oh] = {start, count} x columns xtab[ow] = {start, count} of dout [B][Hs][Ws][C] -- the transposed band map (szn_band_remap's backward
+// forms: a plain shift for almost every pixel, the few rows / columns that stood in for removed copies sum theirs), read here instead of being
+// applied by two passes over the tensor in front of this kernel.  fp32 sum, rounded once; count 1 x 1 moves the bits; count 0 = no gradient.
+struct PoolGather { const int* ytab; const int* xtab; int Hs, Ws; };
+template <typename T, int SKIP, bool GATHER = false>
 __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __restrict__ code, const T* __restrict__ dout,
                                                                T* __restrict__ din, int B, int Hi, int Wi, int C, int Ho, int Wo,
                                                                float* __restrict__ colsum, float* __restrict__ cslab, PoolSkip sk,
-                                                               PoolSkip sk2, float* __restrict__ cslab2) {
+                                                               PoolSkip sk2, float* __restrict__ cslab2, PoolGather pg = PoolGather{}) {
     constexpr int CH = elem<T>::kPer16B;
     __shared__ float red[256 * CH];
     const int cpp = C / CH;
@@ -667,7 +672,28 @@ __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __
         const int ih = 2 * oh, iw = 2 * ow;
         const bool okw = iw + 1 < Wi, okh = ih + 1 < Hi;
         const long p00 = ((long)b * Hi + ih) * Wi + iw;
-        const u32x4_t vd = *(const u32x4_t*)(dout + po * C + cc * CH);
+        u32x4_t vd;
+        if constexpr (GATHER) {
+            const int ys = pg.ytab[2 * oh], yc = pg.ytab[2 * oh + 1], xs = pg.xtab[2 * ow], xc = pg.xtab[2 * ow + 1];
+            const T* src = dout + (((long)b * pg.Hs + ys) * pg.Ws + xs) * C + cc * CH;
+            if (yc == 1 && xc == 1) {
+                vd = *(const u32x4_t*)src;
+            } else {
+                float acc[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+                for (int yy = 0; yy < yc; ++yy)
+                    for (int xx = 0; xx < xc; ++xx) {
+                        const u32x4_t q = *(const u32x4_t*)(src + ((long)yy * pg.Ws + xx) * C);
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) acc[e] += elem<T>::ld((const T*)&q + e);
+                    }
+#pragma unroll
+                for (int e = 0; e < CH; ++e) elem<T>::st((T*)&vd + e, acc[e]);
+            }
+        } else {
+            vd = *(const u32x4_t*)(dout + po * C + cc * CH);
+        }
         const T* de = (const T*)&vd;
         const uint8_t* cp = code + po * C + cc * CH;
         const uint32_t clo = *(const uint32_t*)cp, chi = CH == 8 ? *(const uint32_t*)(cp + 4) : 0u;
@@ -1142,7 +1168,7 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
 
 static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din, float* colsum,
                                  float* colsum_slab, int colsum_slab_rows, const int* skip_tiles, int n_regions, float* skip_sum,
-                                 float* skip_slab, szn_stream_t stream) {
+                                 float* skip_slab, szn_stream_t stream, const PoolGather* gather = nullptr) {
     if (!code || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: bad argument");
     const int ch = szn_is16(dtype) ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_code: C must be a multiple of %d", ch);
@@ -1172,8 +1198,9 @@ static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const 
     hipStream_t st = (hipStream_t)stream;
 #define SZN_POOLBWD_LAUNCH(TT, SK)                                                                                                      \
     hipLaunchKernelGGL((maxpool_bwd_code_kernel<TT, SK>), dim3(grid), dim3(256), 0, st, (const uint8_t*)code, (const TT*)dout, (TT*)din, B, \
-                       Hi, Wi, C, Ho, Wo, colsum, cslab, sk, sk2, skip_slab)
-#define SZN_POOLBWD_BY_SKIP(TT) do { if (nsk == 2) SZN_POOLBWD_LAUNCH(TT, 2); else if (nsk == 1) SZN_POOLBWD_LAUNCH(TT, 1); else SZN_POOLBWD_LAUNCH(TT, 0); } while (0)
+                       Hi, Wi, C, Ho, Wo, colsum, cslab, sk, sk2, skip_slab, PoolGather{})
+#define SZN_POOLBWD_BY_SKIP(TT) do { if (gather) hipLaunchKernelGGL((maxpool_bwd_code_kernel<TT, 0, true>), dim3(grid), dim3(256), 0, st, (const uint8_t*)code, (const TT*)dout, (TT*)din, B, Hi, Wi, C, Ho, Wo, colsum, cslab, sk, sk2, skip_slab, *gather); \
+    else if (nsk == 2) SZN_POOLBWD_LAUNCH(TT, 2); else if (nsk == 1) SZN_POOLBWD_LAUNCH(TT, 1); else SZN_POOLBWD_LAUNCH(TT, 0); } while (0)
     if (dtype == SZN_BF16) SZN_POOLBWD_BY_SKIP(bf16_raw);
     else if (dtype == SZN_F16) SZN_POOLBWD_BY_SKIP(f16_raw);
     else if (dtype == SZN_F32) SZN_POOLBWD_BY_SKIP(float);
@@ -1192,6 +1219,17 @@ static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const 
 extern "C" int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
                                             float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream) {
     return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, nullptr, 0, nullptr, nullptr, stream);
+}
+
+// dout given in ANOTHER coordinate system, [B][Hs][Ws][C], with the transposed band map to this pool's output as per-axis tables
+// ytab[(Hi + 1) / 2][2], xtab[(Wi + 1) / 2][2] = {start, count} (device memory; what szn_band_remap takes): see PoolGather
+extern "C" int szn_maxpool2x2_ceil_bwd_code_gather(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dsrc, int Hs, int Ws,
+                                                   const int* ytab, const int* xtab, void* din, float* colsum, float* colsum_slab,
+                                                   int colsum_slab_rows, szn_stream_t stream) {
+    if (!ytab || !xtab || Hs <= 0 || Ws <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_gather: tables and source size are required");
+    if ((long)B * Hs * Ws * C >= (1L << 40)) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_gather: source too large");
+    const PoolGather pg = {ytab, xtab, Hs, Ws};
+    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dsrc, din, colsum, colsum_slab, colsum_slab_rows, nullptr, 0, nullptr, nullptr, stream, &pg);
 }
 
 extern "C" int szn_maxpool2x2_ceil_bwd_code_cb(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,

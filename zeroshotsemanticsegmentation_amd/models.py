@@ -103,6 +103,7 @@ _BAND_FUSE = os.environ.get("SZN_BAND_FUSE", "1") != "0"      # 0: every block c
 # default of SZN_FC6_CUMASK (see _Engine._masked_stream): CUs of the stream fc6's weight gradient + Adam runs on in a small step.  Off:
 # measured on three boxes, "128:low" moved the one-image step by -0.13 / -0.04 ms for a caller on a non-blocking stream and by -0.05 / +0.02 ms
 # for a caller on the null stream (profiles/r05_ablations.txt 15) -- inside the box-to-box spread
+_POOL_GATHER = os.environ.get("SZN_POOL_GATHER", "1") != "0"   # the pools' backward pass applies the transposed band map while reading (szn_maxpool2x2_ceil_bwd_code_gather) instead of two szn_band_remap passes in front of it
 _FC6_CUMASK = "0"
 _SMALL_STEP_PX = 2 * 512 * 512
 
@@ -155,6 +156,17 @@ def _band_cut(reg, n, L=3):
     return cuts
 
 
+def _gather_form(dev, ty, tx):
+    """a transposed band map (host tables [[start, count], ...] per axis) for the pools' backward pass: the runs with more than one source, to be
+    folded in place first (szn_band_fold: rows, then columns), and the one-source tables szn_maxpool2x2_ceil_bwd_code_gather then reads through"""
+    out = {}
+    for key, t in (("y", ty), ("x", tx)):
+        runs = [[s0, c] for s0, c in t if c > 1]
+        out["runs_" + key] = dev(runs) if runs else None
+    out["tabs"] = (dev([[s0, min(c, 1)] for s0, c in ty]), dev([[s0, min(c, 1)] for s0, c in tx]))
+    return out
+
+
 class _BandPlan(object):
     """index tables (device int32 [n][2] = start, count) of the four maps of szn_band_remap for one (regions, size) geometry"""
 
@@ -186,6 +198,7 @@ class _BandPlan(object):
         ident = lambda n: dev([[i, 1] for i in range(n)])
         self.tabs["uncrop_bwd_y"] = (self.tabs["uncrop_bwd"][0], ident(self.Wp))
         self.tabs["uncrop_bwd_x"] = (ident(self.Hpc), self.tabs["uncrop_bwd"][1])
+        self.gather_uncrop = _gather_form(dev, *self.host["uncrop_bwd"])
         self.x = None
 
     def fused_with(self, nxt):
@@ -211,6 +224,7 @@ class _BandPlan(object):
             out["fwd"] = (dev(per_axis[0][0]), dev(per_axis[1][0]))
             out["bwd_y"] = (dev(per_axis[0][1]), dev(ident(nxt.Wc)))
             out["bwd_x"] = (dev(ident(self.Hpc)), dev(per_axis[1][1]))
+            out["bwd_gather"] = _gather_form(dev, per_axis[0][1], per_axis[1][1])      # (the form the pool's backward pass takes)
             self._fused[key] = out
         return self._fused[key]
 
@@ -984,6 +998,7 @@ class _Engine(object):
             d = self._dgrad(d, "fc6", pool5.shape, 0)
         pi = 4
         prev_out = None
+        pending_gather = None
         cb_sums, border_sums = {}, {}
         items = _BACKBONE
         for idx in range(len(items) - 1, -1, -1):
@@ -993,10 +1008,21 @@ class _Engine(object):
                 pcode = ctx.pools[pi][2] if len(ctx.pools[pi]) > 2 else None
                 pi -= 1
                 producer = items[idx - 1][0]                   # the conv whose (ReLU'd) output this pool reads
+                gather = None          # (ytab, xtab): d is still in the consumer's coordinates, this pool's backward pass reads it through the map
                 if ctx.crop and ("out", producer) in ctx.crop and not ctx.crop.get(("fusedout", producer)):
                     band = ctx.crop[("out", producer)]         # the pooled rows that were copies: their gradients are summed
-                    d = self._band_remap(d, band, "uncrop_bwd_y", band.Hpc, band.Wp)
-                    d = self._band_remap(d, band, "uncrop_bwd_x", band.Hpc, band.Wpc)
+                    if _POOL_GATHER and pcode is not None:
+                        gather = band.gather_uncrop
+                    else:
+                        d = self._band_remap(d, band, "uncrop_bwd_y", band.Hpc, band.Wp)
+                        d = self._band_remap(d, band, "uncrop_bwd_x", band.Hpc, band.Wpc)
+                elif pending_gather is not None:
+                    if pcode is not None:
+                        gather = pending_gather[0]
+                    else:
+                        for tab, ho, wo in pending_gather[1]:
+                            d = self._band_remap(d, pending_gather[2], tab, ho, wo)
+                pending_gather = None
                 B, Hi, Wi, Cc = ctx.pools[pi + 1][3] if pcode is not None else pin.shape
                 dn = torch.empty(B, Hi, Wi, Cc, device=d.device, dtype=pout.dtype)
                 slab, rows = self._cs_slab(B * Hi * Wi, Cc, d.device)
@@ -1028,6 +1054,8 @@ class _Engine(object):
                         if L.load().szn_conv2d_dgrad_border_region(C.byref(dq), r8) == 1 and all(v % 2 == 0 for v in r8):
                             regions += list(r8)
                             want.append("d")
+                if regions and gather is not None:             # (never together in practice: hints belong to un-cropped producers)
+                    raise L.SznError("pool backward of %s: a band map and constant-border regions at once" % producer)
                 if regions:
                     n = len(want)
                     ssum = torch.empty(n, Cc, device=d.device)
@@ -1036,6 +1064,16 @@ class _Engine(object):
                            L.ptr(grads[producer][1]), L.ptr(slab), rows, (C.c_int * len(regions))(*regions), n, L.ptr(ssum), L.ptr(slab2), st)
                     for i, kind in enumerate(want):
                         (cb_sums if kind == "w" else border_sums)[producer] = ssum[i]
+                elif gather is not None:
+                    # the few rows / columns that sum several sources are folded in place (rows, then columns: ~10 % of the tensor), the
+                    # rest of the transposed map is a shift this pool's backward pass applies while it reads d
+                    d = d.contiguous()
+                    for axis, runs in ((0, gather["runs_y"]), (1, gather["runs_x"])):
+                        if runs is not None:
+                            L.call("szn_band_fold", code, B, d.shape[1], d.shape[2], Cc, L.ptr(d), axis, L.ptr(runs), runs.shape[0], st)
+                    ty, tx = gather["tabs"]
+                    L.call("szn_maxpool2x2_ceil_bwd_code_gather", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), d.shape[1], d.shape[2],
+                           L.ptr(ty), L.ptr(tx), L.ptr(dn), L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
                 elif pcode is not None:
                     L.call("szn_maxpool2x2_ceil_bwd_code", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), L.ptr(dn),
                            L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
@@ -1078,8 +1116,12 @@ class _Engine(object):
                     prev_band = ctx.crop.get(("fused", name))
                     if prev_band is not None:                  # ... straight into the previous block's pooled, cropped coordinates
                         ft = prev_band.fused_with(band)
-                        d = self._band_remap(d, band, ft["bwd_y"], prev_band.Hpc, band.Wc)
-                        d = self._band_remap(d, band, ft["bwd_x"], prev_band.Hpc, prev_band.Wpc)
+                        two = [(ft["bwd_y"], prev_band.Hpc, band.Wc), (ft["bwd_x"], prev_band.Hpc, prev_band.Wpc)]
+                        if _POOL_GATHER and not (skips and skips.get(pi) is not None):
+                            pending_gather = (ft["bwd_gather"], two, band)      # applied by the pool's backward pass while it reads d
+                        else:
+                            for tab, ho, wo in two:
+                                d = self._band_remap(d, band, tab, ho, wo)
                     else:
                         d = self._band_remap(d, band, "crop_bwd", band.H, band.W)
                 side = skips.get(pi) if skips else None
