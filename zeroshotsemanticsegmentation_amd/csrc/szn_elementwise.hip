@@ -674,7 +674,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_code_kernel(const uint8_t* __
         const long p00 = ((long)b * Hi + ih) * Wi + iw;
         u32x4_t vd;
         if constexpr (GATHER) {
-            const int ys = pg.ytab[2 * oh], yc = pg.ytab[2 * oh + 1], xs = pg.xtab[2 * ow], xc = pg.xtab[2 * ow + 1];
+            const int2 ye = ((const int2*)pg.ytab)[oh], xe = ((const int2*)pg.xtab)[ow];          // {start, count}: one 8-B load per axis
+            const int ys = ye.x, yc = ye.y, xs = xe.x, xc = xe.y;
             const T* src = dout + (((long)b * pg.Hs + ys) * pg.Ws + xs) * C + cc * CH;
             if (yc == 1 && xc == 1) {
                 vd = *(const u32x4_t*)src;
