@@ -291,3 +291,40 @@ def test_cu_mask_spec_parsing(monkeypatch):
     monkeypatch.setenv("SZN_FC6_CUMASK", "half")
     with pytest.raises(L.SznError):
         models._cumask_spec()
+
+
+def test_gather_form_of_a_transposed_band_map():
+    """models._gather_form (host logic): folding the multi-source runs in place (rows, then columns) and reading ONE source per pooled pixel
+    afterwards is the transposed band map -- checked with integers (exact) against the {start, count} tables it was made from, for the
+    un-crop map of a block and for the composed map of two adjacent blocks"""
+    import torch
+    from zeroshotsemanticsegmentation_amd import models
+    dev = torch.device("cpu")
+    reg, n = (48, 307, 1, 354), 355
+    band = models._BandPlan(reg, reg, n, n, dev, 2)
+    r = reg
+    for _ in range(2):
+        r = models._cb_conv3x3(r, n)
+    rp = models._cb_pool(r, n)
+    nplan = models._BandPlan(rp, rp, band.Hp, band.Wp, dev, 3)
+    assert band.ok and nplan.ok
+    ft = band.fused_with(nplan)
+    cases = [(band.host["uncrop_bwd"], band.gather_uncrop, (band.Hp, band.Wp))]
+    ty = [[int(a), int(b)] for a, b in ft["bwd_y"][0].tolist()]
+    tx = [[int(a), int(b)] for a, b in ft["bwd_x"][1].tolist()]
+    cases.append(((ty, tx), ft["bwd_gather"], (nplan.Hc, nplan.Wc)))
+    rng = np.random.RandomState(0)
+    for (ty, tx), gf, (Hs, Ws) in cases:
+        src = rng.randint(-50, 50, size=(Hs, Ws)).astype(np.int64)
+        want = np.array([[src[ys:ys + yc, xs:xs + xc].sum() for xs, xc in tx] for ys, yc in ty])
+        d = src.copy()
+        assert gf["runs_y"] is not None and gf["runs_x"] is not None
+        for s0, c in gf["runs_y"].tolist():
+            d[s0] = d[s0:s0 + c].sum(axis=0)
+        for s0, c in gf["runs_x"].tolist():
+            d[:, s0] = d[:, s0:s0 + c].sum(axis=1)
+        t1y, t1x = (t.tolist() for t in gf["tabs"])
+        assert all(c in (0, 1) for _, c in t1y + t1x)
+        got = np.array([[d[ys, xs] if (yc and xc) else 0 for xs, xc in t1x] for ys, yc in t1y])
+        assert np.array_equal(got, want)
+        assert max(c for _, c in ty) > 1 and max(c for _, c in tx) > 1
