@@ -441,6 +441,13 @@ int szn_fused_head(int B, int h, int w, int E, int ldc, int c0, int H, int W, in
 int szn_fused_head_strided(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
                            const float* coarse, const float* embed, const int64_t* target, float* loss, float* stats,
                            int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace, szn_stream_t stream);
+/* The class embeddings are constants of a run (trainer_fcn.py:49-62): szn_fused_head_prepare writes their transpose and norms to the head of
+ * `workspace` once, szn_fused_head_prepared is szn_fused_head_strided without that launch (23 us of dependent loads per step) for a caller
+ * that keeps the workspace and prepares again whenever the embeddings or the workspace change.  Same results bit for bit. */
+int szn_fused_head_prepare(int E, int K, const float* embed, void* workspace, szn_stream_t stream);
+int szn_fused_head_prepared(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
+                            const float* coarse, const float* embed, const int64_t* target, float* loss, float* stats,
+                            int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace, szn_stream_t stream);
 
 /* ---- optimizers (train.py:126-133,174-175; torch.optim.Adam / SGD semantics) ----------------------
  * One launch per flat fp32 parameter buffer.  grad_scale multiplies the gradient first (1/world

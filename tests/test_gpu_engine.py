@@ -82,6 +82,22 @@ def test_fused_head_matches_unfused(case):
            None, L.ptr(ws), st)
     torch.cuda.synchronize()
     assert torch.equal(p2, pred)
+    # prepared form: the embedding tables written once (szn_fused_head_prepare), the per-step call without that launch -- the same bits, also
+    # from a second call on the same workspace, and other embeddings need a new preparation
+    ws2 = torch.empty_like(ws)
+    L.call("szn_fused_head_prepare", E, K, L.ptr(e), L.ptr(ws2), st)
+    assert L.last_kernel() == "fh_prep_kernel"
+    for _ in range(2):
+        loss2 = torch.empty(1, device="cuda"); stats2 = torch.empty(B, 2, device="cuda")
+        pred2 = torch.empty_like(pred)
+        dc2 = torch.zeros(B, h, w, CP, device="cuda")
+        L.call("szn_fused_head_prepared", 32, B, h, w, E, CP, 0, H, W, 19, K, L.ptr(c), L.ptr(e), L.ptr(t), L.ptr(loss2), L.ptr(stats2),
+               L.ptr(pred2), L.SZN_F32, L.ptr(dc2), L.ptr(ws2), st)
+        assert L.load().szn_prev_kernel().decode() != "fh_prep_kernel"
+        torch.cuda.synchronize()
+        assert torch.equal(loss2, loss) and torch.equal(stats2, stats) and torch.equal(pred2, pred) and torch.equal(dc2, dc)
+    with pytest.raises(L.SznError):
+        L.call("szn_fused_head_prepare", E, 300, L.ptr(e), L.ptr(ws2), st)
 
 
 PROBE_PARAMS = ["conv1_1.weight", "conv1_1.bias", "conv1_2.weight", "conv3_2.weight", "conv5_3.bias", "fc6.weight",

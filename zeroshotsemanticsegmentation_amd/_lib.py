@@ -137,6 +137,8 @@ SIGNATURES = {
     "szn_fused_head_workspace_bytes": (_SZ, [_I] * 5),
     "szn_fused_head": (_I, [_I] * 10 + [_P] * 6 + [_I, _P, _P, _P]),
     "szn_fused_head_strided": (_I, [_I] * 11 + [_P] * 6 + [_I, _P, _P, _P]),
+    "szn_fused_head_prepare": (_I, [_I, _I, _P, _P, _P]),
+    "szn_fused_head_prepared": (_I, [_I] * 11 + [_P] * 6 + [_I, _P, _P, _P]),
     "szn_adam_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _P, _I, _P]),
     "szn_sgd_momentum_step": (_I, [_L, _P, _P, _P, _F, _F, _F, _I, _F, _P, _I, _P]),
     "szn_adam_step_g16": (_I, [_L, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _F, _P, _I, _P]),

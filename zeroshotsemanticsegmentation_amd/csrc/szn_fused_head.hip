@@ -474,10 +474,45 @@ extern "C" size_t szn_fused_head_workspace_bytes(int B, int h, int w, int E, int
     return fl * sizeof(float) + (cells + B) * 2 * sizeof(double) + (size_t)B * h * w * (KP + 8) * sizeof(float);
 }
 
+static int fused_head_impl(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
+                           const float* coarse, const float* embed, const int64_t* target, float* loss,
+                           float* stats, int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace,
+                           szn_stream_t stream, bool prep);
+
 extern "C" int szn_fused_head_strided(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
                                       const float* coarse, const float* embed, const int64_t* target, float* loss,
                                       float* stats, int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace,
                                       szn_stream_t stream) {
+    return fused_head_impl(stride, B, h, w, E, ldc, c0, H, W, crop, K, coarse, embed, target, loss, stats, pred, dcoarse_dtype, dcoarse, workspace,
+                           stream, true);
+}
+
+// The class embeddings are constants of a training run (trainer_fcn.py:49-62 loads them once): their transpose and norms -- fh_prep_kernel, 23 us of
+// a 2.5-8 ms step, a chain of dependent loads -- need not be rebuilt every step.  szn_fused_head_prepare writes them to the head of `workspace`
+// once; szn_fused_head_prepared is szn_fused_head_strided without that launch, for a caller that keeps the workspace and re-prepares when the
+// embeddings (or the workspace) change.  Same tables, same bits.
+extern "C" int szn_fused_head_prepare(int E, int K, const float* embed, void* workspace, szn_stream_t stream) {
+    if (!embed || !workspace || E <= 0 || K <= 0) SZN_FAIL(SZN_ERR_ARG, "fused_head_prepare: bad argument");
+    if (K > 256) SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head_prepare: K=%d > 256", K);
+    if (((uintptr_t)workspace) & 15) SZN_FAIL(SZN_ERR_ARG, "fused_head_prepare: workspace must be 16-B aligned");
+    const int KP = kp_of(K);
+    hipLaunchKernelGGL(fh_prep_kernel, dim3(szn_div_up((long)E * KP, 256)), dim3(256), 0, (hipStream_t)stream, embed, (float*)workspace, E, K, KP);
+    SZN_CHECK_LAUNCH("fh_prep_kernel");
+    return SZN_OK;
+}
+
+extern "C" int szn_fused_head_prepared(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
+                                       const float* coarse, const float* embed, const int64_t* target, float* loss,
+                                       float* stats, int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace,
+                                       szn_stream_t stream) {
+    return fused_head_impl(stride, B, h, w, E, ldc, c0, H, W, crop, K, coarse, embed, target, loss, stats, pred, dcoarse_dtype, dcoarse, workspace,
+                           stream, false);
+}
+
+static int fused_head_impl(int stride, int B, int h, int w, int E, int ldc, int c0, int H, int W, int crop, int K,
+                           const float* coarse, const float* embed, const int64_t* target, float* loss,
+                           float* stats, int64_t* pred, int dcoarse_dtype, void* dcoarse, void* workspace,
+                           szn_stream_t stream, bool prep) {
     if (stride != 32 && stride != 8) SZN_FAIL(SZN_ERR_UNSUPPORTED, "fused_head: stride %d (32 and 8 are built)", stride);
     if (!coarse || !embed || !workspace || B <= 0 || h <= 0 || w <= 0 || E <= 0 || c0 < 0 || ldc < c0 + E || H <= 0 ||
         W <= 0 || crop < 0 || K <= 0)
@@ -498,8 +533,10 @@ extern "C" int szn_fused_head_strided(int stride, int B, int h, int w, int E, in
     double* sums = part + (size_t)B * cells * 2;             // per-image {sum cos, count}
     float* tabD = (float*)(sums + 2 * (size_t)B);
     float* tabN = tabD + (size_t)B * h * w * KP;
-    hipLaunchKernelGGL(fh_prep_kernel, dim3(szn_div_up((long)E * KP, 256)), dim3(256), 0, st, embed, ws_f, E, K, KP);
-    SZN_CHECK_LAUNCH("fh_prep_kernel");
+    if (prep) {
+        hipLaunchKernelGGL(fh_prep_kernel, dim3(szn_div_up((long)E * KP, 256)), dim3(256), 0, st, embed, ws_f, E, K, KP);
+        SZN_CHECK_LAUNCH("fh_prep_kernel");
+    }
     FhArgs a;
     a.coarse = coarse; a.embed = embed; a.target = target; a.pred = pred; a.ws_f = ws_f; a.part = part;
     a.B = B; a.h = h; a.w = w; a.E = E; a.ldc = ldc; a.c0 = c0; a.H = H; a.W = W; a.crop = crop; a.K = K; a.KP = KP;

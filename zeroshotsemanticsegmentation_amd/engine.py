@@ -456,6 +456,7 @@ class TrainStep(object):
         # a training loop that calls zero_grad() next, train.py:170-175); the default keeps .grad meaningful.
         if fused_adam is None:
             fused_adam = os.environ.get("SZN_FUSED_ADAM", "1") == "1"
+        self._ws_prep = None             # what the head of the fused head's workspace was prepared for (szn_fused_head_prepare)
         self._own_stream = None          # see step(): the non-blocking stream of a small step
         self.fused_adam = bool(fused_adam and optimizer == "adam" and not self.dynamic and not self.buckets.active
                                and self.flat_w_lp is not None and os.environ.get("SZN_EARLY_ADAM", "auto") != "1")
@@ -654,7 +655,13 @@ class TrainStep(object):
             nbytes = L.load().szn_fused_head_workspace_bytes(B, ctx.h, ctx.w, E, K)
             if self._ws is None or self._ws.numel() < nbytes:
                 self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-            L.call("szn_fused_head", B, ctx.h, ctx.w, E, CP, 0, H, W, CROP, K, L.ptr(ctx.coarse), L.ptr(self.emb),
+            # the embeddings are constants of a run: their transpose + norms (fh_prep_kernel: 23 us of dependent loads) are written to the head of
+            # the workspace once -- again whenever the workspace or the embedding tensor (an in-place edit bumps _version) changes
+            prep = (self._ws.data_ptr(), self.emb.data_ptr(), self.emb._version, E, K)
+            if self._ws_prep != prep or os.environ.get("SZN_HEAD_PREP", "1") == "0":         # (0: prepare in every step, as before round 5)
+                L.call("szn_fused_head_prepare", E, K, L.ptr(self.emb), L.ptr(self._ws), st)
+                self._ws_prep = prep
+            L.call("szn_fused_head_prepared", 32, B, ctx.h, ctx.w, E, CP, 0, H, W, CROP, K, L.ptr(ctx.coarse), L.ptr(self.emb),
                    L.ptr(target), L.ptr(self.loss), L.ptr(stats), L.ptr(pred), code, L.ptr(dcoarse), L.ptr(self._ws), st)
         else:
             f = eng.upscore(ctx)
