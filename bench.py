@@ -72,7 +72,7 @@ def parse():
                     help="N > 1: wire format of the gradient exchange.  auto = bf16 written by the weight-gradient kernels themselves on "
                          "the 16-bit paths (271 MB per step instead of 542), fp32 on the fp32 path; bf16-sharded = reduce-scatter + "
                          "rank-sharded Adam + all-gather of the weight image; the `comm` record times the alternatives beside it")
-    ap.add_argument("--sub-record", choices=["fp32", "b1", "comm"], default=None,
+    ap.add_argument("--sub-record", choices=["fp32", "b1", "comm", "c1_fcn8s", "c4_768"], default=None,
                     help="(internal) measure one sub-record and print it as JSON; run by the main process as a child")
     return ap.parse_args()
 
@@ -440,6 +440,66 @@ def sub_record(args):
         return r
 
     out = {}
+    if args.sub_record in ("c1_fcn8s", "c4_768"):
+        # BASELINE configs[1] ("PASCAL-VOC FCN8s + 300-d word2vec pixel projection, 512x512, bf16": K = 21 PASCAL matrix, FCN8s skip head --
+        # not in the reference, parity unpinned) and configs[4] ("PASCAL-Context 768x768, fp16 activations + fp8 MFMA projection GEMM"), one
+        # GPU's share each, through the same engine.TrainStep as the headline
+        c1 = args.sub_record == "c1_fcn8s"
+        import argparse
+        a2 = argparse.Namespace(**vars(args))
+        a2.classes, a2.size = (21, 512) if c1 else (59, 768)
+        H, K, B = a2.size, a2.classes, args.batch
+        emb_np, seen, unseen = _workload(a2, torch)
+        dtype = torch.bfloat16 if c1 else torch.float16
+        torch.manual_seed(1337)
+        m = (models.FCN8s if c1 else models.FCN32s)(n_class=E)
+        m.load_synthetic(1337, device=dev)
+        m.train()
+        if not c1:
+            m.set_head_precision("fp8")
+        ts = engine.TrainStep(m, emb_np, optimizer="adam", lr=1e-5, precision=dtype, fused_head=True, keep_grads=False)
+        x = torch.from_numpy(synth.make_images(B, H, H, seed=1337)).to(dev)
+        t = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337, classes=seen)).to(dev)
+        ms = _time_steps(torch, lambda: ts.step(x, t), max(args.steps, 10), 3)
+        # executed MFMA-class FLOPs of one step (every conv entry's descriptor x the fraction of its tiles that ran; conv1_1's two entry
+        # points counted dense) and the launches of the band plan
+        calls = []
+        tot = [0.0]
+        orig = L.call
+        conv_entries = ("szn_conv2d_fwd", "szn_conv2d_wgrad", "szn_conv2d_dgrad", "szn_conv2d_dgrad_gemm", "szn_conv2d_dgrad_gemm_native",
+                        "szn_conv2d_wgrad_adam")
+
+        def hooked(name, *a):
+            r = orig(name, *a)
+            calls.append(name)
+            if name in conv_entries:
+                fr = L.last_work_fraction() if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad", "szn_conv2d_dgrad") else 1.0
+                tot[0] += _conv_flops(a[0]._obj) * fr
+            return r
+        L.call = models.L.call = engine.L.call = hooked
+        try:
+            ts.step(x, t)
+            torch.cuda.synchronize()
+        finally:
+            L.call = models.L.call = engine.L.call = orig
+        c11 = 2 * 2.0 * B * (H + 198) ** 2 * 64 * 27
+        executed = tot[0] + c11
+        out = {"workload": ("BASELINE configs[1]: FCN8s skip head (public definition, not in the reference: parity unpinned) + 300-d pixel "
+                            "projection, PASCAL-VOC K=21 matrix, 512x512, bf16, fused stride-8 head" if c1 else
+                            "BASELINE configs[4] (one GPU's share): PASCAL-Context K=59 768x768, fp16 activations + dynamic loss scale, fp8 "
+                            "(e4m3) projection GEMM, FCN32s, fused-from-coarse head") + ", B=%d, Adam lr 1e-5, train step" % B,
+               "per_gpu_batch": B, "dtype": "bf16" if c1 else "f16 (+ fp8 e4m3 projection head)", "ms_per_step": round(ms, 3),
+               "value": round(B * H * H / (ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s", "peak_TF": PEAK_BF16,
+               "step_gflop_executed": round(executed / 1e9, 1),
+               "step_mfma_frac": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16, 4),
+               "band_plan": {"band_remap_launches_per_step": calls.count("szn_band_remap"),
+                             "conv1_1_writes_cropped_map": calls.count("szn_conv1_1_fwd_c") > 0,
+                             "pool_backward_through_band_map": calls.count("szn_maxpool2x2_ceil_bwd_code_gather")},
+               "c_abi_calls_per_step": len(calls), "final_loss": round(float(ts.loss.item()), 5)}
+        if not c1 and H in STEP_MFLOP_PER_PX:
+            out["step_gflop_algorithmic"] = round(STEP_MFLOP_PER_PX[H] * 1e6 * B * H * H / 1e9, 1)
+        print("SUBRECORD " + json.dumps(out))
+        return
     if args.sub_record == "comm":
         # BASELINE configs[3]'s exchange on ONE GPU: a one-rank RCCL communicator (RCCL refuses two ranks per device), the step's
         # real gradient buckets forced through librccl on ProcessGroupNCCL's stream (engine.GradBuckets(force=True): pre-multiplied
@@ -962,6 +1022,9 @@ def main():
         if args.phase == "fcn" and args.arch == "fcn32s" and not args.unfused_head:
             out["fp32"] = run_sub_record("fp32", args)
             out["b1"] = run_sub_record("b1", args)
+            if E == 300:
+                out["c1_fcn8s"] = run_sub_record("c1_fcn8s", args)
+                out["c4_768"] = run_sub_record("c4_768", args)
             if dtype == torch.bfloat16:
                 out["comm"] = run_sub_record("comm", args)
     if rank == 0:

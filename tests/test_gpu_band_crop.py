@@ -124,6 +124,63 @@ def test_train_step_with_the_band_removed_equals_the_full_step(precision, size, 
         assert float((a - b).norm() / (b.norm() + 1e-300)) < 5 * tol, n
 
 
+def _step_cfg(crop, arch, precision, size, B, K, head_fp8, monkeypatch):
+    """one train-mode step of a BASELINE configuration (E = 300) with / without the band -> loss, pred, flat gradients, TrainStep, launches"""
+    monkeypatch.setattr(models, "_BAND_CROP", crop)
+    E = 300
+    m = (models.FCN8s if arch == "fcn8s" else models.FCN32s)(E)
+    m.load_synthetic(1337, device=torch.device("cuda", 0))
+    m.train()
+    if head_fp8:
+        m.set_head_precision("fp8")
+    m._engine.dropout_seed, m._engine.dropout_calls = 1337, 0
+    emb = synth.make_embeddings(K, E)
+    ts = engine.TrainStep(m, emb, optimizer="adam", lr=1e-5, precision=precision, fused_head=True, keep_grads=True, fused_adam=False)
+    x = torch.from_numpy(synth.make_images(B, size, size, seed=9)).cuda()
+    t = torch.from_numpy(synth.make_labels(B, size, size, K, seed=10)).cuda()
+    seen = []
+    orig = L.call
+
+    def spy(name, *a):
+        orig(name, *a)
+        seen.append(name)
+    models.L.call = engine.L.call = spy
+    try:
+        loss, pred = ts.step(x, t)
+    finally:
+        models.L.call = engine.L.call = orig
+    torch.cuda.synchronize()
+    return float(loss), pred.cpu(), ts.flat_gw.clone(), ts.flat_gb.clone(), ts, (seen.count("szn_band_remap"), seen.count("szn_conv1_1_fwd_c"),
+                                                                                 seen.count("szn_maxpool2x2_ceil_bwd_code_gather"))
+
+
+@pytest.mark.parametrize("tag,arch,precision,size,B,K,head_fp8", [
+    ("configs[1] FCN8s bf16 512", "fcn8s", torch.bfloat16, 512, 3, 21, False),
+    ("configs[4] 768 fp16 + fp8 head", "fcn32s", torch.float16, 768, 2, 59, True)])
+def test_configs1_and_configs4_steps_with_the_band_removed_equal_their_full_steps(tag, arch, precision, size, B, K, head_fp8, monkeypatch):
+    """the band plan also engages on BASELINE configs[1] (FCN8s: the skip heads read pool3 / pool4, which the engine hands
+    over as full maps -- the copy back behind pool3 -- and whose gradients join the full-map chain in front of the pools' backward pass) and on
+    configs[4] (768 x 768: 966^2 maps, other cut positions; fp16 with the dynamic loss scale and the e4m3 projection).  Same statement as for the
+    headline shape: forward bit for bit, everything behind the cropped blocks bit for bit, the cropped blocks' gradients to the order of fp32
+    additions + one more 16-bit rounding of the summed band gradient."""
+    l0, p0, gw0, gb0, ts0, n0 = _step_cfg(False, arch, precision, size, B, K, head_fp8, monkeypatch)
+    l1, p1, gw1, gb1, ts1, n1 = _step_cfg(True, arch, precision, size, B, K, head_fp8, monkeypatch)
+    print("%s: launches (band_remap, conv1_1_fwd_c, pool bwd gather) full %s, band removed %s" % (tag, n0, n1))
+    assert n0 == (0, 0, 0)
+    assert n1[0] >= 3 and n1[1] == 1 and n1[2] >= (2 if arch == "fcn8s" else 3)    # (FCN8s: pool3's backward also adds the skip gradient: two passes)
+    assert l1 == l0 and torch.equal(p1, p0)
+    o = ts0.woff["conv4_1"][0]
+    assert torch.equal(gw1[o:], gw0[o:])
+    for n in ts0.layers:
+        o, cnt = ts0.woff[n]
+        a, b = gw1[o:o + cnt].double(), gw0[o:o + cnt].double()
+        err = float((a - b).norm() / (b.norm() + 1e-300))
+        assert err < 6e-3, (n, err)
+        bo, bc = ts0.boff[n]
+        a, b = gb1[bo:bo + bc].double(), gb0[bo:bo + bc].double()
+        assert float((a - b).norm() / (b.norm() + 1e-300)) < 3e-2, n
+
+
 def test_inference_forward_with_the_band_removed(monkeypatch):
     out = []
     for crop in (False, True):

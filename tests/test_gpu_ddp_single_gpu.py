@@ -214,7 +214,10 @@ MODES = {"fp32": dict(grad_comm_dtype=torch.float32),
          "fp32-sharded": dict(grad_comm_dtype=torch.float32, sharded=True),
          "bf16-staged": dict(grad_comm_dtype=torch.bfloat16, direct_wire=False),
          "bf16-direct": dict(grad_comm_dtype=torch.bfloat16, direct_wire=True, keep_grads=False),
-         "bf16-direct-sharded": dict(grad_comm_dtype=torch.bfloat16, direct_wire=True, sharded=True, keep_grads=False)}
+         "bf16-direct-sharded": dict(grad_comm_dtype=torch.bfloat16, direct_wire=True, sharded=True, keep_grads=False),
+         # fp32 COMPUTE path: no 16-bit image; the sharded form must still bring the other rank's moments back
+         "f32c": dict(grad_comm_dtype=torch.float32, precision=torch.float32),
+         "f32c-sharded": dict(grad_comm_dtype=torch.float32, precision=torch.float32, sharded=True)}
 
 
 def _worker_modes(rank, world, port, optname, q):
@@ -235,12 +238,14 @@ def _worker_modes(rank, world, port, optname, q):
             m.load_synthetic(1337, device=dev)
             m.eval()
             # (SGD: a learning rate at which two steps move the bf16 weight image, or the comparison below would be vacuous)
-            ts = engine.TrainStep(m, emb, optimizer=optname, lr=1e-4 if optname == "adam" else 0.5, precision=torch.bfloat16,
-                                  fused_head=True, bucket_mb=1, **kw)
+            kw = dict(kw)
+            ts = engine.TrainStep(m, emb, optimizer=optname, lr=1e-4 if optname == "adam" else 0.5,
+                                  precision=kw.pop("precision", torch.bfloat16), fused_head=True, bucket_mb=1, **kw)
             assert ts.buckets.active and ts.buckets.direct == ("direct" in mode) and ts.buckets.sharded == ("sharded" in mode), mode
             kernels = set()
             orig = L.call
-            lp_init = ts.flat_w_lp.clone()
+            image = ts.flat_w_lp if ts.flat_w_lp is not None else ts.flat_w
+            lp_init = image.clone()
 
             def spy(name, *a):
                 orig(name, *a)
@@ -252,10 +257,12 @@ def _worker_modes(rank, world, port, optname, q):
             finally:
                 engine.L.call = orig
             issued = ts.buckets.issued
-            moved = float((ts.flat_w_lp != lp_init).float().mean())
+            moved = float((image != lp_init).float().mean())
+            if "sharded" in mode:            # before the gather this rank's moments of the OTHER rank's slices are stale (zero after init)
+                assert ts._masters_stale, mode
             ts.gather_masters()
             torch.cuda.synchronize()
-            out[mode] = {"loss": float(loss), "lp": ts.flat_w_lp.view(torch.int16).cpu().numpy(), "w": ts.flat_w.cpu().numpy(),
+            out[mode] = {"loss": float(loss), "lp": image.view(torch.int16).cpu().numpy(), "w": ts.flat_w.cpu().numpy(),
                          "b": ts.flat_b.cpu().numpy(), "m1": ts.state["w"][0].cpu().numpy(),
                          "g16": ("adam_kernel_g16" in kernels or "sgd_kernel_g16" in kernels), "issued": issued, "moved": moved,
                          "nb": len(ts.buckets.buckets), "grad_none": m.fc6.weight.grad is None}
@@ -287,7 +294,7 @@ def test_wire_modes_and_sharded_optimizer_bit_identical_two_ranks(optname):
         for key in ("lp", "w", "b", "m1"):
             assert np.array_equal(res[0][mode][key], res[1][mode][key]), (mode, key)
         assert np.isfinite(res[0][mode]["loss"])
-    for a, b in (("fp32", "fp32-sharded"), ("bf16-staged", "bf16-direct"), ("bf16-direct", "bf16-direct-sharded")):
+    for a, b in (("fp32", "fp32-sharded"), ("bf16-staged", "bf16-direct"), ("bf16-direct", "bf16-direct-sharded"), ("f32c", "f32c-sharded")):
         for key in ("lp", "w", "b", "m1"):
             assert np.array_equal(res[0][a][key], res[0][b][key]), (a, b, key)
         assert res[0][a]["loss"] == res[0][b]["loss"]
@@ -299,6 +306,7 @@ def test_wire_modes_and_sharded_optimizer_bit_identical_two_ranks(optname):
     nb = res[0]["fp32"]["nb"]
     assert nb >= 4 and res[0]["fp32"]["issued"] == 2 * (nb + 1) and res[0]["fp32-sharded"]["issued"] == 2 * (2 * nb + 2)
     assert all(res[0][mode]["moved"] > 0.3 for mode in MODES), {mode: res[0][mode]["moved"] for mode in MODES}
+    assert np.abs(res[0]["f32c-sharded"]["m1"]).min() >= 0 and (res[0]["f32c-sharded"]["m1"] != 0).mean() > 0.5   # no slice left at its initial zeros
     # bf16 wire vs fp32 wire: the same training step up to the 2^-9 rounding of the summed gradients
     d = np.abs(res[0]["bf16-direct"]["w"] - res[0]["fp32"]["w"]).max()
     assert d < 5e-4, d

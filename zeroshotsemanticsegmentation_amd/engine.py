@@ -581,9 +581,12 @@ class TrainStep(object):
         # direct 16-bit wire: bf16 compute path only (the kernels that write the image are the 16-bit weight-gradient kernels; the
         # dynamic loss scale's overflow check reads fp32 gradients; the FCN8s skip layers copy theirs in from scratch buffers)
         direct = self._want_direct and not self.dynamic and not self.is8 and self.eng.dtype != torch.float32
+        # sharded optimizer: not with the dynamic loss scale either -- after a reduce-scatter a rank holds summed gradients for its own slices
+        # only, so the overflow check (szn_grad_check_finite over the whole buffer) would see different data on different ranks and the ranks
+        # would disagree on skipping the step / backing the scale off
         self.buckets = GradBuckets(self.flat_gw, layers, bucket_mb * (1 << 20) // 4, extra=[self.flat_gb], group=self.pg,
                                    comm_dtype=self.grad_comm_dtype, force=self.force_comm, enabled=self.exchange, direct=direct,
-                                   sharded=self._want_sharded, tail=(CP - E) * F)
+                                   sharded=self._want_sharded and not self.dynamic, tail=(CP - E) * F)
         self._gather = []
         if self.buckets.direct:
             stage = self.buckets.stage
@@ -916,7 +919,8 @@ class TrainStep(object):
                 works += self.buckets.gather_weights(self.flat_w, first_only=True)
             for wk in works:
                 wk.wait()                # (the compute stream waits, not the host)
-            self._masters_stale = self.flat_w_lp is not None and self.buckets.world > 1
+            # masters (16-bit paths) and moments (every path) of the other ranks' slices are stale from here on
+            self._masters_stale = self.buckets.world > 1
         else:
             # the weight ranges not already updated inside their weight-gradient kernels (_fused_begin)
             lo = 0
@@ -935,11 +939,12 @@ class TrainStep(object):
         self.eng.mark_dirty()
 
     def gather_masters(self):
-        """sharded optimizer on a 16-bit path: bring the fp32 masters and moments of the other ranks' slices up to date on this rank
-        (all-gather over the bucket slices).  Call before reading model parameters / optimizer state: checkpoints, export."""
+        """sharded optimizer: bring the optimizer moments -- and on a 16-bit path the fp32 masters (the fp32 path all-gathers them as the
+        weight image in every step) -- of the other ranks' slices up to date on this rank (all-gather over the bucket slices).  Call before
+        reading model parameters / optimizer state: checkpoints, export."""
         if not getattr(self, "_masters_stale", False):
             return
-        ts = [self.flat_w] + list(self.state["w"])
+        ts = ([self.flat_w] if self.flat_w_lp is not None else []) + list(self.state["w"])
         for t in ts:
             for wk in self.buckets.gather_weights(t):
                 wk.wait()
