@@ -310,7 +310,7 @@ def _conv_family(torch, L, mods, fn):
 
 def _skipped_flops_one_step(L, mods, step_fn, nominal=None):
     """FLOPs of one step that are NOT executed: what the constant-border hint replaces by a broadcast (forward) or a rank-one term (weight
-    gradient) -- szn_last_work_fraction of every szn_conv2d_fwd / szn_conv2d_wgrad / szn_conv2d_dgrad call -- and, with `nominal` (the
+    gradient) -- szn_conv_desc_t.result->work_fraction of every szn_conv2d_fwd / szn_conv2d_wgrad / szn_conv2d_dgrad call -- and, with `nominal` (the
     algorithmic FLOPs of the step without conv1_1, which has its own entry points), also what the band removed from the conv3 block never
     reaches a kernel (round 5: those launches carry smaller descriptors): nominal - sum of the executed FLOPs of every conv call"""
     tot = [0.0, 0.0]
@@ -321,7 +321,7 @@ def _skipped_flops_one_step(L, mods, step_fn, nominal=None):
     def hooked(name, *a):
         r = orig(name, *a)
         if name in conv_entries:
-            fr = L.last_work_fraction() if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad", "szn_conv2d_dgrad") else 1.0
+            fr = a[0]._obj.res.work_fraction if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad", "szn_conv2d_dgrad") else 1.0
             fl = _conv_flops(a[0]._obj)
             tot[0] += fl * (1.0 - fr)
             tot[1] += fl * fr
@@ -473,7 +473,7 @@ def sub_record(args):
             r = orig(name, *a)
             calls.append(name)
             if name in conv_entries:
-                fr = L.last_work_fraction() if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad", "szn_conv2d_dgrad") else 1.0
+                fr = a[0]._obj.res.work_fraction if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad", "szn_conv2d_dgrad") else 1.0
                 tot[0] += _conv_flops(a[0]._obj) * fr
             return r
         L.call = models.L.call = engine.L.call = hooked
@@ -779,7 +779,7 @@ def main():
         e1.record()
         kern = L.last_kernel()
         if name in ("szn_conv2d_fwd", "szn_conv2d_wgrad", "szn_conv2d_dgrad") and wk:      # constant-border hint: only the executed tiles count as FLOPs
-            wk = (wk[0], wk[1] * L.last_work_fraction())
+            wk = (wk[0], wk[1] * a[0]._obj.res.work_fraction)
         helper = {"splitk_epilogue": "+splitk", "col2im_kernel": "+col2im", "maxpool_fwd_kernel": "+maxpool",
                   "wgrad_taps_reduce": "+reduce", "conv1_1_wgrad_reduce": "+reduce"}.get(kern)
         if kern == "wgrad_taps_reduce":                            # (under the constant-border hint two column-sum launches sit in between)

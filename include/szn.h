@@ -67,6 +67,15 @@ int szn_stream_destroy(szn_stream_t stream);
  * score_fr || seenmask_score (1x1): models.py:45-97 (construction), models.py:117-149 (forward),
  * and their autograd backward triggered by trainer_fcn.py:157 / trainer_seenmask.py:81.
  * Ci must be a multiple of 64 (bf16) / 32 (f32); Co is arbitrary.                               */
+/* What a call decided that its caller has to know afterwards (HOST memory, optional): filled before the entry point returns.
+ * colsum_rows   = the partial rows the call wrote into its colsum slab (0: it used no slab) -- a function of the kernel the dispatcher picked;
+ *                 szn_colsum_reduce_batch takes it.
+ * work_fraction = 1.0, or the fraction of the dense tiles the call executed under the constant-border hint (cb_on).                        */
+typedef struct szn_call_result {
+    int colsum_rows;
+    float work_fraction;
+} szn_call_result_t;
+
 typedef struct {
     int dtype;        /* SZN_F32 | SZN_BF16: element type of in / w / gate / out                 */
     int B, Hi, Wi, Ci; /* input  [B][Hi][Wi][Ci], pixel stride ldi >= Ci elements                 */
@@ -85,7 +94,7 @@ typedef struct {
                          kernel supports it (the 710^2 / 355^2 layers), else szn_maxpool2x2_ceil_fwd runs behind it */
     float* colsum_slab; /* optional fp32 workspace [colsum_slab_rows][Co] (dgrad: [..][Ci]), 16-B aligned, declared at the END of
                          the struct.  With it the kernel does NOT touch colsum: every pixel tile / persistent block writes its
-                         partial column sums into its own row (szn_last_colsum_rows() rows, a function of the kernel the
+                         partial column sums into its own row (result->colsum_rows rows, a function of the kernel the
                          dispatcher picked) and the caller adds them with szn_colsum_reduce_batch in a fixed order --
                          bit-reproducible bias gradients.  Without it the partials are added to colsum with fp32 atomics
                          (same value up to the order of the additions).                                            */
@@ -104,7 +113,7 @@ typedef struct {
                          asserts that the INPUT is constant accordingly, so output pixels inside cb_const and outside cb_rect are all
                          equal: a kernel that takes the hint (conv3x3_regw) runs its tiles over cb_rect and the edge frame only, and
                          broadcasts one computed pixel to the rest (out / pool_out / pool_code alike).  Same bits as the dense
-                         computation.  szn_last_work_fraction() = the fraction of the dense tiles the last call executed.
+                         computation.  result->work_fraction = the fraction of the dense tiles the call executed.
                          szn_conv2d_dgrad with a gate (coordinates of DIN): cb_rect = the rows x columns outside of which every pixel of
                          the gate tensor equals gate pixel (row r0 - 1, column c0) of image 0 (needs r0 >= 1) -- the kernel may read that
                          pixel instead; cb_const = the rows x columns of DIN the caller is going to read -- stores outside may be
@@ -115,7 +124,7 @@ typedef struct {
                          cb_const and outside cb_rect holds the same value per channel.  conv_wgrad_taps then runs only the 16 x 16
                          output tiles whose input patch is not constant; the others contribute (their column sum of dout) x (that
                          pixel) to all nine taps -- the same sum in a different order (fp32; <= 1e-5 relative against the dense
-                         result, tests/test_gpu_conv.py), ignored with accumulate != 0.  szn_last_work_fraction() reports it.
+                         result, tests/test_gpu_conv.py), ignored with accumulate != 0.  result->work_fraction reports it.
                          `colsum` (otherwise unused by szn_conv2d_wgrad) may then hold that column sum [Co], computed by the producer
                          of dout over the region szn_conv2d_wgrad_cb_region() names (szn_maxpool2x2_ceil_bwd_code_cb); NULL = the
                          call sums them itself.                                                                                   */
@@ -133,6 +142,7 @@ typedef struct {
                          2 B instead of 4; dw must still be valid fp32 memory of the full size (scratch for the paths that finish in
                          fp32 and convert), its content is UNDEFINED afterwards.  Ignored with accumulate != 0 (error).          */
     int dw_lp_dtype;
+    szn_call_result_t* result; /* optional HOST pointer: szn_conv2d_fwd / _dgrad / _wgrad / _wgrad_adam report through it (no "last call" state) */
 } szn_conv_desc_t;
 
 /* out[m][n] = epi( sum_k in(m,k) * w[n][k] + bias[n] )
@@ -160,7 +170,7 @@ int szn_conv2d_dgrad(const szn_conv_desc_t* d, const void* dout, const void* wT,
  * tiles that ran, and szn_conv2d_dgrad_border_finish adds the rest from region sums of dout -- it is linear in dout there (one gate value
  * per channel), so it needs skip_sum [Co] = sum of dout over the map outside szn_conv2d_dgrad_border_region()'s inner rectangle (from the
  * producer of dout: szn_maxpool2x2_ceil_bwd_code_cb) and 1-pixel strips it reads itself.  Same value up to fp32 summation order.
- * The caller checks szn_last_work_fraction() < 1 after the dgrad call before it calls finish (a kernel that ignores the hint computes the
+ * The caller checks result->work_fraction < 1 after the dgrad call before it calls finish (a kernel that ignores the hint computes the
  * complete column sums).  workspace: 2 * 24 * B * Co floats, 16-B aligned.                                                                */
 int szn_conv2d_dgrad_border_region(const szn_conv_desc_t* d, int region[8]);
 int szn_conv2d_dgrad_border_finish(const szn_conv_desc_t* d, const void* dout, const void* wT, const void* gate,
@@ -218,14 +228,12 @@ int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dout, float* d
 /* the same with a slab for the per-block partial rows ([colsum_slab_rows][Co] fp32, see szn_conv_desc_t.colsum_slab): db is
  * only zeroed (accumulate == 0), the sums arrive through szn_colsum_reduce_batch.  colsum_slab == NULL: as szn_bias_grad. */
 int szn_bias_grad_slab(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
-                       float* colsum_slab, int colsum_slab_rows, szn_stream_t stream);
+                       float* colsum_slab, int colsum_slab_rows, int* colsum_rows_out /* host, optional: rows written */, szn_stream_t stream);
 /* Deterministic bias gradients.  The kernels that produce column sums (szn_conv2d_fwd / _dgrad with colsum,
  * szn_maxpool2x2_ceil_bwd, szn_bias_grad_slab) write partial rows into the caller's slab when one is given;
- * szn_last_colsum_rows() = the number of rows the LAST such call on this thread wrote (0: it used no slab), and
- * szn_colsum_reduce_batch adds out[j][c] += sum_{r < rows[j]} slabs[j][r * C[j] + c] for n jobs in one launch, rows in
+ * every such call reports the number of rows it wrote (0: it used no slab) through its own out-parameter (szn_conv_desc_t.result /
+ * colsum_rows_out), and szn_colsum_reduce_batch adds out[j][c] += sum_{r < rows[j]} slabs[j][r * C[j] + c] for n jobs in one launch, rows in
  * ascending order (host arrays of length n; every bias gradient of a backward pass in ONE launch).                  */
-int szn_last_colsum_rows(void);
-float szn_last_work_fraction(void);   /* 1.0, or the fraction of tiles the last szn_conv2d_fwd executed under cb_on */
 int szn_colsum_reduce_batch(int n, const float* const* slabs, const int* rows, const int* C, float* const* out,
                             szn_stream_t stream);
 
@@ -275,28 +283,28 @@ int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, const void*
 int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void* in,
                             const void* out, const void* dout, void* din, float* colsum /* [C] += sum of din, or NULL */,
                             float* colsum_slab /* optional, see szn_conv_desc_t.colsum_slab */, int colsum_slab_rows,
-                            szn_stream_t stream);
+                            int* colsum_rows_out /* host, optional: partial rows written into the slab */, szn_stream_t stream);
 /* The pair that works from winner codes (one byte per pooled element: 0 .. 3 = position 2 dy + dx of the first maximum, 4 = maximum
  * not positive) instead of the pool's input: the forward pass writes them (here, or fused into the producing conv through
  * szn_conv_desc_t.pool_code), the backward pass reads d(pooled) + codes only.  Same gradients bit for bit.                     */
 int szn_maxpool2x2_ceil_fwd_code(int dtype, int B, int Hi, int Wi, int C, const void* in, void* out, void* code /* or NULL */,
                                  szn_stream_t stream);
 int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
-                                 float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream);
+                                 float* colsum, float* colsum_slab, int colsum_slab_rows, int* colsum_rows_out, szn_stream_t stream);
 /* The same pass with dout given in the coordinates of the NEXT conv block's cropped input, [B][Hs][Ws][C] (szn_band_remap): the transposed band map is
  * applied while reading -- pooled pixel (oh, ow) takes the fp32 sum of source rows ytab[oh] = {start, count} x columns xtab[ow] = {start, count}
  * (device int tables of (Hi + 1) / 2 and (Wi + 1) / 2 pairs; almost every pair is {shifted index, 1}), rounded once.  Replaces the two szn_band_remap
  * passes the engine ran in front of szn_maxpool2x2_ceil_bwd_code at every cropped block boundary. */
 int szn_maxpool2x2_ceil_bwd_code_gather(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dsrc, int Hs, int Ws,
                                         const int* ytab, const int* xtab, void* din, float* colsum, float* colsum_slab,
-                                        int colsum_slab_rows, szn_stream_t stream);
+                                        int colsum_slab_rows, int* colsum_rows_out, szn_stream_t stream);
 /* The same, also summing din over the regions its consumers -- the conv in front of the pool's weight gradient and dgrad -- do not run
  * tile by tile under the constant-border hint: skip_regions [n_regions][8] (pixels, even) from szn_conv2d_wgrad_cb_region() /
  * szn_conv2d_dgrad_border_region(), n_regions = 1 or 2, skip_sum [n_regions][C] out (szn_conv_desc_t.colsum of the weight-gradient call /
  * skip_sum of szn_conv2d_dgrad_border_finish), skip_slab [n_regions][colsum_slab_rows][C] scratch.  colsum / colsum_slab required. */
 int szn_maxpool2x2_ceil_bwd_code_cb(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
-                                    float* colsum, float* colsum_slab, int colsum_slab_rows, const int* skip_regions, int n_regions,
-                                    float* skip_sum, float* skip_slab, szn_stream_t stream);
+                                    float* colsum, float* colsum_slab, int colsum_slab_rows, int* colsum_rows_out, const int* skip_regions,
+                                    int n_regions, float* skip_sum, float* skip_slab, szn_stream_t stream);
 int szn_conv2d_wgrad_cb_region(const szn_conv_desc_t* d, int region[8]);
 
 /* ---- upscore: ConvTranspose2d(E,E,64,stride 32,bias=False) with the fixed bilinear kernel of

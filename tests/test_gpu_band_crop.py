@@ -251,6 +251,7 @@ def test_pool_backward_reads_through_the_transposed_band_map(dt):
 
     def run(form):
         dn = torch.full((B, Hi, Wi, Cc), 3.0, device="cuda", dtype=dt)
+        ro = L.rows_out()
         db = torch.zeros(Cc, device="cuda")
         slab = torch.zeros(1024, Cc, device="cuda")
         if form == "two passes":
@@ -261,7 +262,7 @@ def test_pool_backward_reads_through_the_transposed_band_map(dt):
                 L.call("szn_band_remap", code, B, t.shape[1], t.shape[2], ho, wo, Cc, L.ptr(t), L.ptr(out), L.ptr(ty), L.ptr(tx), L.stream_ptr())
                 t = out
             L.call("szn_maxpool2x2_ceil_bwd_code", code, B, Hi, Wi, Cc, L.ptr(codes), L.ptr(t), L.ptr(dn), L.ptr(db), L.ptr(slab), 1024,
-                   L.stream_ptr())
+                   C.byref(ro), L.stream_ptr())
         else:
             t = d.clone()
             ty, tx = plan.tabs["uncrop_bwd"]
@@ -271,8 +272,8 @@ def test_pool_backward_reads_through_the_transposed_band_map(dt):
                     L.call("szn_band_fold", code, B, plan.Hp, plan.Wp, Cc, L.ptr(t), axis, L.ptr(runs), runs.shape[0], L.stream_ptr())
                 ty, tx = gf["tabs"]
             L.call("szn_maxpool2x2_ceil_bwd_code_gather", code, B, Hi, Wi, Cc, L.ptr(codes), L.ptr(t), plan.Hp, plan.Wp, L.ptr(ty), L.ptr(tx),
-                   L.ptr(dn), L.ptr(db), L.ptr(slab), 1024, L.stream_ptr())
-        rows = L.load().szn_last_colsum_rows()
+                   L.ptr(dn), L.ptr(db), L.ptr(slab), 1024, C.byref(ro), L.stream_ptr())
+        rows = ro.value
         torch.cuda.synchronize()
         return dn, slab[:rows].clone()
     (a, ca), (b, cb), (m, cm) = run("fold"), run("two passes"), run("multi-source")

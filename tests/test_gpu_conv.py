@@ -174,7 +174,7 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
             dgs, _, _ = conv_desc(dt, B, Hi, Wi, Ci, Co, K, pad, ldg=Ci)
             dgs.colsum, dgs.colsum_slab, dgs.colsum_slab_rows = cs2.data_ptr(), slab.data_ptr(), cap
             L.call("szn_conv2d_dgrad", C.byref(dgs), L.ptr(doutd), L.ptr(wT), L.ptr(xd), None, L.ptr(din2), L.stream_ptr())
-            rows = L.load().szn_last_colsum_rows()
+            rows = dgs.res.colsum_rows
             assert 0 < rows <= cap
             assert float(cs2.abs().max()) == 0.0                    # the kernel itself leaves colsum alone
             L.call("szn_colsum_reduce_batch", 1, (C.c_void_p * 1)(slab.data_ptr()), (C.c_int * 1)(rows), (C.c_int * 1)(Ci),
@@ -193,8 +193,9 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     # ... and its deterministic form
     db2 = torch.full((Co,), float("nan"), device=dev)
     bslab = torch.full((2048 * Co,), float("nan"), device=dev)
-    L.call("szn_bias_grad_slab", dt, B * Ho * Wo, Co, d.ldo, L.ptr(doutd), L.ptr(db2), 0, L.ptr(bslab), 2048, L.stream_ptr())
-    brows = L.load().szn_last_colsum_rows()
+    bro = L.rows_out()
+    L.call("szn_bias_grad_slab", dt, B * Ho * Wo, Co, d.ldo, L.ptr(doutd), L.ptr(db2), 0, L.ptr(bslab), 2048, C.byref(bro), L.stream_ptr())
+    brows = bro.value
     L.call("szn_colsum_reduce_batch", 1, (C.c_void_p * 1)(bslab.data_ptr()), (C.c_int * 1)(brows), (C.c_int * 1)(Co),
            (C.c_void_p * 1)(db2.data_ptr()), L.stream_ptr())
     torch.cuda.synchronize()
@@ -335,16 +336,17 @@ def test_maxpool(dtype, hw):
     doutd = nhwc(dout).cuda().to(dtype)
     cs = torch.zeros(Cc, device="cuda")
     L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.ptr(cs), None, 0,
-           L.stream_ptr())
+           None, L.stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(din.float().cpu().permute(0, 3, 1, 2), dref)
     assert relerr(cs.cpu(), dref.sum((0, 2, 3))) < 1e-5          # fused bias gradient = column sums of din
     # deterministic form of the column sums: partial rows + fixed-order reduce
     cs2 = torch.zeros(Cc, device="cuda")
     slab = torch.full((2048 * Cc,), float("nan"), device="cuda")
+    ro = L.rows_out()
     L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.ptr(cs2), L.ptr(slab),
-           2048, L.stream_ptr())
-    rows = L.load().szn_last_colsum_rows()
+           2048, C.byref(ro), L.stream_ptr())
+    rows = ro.value
     assert 0 < rows <= 2048 and float(cs2.abs().max()) == 0.0
     L.call("szn_colsum_reduce_batch", 1, (C.c_void_p * 1)(slab.data_ptr()), (C.c_int * 1)(rows), (C.c_int * 1)(Cc),
            (C.c_void_p * 1)(cs2.data_ptr()), L.stream_ptr())
@@ -352,7 +354,8 @@ def test_maxpool(dtype, hw):
     assert relerr(cs2.cpu(), dref.sum((0, 2, 3))) < 1e-5
     with pytest.raises(L.SznError):
         L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Cc, L.ptr(xd), L.ptr(out), L.ptr(doutd), L.ptr(din), L.ptr(cs2), L.ptr(slab),
-               0, L.stream_ptr())
+               0, C.byref(ro), L.stream_ptr())
+    assert ro.value == 0                                          # a refused call reports no rows
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -600,7 +603,7 @@ def test_wgrad_constant_border_hint_equals_dense(case, dtype):
         dw = torch.full((Co, 3, 3, Ci), 7.0, device="cuda")
         L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, L.stream_ptr())
         torch.cuda.synchronize()
-        return dw, L.last_kernel(), L.load().szn_last_work_fraction()
+        return dw, L.last_kernel(), d.res.work_fraction
 
     dense, k0, f0 = run(False)
     hinted, k1, f1 = run(True)
@@ -663,9 +666,11 @@ def test_pool_backward_sums_the_tiles_the_weight_gradient_skips(dtype):
     cs0, cs1 = torch.zeros(Co, device="cuda"), torch.zeros(Co, device="cuda")
     slab0, slab1, slab2 = (torch.zeros(rows * Co, device="cuda") for _ in range(3))
     ssum = torch.full((Co,), 7.0, device="cuda")
-    L.call("szn_maxpool2x2_ceil_bwd_code", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(din0), L.ptr(cs0), L.ptr(slab0), rows, st)
+    ro0, ro1 = L.rows_out(), L.rows_out()
+    L.call("szn_maxpool2x2_ceil_bwd_code", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(din0), L.ptr(cs0), L.ptr(slab0), rows, C.byref(ro0), st)
     L.call("szn_maxpool2x2_ceil_bwd_code_cb", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(din1), L.ptr(cs1), L.ptr(slab1), rows,
-           tiles, 1, L.ptr(ssum), L.ptr(slab2), st)
+           C.byref(ro1), tiles, 1, L.ptr(ssum), L.ptr(slab2), st)
+    assert 0 < ro0.value == ro1.value <= rows
     assert L.last_kernel() == "slab_rows_sum_kernel" and L.prev_kernel() == "maxpool_bwd_code_kernel"
     torch.cuda.synchronize()
     assert torch.equal(din0, din1) and torch.equal(slab0, slab1)
@@ -739,9 +744,9 @@ def test_dgrad_border_tiles_replaced_by_region_sums(case, dtype):
     even = all(v % 2 == 0 for v in r)
     if even:
         L.call("szn_maxpool2x2_ceil_bwd_code_cb", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(dout), L.ptr(cs), L.ptr(slab), rows,
-               region, 1, L.ptr(ssum), L.ptr(slab2), st)
+               None, region, 1, L.ptr(ssum), L.ptr(slab2), st)
     else:
-        L.call("szn_maxpool2x2_ceil_bwd_code", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(dout), L.ptr(cs), L.ptr(slab), rows, st)
+        L.call("szn_maxpool2x2_ceil_bwd_code", dt, B, H, W, Co, L.ptr(code), L.ptr(dpool), L.ptr(dout), L.ptr(cs), L.ptr(slab), rows, None, st)
     torch.cuda.synchronize()
     mask = torch.ones(H, W, dtype=torch.bool, device="cuda")
     mask[r[4]:r[5], r[6]:r[7]] = False
@@ -756,7 +761,7 @@ def test_dgrad_border_tiles_replaced_by_region_sums(case, dtype):
         colsum = torch.zeros(Ci, device="cuda")
         d.colsum = colsum.data_ptr()
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), None, L.ptr(din), st)
-        frac = lib.szn_last_work_fraction()
+        frac = d.res.work_fraction
         kern = L.last_kernel()
         if mode == 2:
             assert frac < 0.95
@@ -833,10 +838,10 @@ def test_pool_winner_codes(dtype, geom):
         cs = torch.zeros(Co, device="cuda"); slab = torch.zeros(512, Co, device="cuda")
         if use_code:
             L.call("szn_maxpool2x2_ceil_bwd_code", dt, B, Hi, Wi, Co, L.ptr(code), L.ptr(dp), L.ptr(din), L.ptr(cs), L.ptr(slab), 512,
-                   L.stream_ptr())
+                   None, L.stream_ptr())
         else:
             L.call("szn_maxpool2x2_ceil_bwd", dt, B, Hi, Wi, Co, L.ptr(out), L.ptr(pool), L.ptr(dp), L.ptr(din), L.ptr(cs), L.ptr(slab), 512,
-                   L.stream_ptr())
+                   None, L.stream_ptr())
         torch.cuda.synchronize()
         outs.append((din, slab.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
@@ -883,7 +888,7 @@ def test_constant_border_hint_is_bit_exact(case):
                     d.cb_const[i] = v
             L.call("szn_conv2d_fwd", C.byref(d), L.ptr(x), L.ptr(w), L.ptr(bias), None, None, L.ptr(out), L.stream_ptr())
             assert L.last_kernel() == "conv3x3_regw", L.last_kernel()
-            frac = lib.szn_last_work_fraction()
+            frac = d.res.work_fraction
             torch.cuda.synchronize()
             res.append((cb_on, pool_only, out, pool, code, frac))
     dense = res[0]
@@ -924,7 +929,7 @@ def test_constant_border_hint_of_a_gated_dgrad(case):
                 d.cb_rect[i], d.cb_const[i] = grect[i], srect[i]
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), None, L.ptr(din), L.stream_ptr())
         assert L.last_kernel() == "conv3x3_regw", L.last_kernel()
-        rows = L.load().szn_last_colsum_rows()
+        rows = d.res.colsum_rows
         torch.cuda.synchronize()
         res.append((din, slab[:rows].clone()))
     (dense, cs0), (hint, cs1) = res
@@ -965,7 +970,7 @@ def test_splitk_epilogue_with_column_sums(dtype, geom):
                 d.colsum_slab, d.colsum_slab_rows = slab.data_ptr(), slab_rows
         L.call("szn_conv2d_fwd", C.byref(d), L.ptr(dout), L.ptr(wT), None, L.ptr(gate), None, L.ptr(out), st)
         kern = L.last_kernel()
-        rows = L.load().szn_last_colsum_rows()
+        rows = d.res.colsum_rows
         if colsum and slab_rows:
             assert float(cs.abs().max()) == 0.0 and rows > 0
             L.call("szn_colsum_reduce_batch", 1, (C.c_void_p * 1)(slab.data_ptr()), (C.c_int * 1)(rows), (C.c_int * 1)(Cout),

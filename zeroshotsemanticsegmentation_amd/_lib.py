@@ -18,13 +18,25 @@ class SznError(RuntimeError):
     pass
 
 
+class CallResult(C.Structure):
+    """szn_call_result_t: what a call reports back (rows written into its colsum slab, fraction of the dense tiles it executed)"""
+    _fields_ = [("colsum_rows", C.c_int), ("work_fraction", C.c_float)]
+
+
 class ConvDesc(C.Structure):
+    """szn_conv_desc_t.  Every instance owns a CallResult (`d.res`) and points `result` at it, so that after szn_conv2d_fwd / _dgrad /
+    _wgrad / _wgrad_adam `d.res.colsum_rows` / `d.res.work_fraction` hold what THAT call decided (no thread-local "last call" state)."""
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "KH", "KW", "pad", "ldi", "ldo", "ldg", "relu", "out_f32")] + [
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum", C.c_void_p), ("pool_out", C.c_void_p),
         ("colsum_slab", C.c_void_p), ("colsum_slab_rows", C.c_int), ("pool_code", C.c_void_p), ("pool_only", C.c_int),
         ("cb_on", C.c_int), ("cb_rect", C.c_int * 4), ("cb_const", C.c_int * 4), ("reserved_cus", C.c_int),
-        ("dw_lp", C.c_void_p), ("dw_lp_dtype", C.c_int)]
+        ("dw_lp", C.c_void_p), ("dw_lp_dtype", C.c_int), ("result", C.POINTER(CallResult))]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.res = CallResult(0, 1.0)
+        self.result = C.pointer(self.res)
 
 
 class DeviceInfo(C.Structure):
@@ -63,6 +75,7 @@ def class_set(classes):
 
 _P, _I, _L, _F, _U64, _SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_size_t
 _D = C.POINTER(ConvDesc)
+_IP = C.POINTER(C.c_int)
 _CS = C.POINTER(ClassSet)
 
 # name -> (restype, argtypes); must list every symbol of include/szn.h (tests/test_abi.py checks that)
@@ -89,9 +102,7 @@ SIGNATURES = {
     "szn_conv2d_wgrad_adam_supported": (_I, [_D]),
     "szn_conv2d_wgrad_adam": (_I, [_D, _P, _P, _P, C.POINTER(AdamArgs), _P]),
     "szn_bias_grad": (_I, [_I, _L, _I, _I, _P, _P, _I, _P]),
-    "szn_bias_grad_slab": (_I, [_I, _L, _I, _I, _P, _P, _I, _P, _I, _P]),
-    "szn_last_colsum_rows": (_I, []),
-    "szn_last_work_fraction": (C.c_float, []),
+    "szn_bias_grad_slab": (_I, [_I, _L, _I, _I, _P, _P, _I, _P, _I, _IP, _P]),
     "szn_colsum_reduce_batch": (_I, [_I, _P, _P, _P, _P, _P]),
     "szn_gemm_proj_fwd": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "szn_gemm_proj_dgrad": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -103,11 +114,11 @@ SIGNATURES = {
     "szn_conv1_1_wgrad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "szn_conv1_1_wgrad_reads": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_int)]),
     "szn_maxpool2x2_ceil_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
-    "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "szn_maxpool2x2_ceil_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _IP, _P]),
     "szn_maxpool2x2_ceil_fwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "szn_maxpool2x2_ceil_bwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
-    "szn_maxpool2x2_ceil_bwd_code_gather": (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
-    "szn_maxpool2x2_ceil_bwd_code_cb": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
+    "szn_maxpool2x2_ceil_bwd_code": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _IP, _P]),
+    "szn_maxpool2x2_ceil_bwd_code_gather": (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _IP, _P]),
+    "szn_maxpool2x2_ceil_bwd_code_cb": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _IP, _P, _I, _P, _P, _P]),
     "szn_conv2d_wgrad_cb_region": (_I, [_D, _P]),
     "szn_bilinear_up32_crop_fwd": (_I, [_I] * 9 + [_P, _P, _P]),
     "szn_bilinear_up32_crop_bwd": (_I, [_I] * 9 + [_P, _P, _P]),
@@ -189,9 +200,9 @@ def last_kernel():
     return load().szn_last_kernel().decode()
 
 
-def last_work_fraction():
-    """fraction of the dense output tiles the last szn_conv2d_fwd on this thread executed (1.0 without the constant-border hint)"""
-    return float(load().szn_last_work_fraction())
+def rows_out():
+    """a fresh int out-parameter (colsum_rows_out of the pool / bias-gradient entry points): pass C.byref(r), read r.value"""
+    return C.c_int(0)
 
 
 def prev_kernel():

@@ -21,6 +21,11 @@ void szn_set_error(const char* fmt, ...);
 #define SZN_FAIL(code, ...) do { szn_set_error(__VA_ARGS__); return (code); } while (0)
 void szn_note_kernel(const char* name);          /* thread-local: the kernel the dispatcher picked (szn_last_kernel) */
 void szn_note_colsum_rows(int rows);             /* thread-local: partial rows the last call wrote into its colsum slab */
+int szn_noted_colsum_rows(void);                /* (internal: read back inside the SAME entry point, published through its out-parameter) */
+float szn_noted_work_fraction(void);
+static inline void szn_publish_result(const szn_conv_desc_t* d) {
+    if (d && d->result) { d->result->colsum_rows = szn_noted_colsum_rows(); d->result->work_fraction = szn_noted_work_fraction(); }
+}
 void szn_note_work_fraction(float f);            /* thread-local: fraction of the dense tiles the last conv call executed (constant-border hint) */
 #define SZN_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); szn_note_kernel(name); \
     if (e__ != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); } while (0)

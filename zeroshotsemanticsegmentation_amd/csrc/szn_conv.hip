@@ -560,7 +560,7 @@ int szn_conv2d_fwd_v1(const szn_conv_desc_t* d, const void* in, const void* w, c
        : d->dtype == SZN_F16 ? launch_conv<f16_raw>(a, (hipStream_t)stream) : launch_conv<float>(a, (hipStream_t)stream);
     if (rc || !d->colsum) return rc;
     if (d->out_f32 && szn_is16(d->dtype)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_fwd(v1): colsum with out_f32 is unsupported");
-    return szn_bias_grad_slab(d->dtype, a.M, d->Co, d->ldo, out, d->colsum, 1, d->colsum_slab, d->colsum_slab_rows, stream);   // fallback path: separate pass
+    return szn_bias_grad_slab(d->dtype, a.M, d->Co, d->ldo, out, d->colsum, 1, d->colsum_slab, d->colsum_slab_rows, nullptr, stream);   // fallback path: separate pass
 }
 
 extern "C" int szn_pack_weight_dgrad(int dtype, int Co, int KH, int KW, int Ci, const void* w, void* wT,
@@ -846,14 +846,15 @@ int szn_conv2d_wgrad_v1(const szn_conv_desc_t* d, const void* in, const void* do
 }
 
 extern "C" int szn_bias_grad_slab(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
-                                  float* colsum_slab, int colsum_slab_rows, szn_stream_t stream);
+                                  float* colsum_slab, int colsum_slab_rows, int* colsum_rows_out, szn_stream_t stream);
 extern "C" int szn_bias_grad(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
                              szn_stream_t stream) {
-    return szn_bias_grad_slab(dtype, M, Co, ldd, dout, db, accumulate, nullptr, 0, stream);
+    return szn_bias_grad_slab(dtype, M, Co, ldd, dout, db, accumulate, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int szn_bias_grad_slab(int dtype, long M, int Co, int ldd, const void* dout, float* db, int accumulate,
-                                  float* slab, int slab_rows, szn_stream_t stream) {
+                                  float* slab, int slab_rows, int* colsum_rows_out, szn_stream_t stream) {
+    if (colsum_rows_out) *colsum_rows_out = 0;
     if (!dout || !db || M <= 0 || Co <= 0 || ldd < Co) SZN_FAIL(SZN_ERR_ARG, "bias_grad: bad argument");
     if (ldd % (szn_is16(dtype) ? 8 : 4) || ((uintptr_t)dout & 15))
         SZN_FAIL(SZN_ERR_UNSUPPORTED, "bias_grad: rows must be 16-B aligned (ldd multiple of %d)", szn_is16(dtype) ? 8 : 4);
@@ -867,6 +868,7 @@ extern "C" int szn_bias_grad_slab(int dtype, long M, int Co, int ldd, const void
     const int blocks = szn_div_up(M, rpb);
     if (slab && slab_rows < blocks) SZN_FAIL(SZN_ERR_ARG, "bias_grad: colsum_slab holds %d rows, %d needed", slab_rows, blocks);
     szn_note_colsum_rows(slab ? blocks : 0);
+    if (colsum_rows_out) *colsum_rows_out = slab ? blocks : 0;
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(bias_grad_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)dout, db, M, Co, ldd,
                            (int)rpb, slab);

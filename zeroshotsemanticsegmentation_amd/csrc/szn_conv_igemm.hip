@@ -591,11 +591,20 @@ extern "C" int szn_maxpool2x2_ceil_fwd(int dtype, int B, int Hi, int Wi, int C, 
 static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                                const float* chan_scale, void* out, szn_stream_t stream, int* pooled);
 
+static int conv2d_fwd_entry(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias,
+                            const void* gate, const float* chan_scale, void* out, szn_stream_t stream);
 extern "C" int szn_conv2d_fwd(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias,
                               const void* gate, const float* chan_scale, void* out, szn_stream_t stream) {
     if (!d) SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: null descriptor");
     szn_note_colsum_rows(0);
     szn_note_work_fraction(1.f);
+    const int rc = conv2d_fwd_entry(d, in, w, bias, gate, chan_scale, out, stream);
+    szn_publish_result(d);           // (szn_conv_desc_t.result: what the kernel that ran decided -- no state survives the call)
+    return rc;
+}
+
+static int conv2d_fwd_entry(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias,
+                            const void* gate, const float* chan_scale, void* out, szn_stream_t stream) {
     if (d->colsum_slab && ((uintptr_t)d->colsum_slab & 15)) SZN_FAIL(SZN_ERR_ARG, "conv2d: colsum_slab must be 16-B aligned");
     if (d->pool_out && (!d->relu || d->ldo != d->Co || gate || chan_scale))
         SZN_FAIL(SZN_ERR_ARG, "conv2d_fwd: pool_out needs relu, ldo == Co and no gate / chan_scale");

@@ -858,7 +858,7 @@ static bool border_desc_ok(const szn_conv_desc_t* d) {
 
 // region[8] = pixels {0, Hi, 0, Wi, wy0, wy1, wx0, wx1}: a szn_conv2d_dgrad call with this descriptor (cb_on == 2, gate, colsum) runs only
 // the tiles inside rows [wy0, wy1) x columns [wx0, wx1); the sum of dout over the rest of the map is what szn_conv2d_dgrad_border_finish
-// wants as skip_sum.  Returns 1, or 0 when the call would run every tile (then no finish call either: szn_last_work_fraction() == 1).
+// wants as skip_sum.  Returns 1, or 0 when the call would run every tile (then no finish call either: result->work_fraction == 1).
 extern "C" int szn_conv2d_dgrad_border_region(const szn_conv_desc_t* d, int region[8]) {
     if (!border_desc_ok(d) || !region) return 0;
     static int cbe = -1;

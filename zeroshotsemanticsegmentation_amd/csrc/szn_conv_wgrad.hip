@@ -337,7 +337,10 @@ extern "C" int szn_conv2d_wgrad_adam(const szn_conv_desc_t* d, const void* in, c
     if (opt->w_lp && opt->w_lp_dtype != d->dtype) SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad_adam: the weight image must have the compute dtype");
     if (!szn_conv2d_wgrad_adam_supported(d))
         SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad_adam: this layer does not take conv_wgrad_wide (use szn_conv2d_wgrad + szn_adam_step)");
+    szn_note_colsum_rows(0);
+    szn_note_work_fraction(1.f);
     const int rc = szn_conv_wgrad_wide_try(d, in, dout, dw, 0, 96, stream, opt);
+    szn_publish_result(d);
     if (rc > 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad_adam: conv_wgrad_wide declined the layer");
     return rc;
 }
@@ -351,7 +354,9 @@ extern "C" int szn_conv2d_wgrad(const szn_conv_desc_t* d, const void* in, const 
     if (d->dw_lp && (accumulate || !szn_is16(d->dw_lp_dtype) || ((uintptr_t)d->dw_lp & 7) || !dw))
         SZN_FAIL(SZN_ERR_ARG, "conv2d_wgrad: dw_lp needs accumulate == 0, a 16-bit dw_lp_dtype, an 8-B aligned image and dw as fp32 scratch");
     int lp_native = 0;
+    szn_note_colsum_rows(0);
     const int rc = wgrad_dispatch(d, in, dout, dw, accumulate, stream, &lp_native);
+    szn_publish_result(d);
     if (rc != SZN_OK || !d->dw_lp || lp_native) return rc;
     // the kernel family that took the layer finishes in fp32 (head / skip layers, fp32 layers: a few MB): one conversion pass
     return szn_cast(SZN_F32, d->dw_lp_dtype, (long)d->Co * d->KH * d->KW * d->Ci, dw, d->dw_lp, stream);

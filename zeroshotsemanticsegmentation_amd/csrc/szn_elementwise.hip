@@ -28,10 +28,10 @@ extern "C" const char* szn_last_kernel(void) { return g_last_kernel; }
 extern "C" const char* szn_prev_kernel(void) { return g_prev_kernel; }
 static thread_local int g_colsum_rows = 0;
 void szn_note_colsum_rows(int rows) { g_colsum_rows = rows; }
-extern "C" int szn_last_colsum_rows(void) { return g_colsum_rows; }
+int szn_noted_colsum_rows(void) { return g_colsum_rows; }
 static thread_local float g_work_fraction = 1.f;
 void szn_note_work_fraction(float f) { g_work_fraction = f; }
-extern "C" float szn_last_work_fraction(void) { return g_work_fraction; }
+float szn_noted_work_fraction(void) { return g_work_fraction; }
 
 extern "C" int szn_version(void) { return 100; /* 0.1.0 */ }
 extern "C" int szn_device_info(int device, szn_device_info_t* out) {
@@ -1133,7 +1133,8 @@ extern "C" int szn_maxpool2x2_ceil_fwd_code(int dtype, int B, int Hi, int Wi, in
 
 extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, const void* in, const void* out,
                                        const void* dout, void* din, float* colsum, float* colsum_slab, int colsum_slab_rows,
-                                       szn_stream_t stream) {
+                                       int* colsum_rows_out, szn_stream_t stream) {
+    if (colsum_rows_out) *colsum_rows_out = 0;
     if (!in || !out || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0)
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: bad argument");
     const int ch = szn_is16(dtype) ? 8 : 4;
@@ -1150,6 +1151,7 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
     if (cslab && colsum_slab_rows < grid)
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd: colsum_slab holds %d rows, %d needed", colsum_slab_rows, grid);
     szn_note_colsum_rows(cslab ? grid : 0);
+    if (colsum_rows_out) *colsum_rows_out = cslab ? grid : 0;
     if (dtype == SZN_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_raw*)in, (const bf16_raw*)out, (const bf16_raw*)dout, (bf16_raw*)din, B, Hi, Wi, C,
@@ -1168,8 +1170,9 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
 }
 
 static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din, float* colsum,
-                                 float* colsum_slab, int colsum_slab_rows, const int* skip_tiles, int n_regions, float* skip_sum,
-                                 float* skip_slab, szn_stream_t stream, const PoolGather* gather = nullptr) {
+                                 float* colsum_slab, int colsum_slab_rows, int* colsum_rows_out, const int* skip_tiles, int n_regions,
+                                 float* skip_sum, float* skip_slab, szn_stream_t stream, const PoolGather* gather = nullptr) {
+    if (colsum_rows_out) *colsum_rows_out = 0;
     if (!code || !dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: bad argument");
     const int ch = szn_is16(dtype) ? 8 : 4;
     if (C % ch) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd_code: C must be a multiple of %d", ch);
@@ -1190,6 +1193,7 @@ static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const 
     if (cslab && colsum_slab_rows < grid)
         SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code: colsum_slab holds %d rows, %d needed", colsum_slab_rows, grid);
     szn_note_colsum_rows(cslab ? grid : 0);
+    if (colsum_rows_out) *colsum_rows_out = cslab ? grid : 0;
     PoolSkip sk = {}, sk2 = {};
     if (skip_tiles) { sk.fy0 = skip_tiles[0]; sk.fy1 = skip_tiles[1]; sk.fx0 = skip_tiles[2]; sk.fx1 = skip_tiles[3];
                       sk.wy0 = skip_tiles[4]; sk.wy1 = skip_tiles[5]; sk.wx0 = skip_tiles[6]; sk.wx1 = skip_tiles[7]; }
@@ -1218,27 +1222,29 @@ static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const 
 }
 
 extern "C" int szn_maxpool2x2_ceil_bwd_code(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
-                                            float* colsum, float* colsum_slab, int colsum_slab_rows, szn_stream_t stream) {
-    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, nullptr, 0, nullptr, nullptr, stream);
+                                            float* colsum, float* colsum_slab, int colsum_slab_rows, int* colsum_rows_out, szn_stream_t stream) {
+    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, colsum_rows_out, nullptr, 0, nullptr,
+                                 nullptr, stream);
 }
 
 // dout given in ANOTHER coordinate system, [B][Hs][Ws][C], with the transposed band map to this pool's output as per-axis tables
 // ytab[(Hi + 1) / 2][2], xtab[(Wi + 1) / 2][2] = {start, count} (device memory; what szn_band_remap takes): see PoolGather
 extern "C" int szn_maxpool2x2_ceil_bwd_code_gather(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dsrc, int Hs, int Ws,
                                                    const int* ytab, const int* xtab, void* din, float* colsum, float* colsum_slab,
-                                                   int colsum_slab_rows, szn_stream_t stream) {
+                                                   int colsum_slab_rows, int* colsum_rows_out, szn_stream_t stream) {
     if (!ytab || !xtab || Hs <= 0 || Ws <= 0) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_gather: tables and source size are required");
     if ((long)B * Hs * Ws * C >= (1L << 40)) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_gather: source too large");
     const PoolGather pg = {ytab, xtab, Hs, Ws};
-    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dsrc, din, colsum, colsum_slab, colsum_slab_rows, nullptr, 0, nullptr, nullptr, stream, &pg);
+    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dsrc, din, colsum, colsum_slab, colsum_slab_rows, colsum_rows_out, nullptr, 0, nullptr,
+                                 nullptr, stream, &pg);
 }
 
 extern "C" int szn_maxpool2x2_ceil_bwd_code_cb(int dtype, int B, int Hi, int Wi, int C, const void* code, const void* dout, void* din,
-                                               float* colsum, float* colsum_slab, int colsum_slab_rows, const int* skip_regions,
-                                               int n_regions, float* skip_sum, float* skip_slab, szn_stream_t stream) {
+                                               float* colsum, float* colsum_slab, int colsum_slab_rows, int* colsum_rows_out,
+                                               const int* skip_regions, int n_regions, float* skip_sum, float* skip_slab, szn_stream_t stream) {
     if (!skip_regions) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_cb: skip_regions is NULL (use szn_maxpool2x2_ceil_bwd_code)");
-    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, skip_regions, n_regions, skip_sum,
-                                 skip_slab, stream);
+    return maxpool_bwd_code_impl(dtype, B, Hi, Wi, C, code, dout, din, colsum, colsum_slab, colsum_slab_rows, colsum_rows_out, skip_regions, n_regions,
+                                 skip_sum, skip_slab, stream);
 }
 
 extern "C" int szn_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, szn_stream_t stream) {

@@ -450,12 +450,12 @@ class _Engine(object):
         self._cs_off += n
         return slab, rows
 
-    def _cs_register(self, slab, Cc, out, rows=None):
-        """after a call that was handed `slab`: remember how many rows it wrote (rows: already read from szn_last_colsum_rows)"""
+    def _cs_register(self, slab, Cc, out, rows):
+        """after a call that was handed `slab`: remember how many rows it wrote (rows: the call's own out-parameter --
+        szn_conv_desc_t.result->colsum_rows / colsum_rows_out)"""
         if slab is None:
             return
-        if rows is None:
-            rows = L.load().szn_last_colsum_rows()
+        rows = int(getattr(rows, "value", rows))
         if rows > 0:
             self._cs_jobs.append((slab, rows, Cc, out))
 
@@ -684,8 +684,9 @@ class _Engine(object):
                L.ptr(dwh), L.ptr(ws), st)
         if dbh is not None:
             slab, rows = self._cs_slab(M, CP, dc.device)
-            L.call("szn_bias_grad_slab", L.dtype_code(dc.dtype), M, CP, CP, L.ptr(dc), L.ptr(dbh), 0, L.ptr(slab), rows, st)
-            self._cs_register(slab, CP, dbh)
+            ro = L.rows_out()
+            L.call("szn_bias_grad_slab", L.dtype_code(dc.dtype), M, CP, CP, L.ptr(dc), L.ptr(dbh), 0, L.ptr(slab), rows, C.byref(ro), st)
+            self._cs_register(slab, CP, dbh, ro)
 
     def _head_dgrad_fp8(self, dc, feat, scale, colsum):
         """d(fc7 output) = dc . W_head on the fp8 matrix cores (szn_proj_fp8_dgrad) with the ReLU gate / Dropout2d factor of fc7
@@ -701,8 +702,9 @@ class _Engine(object):
                L.ptr(feat), L.dtype_code(feat.dtype), F, L.ptr(scale), h * w, code, L.ptr(d), F, L.ptr(ws), st)
         if colsum is not None:
             slab, rows = self._cs_slab(M, F, d.device)
-            L.call("szn_bias_grad_slab", code, M, F, F, L.ptr(d), L.ptr(colsum), 1, L.ptr(slab), rows, st)
-            self._cs_register(slab, F, colsum)
+            ro = L.rows_out()
+            L.call("szn_bias_grad_slab", code, M, F, F, L.ptr(d), L.ptr(colsum), 1, L.ptr(slab), rows, C.byref(ro), st)
+            self._cs_register(slab, F, colsum, ro)
         return d
 
     def upscore(self, ctx):
@@ -862,8 +864,9 @@ class _Engine(object):
                 L.call("szn_conv2d_wgrad", C.byref(d), L.ptr(x), L.ptr(dout), L.ptr(dw), 0, st)
             if db is not None:
                 slab, rows = self._cs_slab(B * Ho * Wo, co, dout.device)
-                L.call("szn_bias_grad_slab", code, B * Ho * Wo, co, ldo, L.ptr(dout), L.ptr(db), 0, L.ptr(slab), rows, st)
-                self._cs_register(slab, co, db)
+                ro = L.rows_out()
+                L.call("szn_bias_grad_slab", code, B * Ho * Wo, co, ldo, L.ptr(dout), L.ptr(db), 0, L.ptr(slab), rows, C.byref(ro), st)
+                self._cs_register(slab, co, db, ro)
             if after is not None:
                 after()
 
@@ -923,12 +926,12 @@ class _Engine(object):
             for i in range(4):
                 d.cb_rect[i], d.cb_const[i] = grect[i], srect[i]
         L.call("szn_conv2d_dgrad", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(scale), L.ptr(din), L.stream_ptr())
-        cs_rows = L.load().szn_last_colsum_rows()      # (thread-local "last call" state: read before any other library call)
-        if d.cb_on == 2 and L.load().szn_last_work_fraction() < 1.0:
+        cs_rows = d.res.colsum_rows                    # (the call's own report: szn_conv_desc_t.result)
+        if d.cb_on == 2 and d.res.work_fraction < 1.0:
             bws = torch.empty(2 * 24 * B * Co, device=dout.device)
             L.call("szn_conv2d_dgrad_border_finish", C.byref(d), L.ptr(dout), L.ptr(wT), L.ptr(gate), L.ptr(border_sum), L.ptr(colsum),
                    L.ptr(bws), L.stream_ptr())
-        self._cs_register(slab, Ci, colsum, rows=cs_rows)
+        self._cs_register(slab, Ci, colsum, cs_rows)
         return din
 
     def backward(self, ctx, dcoarse, grads, backbone=True, layer_done=None, head_first=None, skips=None):
@@ -1026,6 +1029,7 @@ class _Engine(object):
                 B, Hi, Wi, Cc = ctx.pools[pi + 1][3] if pcode is not None else pin.shape
                 dn = torch.empty(B, Hi, Wi, Cc, device=d.device, dtype=pout.dtype)
                 slab, rows = self._cs_slab(B * Hi * Wi, Cc, d.device)
+                ro = L.rows_out()
                 # constant-border hint of the producer's weight gradient (which reads dn next): let this pass sum dn over the tiles
                 # that call is going to skip, instead of a second pass over them (szn_conv2d_wgrad_cb_tiles)
                 regions, want = [], []
@@ -1061,7 +1065,8 @@ class _Engine(object):
                     ssum = torch.empty(n, Cc, device=d.device)
                     slab2 = torch.empty(n * rows * Cc, device=d.device)
                     L.call("szn_maxpool2x2_ceil_bwd_code_cb", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), L.ptr(dn),
-                           L.ptr(grads[producer][1]), L.ptr(slab), rows, (C.c_int * len(regions))(*regions), n, L.ptr(ssum), L.ptr(slab2), st)
+                           L.ptr(grads[producer][1]), L.ptr(slab), rows, C.byref(ro), (C.c_int * len(regions))(*regions), n, L.ptr(ssum),
+                           L.ptr(slab2), st)
                     for i, kind in enumerate(want):
                         (cb_sums if kind == "w" else border_sums)[producer] = ssum[i]
                 elif gather is not None:
@@ -1073,14 +1078,14 @@ class _Engine(object):
                             L.call("szn_band_fold", code, B, d.shape[1], d.shape[2], Cc, L.ptr(d), axis, L.ptr(runs), runs.shape[0], st)
                     ty, tx = gather["tabs"]
                     L.call("szn_maxpool2x2_ceil_bwd_code_gather", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), d.shape[1], d.shape[2],
-                           L.ptr(ty), L.ptr(tx), L.ptr(dn), L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
+                           L.ptr(ty), L.ptr(tx), L.ptr(dn), L.ptr(grads[producer][1]), L.ptr(slab), rows, C.byref(ro), st)
                 elif pcode is not None:
                     L.call("szn_maxpool2x2_ceil_bwd_code", code, B, Hi, Wi, Cc, L.ptr(pcode), L.ptr(d), L.ptr(dn),
-                           L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
+                           L.ptr(grads[producer][1]), L.ptr(slab), rows, C.byref(ro), st)
                 else:
                     L.call("szn_maxpool2x2_ceil_bwd", code, B, Hi, Wi, Cc, L.ptr(pin), L.ptr(pout), L.ptr(d), L.ptr(dn),
-                           L.ptr(grads[producer][1]), L.ptr(slab), rows, st)
-                self._cs_register(slab, Cc, grads[producer][1])
+                           L.ptr(grads[producer][1]), L.ptr(slab), rows, C.byref(ro), st)
+                self._cs_register(slab, Cc, grads[producer][1], ro)
                 d = dn
                 continue
             name, pad = item
