@@ -45,6 +45,11 @@ const char* szn_last_error(void);
 const char* szn_last_kernel(void);
 const char* szn_prev_kernel(void);   /* the launch before it (e.g. the GEMM kernel in front of a split-K epilogue) */
 int szn_version(void); /* major*10000 + minor*100 + patch */
+/* The environment knobs this build reads (A/B switches and dispatch thresholds; defaults = the shipped behaviour): szn_knob_count() names,
+ * szn_knob_name(i) for 0 <= i < count (NULL outside).  The library refuses to read a variable that is not in this list, and
+ * tests/test_gpu_knobs.py runs a training step under a non-default value of every one of them.                                              */
+int szn_knob_count(void);
+const char* szn_knob_name(int i);
 typedef struct {
     char name[128];
     char arch[32];

@@ -69,3 +69,36 @@ def test_conv1_1_wgrad_read_set_is_host_logic():
     assert tuple(rect) == (0, 710, 0, 710)
     assert lib.szn_conv1_1_wgrad_reads(_lib.SZN_BF16, 1, 64, 64, 1, rect) == 0
     assert tuple(rect) == (0, 64, 0, 64)                            # pad 1: the map is 64 x 64, every window meets the image
+
+
+def test_every_knob_has_a_case():
+    """no environment knob without a test case -- the library's table (szn_knob_count / szn_knob_name), the package's
+    os.environ reads and the C sources' getenv calls against tests/test_gpu_knobs.py's groups"""
+    import re
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_knobs import ELSEWHERE, GROUPS, PY_KNOBS
+    from zeroshotsemanticsegmentation_amd import _lib as L
+    lib = L.load()
+    names = {lib.szn_knob_name(i).decode() for i in range(lib.szn_knob_count())}
+    assert lib.szn_knob_name(lib.szn_knob_count()) is None and len(names) == lib.szn_knob_count()
+    covered = set()
+    for env in GROUPS.values():
+        covered |= set(env)
+    assert names <= covered, "library knobs without a test case: %s" % sorted(names - covered)
+    # the Python side: every SZN_* variable the package reads is in PY_KNOBS (and through it in a group or in the test file named above)
+    found = set()
+    pkg = os.path.join(ROOT, "zeroshotsemanticsegmentation_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            found |= set(re.findall(r'environ[^\n]*?"(SZN_[A-Z0-9_]+)"', open(os.path.join(pkg, fn)).read()))
+    assert found == PY_KNOBS, (sorted(found - PY_KNOBS), sorted(PY_KNOBS - found))
+    assert PY_KNOBS - ELSEWHERE <= covered, sorted(PY_KNOBS - ELSEWHERE - covered)
+    # and no C source reads the environment behind szn_knob's back (the ablation switches exist in `make ABLATE=1` builds only)
+    src = os.path.join(pkg, "csrc")
+    for fn in os.listdir(src):
+        if fn.endswith((".hip", ".h")):
+            for ln in open(os.path.join(src, fn)).read().splitlines():
+                if "getenv(" in ln:
+                    assert fn == "szn_elementwise.hip" and "getenv(name)" in ln or fn == "szn_common.h", (fn, ln.strip())
+
+

@@ -84,6 +84,8 @@ SIGNATURES = {
     "szn_last_kernel": (C.c_char_p, []),
     "szn_prev_kernel": (C.c_char_p, []),
     "szn_version": (_I, []),
+    "szn_knob_count": (_I, []),
+    "szn_knob_name": (C.c_char_p, [_I]),
     "szn_device_info": (_I, [_I, C.POINTER(DeviceInfo)]),
     "szn_stream_create_cu_mask": (_I, [_I, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),
     "szn_stream_destroy": (_I, [C.c_void_p]),

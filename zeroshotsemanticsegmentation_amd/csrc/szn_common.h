@@ -26,7 +26,9 @@ float szn_noted_work_fraction(void);
 static inline void szn_publish_result(const szn_conv_desc_t* d) {
     if (d && d->result) { d->result->colsum_rows = szn_noted_colsum_rows(); d->result->work_fraction = szn_noted_work_fraction(); }
 }
-void szn_note_work_fraction(float f);            /* thread-local: fraction of the dense tiles the last conv call executed (constant-border hint) */
+void szn_note_work_fraction(float f);
+int szn_knob(const char* name, int dflt);        /* environment knob, registered in szn_elementwise.hip's table (aborts on an unlisted name) */
+int szn_knob_live(const char* name, int dflt);   /* the same, re-read on every call (the tests flip it inside one process) */            /* thread-local: fraction of the dense tiles the last conv call executed (constant-border hint) */
 #define SZN_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); szn_note_kernel(name); \
     if (e__ != hipSuccess) SZN_FAIL(SZN_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); } while (0)
 

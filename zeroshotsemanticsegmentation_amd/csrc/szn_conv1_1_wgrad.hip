@@ -335,15 +335,8 @@ int szn_conv1_1_wgrad_fused_try(int dtype, int B, int H, int W, int pad, const f
     if (blocks < 1) blocks = 1;
     if (workspace_bytes < (size_t)blocks * 2048 * sizeof(float)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    static int gather = -1;                  // SZN_C11_WGRAD_GATHER=1: the round-2 form (taps gathered straight from memory)
-    if (gather < 0) { const char* e = getenv("SZN_C11_WGRAD_GATHER"); gather = e ? atoi(e) : 0; }
-    if (gather) {
-        if (dtype == SZN_F16) hipLaunchKernelGGL((conv1_1_wgrad_kernel<f16_raw, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv1_1_wgrad_kernel<bf16_raw, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    } else {
-        if (dtype == SZN_F16) hipLaunchKernelGGL((conv1_1_wgrad_kernel<f16_raw, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv1_1_wgrad_kernel<bf16_raw, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    }
+    if (dtype == SZN_F16) hipLaunchKernelGGL((conv1_1_wgrad_kernel<f16_raw, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv1_1_wgrad_kernel<bf16_raw, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     SZN_CHECK_LAUNCH("conv1_1_wgrad_kernel");
     hipLaunchKernelGGL(conv1_1_wgrad_reduce, dim3(64 * 27 / 8), dim3(256), 0, st, (const float*)workspace, dw,
                        (int)blocks, accumulate);

@@ -421,8 +421,7 @@ int launch_8ph_v(const WideArgs& a, hipStream_t st) {
     // SZN_8PH_KORD (default 1): cin-chunk-major K order for the K x K layers (MODE 2 only; see the kernel).  The kernel alone is 0-4 %
     // slower that way, the step 0.17 ms FASTER (same box, eight alternating runs: 9.08-9.16 -> 8.93-8.96 ms): its fabric traffic no longer
     // pushes everybody else's operands out of the caches.  0 = tap-major: bit-identical to conv_igemm_wide / conv_igemm_v2.
-    static int kord = -1;
-    if (kord < 0) { const char* e = getenv("SZN_8PH_KORD"); kord = e ? atoi(e) : 1; }
+    static const int kord = szn_knob("SZN_8PH_KORD", 1);
     if (kord && MODE == 2 && a.KH * a.KW > 1 && !(kord == 2 && a.KH != 3)) {       // (2: the 3 x 3 layers only -- A/B of fc6's 7 x 7 forward)
         hipLaunchKernelGGL((conv_igemm_8ph<T, NF0, NF1, 2, true>), dim3(a.mtiles * a.ntiles, a.nsplit), dim3(512), lds, st, a);
         SZN_CHECK_LAUNCH(NF0 + NF1 == 2 ? "conv_igemm_8ph_n128" : "conv_igemm_8ph");
@@ -437,11 +436,7 @@ template <typename T, int NF0, int NF1>
 int launch_8ph(const WideArgs& a, hipStream_t st) {
     // SZN_8PH_MODE: 2 (default) = two phases of 32 MFMA per K tile; 0 = four phases of 16 (the template's form: 2-4 % slower per kernel,
     // profiles/r04_ablations.txt section 8); 1 = four phases with the second LDS-DMA load issued among the MFMAs (6-8 % slower, section 6)
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("SZN_8PH_MODE"); mode = e ? atoi(e) : 2; }
-    if (mode == 1) return launch_8ph_v<T, NF0, NF1, 1>(a, st);
-    if (mode == 2) return launch_8ph_v<T, NF0, NF1, 2>(a, st);
-    return launch_8ph_v<T, NF0, NF1, 0>(a, st);
+    return launch_8ph_v<T, NF0, NF1, 2>(a, st);
 }
 
 }  // namespace
@@ -456,8 +451,6 @@ int szn_conv_8ph_launch(const void* args, int dtype, int bn, szn_stream_t stream
     // (a 320-cout tile -- the 300-d projection as one cout tile -- does not fit this form: 160 accumulator + 72 fragment registers
     // spill, <3, 2> is not instantiated; a form with the whole weight operand resident and the pixel operand in quarters fits but
     // concentrates the LDS-DMA issue in two phases and measured 12-25 % slower: profiles/r04_ablations.txt)
-    if (bn == 128)                     // 256 pixels x 128 couts (conv5_x at B = 8; every 3x3 layer of a one-image step): <1, 1>
-        return dtype == SZN_F16 ? launch_8ph<f16_raw, 1, 1>(a, (hipStream_t)stream) : launch_8ph<bf16_raw, 1, 1>(a, (hipStream_t)stream);
-    if (bn != 256) return 1;
+    if (bn != 256) return 1;           // (the 256 x 128 form <1, 1> was removed in round 6: never faster inside a step)
     return dtype == SZN_F16 ? launch_8ph<f16_raw, 2, 2>(a, (hipStream_t)stream) : launch_8ph<bf16_raw, 2, 2>(a, (hipStream_t)stream);
 }

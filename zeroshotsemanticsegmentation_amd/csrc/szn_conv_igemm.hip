@@ -628,8 +628,7 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
                        in_bytes < 0x7fff0000ul && w_bytes < 0x7fff0000ul && d->Hi < 32000 && d->Wi < 32000 && d->pad < 16000 &&
                        ((size_t)d->ldi * es) % 16 == 0;
     {   // the pixel projection at full-resolution sizes (>= 256 pixel tiles x one 320-wide cout tile): HBM-streaming kernel
-        static int wide_min0 = -1;
-        if (wide_min0 < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min0 = e ? atoi(e) : 240; }
+        static const int wide_min0 = szn_knob("SZN_WIDE_MINTILES", 240);
         const int rc = szn_proj_stream_try(d, in, w, bias, gate, chan_scale, out, wide_min0, stream);
         if (rc <= 0) return rc;
     }
@@ -644,8 +643,7 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     // 64/128 -> 64/128 channel 3x3 layers (conv1_2, conv2_x forward / dgrad): register-resident filter bank,
     // szn_conv_regw.hip; SZN_REGW_MINTILES = fewest 256-pixel tiles for which it is used
     if (d->KH == 3 && d->KW == 3 && d->Ci <= 128 && d->Co <= 128) {
-        static int regw_min = -1;
-        if (regw_min < 0) { const char* e = getenv("SZN_REGW_MINTILES"); regw_min = e ? atoi(e) : 128; }
+        static const int regw_min = szn_knob("SZN_REGW_MINTILES", 128);
         const int rc = szn_conv_regw_try(d, in, w, bias, gate, chan_scale, out, regw_min, stream);
         if (rc == 0 && d->pool_out) *pooled = 1;        // conv3x3_regw pools in its epilogue
         if (rc <= 0) return rc;
@@ -658,18 +656,17 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.ldi = d->ldi; a.ldo = d->ldo; a.ldg = d->ldg;
     a.relu = d->relu; a.out_f32 = d->out_f32;
     a.M = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo;
-    { static int stg = -1; if (stg < 0) { const char* e = getenv("SZN_IGEMM_STAGGER"); stg = e ? atoi(e) : 1; } a.stagger = stg; }
+    { const int stg = 1; /* (was SZN_IGEMM_STAGGER) */ a.stagger = stg; }
     {
         // epilogue from registers (szn_epilogue.h): whole 16-B pieces of 8 couts, so rows and bases have to be 16-B aligned
-        static int de = -1;
-        if (de < 0) { const char* e = getenv("SZN_IGEMM_DIRECT"); de = e ? atoi(e) : 1; }
+        static const int de = szn_knob("SZN_IGEMM_DIRECT", 1);
         const size_t oes = d->out_f32 ? 4 : 2;
         const uintptr_t al = (uintptr_t)out | (uintptr_t)gate | (uintptr_t)bias | (uintptr_t)chan_scale;
         a.direct_ep = de && szn_is16(d->dtype) && (d->Co % 8) == 0 && (((size_t)d->ldo * oes) & 15) == 0 && (al & 15) == 0 &&
                       (!gate || (((size_t)d->ldg * 2) & 15) == 0);
         a.abl_ep = 0;
     }
-    { static int nm = -1; if (nm < 0) { const char* e = getenv("SZN_NMAJOR"); nm = e ? atoi(e) : 0; } a.nmajor = (nm && w_bytes > in_bytes) ? 1 : 0; }   // measured slower on fc6/fc7: off
+    { const int nm = 0; /* (was SZN_NMAJOR) */ a.nmajor = (nm && w_bytes > in_bytes) ? 1 : 0; }   // measured slower on fc6/fc7: off
     const bool narrow = d->Co <= 64;
     const int BN = narrow ? 64 : 128;
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(a.Co, BN);
@@ -688,8 +685,7 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     const bool out32_ = d->out_f32 || d->dtype == SZN_F32;
     const int cs_rpb = 32;
     const long cs_rows = ((long)a.M + cs_rpb - 1) / cs_rpb;
-    static int cs_split = -1;
-    if (cs_split < 0) { const char* e = getenv("SZN_SPLITK_COLSUM"); cs_split = e ? atoi(e) : 1; }
+    const int cs_split = 1; /* (was SZN_SPLITK_COLSUM) */
     const bool cs_ok = d->colsum && cs_split && !(d->Co & 3) && (d->Co >> 2) <= 256 && 256 % (d->Co >> 2) == 0 && !(d->ldo & 3) &&
                        (!gate || !(d->ldg & 3)) && !((uintptr_t)d->workspace & 15) && !((uintptr_t)bias & 15) && !((uintptr_t)chan_scale & 15) &&
                        !((uintptr_t)out & (out32_ ? 15 : 7)) && (!d->colsum_slab || d->colsum_slab_rows >= cs_rows) &&
@@ -720,8 +716,8 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
                 if ((cand == 0 && ns == 1) || t < best_t * 0.97) { best = ns; best_t = t; best_wide = cand != 0; }
             }
         }
-        static int force_ns = -1;                   // tuning knob: SZN_SPLITK_NS=n forces the split count (0 = model)
-        if (force_ns < 0) { const char* e = getenv("SZN_SPLITK_NS"); force_ns = e ? atoi(e) : 0; }
+        const int force_ns = 0; /* (was SZN_SPLITK_NS) */                   // tuning knob: SZN_SPLITK_NS=n forces the split count (0 = model)
+
         if (force_ns > 0 && force_ns <= nK / 8 && (size_t)force_ns * a.M * a.Co * sizeof(float) <= d->workspace_bytes) best = force_ns;
         if (best > 1) {
             a.chunks_per_split = (int)((nK + best - 1) / best);
@@ -733,34 +729,13 @@ static int conv2d_fwd_dispatch(const szn_conv_desc_t* d, const void* in, const v
     int rc = 1;
     // >= 256 couts and enough tiles to fill the chip: 256 x 256 tiles (1.5x less LDS fill per FLOP), szn_conv_wide.hip
     if (a.nsplit == 1 || use_wide) {
-        static int wide_min = -1;
-        if (wide_min < 0) { const char* e = getenv("SZN_WIDE_MINTILES"); wide_min = e ? atoi(e) : 240; }
+        static const int wide_min = szn_knob("SZN_WIDE_MINTILES", 240);
         rc = szn_conv_wide_try(d, in, w, bias, gate, chan_scale, out, a.in_bytes, a.w_bytes, use_wide ? 1 : wide_min, a.ws,
                                a.nsplit, a.chunks_per_split, stream);
         if (rc < 0 || (rc == 0 && a.nsplit == 1)) return rc;
     }
-    if (rc != 0 && !narrow && szn_is16(d->dtype)) {
-        // round 4: the 256 x 128 tile on the 8-phase schedule (szn_conv_8ph.hip <1, 1>: staggered wave groups, counted vmcnt).  Alone on
-        // the device conv5_1 runs 9-18 % faster than on conv_igemm_v2 (1,120 against 1,000-1,030 TF/s), inside the train step the six conv5_x
-        // launches take the same 0.54 ms and the step came out 0.13 ms SLOWER in two alternating pairs (profiles/r04_ablations.txt section
-        // 10): off by default, SZN_IGEMM_8PH=1 turns it on
-        static int p8 = -1;
-        if (p8 < 0) { const char* e = getenv("SZN_IGEMM_8PH"); p8 = e ? atoi(e) : 0; }
-        // one round of >= 200 full-length tiles: with few tiles per launch or short split-K ranges (a one-image step) the longer
-        // pipeline fill of the 8-phase kernel costs more than its loop returns (B = 1: 3.00 -> 3.09-3.16 ms, profiles/r04_ablations.txt 10)
-        if (p8 && a.nsplit == 1 && (long)a.mtiles * a.ntiles >= 200) {
-            WideArgs wa = {};
-            wa.in = a.in; wa.w = a.w; wa.bias = a.bias; wa.gate = a.gate; wa.cscale = a.cscale; wa.out = a.out;
-            wa.colsum = a.colsum; wa.cslab = a.cslab; wa.in_bytes = a.in_bytes; wa.w_bytes = a.w_bytes;
-            wa.B = a.B; wa.Hi = a.Hi; wa.Wi = a.Wi; wa.Ci = a.Ci; wa.Ho = a.Ho; wa.Wo = a.Wo; wa.Co = a.Co; wa.KH = a.KH; wa.KW = a.KW;
-            wa.pad = a.pad; wa.ldi = a.ldi; wa.ldo = a.ldo; wa.ldg = a.ldg; wa.relu = a.relu; wa.out_f32 = a.out_f32;
-            wa.M = a.M; wa.HoWo = a.HoWo; wa.mtiles = a.mtiles; wa.ntiles = a.ntiles; wa.nmajor = a.nmajor;
-            wa.ws = a.ws; wa.nsplit = a.nsplit; wa.chunks_per_split = a.chunks_per_split; wa.direct_ep = a.direct_ep;
-            const int r8 = szn_conv_8ph_launch(&wa, d->dtype, 128, stream);
-            if (r8 < 0) return r8;
-            if (r8 == 0) rc = 0;
-        }
-    }
+    // (conv_igemm_8ph<T, 1, 1> -- the 8-phase schedule on this 256 x 128 tile -- was built in round 4, measured faster alone and slower inside the
+    //  step twice (profiles/r04_ablations.txt 10, r05_ablations.txt 4 and 24) and removed in round 6)
     if (rc != 0) {                                    // (rc == 0: the wide / 8-phase kernel ran, or wrote the slabs)
         if (d->dtype == SZN_BF16) rc = narrow ? launch_v2<bf16_raw, 2>(a, st) : launch_v2<bf16_raw, 4>(a, st);
         else if (d->dtype == SZN_F16) rc = narrow ? launch_v2<f16_raw, 2>(a, st) : launch_v2<f16_raw, 4>(a, st);

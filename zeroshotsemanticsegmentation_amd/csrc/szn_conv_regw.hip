@@ -616,8 +616,7 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     bool use_cb = false;
     int ref_oh = 0, ref_ow = 0;
     {
-        static int cbe = -1;
-        if (cbe < 0) { const char* e = getenv("SZN_CONST_BORDER"); cbe = e ? atoi(e) : 1; }
+        static const int cbe = szn_knob("SZN_CONST_BORDER", 1);
         if (cbe && d->cb_on && !gate && !d->colsum) {
             cb.tiles_y = a.tiles_y; cb.tiles_x = a.tiles_x;
             cb.fy0 = (std::max(d->cb_const[0], 0) + tr - 1) / tr; cb.fy1 = std::min(d->cb_const[1], d->Ho) / tr;
@@ -644,8 +643,7 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.cb = cb;
     a.dg_on = 0; a.gy0 = a.gy1 = a.gx0 = a.gx1 = a.sy0 = a.sy1 = a.sx0 = a.sx1 = 0; a.gref = 0;
     {
-        static int cbe = -1;
-        if (cbe < 0) { const char* e = getenv("SZN_CONST_BORDER"); cbe = e ? atoi(e) : 1; }
+        static const int cbe = szn_knob("SZN_CONST_BORDER", 1);
         // (dgrad form of the hint: see szn_conv_desc_t.cb_on)
         if (cbe && d->cb_on && gate && d->cb_rect[0] >= 1 && d->cb_rect[0] <= d->Ho && d->cb_rect[2] >= 0 && d->cb_rect[2] < d->Wo) {
             a.dg_on = 1;
@@ -663,7 +661,7 @@ int szn_conv_regw_try(const szn_conv_desc_t* d, const void* in, const void* w, c
         }
     }
     { static int abl = -1; if (abl < 0) abl = szn_ablate_env("SZN_REGW_ABLATE"); a.ablate = abl; }
-    { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_REGW_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
+    { const int sh = 1; /* (was SZN_REGW_SHIFT) */ a.shift = sh; }
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t p;
@@ -861,10 +859,8 @@ static bool border_desc_ok(const szn_conv_desc_t* d) {
 // wants as skip_sum.  Returns 1, or 0 when the call would run every tile (then no finish call either: result->work_fraction == 1).
 extern "C" int szn_conv2d_dgrad_border_region(const szn_conv_desc_t* d, int region[8]) {
     if (!border_desc_ok(d) || !region) return 0;
-    static int cbe = -1;
-    if (cbe < 0) { const char* e = getenv("SZN_CONST_BORDER"); cbe = e ? atoi(e) : 1; }
-    static int dgb = -1;
-    if (dgb < 0) { const char* e = getenv("SZN_DGRAD_BORDER"); dgb = e ? atoi(e) : 1; }
+    static const int cbe = szn_knob("SZN_CONST_BORDER", 1);
+    static const int dgb = szn_knob("SZN_DGRAD_BORDER", 1);
     if (!cbe || !dgb) return 0;
     szn_conv_desc_t s = *d;                                                // the swap of szn_conv2d_dgrad
     s.Hi = d->Ho; s.Wi = d->Wo; s.Ci = d->Co; s.Ho = d->Hi; s.Wo = d->Wi; s.Co = d->Ci; s.pad = 1;

@@ -380,15 +380,13 @@ static int wgrad_dispatch(const szn_conv_desc_t* d, const void* in, const void* 
     // 3x3 bf16 layers with a workspace: all nine taps from one staged patch, deterministic slab reduction
     // (szn_conv_wgrad_taps.hip); SZN_WGT_MINTILES = fewest 16x16 tiles per block for which it is used
     if (d->KH == 3 && d->KW == 3 && d->workspace) {
-        static int taps_min = -1;
-        if (taps_min < 0) { const char* e = getenv("SZN_WGT_MINTILES"); taps_min = e ? atoi(e) : 8; }
+        static const int taps_min = szn_knob("SZN_WGT_MINTILES", 8);
         const int rc = szn_conv_wgrad_taps_try(d, in, dout, dw, accumulate, taps_min, stream);
         if (rc <= 0) { *lp_native = 1; return rc; }
     }
     // many channels, few pixels (fc6, fc7): 256 x 256 tiles, one pixel split (szn_conv_wgrad_wide.hip)
     {
-        static int wide_min = -1;
-        if (wide_min < 0) { const char* e = getenv("SZN_WGW_MINTILES"); wide_min = e ? atoi(e) : 96; }
+        static const int wide_min = szn_knob("SZN_WGW_MINTILES", 96);
         const int rc = szn_conv_wgrad_wide_try(d, in, dout, dw, accumulate, wide_min, stream);
         if (rc <= 0) { *lp_native = 1; return rc; }
     }
@@ -403,8 +401,7 @@ static int wgrad_dispatch(const szn_conv_desc_t* d, const void* in, const void* 
     a.cotiles = szn_div_up(d->Co, 32 * FA); a.citiles = szn_div_up(d->Ci, 32 * FB);
     const long tiles = (long)a.cotiles * a.citiles * d->KH * d->KW;
     // ~3 blocks per CU x 256 CUs x a few waves of blocks; each split covers a multiple of 64 pixels, at least 1024
-    static int wg_target = -1;
-    if (wg_target < 0) { const char* e = getenv("SZN_WG_BLOCKS"); wg_target = e ? atoi(e) : 3072; }
+    const int wg_target = 3072; /* (was SZN_WG_BLOCKS) */
     long want = (wg_target + tiles - 1) / tiles;
     if (want < 1) want = 1;
     long span = (a.M + want - 1) / want;

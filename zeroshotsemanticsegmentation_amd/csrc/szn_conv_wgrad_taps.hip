@@ -463,8 +463,7 @@ __global__ __launch_bounds__(256) void wgrad_cb_colsum_reduce(WtArgs a, int rows
 // input patch -- rows [16 ty - pad, 16 ty + 18 - pad) -- lies inside cb_const, does not meet cb_rect, and the tile is a full 16 x 16 one.
 // -> true + the tile bookkeeping + the reference pixel (top-left pixel of the first skipped tile's patch) when the hint is worth taking.
 static bool taps_cb_geometry(const szn_conv_desc_t* d, int ncombo, int ncu, int min_tiles_per_block, CbGeom& out, int& ry, int& rx) {
-    static int cbon = -1;
-    if (cbon < 0) { const char* e = getenv("SZN_WGT_CB"); cbon = e ? atoi(e) : 1; }
+    static const int cbon = szn_knob("SZN_WGT_CB", 1);
     if (!cbon || !d->cb_on) return false;
     auto fdiv = [](int x, int y) { return x >= 0 ? x / y : -((-x + y - 1) / y); };       // floor
     auto cdiv = [&](int x, int y) { return -fdiv(-x, y); };                              // ceil
@@ -531,8 +530,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     // static partition has a full-kernel tail whenever another queue (an RCCL all-reduce running under the backward
     // pass) holds CUs; k = 2 halves the late blocks.  Measured with a 32-CU stand-in hog (profiles/r01_ablations.txt): 12.2 vs 12.3
     // ms/step under contention, 11.7 vs 11.9 without -- no net gain, so nothing sets it by default.
-    static int oversub = 0;
-    if (!oversub) { const char* e = getenv("SZN_WGT_OVERSUB"); oversub = e ? atoi(e) : 1; if (oversub < 1) oversub = 1; }
+    const int oversub = 1; /* (was SZN_WGT_OVERSUB) */
     // reserved_cus: CUs left to another queue (the RCCL all-reduce under the backward pass), see szn_conv_desc_t
     const int cus = (d->reserved_cus > 0 && ncu - d->reserved_cus >= ncombo) ? ncu - d->reserved_cus : ncu;
     long ns = (long)cus * oversub / ncombo;
@@ -540,8 +538,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     if (ns > nt / min_tiles_per_block) {
         // few tiles (conv5_x of ONE image: 9 tiles, 64 combos): the min_tiles rule would leave three quarters of the chip idle while 64
         // blocks walk 9 tiles each; down to two tiles per block the extra slabs cost less than the idle CUs (round 5, B = 1)
-        static int small = -1;
-        if (small < 0) { const char* e = getenv("SZN_WGT_SMALLSPLIT"); small = e ? atoi(e) : 1; }
+        const int small = 1; /* (was SZN_WGT_SMALLSPLIT) */
         const long relaxed = small ? std::max<long>(nt / min_tiles_per_block, std::min<long>(ns, nt / 2)) : nt / min_tiles_per_block;
         ns = relaxed;
     }
@@ -557,8 +554,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     const size_t cb_bytes = a.cb.on ? ((size_t)cb_rows + 1) * d->Co * sizeof(float) : 0;
     if (cb_bytes + slab_bytes > d->workspace_bytes) return 1;
     if (ns > (long)((d->workspace_bytes - cb_bytes) / slab_bytes)) ns = (long)((d->workspace_bytes - cb_bytes) / slab_bytes);
-    static int minblk = -1;
-    if (minblk < 0) { const char* e = getenv("SZN_WGT_MINBLOCKS"); minblk = e ? atoi(e) : 32; }
+    const int minblk = 32; /* (was SZN_WGT_MINBLOCKS) */
     if (ns < 1 || ns * ncombo < minblk) return 1;
     a.nsplit = (int)ns;
     const bool own_sum = a.cb.on && !d->colsum;        // d->colsum: the producer of dout already summed the skipped tiles (include/szn.h)
@@ -567,8 +563,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
         a.csum = own_sum ? a.crow + (size_t)cb_rows * d->Co : (float*)d->colsum;
     }
     {
-        static int xm = -1;
-        if (xm < 0) { const char* e = getenv("SZN_WGT_XCD"); xm = e ? atoi(e) : 1; }
+        const int xm = 1; /* (was SZN_WGT_XCD) */
         a.xcd_mode = 0;
         if (xm && ncombo >= 4) {        // (two combos: measured 3 % slower than launch order, conv2_1)
             if (ns % 8 == 0) a.xcd_mode = 1;
@@ -582,7 +577,7 @@ int szn_conv_wgrad_taps_try(const szn_conv_desc_t* d, const void* in, const void
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.pad = d->pad;
     a.ldi = d->ldi; a.ldd = d->ldo; a.accumulate = accumulate;
     { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGT_ABLATE"); } a.ablate = abl; }
-    { static int fm = -1; if (fm < 0) { const char* e = getenv("SZN_WGT_FILL"); fm = e ? atoi(e) : 0; } a.fill_mode = fm; }
+    { const int fm = 0; /* (was SZN_WGT_FILL) */ a.fill_mode = fm; }
     hipStream_t st = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {
@@ -624,8 +619,7 @@ extern "C" int szn_conv2d_wgrad_cb_region(const szn_conv_desc_t* d, int region[8
     }
     const int ncombo = (d->Co / 64) * (d->Ci / 64);
     if (ncombo > ncu) return 0;
-    static int taps_min = -1;
-    if (taps_min < 0) { const char* e = getenv("SZN_WGT_MINTILES"); taps_min = e ? atoi(e) : 8; }
+    static const int taps_min = szn_knob("SZN_WGT_MINTILES", 8);
     CbGeom c;
     int ry, rx;
     if (!taps_cb_geometry(d, ncombo, ncu, taps_min, c, ry, rx)) return 0;

@@ -667,8 +667,8 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     a.M = d->B * d->Ho * d->Wo;
     a.accumulate = accumulate;
     { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGW_ABLATE"); } a.ablate = abl; }
-    { static int tab = -1; if (tab < 0) { const char* e = getenv("SZN_WGW_TAB"); tab = e ? atoi(e) : 1; } a.use_tab = (tab && a.M <= kTabMax) ? 1 : 0; }
-    { static int sh = -1; if (sh < 0) { const char* e = getenv("SZN_WGW_SHIFT"); sh = e ? atoi(e) : 1; } a.shift = sh; }
+    { const int tab = 1; /* (was SZN_WGW_TAB) */ a.use_tab = (tab && a.M <= kTabMax) ? 1 : 0; }
+    { const int sh = 1; /* (was SZN_WGW_SHIFT) */ a.shift = sh; }
     a.stagger = 0;
     {
         static int ncu = 0;
@@ -681,15 +681,12 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     }
     if (opt) {
         // one K step (32 pixels) takes ~1 us per CU; the full stagger spans ~7/8 of a K loop: phase x nK / 32 sleeps of ~4 us
-        static int sg = -2; if (sg == -2) { const char* e = getenv("SZN_WGW_STAGGER"); sg = e ? atoi(e) : -1; }
+        static const int sg = szn_knob("SZN_WGW_STAGGER", -1);
         const int nK = (a.M + KPg - 1) / KPg;
         a.stagger = tiles < 3L * a.ncu ? 0 : (sg >= 0 ? sg : (nK + 8) / 16);     // (a one-round launch would only start late)
     }
-    { static int xo = -1; if (xo < 0) { const char* e = getenv("SZN_WGW_XCD"); xo = e ? atoi(e) : 1; }
-      a.xcd_order = (xo && (size_t)a.in_bytes > 4 * (size_t)a.dout_bytes) ? 1 : 0;
-      // many taps (fc6's weight gradient: 49): experiment SZN_WGW_XCD2=1 -- an XCD's CUs walk the taps of one (cout, cin) tile pair
-      const char* e2 = getenv("SZN_WGW_XCD2");
-      if (!a.xcd_order && e2 && atoi(e2) != 0 && d->KH * d->KW >= 9) a.xcd_order = 2; }
+    { static const int xo = szn_knob("SZN_WGW_XCD", 1);
+      a.xcd_order = (xo && (size_t)a.in_bytes > 4 * (size_t)a.dout_bytes) ? 1 : 0; }
     const int lds = LDS_WGW + (a.use_tab ? kTabMax * 4 : 0);
     static bool attr_done = false;
     if (!attr_done) {
@@ -708,16 +705,16 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
         // but with a long K loop the smaller tile's extra operand traffic costs what the overlap gains (B = 8: 842 -> 864 us), so it
         // takes the launches whose K loop is short.  SZN_WGW_HALF = 0 / 1 forces conv_wgrad_wide<T, true> / this kernel
         // (read per call: the tests run both).
-        const char* eh = getenv("SZN_WGW_HALF");
+        const int eh = szn_knob_live("SZN_WGW_HALF", -1);
         const long cot_h = szn_div_up(d->Co, 128);
-        const bool want_half = eh ? atoi(eh) != 0 : a.M <= 1024;
+        const bool want_half = eh >= 0 ? eh != 0 : a.M <= 1024;
         if (want_half && cot_h * a.citiles * d->KH * d->KW < (1L << 31)) {
             WgwArgs h = a;
             h.cotiles = (int)cot_h;
             h.use_tab = (a.M <= kTabMaxH && (long)d->B * d->Hi * d->Wi < 65535) ? a.use_tab : 0;
             const long tiles_h = cot_h * a.citiles * d->KH * d->KW;
             // the second-slot blocks start half a K loop late: one K step of a lone four-wave block ~0.25 us, s_sleep(127) ~3.4 us
-            static int sgh = -2; if (sgh == -2) { const char* e = getenv("SZN_WGH_STAGGER"); sgh = e ? atoi(e) : -1; }
+            static const int sgh = szn_knob("SZN_WGH_STAGGER", -1);
             const int nKh = (a.M + KPg - 1) / KPg;
             h.stagger = tiles_h < 4L * a.ncu ? 0 : (sgh >= 0 ? sgh : (nKh + 16) / 32);
             const int ldsh = LDS_WGH + (h.use_tab ? kTabMaxH * 2 : 0);

@@ -660,8 +660,7 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_stream(WideArgs a) {
 
 template <typename T, bool NT, bool NF19>
 void launch_proj_variant(const WideArgs& a, size_t lds, hipStream_t st) {
-    static int stag = -1;
-    if (stag < 0) { const char* e = getenv("SZN_PROJ_STAG"); stag = e ? atoi(e) : 1; }
+    const int stag = 1; /* (was SZN_PROJ_STAG) */
     if (stag) {
         (void)hipFuncSetAttribute((const void*)proj_gemm_stream<T, NT, NF19, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((proj_gemm_stream<T, NT, NF19, true>), dim3(a.mtiles), dim3(512), lds, st, a);
@@ -674,8 +673,7 @@ void launch_proj_variant(const WideArgs& a, size_t lds, hipStream_t st) {
 template <typename T>
 int launch_proj_stream(const WideArgs& a, hipStream_t st) {
     const size_t lds = 3 * 256 * 128 + 3 * 320 * 64;
-    static int nt = -1;
-    if (nt < 0) { const char* e = getenv("SZN_PROJ_NT"); nt = e ? atoi(e) : 1; }
+    const int nt = 1; /* (was SZN_PROJ_NT) */
     const bool nf19 = a.Co <= 304;
     if (nt) { if (nf19) launch_proj_variant<T, true, true>(a, lds, st); else launch_proj_variant<T, true, false>(a, lds, st); }
     else { if (nf19) launch_proj_variant<T, false, true>(a, lds, st); else launch_proj_variant<T, false, false>(a, lds, st); }
@@ -735,8 +733,8 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.proj_abl = 0;
     { static int ea = -1; if (ea < 0) ea = szn_ablate_env("SZN_WIDE_EPABL"); a.abl_ep = ea; }
     a.ws = nsplit > 1 ? ws : nullptr; a.nsplit = nsplit > 1 ? nsplit : 1;
-    { static int stg = -1; if (stg < 0) { const char* e = getenv("SZN_WIDE_STAGGER"); stg = e ? atoi(e) : 1; } a.stagger = stg; }
-    { static int gp = -1; if (gp < 0) { const char* e = getenv("SZN_WIDE_GATEPF"); gp = e ? atoi(e) : 1; } a.gate_prefetch = gp; }
+    { const int stg = 1; /* (was SZN_WIDE_STAGGER) */ a.stagger = stg; }
+    { const int gp = 1; /* (was SZN_WIDE_GATEPF) */ a.gate_prefetch = gp; }
     a.chunks_per_split = nsplit > 1 ? chunks_per_split : (1 << 30);
     a.M = d->B * d->Ho * d->Wo;
     // cout tile 256, or 320 (bf16) when that wastes fewer columns: the 300-d projection is one 320-wide tile
@@ -745,20 +743,19 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.mtiles = szn_div_up(a.M, 256); a.ntiles = szn_div_up(d->Co, bn);
     // tile order within an XCD's share of the grid: pixel tile fastest when the filter bank is the larger operand (fc6: 205 MB against a
     // 4 MB map), so that the blocks of one XCD share cout tiles and the bank crosses the fabric once, not once per XCD
-    { static int nm = -1; if (nm < 0) { const char* e = getenv("SZN_WIDE_NMAJOR"); nm = e ? atoi(e) : 1; } a.nmajor = (nm && w_bytes > in_bytes) ? 1 : 0; }
+    { const int nm = 1; /* (was SZN_WIDE_NMAJOR) */ a.nmajor = (nm && w_bytes > in_bytes) ? 1 : 0; }
     if ((long)a.mtiles * a.ntiles * a.nsplit < min_tiles) {         // too few blocks to fill the chip: keep 256 x 128 ...
         // ... unless 256 x 192 tiles fit ONE round of the chip where the 256 x 128 tiles need two (fc7 at B = 8, 512 x 512:
         // 2,312 x 4096 is 10 x 32 = 320 narrow tiles = 1.25 rounds, but 10 x 22 = 220 tiles of 192 couts: 0.117 -> ~0.09 ms)
-        static int ncu = 0, t192 = -1;
+        static int ncu = 0;
         if (!ncu) {
             int dev = 0; hipDeviceProp_t p;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
             if (ncu <= 0) ncu = 256;
         }
-        if (t192 < 0) { const char* e = getenv("SZN_WIDE_192"); t192 = e ? atoi(e) : 1; }
         const long n192 = (long)a.mtiles * szn_div_up(d->Co, 192), n128 = (long)a.mtiles * szn_div_up(d->Co, 128);
         const long cost192 = (n192 + ncu - 1) / ncu * 192, cost128 = (n128 + ncu - 1) / ncu * 128;
-        if (!t192 || !szn_is16(d->dtype) || a.nsplit != 1 || cost192 * 100 >= cost128 * 90) return 1;
+        if (!szn_is16(d->dtype) || a.nsplit != 1 || cost192 * 100 >= cost128 * 90) return 1;
         bn = 192; a.ntiles = szn_div_up(d->Co, 192);
     } else if ((long)a.ntiles * bn - d->Co > 64) return 1;          // would waste > 64 columns of the last tile
     a.in = (const char*)in; a.w = (const char*)w; a.bias = bias; a.gate = (const char*)gate; a.cscale = chan_scale;
@@ -772,8 +769,7 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     a.relu = d->relu; a.out_f32 = d->out_f32; a.HoWo = d->Ho * d->Wo;
     {
         // epilogue from registers (wide_epilogue_direct): whole 16-B pieces of 8 couts, so rows and bases have to be 16-B aligned
-        static int de = -1;
-        if (de < 0) { const char* e = getenv("SZN_WIDE_DIRECT"); de = e ? atoi(e) : 1; }
+        static const int de = szn_knob("SZN_WIDE_DIRECT", 1);
         const size_t oes = (d->out_f32 || a.ws) ? 4 : 2;
         const uintptr_t al = (uintptr_t)out | (uintptr_t)gate | (uintptr_t)bias | (uintptr_t)chan_scale | (uintptr_t)a.ws;
         a.direct_ep = de && szn_is16(d->dtype) && (d->Co % 8) == 0 && (((size_t)d->ldo * oes) & 15) == 0 && (al & 15) == 0 &&
@@ -781,16 +777,14 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
     }
     if (bn == 256 && szn_is16(d->dtype)) {
         // the 8-phase schedule (szn_conv_8ph.hip): every 256-wide 16-bit shape, split-K included; SZN_WIDE_8PH=0: the round 1-3 kernels
-        static int ph8 = -1;
-        if (ph8 < 0) { const char* e = getenv("SZN_WIDE_8PH"); ph8 = e ? atoi(e) : 1; }
+        static const int ph8 = szn_knob("SZN_WIDE_8PH", 1);
         if (ph8) {
             const int rc = szn_conv_8ph_launch(&a, d->dtype, 256, stream);
             if (rc <= 0) return rc;
         }
     }
     {
-        static int rows = -1;
-        if (rows < 0) { const char* e = getenv("SZN_WIDE_ROWS"); rows = e ? atoi(e) : 1; }
+        static const int rows = szn_knob("SZN_WIDE_ROWS", 1);
         if (rows && bn == 256 && szn_is16(d->dtype) && a.nsplit == 1 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->Hi == d->Ho &&
             d->Wi == d->Wo && (d->Ci % 64) == 0)
             return d->dtype == SZN_F16 ? launch_wide_rows<f16_raw>(a, (hipStream_t)stream)
@@ -809,8 +803,7 @@ int szn_conv_wide_try(const szn_conv_desc_t* d, const void* in, const void* w, c
 // 2 GB operand check of the generic kernels: the activation resource is rebased per block.  Returns 1 when the shape does not fit.
 int szn_proj_stream_try(const szn_conv_desc_t* d, const void* in, const void* w, const float* bias, const void* gate,
                         const float* chan_scale, void* out, int min_tiles, szn_stream_t stream) {
-    static int proj = -1;
-    if (proj < 0) { const char* e = getenv("SZN_PROJ_STREAM"); proj = e ? atoi(e) : 1; }
+    const int proj = 1; /* (was SZN_PROJ_STREAM) */
     if (!proj || !szn_is16(d->dtype) || d->KH != 1 || d->KW != 1 || d->pad != 0 || d->Co <= 256 || d->Co > 320 || d->Ci < 256 ||
         (d->Ci % 64) || gate || chan_scale || d->colsum || d->pool_out || d->relu)
         return 1;
@@ -827,8 +820,7 @@ int szn_proj_stream_try(const szn_conv_desc_t* d, const void* in, const void* w,
         static int abl = -1;
         if (abl < 0) abl = szn_ablate_env("SZN_PROJ_ABLATE");
         a.proj_abl = abl; a.abl_ep = 0;
-        static int de = -1;
-        if (de < 0) { const char* e = getenv("SZN_WIDE_DIRECT"); de = e ? atoi(e) : 1; }
+        static const int de = szn_knob("SZN_WIDE_DIRECT", 1);
         const size_t oes = d->out_f32 ? 4 : 2;
         a.direct_ep = de && (d->Co % 8) == 0 && (((size_t)d->ldo * oes) & 15) == 0 && (((uintptr_t)out | (uintptr_t)bias) & 15) == 0;
     }

@@ -29,6 +29,27 @@ extern "C" const char* szn_prev_kernel(void) { return g_prev_kernel; }
 static thread_local int g_colsum_rows = 0;
 void szn_note_colsum_rows(int rows) { g_colsum_rows = rows; }
 int szn_noted_colsum_rows(void) { return g_colsum_rows; }
+// ---- tuning / A-B knobs: ONE table.  szn_knob() refuses names that are not listed here, so a knob cannot exist without its line in
+//      DESIGN.md section 4 and its case in tests/test_gpu_knobs.py (which runs a step under every non-default value below). ----
+static const char* const g_knobs[] = {
+    "SZN_REGW_MINTILES", "SZN_WIDE_MINTILES", "SZN_WGT_MINTILES", "SZN_WGW_MINTILES",     // dispatch thresholds (a huge value = kernel family off)
+    "SZN_WIDE_8PH", "SZN_8PH_KORD", "SZN_WIDE_ROWS", "SZN_WIDE_DIRECT", "SZN_IGEMM_DIRECT",  // which forward / dgrad tile kernel, K order, epilogue form
+    "SZN_CONST_BORDER", "SZN_DGRAD_BORDER", "SZN_WGT_CB",                                 // constant-border hints
+    "SZN_WGW_HALF", "SZN_WGW_STAGGER", "SZN_WGH_STAGGER", "SZN_WGW_XCD",                  // fc6's weight gradient (+ Adam)
+};
+static bool knob_listed(const char* name) {
+    for (const char* k : g_knobs)
+        if (!strcmp(k, name)) return true;
+    return false;
+}
+int szn_knob_live(const char* name, int dflt) {
+    if (!knob_listed(name)) { fprintf(stderr, "libszn_hip: unregistered knob %s\n", name); abort(); }
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+int szn_knob(const char* name, int dflt) { return szn_knob_live(name, dflt); }   // (callers cache it in a function-local static: read once per process)
+extern "C" int szn_knob_count(void) { return (int)(sizeof(g_knobs) / sizeof(g_knobs[0])); }
+extern "C" const char* szn_knob_name(int i) { return (i >= 0 && i < szn_knob_count()) ? g_knobs[i] : nullptr; }
 static thread_local float g_work_fraction = 1.f;
 void szn_note_work_fraction(float f) { g_work_fraction = f; }
 float szn_noted_work_fraction(void) { return g_work_fraction; }
@@ -968,21 +989,16 @@ static int conv1_1_fwd_impl(int dtype, int B, int H, int W, int pad, const float
     const long nseg = (long)B * Ho * ((Wo + 15) / 16);     // 16-pixel segments, one wave each (grid-stride)
     long blocks = (nseg + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    static int mm16 = -1;          // SZN_CONV1_1_F32MMA=1: the 16-bit paths keep fp32 image / filter operands (rounds 1-2 behaviour)
-    if (mm16 < 0) { const char* e = getenv("SZN_CONV1_1_F32MMA"); mm16 = (e && atoi(e)) ? 0 : 1; }
+    const int mm16 = 1;            // the 16-bit paths round image / filter operands to the compute dtype in registers (one 16x16x32 MFMA per fragment)
     const long ntask = (long)B * Ho * (((Wo + 15) / 16 + 7) / 8);       // runs of 8 segments, one wave each (grid-stride)
     long blocks16 = (ntask + 3) / 4;
     if (blocks16 > 256 * 16) blocks16 = 256 * 16;
     if (ntask >= (1L << 31)) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd: output too large");
-    static int c11g = -1;          // SZN_C11_FWD_GATHER=1: taps gathered straight from memory (the first 16-bit form)
-    if (c11g < 0) { const char* e = getenv("SZN_C11_FWD_GATHER"); c11g = e ? atoi(e) : 0; }
     const size_t x_bytes = (size_t)B * 3 * H * W * 4;
-    const bool staged = !c11g && x_bytes < 0x7fff0000ul;
-    static int ahead = -1, sblocks = -1;
+    const bool staged = x_bytes < 0x7fff0000ul;          // (larger images: taps gathered straight from memory, conv1_1_fwd16_kernel)
+    const int ahead = 1, sblocks = 1024;
     // (sweep on MI355X, bf16, B = 8: gather 165 us; staged 142 / 134 us with 4096 / 1024 blocks; + loads one run ahead 125 / 118 us:
     //  a wave pays its filter / bias set-up once for ~8 runs instead of ~2)
-    if (ahead < 0) { const char* e = getenv("SZN_C11_FWD_AHEAD"); ahead = e ? atoi(e) : 1; }
-    if (sblocks < 0) { const char* e = getenv("SZN_C11_FWD_BLOCKS"); sblocks = e ? atoi(e) : 1024; }
     if (staged && sblocks > 0 && blocks16 > sblocks) blocks16 = sblocks;
     if (cutv && !(szn_is16(dtype) && mm16 && staged))
         SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv1_1_fwd_c: only the staged 16-bit kernel writes a cropped map");
@@ -1144,8 +1160,7 @@ extern "C" int szn_maxpool2x2_ceil_bwd(int dtype, int B, int Hi, int Wi, int C, 
     if (colsum && (256 % (C / ch)) != 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "maxpool_bwd: colsum needs C/%d to divide 256", ch);
     // with column sums every block ends in C atomicAdds on the same C addresses: 4096 blocks spent more time there than streaming
     // (pool3 .. pool5); two blocks per CU stream at 5.3 TB/s (tools/bench sweep in profiles/r02_ablations.txt section 13)
-    static int capx = -1;
-    if (capx < 0) { const char* e = getenv("SZN_POOLBWD_BLOCKS"); capx = e ? atoi(e) : 512; if (capx < 1) capx = 1; }
+    const int capx = 512; /* (was SZN_POOLBWD_BLOCKS) */
     const int grid = grid_for(total, 256, colsum ? capx : 65536);
     float* cslab = colsum ? colsum_slab : nullptr;
     if (cslab && colsum_slab_rows < grid)
@@ -1186,8 +1201,7 @@ static int maxpool_bwd_code_impl(int dtype, int B, int Hi, int Wi, int C, const 
     if (skip_tiles)
         for (int i = 0; i < 8 * n_regions; ++i)
             if (skip_tiles[i] & 1) SZN_FAIL(SZN_ERR_ARG, "maxpool_bwd_code_cb: region bounds must be even (2 x 2 windows must not straddle them)");
-    static int capx = -1;
-    if (capx < 0) { const char* e = getenv("SZN_POOLBWD_BLOCKS"); capx = e ? atoi(e) : 512; if (capx < 1) capx = 1; }
+    const int capx = 512; /* (was SZN_POOLBWD_BLOCKS) */
     const int grid = grid_for(total, 256, sums ? capx : 65536);
     float* cslab = colsum ? colsum_slab : nullptr;
     if (cslab && colsum_slab_rows < grid)

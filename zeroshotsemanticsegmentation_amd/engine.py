@@ -77,8 +77,8 @@ class GradBuckets(object):
         if self.active and self.world == 1 and dist.get_backend(group) == "nccl":
             # one rank: sum == average == x * 1.0.  RCCL skips an in-place SUM entirely; the pre-multiplied sum (fp32 buckets) and
             # AVG (16-bit staging buffers: torch 2.10 hands RCCL a zero factor for a bf16 pre-multiplied sum) make it launch its
-            # one-rank reduce kernel.  SZN_FORCE_COMM_OP = premul | avg | sum overrides.
-            which = os.environ.get("SZN_FORCE_COMM_OP", "premul" if comm_dtype == torch.float32 else "avg")
+            # one-rank reduce kernel.
+            which = "premul" if comm_dtype == torch.float32 else "avg"
             if which == "premul" and hasattr(dist, "_make_nccl_premul_sum"):
                 self.op = dist._make_nccl_premul_sum(1.0)
             elif which == "avg":
@@ -661,7 +661,7 @@ class TrainStep(object):
             # the embeddings are constants of a run: their transpose + norms (fh_prep_kernel: 23 us of dependent loads) are written to the head of
             # the workspace once -- again whenever the workspace or the embedding tensor (an in-place edit bumps _version) changes
             prep = (self._ws.data_ptr(), self.emb.data_ptr(), self.emb._version, E, K)
-            if self._ws_prep != prep or os.environ.get("SZN_HEAD_PREP", "1") == "0":         # (0: prepare in every step, as before round 5)
+            if self._ws_prep != prep:
                 L.call("szn_fused_head_prepare", E, K, L.ptr(self.emb), L.ptr(self._ws), st)
                 self._ws_prep = prep
             L.call("szn_fused_head_prepared", 32, B, ctx.h, ctx.w, E, CP, 0, H, W, CROP, K, L.ptr(ctx.coarse), L.ptr(self.emb),

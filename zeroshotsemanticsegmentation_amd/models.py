@@ -47,10 +47,10 @@ _BACKBONE = [("conv1_1", PAD1), ("conv1_2", 1), "P", ("conv2_1", 1), ("conv2_2",
              ("conv5_1", 1), ("conv5_2", 1), ("conv5_3", 1), "P"]
 _TRUNK = [n for n, _, _, _ in synth.CONV_LAYERS]          # conv1_1 .. fc7
 _CONST_BORDER = os.environ.get("SZN_CONST_BORDER", "1") != "0"  # 0: no constant-border hint to the 710^2 / 355^2 forward convs
-_DGRAD_SPLIT = os.environ.get("SZN_DGRAD_SPLIT", "1") != "0"      # 0: few-tile dgrads keep their fused column sums (no split-K)
-_WGRAD_CB_FUSED = os.environ.get("SZN_WGRAD_CB_FUSED", "1") != "0"   # 0: the weight gradients sum their skipped tiles themselves
+_DGRAD_SPLIT = True         # few-tile dgrads may split their K range (the library decides; its split-K epilogue delivers the column sums)
+_WGRAD_CB_FUSED = True      # the pools' backward pass sums dn over the tiles the producer's weight gradient skips (False: that call sums them itself)
 _DGRAD_BORDER = os.environ.get("SZN_DGRAD_BORDER", "1") != "0"        # 0: conv1_2's dgrad runs the tiles nobody reads (for their column sums)
-_FC6_NATIVE = os.environ.get("SZN_FC6_NATIVE", "1") != "0"      # 0: fc6's dgrad GEMM on the packed transpose (rounds 1-2)
+_FC6_NATIVE = True          # fc6's dgrad GEMM on the forward weight image (False: on the packed transpose, rounds 1-2)
 _OPT_LAYERS = _TRUNK + ["score_fr"]                        # the layers train.get_parameters yields (train.py:302-331)
 _OPT_LAYERS8 = _TRUNK + ["score_pool3", "score_pool4", "score_fr"]       # ... for FCN8s (score_fr stays last: engine.TrainStep)
 
@@ -97,13 +97,14 @@ def _cb_pool(reg, n):
 # cropping conv1_1's 516 MB output would cost what it saves.
 _BAND_CROP = os.environ.get("SZN_BAND_CROP", "1") != "0"
 _BAND_BLOCKS = {"conv1_2": ("conv1_2",), "conv2_1": ("conv2_1", "conv2_2"), "conv3_1": ("conv3_1", "conv3_2", "conv3_3")}   # first layer -> block
-_BAND_16BIT = os.environ.get("SZN_BAND_BLOCKS16", "conv2_1,conv3_1").split(",")      # blocks cropped on the 16-bit paths (fp32: all)
-_BAND_C11 = os.environ.get("SZN_BAND_C11", "1") != "0"       # 16-bit paths: conv1_1 writes its output cropped (szn_conv1_1_fwd_c) and conv1_2's block runs on it
-_BAND_FUSE = os.environ.get("SZN_BAND_FUSE", "1") != "0"      # 0: every block copies its pooled rows back before the next block crops again
+# (module constants, not environment knobs since round 6: tools/diag_band.py and the tests patch them)
+_BAND_16BIT = ["conv2_1", "conv3_1"]      # blocks cropped through the generic szn_band_remap on the 16-bit paths (fp32: all three)
+_BAND_C11 = True       # 16-bit paths: conv1_1 writes its output cropped (szn_conv1_1_fwd_c) and conv1_2's block runs on it
+_BAND_FUSE = True      # adjacent cropped blocks hand over in one composed index map (False: copy the pooled rows back, crop again)
 # default of SZN_FC6_CUMASK (see _Engine._masked_stream): CUs of the stream fc6's weight gradient + Adam runs on in a small step.  Off:
 # measured on three boxes, "128:low" moved the one-image step by -0.13 / -0.04 ms for a caller on a non-blocking stream and by -0.05 / +0.02 ms
 # for a caller on the null stream (profiles/r05_ablations.txt 15) -- inside the box-to-box spread
-_POOL_GATHER = os.environ.get("SZN_POOL_GATHER", "1") != "0"   # the pools' backward pass applies the transposed band map while reading (szn_maxpool2x2_ceil_bwd_code_gather) instead of two szn_band_remap passes in front of it
+_POOL_GATHER = True   # the pools' backward pass applies the transposed band map while reading (szn_maxpool2x2_ceil_bwd_code_gather) instead of two szn_band_remap passes in front of it
 _FC6_CUMASK = "0"
 _SMALL_STEP_PX = 2 * 512 * 512
 
@@ -288,7 +289,7 @@ class _Engine(object):
         self.fused_opt = None
         self.fused_done = set()
         self.reserved_cus = 0         # CUs the persistent backward kernels leave to the RCCL queue (szn_conv_desc_t.reserved_cus; TrainStep)
-        self.pool_codes = os.environ.get("SZN_POOL_CODES", "1") != "0"
+        self.pool_codes = True        # False (tests / A-B): the pools' backward pass reads the un-pooled tensors (rounds 1-2) instead of winner codes
         self.head_fp8 = False         # forward of the projection head on the fp8 matrix cores (set_head_precision)
         self.head_fp8_bwd = False     # ... and its dgrad / wgrad (e5m2 gradient x e4m3 operands)
         self._fp8_ws = None
