@@ -140,6 +140,24 @@ def _worker_sharded(rank, world, port, q):
         ws, gs = run(True, comm, direct)
         ok = ok and torch.equal(wa, ws) and gs.sharded and not ga.sharded
         ok = ok and gs.issued == 2 * len(gs.buckets) and ga.issued == len(ga.buckets)
+    # the all-gathers waited for ONE BUCKET AT A TIME in forward order (what the next forward pass of engine.TrainStep does through
+    # wait_weights): after bucket k's wait its range holds the replicated result, whatever the later buckets are doing
+    wa, _ = run(False, torch.float32, False)
+    flat = grads[rank].clone()
+    gb = GradBuckets(flat, layers, bucket_elems=4000, sharded=True)
+    for name, _, _ in reversed(layers):
+        gb.layer_done(name)
+    gb.finish()
+    w = w0.clone()
+    for o, e, _ in gb.buckets:
+        lo, hi = gb.shard(o, e)
+        w[lo:hi] -= 0.1 * flat[lo:hi] / world
+    pend = gb.gather_weights(w, spans=True)
+    ok = ok and [sp for sp, _ in pend] == sorted(sp for sp, _ in pend) and pend[0][0][0] == 0 and len(pend) == len(gb.buckets)
+    for (o, e), wk in pend:
+        wk.wait()
+        ok = ok and torch.equal(w[o:e], wa[o:e])
+    ok = ok and torch.equal(w, wa)
     exact = w0 - 0.1 * sum(grads) / world
     wa, _ = run(False, torch.float32, False)
     ok = ok and torch.allclose(wa, exact, rtol=0, atol=1e-6)

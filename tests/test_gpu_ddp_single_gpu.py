@@ -257,6 +257,11 @@ def _worker_modes(rank, world, port, optname, q):
             finally:
                 engine.L.call = orig
             issued = ts.buckets.issued
+            # sharded: nobody waited for the all-gathers at the end of the step -- the second step's forward pass asked for them bucket by bucket
+            # (conv1_1 first, the head last), and the last step's are still pending here
+            log = list(ts.gather_wait_log)
+            pending = len(ts._pending_gather)
+            ts.wait_weights()
             moved = float((image != lp_init).float().mean())
             if "sharded" in mode:            # before the gather this rank's moments of the OTHER rank's slices are stale (zero after init)
                 assert ts._masters_stale, mode
@@ -265,7 +270,8 @@ def _worker_modes(rank, world, port, optname, q):
             out[mode] = {"loss": float(loss), "lp": image.view(torch.int16).cpu().numpy(), "w": ts.flat_w.cpu().numpy(),
                          "b": ts.flat_b.cpu().numpy(), "m1": ts.state["w"][0].cpu().numpy(),
                          "g16": ("adam_kernel_g16" in kernels or "sgd_kernel_g16" in kernels), "issued": issued, "moved": moved,
-                         "nb": len(ts.buckets.buckets), "grad_none": m.fc6.weight.grad is None}
+                         "nb": len(ts.buckets.buckets), "grad_none": m.fc6.weight.grad is None, "wait_log": log, "pending": pending,
+                         "layers": list(ts.layers)}
             del m, ts
         q.put(out)
         dist.barrier()
@@ -306,6 +312,18 @@ def test_wire_modes_and_sharded_optimizer_bit_identical_two_ranks(optname):
     nb = res[0]["fp32"]["nb"]
     assert nb >= 4 and res[0]["fp32"]["issued"] == 2 * (nb + 1) and res[0]["fp32-sharded"]["issued"] == 2 * (2 * nb + 2)
     assert all(res[0][mode]["moved"] > 0.3 for mode in MODES), {mode: res[0][mode]["moved"] for mode in MODES}
+    # sharded: the all-gathers of the weight image are waited for layer by layer inside the NEXT forward pass
+    for mode in MODES:
+        r = res[0][mode]
+        if "sharded" not in mode:
+            assert not r["wait_log"] and r["pending"] == 0
+            continue
+        order = {n: i for i, n in enumerate(r["layers"] + ["head"])}
+        asked = [order[a[0]] for a in r["wait_log"]]
+        assert r["pending"] >= r["nb"] and len(r["wait_log"]) >= r["nb"], (mode, r["pending"], len(r["wait_log"]))
+        assert asked == sorted(asked) and asked[0] == 0 and len(set(asked)) >= 4, (mode, r["wait_log"])      # conv1_1 first, spread over the pass
+        starts = [a[1] for a in r["wait_log"] if a[2] - a[1] > 0]
+        assert max(starts) > 0
     assert np.abs(res[0]["f32c-sharded"]["m1"]).min() >= 0 and (res[0]["f32c-sharded"]["m1"] != 0).mean() > 0.5   # no slice left at its initial zeros
     # bf16 wire vs fp32 wire: the same training step up to the 2^-9 rounding of the summed gradients
     d = np.abs(res[0]["bf16-direct"]["w"] - res[0]["fp32"]["w"]).max()

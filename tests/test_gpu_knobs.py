@@ -2,7 +2,7 @@
 
 The library reads an environment variable only through szn_knob(), which refuses names that are not in its table (szn_knob_count /
 szn_knob_name enumerate it); the Python side's switches are listed in PY_KNOBS below and checked against a grep of the package.  Each
-GROUP sets non-default values for a few knobs that do not interact and runs ONE bf16 training step (B = 2, 512 x 512, E = 20, K = 33)
+GROUP sets non-default values for a few knobs that do not interact and runs two bf16 training steps (B = 3, 512 x 512, E = 20, K = 33)
 in a child process (the switches are read once per process); loss, class map and every layer's gradient must agree with the default
 run -- different kernels / summation orders / hints, same step.  A knob that appears in no group fails tests/test_abi.py::test_every_knob_has_a_case (CPU)."""
 import os
@@ -54,7 +54,7 @@ def _child(out):
     from zeroshotsemanticsegmentation_amd import _lib as L
     from zeroshotsemanticsegmentation_amd import engine, models, synth
     dev = torch.device("cuda", 0)
-    E, K, H, B = 20, 33, 512, 2
+    E, K, H, B = 20, 33, 512, 3          # (three images: conv3_x reaches the 240 tiles from which the 256-wide kernels take a layer)
     m = models.FCN32s(E)
     m.load_synthetic(1337, device=dev)
     m.eval()
@@ -107,7 +107,7 @@ def default_run(tmp_path_factory):
 EXPECT = {   # group -> kernels that must (+) / must not (-) have run
     "default": ("+conv_igemm_8ph", "+conv3x3_regw", "+wgrad_taps_reduce", "+band_remap_kernel", "+conv_wgrad_half_adam"),
     # (fc6's split-K forward and its dgrad GEMM on the forward layout ask for the 256-wide kernels by themselves, whatever the thresholds say)
-    "generic kernels only": ("-conv_igemm_8ph", "-conv3x3_regw", "-wgrad_taps_reduce", "-conv_wgrad_wide_adam", "-conv_wgrad_half_adam",
+    "generic kernels only": ("-conv3x3_regw", "-conv3x3_wide_rows", "-wgrad_taps_reduce", "-conv_wgrad_wide_adam", "-conv_wgrad_half_adam",
                              "+conv_igemm_v2", "+conv_wgrad_v2"),
     "wide kernels of rounds 1-3": ("-conv_igemm_8ph", "+conv_igemm_wide"),
     "tap-major K order": ("+conv_igemm_8ph",),
@@ -127,6 +127,7 @@ EXPECT = {   # group -> kernels that must (+) / must not (-) have run
 def test_step_under_non_default_knobs_equals_the_default_step(tag, default_run):
     d, ref = default_run
     got = _run(tag, d)
+    print(tag, "kernels:", " ".join(got["kernels"]))
     for rule in EXPECT[tag]:
         hit = any(rule[1:] in k for k in got["kernels"])
         assert hit == (rule[0] == "+"), (tag, rule, got["kernels"])

@@ -15,7 +15,12 @@ csv.field_size_limit(1 << 30)
 def short(n):
     n = n.replace('void ', '').replace('(anonymous namespace)::', '')
     m = re.match(r'([A-Za-z0-9_:]+)', n)
-    return m.group(1) if m else n
+    base = m.group(1) if m else n
+    if base == "conv_wgrad_wide":              # the Adam form <T, true> (fc6's weight gradient + update) apart from <T, false> (fc7 / fc6's dgrad GEMM)
+        t = re.search(r'<[^,>]*,\s*(true|false|1|0)\s*>', n)
+        if t:
+            base += "<T,%s>" % ("true" if t.group(1) in ("true", "1") else "false")
+    return base
 
 
 def collect(d, counter):

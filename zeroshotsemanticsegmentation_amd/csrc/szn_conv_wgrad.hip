@@ -310,12 +310,18 @@ void launch_wg2(const Wg2Args& a, long blocks, hipStream_t st) {
 // pass streams 30 B per weight (gradient, master, two moments in; master, moments, 16-bit image out) after the backward pass; here the
 // gradient tile is still in LDS when the update is applied, so 4 B per weight are never written and never read back, and the other 26
 // move while the other CUs are in their K loops.  Same arithmetic (adam_elem) on the same gradient values: bit-identical.
+// fewest 256 x 256 tiles for which conv_wgrad_wide (and with it the fused Adam form) takes a layer
+static int wgw_min_tiles() {
+    static const int wide_min = szn_knob("SZN_WGW_MINTILES", 96);
+    return wide_min;
+}
+
 extern "C" int szn_conv2d_wgrad_adam_supported(const szn_conv_desc_t* d) {
     if (!d || !szn_is16(d->dtype) || d->Co < 256 || d->Ci < 256 || (d->ldi & 7) || (d->ldo & 7) || (d->Ci & 7)) return 0;
     if (d->KH == 3 && d->KW == 3 && d->workspace) return 0;                  // the all-taps kernel takes these
     const long cot = szn_div_up(d->Co, 256), cit = szn_div_up(d->Ci, 256);
     const long tiles = cot * cit * d->KH * d->KW;
-    if (tiles < 96 || (long)d->B * d->Ho * d->Wo >= (1L << 22)) return 0;
+    if (tiles < wgw_min_tiles() || (long)d->B * d->Ho * d->Wo >= (1L << 22)) return 0;
     if (cot * 256 * cit * 256 > (long)d->Co * d->Ci * 5 / 4) return 0;
     return 1;
 }
@@ -339,7 +345,7 @@ extern "C" int szn_conv2d_wgrad_adam(const szn_conv_desc_t* d, const void* in, c
         SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad_adam: this layer does not take conv_wgrad_wide (use szn_conv2d_wgrad + szn_adam_step)");
     szn_note_colsum_rows(0);
     szn_note_work_fraction(1.f);
-    const int rc = szn_conv_wgrad_wide_try(d, in, dout, dw, 0, 96, stream, opt);
+    const int rc = szn_conv_wgrad_wide_try(d, in, dout, dw, 0, wgw_min_tiles(), stream, opt);
     szn_publish_result(d);
     if (rc > 0) SZN_FAIL(SZN_ERR_UNSUPPORTED, "conv2d_wgrad_adam: conv_wgrad_wide declined the layer");
     return rc;
@@ -386,8 +392,7 @@ static int wgrad_dispatch(const szn_conv_desc_t* d, const void* in, const void* 
     }
     // many channels, few pixels (fc6, fc7): 256 x 256 tiles, one pixel split (szn_conv_wgrad_wide.hip)
     {
-        static const int wide_min = szn_knob("SZN_WGW_MINTILES", 96);
-        const int rc = szn_conv_wgrad_wide_try(d, in, dout, dw, accumulate, wide_min, stream);
+        const int rc = szn_conv_wgrad_wide_try(d, in, dout, dw, accumulate, wgw_min_tiles(), stream);
         if (rc <= 0) { *lp_native = 1; return rc; }
     }
     const long nw = (long)d->Co * d->KH * d->KW * d->Ci;

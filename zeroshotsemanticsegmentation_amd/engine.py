@@ -174,10 +174,11 @@ class GradBuckets(object):
                 self._t0 = None
         self.works = []
 
-    def gather_weights(self, image, first_only=False):
+    def gather_weights(self, image, first_only=False, spans=False):
         """sharded optimizer: all-gather the slices of `image` (a tensor laid out like `flat`: the 16-bit weight image, or the
-        fp32 masters) that the ranks just updated; returns the async works (wait before the next forward pass reads it).
-        first_only: the bucket of the first layers only (conv1_1 reads its fp32 master in the forward pass)"""
+        fp32 masters) that the ranks just updated; returns the async works (wait before anything reads the gathered range: the next
+        forward pass waits bucket by bucket, TrainStep.wait_weights).  first_only: the bucket of the first layers only (conv1_1 reads
+        its fp32 master in the forward pass).  spans=True: [((start, end) of the bucket, work)] instead of the bare works."""
         works = []
         if self.sharded and self.world > 1:
             for o, e, _ in list(reversed(self.buckets))[:1 if first_only else None]:       # forward order: conv1_1's bucket first
@@ -185,10 +186,11 @@ class GradBuckets(object):
                 self.issued += 1
                 if self._emulate(image):
                     n = (e - o) // self.world
-                    works.append(dist.all_gather([image[o + r * n:o + (r + 1) * n] for r in range(self.world)], image[lo:hi].clone(),
-                                                 group=self.group, async_op=True))
+                    wk = dist.all_gather([image[o + r * n:o + (r + 1) * n] for r in range(self.world)], image[lo:hi].clone(),
+                                         group=self.group, async_op=True)
                 else:
-                    works.append(dist.all_gather_into_tensor(image[o:e], image[lo:hi], group=self.group, async_op=True))
+                    wk = dist.all_gather_into_tensor(image[o:e], image[lo:hi], group=self.group, async_op=True)
+                works.append(((o, e), wk) if spans else wk)
         return works
 
     def timing_report(self):
@@ -466,6 +468,8 @@ class TrainStep(object):
             for n in os.environ.get("SZN_FUSED_ADAM_LAYERS", "fc6").split(","):
                 if n in self.woff and n in ("fc6", "fc7"):
                     getattr(model, n).weight.grad = None
+        self._pending_gather = []    # sharded optimizer: [((start, end), work)] all-gathers of the weight image nobody has waited for yet
+        self.gather_wait_log = []    # (tests) (layer that asked, bucket start, bucket end) in the order the waits were issued
         self.keep_ctx = False        # tests: keep the forward state of the last step (activations stay alive one step longer)
         self.last_ctx = None
 
@@ -914,11 +918,14 @@ class TrainStep(object):
                 lo, hi = self.buckets.shard(o, e)
                 self._opt_launch("w", lo, hi, self.nstep)
             image = self.flat_w_lp if self.flat_w_lp is not None else self.flat_w
-            works = self.buckets.gather_weights(image)
+            works = self.buckets.gather_weights(image, spans=True)
             if self.flat_w_lp is not None:       # conv1_1's kernel reads the fp32 master (3 input channels: no 16-bit image): its bucket's too
-                works += self.buckets.gather_weights(self.flat_w, first_only=True)
-            for wk in works:
-                wk.wait()                # (the compute stream waits, not the host)
+                works += self.buckets.gather_weights(self.flat_w, first_only=True, spans=True)
+            # Nobody waits here: the all-gathers (forward order, conv1_1's 2 MiB bucket first, fc6's 196 MB fourth) run on RCCL's stream
+            # under the tail of this step and the head of the next forward pass, whose layers wait for THEIR bucket only
+            # (_Engine.weight_gate -> wait_weights(layer)): conv1_1 .. conv5_3 of the next step run while fc6's image is still on the links
+            self._pending_gather = works
+            self.eng.weight_gate = self.wait_weights
             # masters (16-bit paths) and moments (every path) of the other ranks' slices are stale from here on
             self._masters_stale = self.buckets.world > 1
         else:
@@ -938,10 +945,34 @@ class TrainStep(object):
             L.call("szn_loss_scale_update", L.ptr(dyn), g, b, iv, lo, hi, st)
         self.eng.mark_dirty()
 
+    def wait_weights(self, layer=None):
+        """sharded optimizer: make the current stream wait for the pending all-gathers of the weight image -- of the bucket that holds
+        `layer` (and of every bucket in front of it: forward order), or of all of them (None).  Called by the engine in front of every
+        layer's first use of its weights in the next forward pass, and by everything else that reads parameters (gather_masters)."""
+        pend = getattr(self, "_pending_gather", None)
+        if not pend:
+            return
+        if layer is None:
+            upto = self.flat_w.numel()
+        else:
+            o, cnt = self.woff["score_fr" if layer == "head" else layer]
+            upto = o + cnt
+        keep = []
+        for (o, e), wk in pend:
+            if o < upto:
+                wk.wait()                # (the compute stream waits, not the host)
+                self.gather_wait_log.append((layer, o, e))
+            else:
+                keep.append(((o, e), wk))
+        self._pending_gather = keep
+        if not keep:
+            self.eng.weight_gate = None
+
     def gather_masters(self):
         """sharded optimizer: bring the optimizer moments -- and on a 16-bit path the fp32 masters (the fp32 path all-gathers them as the
         weight image in every step) -- of the other ranks' slices up to date on this rank (all-gather over the bucket slices).  Call before
         reading model parameters / optimizer state: checkpoints, export."""
+        self.wait_weights()
         if not getattr(self, "_masters_stale", False):
             return
         ts = ([self.flat_w] if self.flat_w_lp is not None else []) + list(self.state["w"])

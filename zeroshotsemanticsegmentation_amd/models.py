@@ -301,6 +301,11 @@ class _Engine(object):
         self.deterministic = os.environ.get("SZN_DETERMINISTIC", "1") != "0"
         self._cs_pool, self._cs_off, self._cs_jobs = None, 0, []
         self._seen_versions = None    # versions of seenmask_score mirrored into the TrainStep-owned head image
+        # TrainStep with the rank-sharded optimizer: callable(layer) that makes the stream wait for the all-gather of the bucket holding that
+        # layer's weight image (engine.TrainStep.wait_weights); None = nothing pending.  While it is set the dgrad images (_pack: one batched
+        # launch that reads EVERY layer's image) are built at the end of the forward pass instead of at its start.
+        self.weight_gate = None
+        self._pack_pending = None
 
     def _workspace(self, desc, nbytes, device):
         """split-K scratch handed to the conv kernels (they use it only for few-tile / long-K shapes: fc6, fc7)"""
@@ -391,7 +396,7 @@ class _Engine(object):
             img["up.w"] = m.seenmask_upscore.weight.detach().float().contiguous()
             lv["up"] = uver
         if lv.get("head") == hver and "head.w" in img:
-            self._pack(jobs, code, st)
+            self._pack_or_defer(jobs, code, st)
             self._images = img
             self._versions = v
             return
@@ -416,10 +421,29 @@ class _Engine(object):
             whc = wh if dt == torch.float32 else wh.to(dt)
         wht = torch.empty(F, CP, device=dev, dtype=dt)
         jobs.append((whc, wht, CP, 1, F))
-        self._pack(jobs, code, st)
+        self._pack_or_defer(jobs, code, st)
         img["head.w"], img["head.b"], img["head.wT"] = whc.view(CP, 1, 1, F), bh, wht.view(F, 1, 1, CP)
         self._images = img
         self._versions = v
+
+    def _gate(self, name):
+        if self.weight_gate is not None:
+            self.weight_gate(name)
+
+    def _pack_or_defer(self, jobs, code, st):
+        if self.weight_gate is not None:
+            self._pack_pending = (self._pack_pending[0] if self._pack_pending else []) + list(jobs), code
+        else:
+            self._pack(jobs, code, st)
+
+    def _flush_pack(self):
+        """the deferred dgrad images (see weight_gate): every all-gather has been waited for by now"""
+        if self._pack_pending:
+            if self.weight_gate is not None:
+                self.weight_gate(None)
+            jobs, code = self._pack_pending
+            self._pack_pending = None
+            self._pack(jobs, code, L.stream_ptr())
 
     @staticmethod
     def _pack(jobs, code, st):
@@ -514,6 +538,8 @@ class _Engine(object):
         output (the descriptor's pool_out: fused into the epilogue of the kernels that support it)"""
         B, Hi, Wi, Ci = x.shape
         img = self._images
+        if w is None:
+            self._gate(name)
         w = img[name + ".w"] if w is None else w
         b = img[name + ".b"] if b is None else b
         co = w.shape[0] if co is None else co
@@ -568,6 +594,7 @@ class _Engine(object):
         ctx.x, ctx.B, ctx.H, ctx.W, ctx.train = x, B, H, W, train
         H1, W1 = H + 2 * PAD1 - 2, W + 2 * PAD1 - 2
         regy, regx = _cb_conv1_1(H, PAD1), _cb_conv1_1(W, PAD1)         # constant-border regions of the current tensor, per axis
+        self._gate("conv1_1")
         ctx.crop = {}
         a = c11 = None
         if _BAND_CROP and _BAND_C11 and self.dtype != torch.float32 and not self.keep_prepool and (self.pool_codes or not keep):
@@ -650,8 +677,11 @@ class _Engine(object):
         if not keep:
             ctx.relu6 = None
         ctx.acts, ctx.pools = acts, pools
+        if self.head_fp8:
+            self._gate("head")
         ctx.coarse = self._head_fp8(ctx.relu7) if self.head_fp8 else self._conv(ctx.relu7, "head", 0, relu=False, out_f32=True)
         ctx.h, ctx.w = ctx.coarse.shape[1:3]
+        self._flush_pack()
         return ctx
 
     def _head_fp8(self, feat):
