@@ -376,6 +376,7 @@ class _Engine(object):
             elif name in self.lp_views and self.lp_views[name].dtype == dt:
                 wc = self.lp_views[name]                     # already written by szn_adam_step / szn_sgd_momentum_step
             else:
+                self._gate(name)                             # (a copy made NOW: the layer's master must be complete)
                 wc = w32.to(dt)
             img[name + ".w"] = wc
             if k >= 5:      # fc6: dgrad runs as GEMM + col2im (szn_conv2d_dgrad_gemm*).  On the 16-bit paths the GEMM takes the
@@ -412,6 +413,9 @@ class _Engine(object):
                 bh[E:E + 2].copy_(m.seenmask_score.bias.detach())
                 self._seen_versions = sv
         else:
+            # assembled by copy (fp32 path / no TrainStep-owned image): with a sharded optimizer's all-gathers still pending this needs all of
+            # them (score_fr is the last layer of the flat layout) -- the per-layer waits pay on the 16-bit paths, whose images are views
+            self._gate("head")
             wh = torch.zeros(CP, F, device=dev, dtype=torch.float32)
             bh = torch.zeros(CP, device=dev, dtype=torch.float32)
             wh[:E] = m.score_fr.weight.detach().float().reshape(E, F)
