@@ -321,7 +321,10 @@ def test_wire_modes_and_sharded_optimizer_bit_identical_two_ranks(optname):
         order = {n: i for i, n in enumerate(r["layers"] + ["head"])}
         asked = [order[a[0]] for a in r["wait_log"]]
         assert r["pending"] >= r["nb"] and len(r["wait_log"]) >= r["nb"], (mode, r["pending"], len(r["wait_log"]))
-        assert asked == sorted(asked) and asked[0] == 0 and len(set(asked)) >= 4, (mode, r["wait_log"])      # conv1_1 first, spread over the pass
+        if mode.startswith("f32c"):      # the fp32 path assembles its fused head image by COPY when the pass starts: that copy asks for everything
+            assert set(asked) == {order["head"]}, (mode, r["wait_log"])
+        else:
+            assert asked == sorted(asked) and asked[0] == 0 and len(set(asked)) >= 4, (mode, r["wait_log"])  # conv1_1 first, spread over the pass
         starts = [a[1] for a in r["wait_log"] if a[2] - a[1] > 0]
         assert max(starts) > 0
     assert np.abs(res[0]["f32c-sharded"]["m1"]).min() >= 0 and (res[0]["f32c-sharded"]["m1"] != 0).mean() > 0.5   # no slice left at its initial zeros
