@@ -689,6 +689,9 @@ def main():
     target = torch.from_numpy(synth.make_labels(B, H, H, K, seed=1337 + rank, classes=seen)).to(dev)
     target_all = torch.from_numpy(synth.make_labels(B, H, H, K, seed=4337 + rank)).to(dev)
 
+    # N > 1 headline: the direct bf16 wire (per-rank gradients rounded once to bf16, summed by RCCL in bf16; 271 MB instead of 542 MB on the links).
+    # The trainer's default is the fp32 wire (SZN_GRAD_COMM=fp32: exact sums, the reference-equivalent numerics) -- `config.grad_wire` on the line says
+    # which one was measured, `comm` carries both, and `--grad-comm fp32` / SZN_GRAD_COMM=bf16 move either side.
     wire = args.grad_comm
     if wire == "auto":
         wire = "bf16" if (dtype == torch.bfloat16 and args.arch == "fcn32s") else "fp32"
@@ -743,11 +746,21 @@ def main():
     if world > 1 and args.phase == "fcn" and wire != "fp32" and not (args.arch == "fcn8s" and args.unfused_head):
         # insurance for the first run on a real node: if the 16-bit / sharded exchange fails where this build could not test it (one-GPU
         # boxes only), the headline falls back to the plain fp32 all-reduce instead of losing the line; every rank sees the same error
+        err = None
         try:
             ts.step(x, target)
             torch.cuda.synchronize()
         except Exception as ex:
-            wire_note = "grad wire %s failed (%r): fell back to fp32" % (wire, ex)
+            err = ex
+        # every rank takes the same decision (a fallback decided per rank leaves the others inside a collective of the old
+        # configuration): the failure flags are summed over a fresh fp32 all-reduce before anybody rebuilds its TrainStep
+        flag = torch.tensor([1.0 if err is not None else 0.0], device=dev)
+        try:
+            dist.all_reduce(flag)
+        except Exception:
+            flag.fill_(1.0)
+        if float(flag.item()) > 0:
+            wire_note = "grad wire %s failed on %d rank(s) (%r): fell back to fp32" % (wire, int(flag.item()), err)
             sys.stderr.write(wire_note + "\n")
             wire = "fp32"
             ts = make_phase1()

@@ -250,3 +250,36 @@ def test_deterministic_bias_gradients_equal_the_atomic_ones(monkeypatch):
         ts.step(x, t)
         out[det] = (ts.flat_gb.clone(), ts.flat_gw.clone())
     assert rel(out[True][0], out[False][0]) < 1e-5 and rel(out[True][1], out[False][1]) < 1e-5
+
+
+def test_fused_head_tables_follow_the_embedding_tensor():
+    """the prepared embedding tables (szn_fused_head_prepare, once per workspace / embedding tensor) must not survive a new
+    embedding tensor -- even one that reuses the old one's address -- nor an in-place write that torch does not see (invalidate_head_prep)"""
+    E, K, H = 20, 33, 64
+    dev = torch.device("cuda", 0)
+    emb0, emb1 = synth.make_embeddings(K, E, seed=5), synth.make_embeddings(K, E, seed=6)
+    x = cu(synth.make_images(1, H, H, seed=3))
+    t = cu(synth.make_labels(1, H, H, K, seed=4, block=8))
+
+    def fresh(emb):
+        m = models.FCN32s(E)
+        m.load_synthetic(1337, device=dev)
+        m.eval()
+        return engine.TrainStep(m, emb, optimizer="adam", lr=0.0, precision=torch.float32, fused_head=True)
+    ts = fresh(emb0)
+    la = float(ts.step(x, t)[0])
+    lc = float(fresh(emb1).step(x, t)[0])
+    assert abs(la - lc) > 1e-4                                            # the two matrices give different losses
+    # 1. a new tensor (the setter invalidates; its address may or may not be the old one's)
+    ts.emb = cu(emb1)
+    assert float(ts.step(x, t)[0]) == lc
+    # 2. the same tensor rewritten behind torch's back (a raw copy through the library does not bump _version)
+    src = cu(emb0)
+    ver = ts.emb._version
+    L.call("szn_cast", L.SZN_F32, L.SZN_F32, src.numel(), L.ptr(src), L.ptr(ts.emb), L.stream_ptr())
+    assert ts.emb._version == ver
+    ts.invalidate_head_prep()
+    assert float(ts.step(x, t)[0]) == la
+    # 3. an in-place torch write is seen through _version
+    ts.emb.copy_(cu(emb1))
+    assert float(ts.step(x, t)[0]) == lc

@@ -168,28 +168,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsptr_t)(sb + KPg * 512 + (2 * w + i) * 1024), 16, vB[i], 0, 0, 0);
     };
 
-#ifdef SZN_WGW_REGSTAGE
-    // Experiment (round 6): the steady-state fill through REGISTERS -- four buffer_load_dwordx4 into 16 VGPRs behind barrier k, written to LDS
-    // with four ds_write_b128 behind barrier k + 1 (same lane-linear image, same source-side swizzle) -- instead of four LDS-DMA pieces, whose
-    // issue stalls the wave for 100-250 cycles each (profiles/r05_ablations.txt 18).  The prologue keeps the DMA form.
-    u32x4_t rA[2], rB[2];
-    auto rissue = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) rA[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vA[i], 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) rB[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, vB[i], 0, 0);
-    };
-    auto rwrite = [&](int stage) {
-        const int sb = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem + stage * STAGEg + lane * 16;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            asm volatile("ds_write_b128 %0, %1 offset:0" ::"v"(sb + (2 * w + i) * 1024), "v"(rA[i]) : "memory");
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            asm volatile("ds_write_b128 %0, %1 offset:0" ::"v"(sb + KPg * 512 + (2 * w + i) * 1024), "v"(rB[i]) : "memory");
-    };
-    int rpend = -1;                                   // ring buffer the loads in rA / rB belong to (-1: nothing in flight)
-#endif
     f32x4_t acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -230,29 +208,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
     //   * a wave fires stage k + 3 (the buffer of step k - 1) only behind barrier k, when everybody has finished reading step k - 1.
     const bool grpB = a.shift && w >= 4;
     // stage 0 has landed for every wave before group B reads it (the prologue fired min(nK, 3) stages of four loads each)
-#ifdef SZN_WGW_REGSTAGE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the three DMA stages of the prologue; the loop's loads go through registers)
-#else
     if (nK > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (nK > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_s_barrier();
     int stage = 0;
     for (int kc = 0; kc < nK; ++kc) {
         // four LDS-DMA instructions per wave per stage: only stage kc + 2 may stay in flight here
-#ifdef SZN_WGW_REGSTAGE
-        if (!grpB) {
-            __builtin_amdgcn_s_barrier();
-            if (rpend >= 0) { rwrite(rpend); rpend = -1; }                      // (the compiler waits for rA / rB: loads issued one step ago)
-            if (kc + 3 < nK && a.ablate != 1) { rissue(); rpend = (stage + 3) & 3; }
-        }
-#else
         if (kc + 2 < nK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!grpB) __builtin_amdgcn_s_barrier();
         if (!grpB && kc + 3 < nK && a.ablate != 1) fire((stage + 3) & 3);       // the stage drained in step kc - 1
-#endif
         prepare_issue();                              // offsets of step kc + 4 (table reads go out in front of the fragment reads)
         // Transpose reads as inline asm with explicit waits: behind the `buffer_load ... lds` of fire() the compiler puts
         // s_waitcnt vmcnt(0) in front of the next LDS read it knows about (the DMA might alias it) -- every K step then waited for
@@ -298,14 +264,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]) : : "memory");
         if (grpB && a.ablate == 2) __builtin_amdgcn_s_barrier();
-#ifdef SZN_WGW_REGSTAGE
-        if (grpB) {
-            if (rpend >= 0) { rwrite(rpend); rpend = -1; }
-            if (kc + 3 < nK && a.ablate != 1) { rissue(); rpend = (stage + 3) & 3; }
-        }
-#else
         if (grpB && kc + 3 < nK && a.ablate != 1) fire((stage + 3) & 3);        // (behind B's barrier)
-#endif
         prepare_finish();
         stage = (stage + 1) & 3;
     }

@@ -401,6 +401,7 @@ class TrainStep(object):
         self.dev = model.conv1_1.weight.device
         if self.dev.type != "cuda":
             raise L.SznError("TrainStep needs the model on the GPU")
+        self._ws_prep = None             # what the head of the fused head's workspace was prepared for (szn_fused_head_prepare)
         self.emb = torch.as_tensor(embeddings).to(self.dev, torch.float32).contiguous()
         self.K, self.E = self.emb.shape
         if self.E != model.n_class:
@@ -458,7 +459,6 @@ class TrainStep(object):
         # a training loop that calls zero_grad() next, train.py:170-175); the default keeps .grad meaningful.
         if fused_adam is None:
             fused_adam = os.environ.get("SZN_FUSED_ADAM", "1") == "1"
-        self._ws_prep = None             # what the head of the fused head's workspace was prepared for (szn_fused_head_prepare)
         self._own_stream = None          # see step(): the non-blocking stream of a small step
         self.fused_adam = bool(fused_adam and optimizer == "adam" and not self.dynamic and not self.buckets.active
                                and self.flat_w_lp is not None and os.environ.get("SZN_EARLY_ADAM", "auto") != "1")
@@ -472,6 +472,21 @@ class TrainStep(object):
         self.gather_wait_log = []    # (tests) (layer that asked, bucket start, bucket end) in the order the waits were issued
         self.keep_ctx = False        # tests: keep the forward state of the last step (activations stay alive one step longer)
         self.last_ctx = None
+
+    # the class-embedding matrix: assigning a new tensor (or calling invalidate_head_prep() after writing into it behind torch's back --
+    # a raw kernel does not bump _version, and a new tensor may reuse the address of the old one) makes the fused head rebuild its tables
+    @property
+    def emb(self):
+        return self._emb
+
+    @emb.setter
+    def emb(self, t):
+        self._emb = t
+        self.invalidate_head_prep()
+
+    def invalidate_head_prep(self):
+        self._emb_serial = getattr(self, "_emb_serial", 0) + 1
+        self._ws_prep = None
 
     @property
     def loss_scale(self):
@@ -664,7 +679,7 @@ class TrainStep(object):
                 self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
             # the embeddings are constants of a run: their transpose + norms (fh_prep_kernel: 23 us of dependent loads) are written to the head of
             # the workspace once -- again whenever the workspace or the embedding tensor (an in-place edit bumps _version) changes
-            prep = (self._ws.data_ptr(), self.emb.data_ptr(), self.emb._version, E, K)
+            prep = (self._ws.data_ptr(), self.emb.data_ptr(), self.emb._version, self._emb_serial, E, K)
             if self._ws_prep != prep:
                 L.call("szn_fused_head_prepare", E, K, L.ptr(self.emb), L.ptr(self._ws), st)
                 self._ws_prep = prep

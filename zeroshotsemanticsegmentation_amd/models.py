@@ -601,7 +601,10 @@ class _Engine(object):
         self._gate("conv1_1")
         ctx.crop = {}
         a = c11 = None
-        if _BAND_CROP and _BAND_C11 and self.dtype != torch.float32 and not self.keep_prepool and (self.pool_codes or not keep):
+        # (the cropped pair has no fallback in the backward pass -- szn_conv1_1_wgrad_c is the fused kernel or nothing -- so the forward pass takes
+        #  it only where that kernel's own admission rule holds: full-map gradient and image below 2 GiB, i.e. B < 34 at 512 x 512)
+        c11_fits = B * H1 * W1 * 128 < 0x7fff0000 and B * 3 * H * W * 4 < 0x7fff0000
+        if _BAND_CROP and _BAND_C11 and c11_fits and self.dtype != torch.float32 and not self.keep_prepool and (self.pool_codes or not keep):
             # 16-bit paths: conv1_1 never stores the rows / columns of the constant band that conv1_2's block does without (92 per side
             # at 512 x 512: 526^2 instead of 710^2 pixels written here, read by conv1_2, pooled, and walked by the backward pass)
             c11 = self._band_plan(regy, regx, H1, W1, x.device, len(_BAND_BLOCKS["conv1_2"]))
