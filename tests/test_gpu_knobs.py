@@ -58,7 +58,8 @@ def _child(out):
     m = models.FCN32s(E)
     m.load_synthetic(1337, device=dev)
     m.eval()
-    ts = engine.TrainStep(m, synth.make_embeddings(K, E), optimizer="adam", lr=1e-4, precision=torch.bfloat16, fused_head=True, keep_grads=True)
+    prec = torch.float32 if os.environ.get("KNOBTEST_FP32") == "1" else torch.bfloat16      # (test-only switch: the envelope run, see default_run)
+    ts = engine.TrainStep(m, synth.make_embeddings(K, E), optimizer="adam", lr=1e-4, precision=prec, fused_head=True, keep_grads=True)
     x = torch.from_numpy(synth.make_images(B, H, H, seed=5)).to(dev)
     t = torch.from_numpy(synth.make_labels(B, H, H, K, seed=6)).to(dev)
     kernels = set()
@@ -87,7 +88,7 @@ def _child(out):
 def _run(tag, fast_tmp):
     out = os.path.join(fast_tmp, re.sub(r"\W+", "_", tag) + ".pt")
     env = {k: v for k, v in os.environ.items() if not k.startswith("SZN_") or k == "SZN_LIB_PATH"}
-    env.update(GROUPS[tag])
+    env.update({"KNOBTEST_FP32": "1"} if tag == "fp32" else GROUPS[tag])
     p = subprocess.run([sys.executable, os.path.abspath(__file__), out], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, (tag, p.stderr[-3000:])
     return torch.load(out)
@@ -100,11 +101,21 @@ def default_run(tmp_path_factory):
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     d = tempfile.mkdtemp(prefix="szn_knobs_", dir=base)
     try:
-        yield d, _run("default", d)
+        ref = _run("default", d)
+        # the envelope of THIS configuration: the same step in fp32.  A bf16 pass whose forward kernels sum in another order ends up with activations
+        # that differ from the default pass by independent bf16 roundings -- the same kind and size of difference as bf16 against fp32 -- so its
+        # gradients may differ from the default's by about as much as the default's differ from the fp32 step's (ReLU-gate / pooling-winner flips)
+        f32 = _run("fp32", d)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from test_gpu_headline_pin import rel_l2
+        ref["envelope"] = {n: rel_l2(ref["grads"][n], f32["grads"][n]) for n in ref["grads"]}
+        print("envelope (bf16 default vs fp32, relative L2 per layer): " + "  ".join("%s %.2e" % kv for kv in ref["envelope"].items()))
+        yield d, ref
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
+FORWARD_CHANGES = {"generic kernels only", "wide kernels of rounds 1-3", "tap-major K order", "LDS-staged epilogues"}
 EXPECT = {   # group -> kernels that must (+) / must not (-) have run
     "default": ("+conv_igemm_8ph", "+conv3x3_regw", "+wgrad_taps_reduce", "+band_remap_kernel", "+conv_wgrad_half_adam"),
     # (fc6's split-K forward and its dgrad GEMM on the forward layout ask for the 256-wide kernels by themselves, whatever the thresholds say)
@@ -150,8 +161,15 @@ def test_step_under_non_default_knobs_equals_the_default_step(tag, default_run):
     rows = [(n, rel_l2(got["grads"][n], ref["grads"][n]), cosine(got["grads"][n], ref["grads"][n])) for n in ref["grads"]]
     print("%s: relative L2 / cosine of every layer's weight gradient against the default step: %s"
           % (tag, "  ".join("%s %.2e/%.4f" % r for r in rows)))
-    bad = [r for r in rows if not (r[1] <= 2.0 * MEASURED[r[0]] and r[2] >= 0.7)]
-    assert not bad, (tag, bad)
+    # groups that leave the FORWARD kernels alone reproduce the forward state bit for bit (loss equal): their gradients are held to the headline
+    # envelope; groups that change a forward kernel's summation order are held to THIS configuration's own bf16-against-fp32 envelope (default_run:
+    # measured 0.03 at score_fr .. 0.6 at conv1_1 at B = 3, E = 20, eval mode -- the flips average over fewer pixels than in the headline test) x 2,
+    # plus the direction; the kernels themselves are compared bit for bit in tests/test_gpu_conv.py
+    same_forward = got["loss"] == ref["loss"]
+    assert same_forward == (tag not in FORWARD_CHANGES), (tag, got["loss"], ref["loss"])
+    env = ref["envelope"]
+    bad = [r for r in rows if not ((r[1] <= 2.0 * MEASURED[r[0]] if same_forward else r[1] <= min(2.0 * env[r[0]], 0.9)) and r[2] >= 0.7)]
+    assert not bad, (tag, bad, env)
     assert float((got["w"] - ref["w"]).abs().max()) < 2.5e-4          # two Adam steps at lr 1e-4: a flipped sign of a tiny gradient moves 2 lr
 
 
