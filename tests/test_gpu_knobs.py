@@ -170,7 +170,7 @@ def test_step_under_non_default_knobs_equals_the_default_step(tag, default_run):
     env = ref["envelope"]
     bad = [r for r in rows if not ((r[1] <= 2.0 * MEASURED[r[0]] if same_forward else r[1] <= min(2.0 * env[r[0]], 0.9)) and r[2] >= 0.7)]
     assert not bad, (tag, bad, env)
-    assert float((got["w"] - ref["w"]).abs().max()) < 2.5e-4          # two Adam steps at lr 1e-4: a flipped sign of a tiny gradient moves 2 lr
+    assert float((got["w"] - ref["w"]).abs().max()) < 4.5e-4          # two Adam steps at lr 1e-4: a tiny gradient whose sign flips moves 2 lr per step
 
 
 if __name__ == "__main__":
