@@ -189,3 +189,62 @@ def test_sharded_optimizer_equals_allreduce_world2_gloo():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def _worker_world8(rank, world, port, q):
+    """the bucket / shard arithmetic at the rank count of BASELINE configs[3] (eight ranks; CPU tensors over gloo): every wire mode, all-reduce and
+    reduce-scatter + sharded update + bucket-by-bucket all-gather, against the exact mean gradient -- with eight terms the order of the sum matters, so
+    the comparison is to fp32 rounding (fp32 wire) / one bf16 rounding per rank (16-bit wires), and all ranks must end with IDENTICAL weights"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zeroshotsemanticsegmentation_amd.engine import GradBuckets
+    layers, off = [], 0
+    for i, n in enumerate([64, 4096, 128, 8192, 64, 32]):             # forward order; every bucket splits into 8 x whole 16-B groups
+        layers.append(("L%d" % i, off, n))
+        off += n
+    grads = [torch.randn(off, generator=torch.Generator().manual_seed(11 + r)) for r in range(world)]
+    w0 = torch.randn(off, generator=torch.Generator().manual_seed(5))
+    exact = w0 - 0.1 * sum(g.double() for g in grads).float() / world
+    ok = True
+    for comm, direct, sharded, tol in ((torch.float32, False, False, 1e-6), (torch.float32, False, True, 1e-6), (torch.bfloat16, False, False, 4e-3),
+                                       (torch.bfloat16, True, False, 4e-3), (torch.bfloat16, True, True, 4e-3)):
+        flat = grads[rank].clone()
+        gb = GradBuckets(flat, layers, bucket_elems=4000, comm_dtype=comm, sharded=sharded, direct=direct)
+        ok = ok and gb.world == 8 and gb.active
+        if gb.direct:
+            gb.stage.copy_(flat)
+        for name, _, _ in reversed(layers):
+            gb.layer_done(name)
+        gb.finish()
+        g = gb.stage.float() if gb.direct else flat
+        w = w0.clone()
+        if sharded:
+            for o, e, _ in gb.buckets:
+                lo, hi = gb.shard(o, e)
+                ok = ok and (hi - lo) * world == e - o and (hi - lo) % 4 == 0
+                w[lo:hi] -= 0.1 * g[lo:hi] / world
+            for (o, e), wk in gb.gather_weights(w, spans=True):
+                wk.wait()
+        else:
+            w -= 0.1 * g / world
+        ok = ok and float((w - exact).abs().max()) < tol
+        # every rank holds the same weights afterwards (rank 0's copy is broadcast and compared)
+        ref = w.clone()
+        dist.broadcast(ref, 0)
+        ok = ok and torch.equal(ref, w)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bucket_and_shard_arithmetic_at_eight_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 27500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_world8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(r, True) for r in range(8)]
