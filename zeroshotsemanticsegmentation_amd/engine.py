@@ -764,7 +764,12 @@ class TrainStep(object):
         nbytes = L.load().szn_fused_head_workspace_bytes(B, n3, m3, E, K)
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-        L.call("szn_fused_head_strided", 8, B, n3, m3, E, CP, 0, H, W, CROP_UP8, K, L.ptr(fuse3), L.ptr(self.emb), L.ptr(target),
+        # (the embedding tables at the head of the workspace are prepared once per workspace / embedding tensor, as in _step)
+        prep = (self._ws.data_ptr(), self.emb.data_ptr(), self.emb._version, self._emb_serial, E, K)
+        if self._ws_prep != prep:
+            L.call("szn_fused_head_prepare", E, K, L.ptr(self.emb), L.ptr(self._ws), st)
+            self._ws_prep = prep
+        L.call("szn_fused_head_prepared", 8, B, n3, m3, E, CP, 0, H, W, CROP_UP8, K, L.ptr(fuse3), L.ptr(self.emb), L.ptr(target),
                L.ptr(self.loss), L.ptr(stats), L.ptr(pred), L.SZN_F32, L.ptr(dfuse3), L.ptr(self._ws), st)
         self.stats = stats
         if self.dynamic:
