@@ -61,7 +61,11 @@ template <int VARIANT> __device__ __forceinline__ int swz(int r, int c) {
     else return c << 4;
 }
 
-template <int VARIANT, bool PRIO, bool STAGGER>
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+// Round 6 experiment (MMA32, TIMING ONLY -- the results are wrong): the same schedule, the same LDS reads and the same registers, but every quadrant's
+// 16 v_mfma_f32_16x16x32_bf16 replaced by 8 v_mfma_f32_32x32x16_bf16 on the same operand registers (the guide's micro-benchmark table has the
+// 32 x 32 shape at 2,382 TF against 2,075 TF for 16 x 16: is the matrix INSTRUCTION part of what keeps this kernel at 0.53?)
+template <int VARIANT, bool PRIO, bool STAGGER, bool MMA32 = false>
 __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -135,6 +139,13 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    f32x16_t acc32[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc32[q][mb][e] = 0.f;
     u32x4_t fa[4][2], fb0[2][2], fb1[2][2];                       // A sub-tile [j][s]; B0 / B1 sub-tiles [i][s]
 
     // ---- prologue: A0 B0 B1 A1 of tile 0, A0 B0 of tile 1 (what phases -6 .. -1 of the steady state would have issued)
@@ -166,10 +177,18 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
                        "+v"(fa[2][1]), "+v"(fa[3][1]), "+v"(FB[0][0]), "+v"(FB[1][0]), "+v"(FB[0][1]), "+v"(FB[1][1])); \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         if (prio) __builtin_amdgcn_s_setprio(1);                                                                     \
+        if constexpr (MMA32) {                                                                                       \
+            _Pragma("unroll") for (int kq = 0; kq < 4; ++kq)                                                         \
+                _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                     \
+                    acc32[Q][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                          \
+                        __builtin_bit_cast(bf16x8_t, FB[kq & 1][kq >> 1]), __builtin_bit_cast(bf16x8_t, fa[2 * mb + (kq & 1)][kq >> 1]), \
+                        acc32[Q][mb], 0, 0, 0);                                                                      \
+        } else {                                                                                                     \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
                     acc[Q][i][j] = mfma16<bf16_raw>(FB[i][s], fa[j][s], acc[Q][i][j]);                               \
+        }                                                                                                            \
         if (prio) __builtin_amdgcn_s_setprio(0);                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         __builtin_amdgcn_s_barrier();                                                                                \
@@ -192,6 +211,16 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead prefetches of the tail
 
     // ---- epilogue: each quadrant is a 64 x 32 block = acc[2][4] of the register epilogue (pairs swapped by v_permlane16_swap)
+    if constexpr (MMA32) {                                        // (hand the 32 x 32 accumulators to the 16 x 16 epilogue as they are: timing only)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q][i][j][e] = acc32[q][i][j * 4 + e];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int mh = q >> 1, nh = (q == 1 || q == 2) ? 1 : 0;   // (A0,B0) (A0,B1) (A1,B1) (A1,B0)
@@ -222,6 +251,11 @@ extern "C" int gemm8_bf16(long M, int N, int K, int ldc, const void* A, const vo
     a.mtiles = (int)((M + 255) / 256); a.ntiles = (N + 255) / 256;
     a.flags = flags;
     hipStream_t st = (hipStream_t)stream;
+    if (variant == 3) {
+        (void)hipFuncSetAttribute((const void*)gemm_256sq_8phase<0, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+        hipLaunchKernelGGL((gemm_256sq_8phase<0, true, true, true>), dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF, st, a);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (variant == 1) return launch<1, true, true>(a, st);
     if (variant == 2) return launch<2, true, true>(a, st);
     if (flags == 1) return launch<0, false, true>(a, st);
