@@ -65,7 +65,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // Round 6 experiment (MMA32, TIMING ONLY -- the results are wrong): the same schedule, the same LDS reads and the same registers, but every quadrant's
 // 16 v_mfma_f32_16x16x32_bf16 replaced by 8 v_mfma_f32_32x32x16_bf16 on the same operand registers (the guide's micro-benchmark table has the
 // 32 x 32 shape at 2,382 TF against 2,075 TF for 16 x 16: is the matrix INSTRUCTION part of what keeps this kernel at 0.53?)
-template <int VARIANT, bool PRIO, bool STAGGER, bool MMA32 = false>
+// PERSIST (round 6 experiment): 0 = one tile per block (the template); 1 = a block walks tiles blockIdx.x, + gridDim.x, ... and issues the NEXT
+// tile's six prologue half-tiles before the epilogue stores of the finished one (the LDS ring is idle during the register epilogue); 2 = the same
+// loop with the prologue behind the epilogue (what persistence alone buys: no block dispatch between tiles)
+template <int VARIANT, bool PRIO, bool STAGGER, bool MMA32 = false, int PERSIST = 0>
 __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,9 +79,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
     constexpr bool stagger = STAGGER, prio = PRIO;
 
     const int nwg = a.mtiles * a.ntiles;
-    const int lid = xcd_remap(blockIdx.x, nwg);
-    const int nt = lid % a.ntiles, mt = lid / a.ntiles;
-    const int m0 = mt * 256, n0 = nt * 256;
+    int m0, n0;
+    auto tile_of = [&](int bid) { const int lid = xcd_remap(bid, nwg); m0 = (lid / a.ntiles) * 256; n0 = (lid % a.ntiles) * 256; };
+    tile_of(blockIdx.x);
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
     // ---- staging: a half-tile is 16 wave-instructions of 8 rows x 128 B; wave w issues instructions 2 w and 2 w + 1
     // voff[kind][i]: kind 0 = A0, 1 = A1, 2 = B0, 3 = B1
     unsigned voff[4][2];
+    auto setup = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (2 * w + i) * 8 + (lane >> 3);           // row of the half-tile image
@@ -102,6 +106,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
             voff[2 + h][i] = n < a.Co ? (unsigned)(((size_t)n * a.K + sc * 8) * 2) : kOOB;
         }
     }
+    };
+    setup();
     const int nkt = a.K / 64;
     auto stage = [&](int kind, int buf, int kt) {               // kind / buf are compile-time after unrolling
         const unsigned kill = kt < nkt ? 0u : kOOB;               // beyond K: zeros into a slot nobody reads (keeps vmcnt uniform)
@@ -132,12 +138,6 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
     // (the swizzles depend on row bits 0..2 only, and fragments are 16 rows apart: the fragment offset is a plain immediate)
 
     f32x4_t acc[4][2][4];                                         // [quadrant][n fragment i][m fragment j]
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     f32x16_t acc32[4][2];
 #pragma unroll
@@ -149,8 +149,18 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
     u32x4_t fa[4][2], fb0[2][2], fb1[2][2];                       // A sub-tile [j][s]; B0 / B1 sub-tiles [i][s]
 
     // ---- prologue: A0 B0 B1 A1 of tile 0, A0 B0 of tile 1 (what phases -6 .. -1 of the steady state would have issued)
-    stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(0, 1, 1); stage(2, 1, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // A0, B0 of tile 0 landed (this wave's pieces)
+    auto prologue = [&]() { stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(0, 1, 1); stage(2, 1, 1); };
+    prologue();
+    for (int bid = blockIdx.x; bid < nwg; bid += (PERSIST ? (int)gridDim.x : nwg)) {
+    const int m0c = m0, n0c = n0;                                 // the tile this iteration finishes (the epilogue's coordinates)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (PERSIST && bid != (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (behind epilogue stores: every older operation, loads and stores)
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // A0, B0 of tile 0 landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();                                 // ... everyone's
     if (stagger && wr == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind group 0
 
@@ -209,6 +219,11 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
     if (t < nkt) G8_TILE(0, t)
     if (stagger && wr == 0) __builtin_amdgcn_s_barrier();         // group 0 waits for group 1's last phase
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead prefetches of the tail
+    const bool has_next = PERSIST && bid + (int)gridDim.x < nwg;
+    if (PERSIST == 1 && has_next) {                               // nobody reads the ring any more: the next tile's first stages go out now
+        __builtin_amdgcn_s_barrier();                             // (... every wave's dead prefetches have landed, not only this wave's)
+        tile_of(bid + (int)gridDim.x); setup(); prologue();
+    }
 
     // ---- epilogue: each quadrant is a 64 x 32 block = acc[2][4] of the register epilogue (pairs swapped by v_permlane16_swap)
     if constexpr (MMA32) {                                        // (hand the 32 x 32 accumulators to the 16 x 16 epilogue as they are: timing only)
@@ -224,9 +239,14 @@ __global__ __launch_bounds__(512, 2) void gemm_256sq_8phase(G8Args a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int mh = q >> 1, nh = (q == 1 || q == 2) ? 1 : 0;   // (A0,B0) (A0,B1) (A1,B1) (A1,B0)
-        tile_epilogue_direct<bf16_raw, 2, false, false>(a, acc[q], smem, tid, 0, 0, g, r16, m0 + wr * 128 + mh * 64,
-                                                        n0 + wc * 64 + nh * 32);
+        tile_epilogue_direct<bf16_raw, 2, false, false>(a, acc[q], smem, tid, 0, 0, g, r16, m0c + wr * 128 + mh * 64,
+                                                        n0c + wc * 64 + nh * 32);
     }
+    if (PERSIST == 2 && has_next) {
+        __builtin_amdgcn_s_barrier();
+        tile_of(bid + (int)gridDim.x); setup(); prologue();
+    }
+    }   // tiles of this block
 #endif
 }
 
@@ -251,6 +271,19 @@ extern "C" int gemm8_bf16(long M, int N, int K, int ldc, const void* A, const vo
     a.mtiles = (int)((M + 255) / 256); a.ntiles = (N + 255) / 256;
     a.flags = flags;
     hipStream_t st = (hipStream_t)stream;
+    if (variant == 4 || variant == 5) {
+        int ncu = 256;
+        { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; }
+        const int nwg_ = a.mtiles * a.ntiles, grid = nwg_ < ncu ? nwg_ : ncu;
+        if (variant == 4) {
+            (void)hipFuncSetAttribute((const void*)gemm_256sq_8phase<0, true, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+            hipLaunchKernelGGL((gemm_256sq_8phase<0, true, true, false, 1>), dim3(grid), dim3(512), 2 * BUF, st, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_256sq_8phase<0, true, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+            hipLaunchKernelGGL((gemm_256sq_8phase<0, true, true, false, 2>), dim3(grid), dim3(512), 2 * BUF, st, a);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (variant == 3) {
         (void)hipFuncSetAttribute((const void*)gemm_256sq_8phase<0, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
         hipLaunchKernelGGL((gemm_256sq_8phase<0, true, true, true>), dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF, st, a);
