@@ -194,6 +194,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
         const int phase = (blockIdx.x >> 3) & 7;
         for (int i = 0; i < phase * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
+#ifdef SZN_ABLATE_BUILD
+    long long pt[12];                                 // SZN_WGW_ABLATE=9: clock64 at the phase boundaries of the tile (tools/probe_wgw_cycles.py)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pt[i] = 0;
+    if (a.ablate == 9) pt[0] = clock64();
+#endif
     prepare(); fire(0);
     prepare(); if (nK > 1) fire(1);
     prepare(); if (nK > 2) fire(2);
@@ -269,6 +275,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
         stage = (stage + 1) & 3;
     }
 
+#ifdef SZN_ABLATE_BUILD
+    if (a.ablate == 9) pt[1] = clock64();
+#endif
     // ---- epilogue: D[co][ci] (lane: rows co = 4 g + e, column ci = r16) staged through LDS in four 64-row passes so that
     //      every store instruction covers whole 1-KiB rows of the OHWI gradient ----
     constexpr int PT = 256 + 4;
@@ -301,7 +310,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
                 vq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsV, off, 0, SZN_WGW_ADAM_AUX);
             }
         }
+#ifdef SZN_ABLATE_BUILD
+        if (a.ablate == 9 && pass == 1) pt[2] = clock64();            // pass 1: loads issued
+#endif
         __syncthreads();
+#ifdef SZN_ABLATE_BUILD
+        if (a.ablate == 9 && pass == 1) pt[3] = clock64();            // ... first barrier passed
+#endif
         if (wm == (pass >> 1)) {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
@@ -312,9 +327,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
                         tile[(ii * 16 + g * 4 + e) * PT + wn * 64 + j * 16 + r16] = acc[(pass & 1) * 4 + ii][j][e];
         }
         __syncthreads();
+#ifdef SZN_ABLATE_BUILD
+        if (a.ablate == 9 && pass == 1) pt[4] = clock64();            // ... gradient tile staged
+#endif
         if (ADAM) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
+#ifdef SZN_ABLATE_BUILD
+                if (a.ablate == 9 && pass == 1 && it == 1) pt[5] = clock64();     // ... first group updated and stored (its loads had landed)
+                if (a.ablate == 9 && pass == 1 && it == 7) pt[6] = clock64();
+#endif
                 if (eo[it] < 0) continue;
                 const int idx = tid + it * 512;
                 const int r = idx >> 6, c4 = (idx & 63) * 4;
@@ -341,6 +363,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide(WgwArgs a) {
                     __builtin_amdgcn_raw_buffer_store_b128(go, rsG, off, 0, 0);
                 }
             }
+#ifdef SZN_ABLATE_BUILD
+            if (a.ablate == 9 && pass == 1) pt[7] = clock64();        // pass 1 done (stores issued)
+            if (a.ablate == 9 && pass == 3 && tid == 0 && a.dw_lp) {  // the block's split: cycles in {prologue + K loop, pass 0, pass 1 parts, passes 2-3}
+                pt[8] = clock64();
+                float* dbg = (float*)a.dw_lp + (size_t)blockIdx.x * 16;   // (probe runs hand a scratch buffer over in szn_conv_desc_t.dw_lp)
+                dbg[0] = (float)(pt[1] - pt[0]); dbg[1] = (float)(pt[2] - pt[1]); dbg[2] = (float)(pt[3] - pt[2]); dbg[3] = (float)(pt[4] - pt[3]);
+                dbg[4] = (float)(pt[5] - pt[4]); dbg[5] = (float)(pt[6] - pt[5]); dbg[6] = (float)(pt[7] - pt[6]); dbg[7] = (float)(pt[8] - pt[7]);
+                dbg[8] = (float)(pt[8] - pt[0]);
+            }
+#endif
             continue;
         }
         for (int idx = tid; idx < 64 * 64; idx += 512) {              // 64 rows x 64 float4
@@ -667,6 +699,7 @@ int szn_conv_wgrad_wide_try(const szn_conv_desc_t* d, const void* in, const void
     a.M = d->B * d->Ho * d->Wo;
     a.accumulate = accumulate;
     { static int abl = -1; if (abl < 0) { abl = szn_ablate_env("SZN_WGW_ABLATE"); } a.ablate = abl; }
+    if (a.ablate == 9 && opt) a.dw_lp = (uint16_t*)d->dw_lp;      // (ablation build: the cycle probe's output buffer, >= 64 B per tile)
     { const int tab = 1; /* (was SZN_WGW_TAB) */ a.use_tab = (tab && a.M <= kTabMax) ? 1 : 0; }
     { const int sh = 1; /* (was SZN_WGW_SHIFT) */ a.shift = sh; }
     a.stagger = 0;
