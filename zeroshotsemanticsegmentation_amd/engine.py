@@ -945,7 +945,7 @@ class TrainStep(object):
             # under the tail of this step and the head of the next forward pass, whose layers wait for THEIR bucket only
             # (_Engine.weight_gate -> wait_weights(layer)): conv1_1 .. conv5_3 of the next step run while fc6's image is still on the links
             self._pending_gather = works
-            self.eng.weight_gate = self.wait_weights
+            self.eng.weight_gate = self.wait_weights if works else None       # (one rank owns every slice: nothing to wait for)
             # masters (16-bit paths) and moments (every path) of the other ranks' slices are stale from here on
             self._masters_stale = self.buckets.world > 1
         else:
